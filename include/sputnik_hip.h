@@ -1,0 +1,150 @@
+/*
+ * sputnik_hip.h -- C ABI of the MI355X (gfx950) sparse kernel library
+ * (libsputnik_hip.so).
+ *
+ * This is the drop-in boundary for the device side of the torch_sputnik
+ * operator surface.  Each entry point replaces one library call the
+ * reference's host wrappers make (file:line below are in the reference
+ * checkout); the host side above it (torch_sputnik_amd/csrc/torch_binding.cpp)
+ * mirrors the reference's five operators, src/sputnik.cpp:36-42.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless
+ *     its name says otherwise; no torch types.
+ *   - all launches are asynchronous on `stream`; no entry point synchronises,
+ *     allocates or frees device memory, so calls can be captured into a
+ *     hipGraph.  Scratch memory is passed in by the caller (query its size
+ *     with the matching *_workspace_bytes function), in the way the reference
+ *     drives cusparseCsr2cscEx2_bufferSize (src/transpose_cuda.cu:22-31).
+ *   - return value: 0 on success, otherwise the hipError_t of the failed
+ *     launch, or SPUTNIK_HIP_INVALID_ARGUMENT for a shape the library
+ *     rejects.  (The reference returns cudaError_t and aborts on != success,
+ *     include/error_check.h:5-10.)
+ *   - fp32 values, int32 indices, row-major dense operands, zero-based CSR:
+ *     exactly the reference's layout (src/spmm_cuda.cu:49-56).
+ *   - every output element is written by the kernels (rows without nonzeros
+ *     get zeros), so outputs need no memset (the reference zero-fills them
+ *     first, src/spmm_cuda.cu:46).
+ *   - `row_indices` is a permutation of [0,m) giving the order in which rows
+ *     are dealt to workgroups (load balancing); results never depend on it.
+ *   - batched entry points run all replicas in ONE launch; a stride is the
+ *     element distance between consecutive replicas (0 = operand shared).
+ */
+#ifndef SPUTNIK_HIP_H_
+#define SPUTNIK_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Opaque HIP stream handle (same type as hipStream_t in <hip/hip_runtime_api.h>). */
+typedef struct ihipStream_t* sputnik_hip_stream_t;
+
+#define SPUTNIK_HIP_INVALID_ARGUMENT (-1)
+
+/* Exported-symbol marker (the library is built with -fvisibility=hidden). */
+#define SPUTNIK_HIP_API __attribute__((visibility("default")))
+
+/* Library / build identification: "sputnik_hip <version> gfx950". */
+SPUTNIK_HIP_API const char* sputnik_hip_version(void);
+
+/* ------------------------------------------------------------------------
+ * SpMM   C[m,n] = A_csr[m,k] * B[k,n]
+ * replaces sputnik::CudaSpmm(m,k,n,nnz,row_indices,values,row_offsets,
+ *          column_indices,dense,out,stream)          src/spmm_cuda.cu:49-56
+ * ---------------------------------------------------------------------- */
+SPUTNIK_HIP_API int sputnik_hip_spmm(int m, int k, int n, int nonzeros,
+                     const int* row_indices, const float* values,
+                     const int* row_offsets, const int* column_indices,
+                     const float* dense, float* out,
+                     sputnik_hip_stream_t stream);
+
+/*
+ * Batched SpMM, one launch for all replicas.  Replaces the host loops
+ *   src/spmm_cuda.cu:48-57               (values_stride = nonzeros)
+ *   src/left_replicated_spmm.cu:32-41    (values_stride = 0: shared weights)
+ * dense_stride is normally k*n and out_stride m*n.
+ * `workspace` may be NULL (then only the workspace-free kernels are used);
+ * otherwise it must hold sputnik_hip_spmm_workspace_bytes(m,k,n,nonzeros).
+ */
+SPUTNIK_HIP_API size_t sputnik_hip_spmm_workspace_bytes(int m, int k, int n, int nonzeros);
+
+SPUTNIK_HIP_API int sputnik_hip_spmm_batched(int m, int k, int n, int nonzeros, int replicas,
+                             const int* row_indices, const float* values,
+                             int64_t values_stride, const int* row_offsets,
+                             const int* column_indices, const float* dense,
+                             int64_t dense_stride, float* out,
+                             int64_t out_stride, void* workspace,
+                             size_t workspace_bytes,
+                             sputnik_hip_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * SDDMM  out[p] = < lhs[i_p, 0:k], rhs[j_p, 0:k] >  for each stored (i_p,j_p)
+ * lhs is [m,k], rhs is [n,k] (row-major, i.e. already "transposed").
+ * replaces sputnik::CudaSddmm(m,k,n,nnz,row_indices,row_offsets,
+ *          column_indices,lhs,rhs,out,stream)       src/sddmm_cuda.cu:46-53
+ * and the host loop src/sddmm_cuda.cu:45-54 (batched form).
+ * ---------------------------------------------------------------------- */
+SPUTNIK_HIP_API int sputnik_hip_sddmm(int m, int k, int n, int nonzeros,
+                      const int* row_indices, const int* row_offsets,
+                      const int* column_indices, const float* lhs,
+                      const float* rhs, float* out,
+                      sputnik_hip_stream_t stream);
+
+SPUTNIK_HIP_API int sputnik_hip_sddmm_batched(int m, int k, int n, int nonzeros, int replicas,
+                              const int* row_indices, const int* row_offsets,
+                              const int* column_indices, const float* lhs,
+                              int64_t lhs_stride, const float* rhs,
+                              int64_t rhs_stride, float* out,
+                              int64_t out_stride, sputnik_hip_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Sparse softmax: per CSR row, exp(x - max) / sum(exp(x - max)) over the
+ * stored entries.  `n` is unused (the reference passes -1,
+ * src/softmax_cuda.cu:22).
+ * replaces sputnik::SparseSoftmax(m,n,nnz,values,row_indices,row_offsets,
+ *          column_indices,out,stream)               src/softmax_cuda.cu:36-42
+ * and the host loop src/softmax_cuda.cu:35-43 (batched form).
+ * ---------------------------------------------------------------------- */
+SPUTNIK_HIP_API int sputnik_hip_sparse_softmax(int m, int n, int nonzeros, const float* values,
+                               const int* row_indices, const int* row_offsets,
+                               const int* column_indices, float* out,
+                               sputnik_hip_stream_t stream);
+
+SPUTNIK_HIP_API int sputnik_hip_sparse_softmax_batched(int m, int n, int nonzeros, int replicas,
+                                       const float* values, int64_t values_stride,
+                                       const int* row_indices,
+                                       const int* row_offsets,
+                                       const int* column_indices, float* out,
+                                       int64_t out_stride,
+                                       sputnik_hip_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * CSR transpose  CSR(m x n) -> CSR(n x m), stable (source rows ascend within
+ * each output row: the ordering of cuSPARSE CSR2CSC_ALG1).
+ * replaces cusparseCsr2cscEx2_bufferSize            src/transpose_cuda.cu:22-31
+ *      and cusparseCsr2cscEx2                       src/transpose_cuda.cu:90-99
+ * `replicas` value arrays (stride values_stride / out_values_stride elements)
+ * share one permutation; the reference only ever has replicas = 1.
+ * `out_permutation` (may be NULL) receives, for every output slot, the index
+ * of the source nonzero, so a caller can reuse a static topology's transpose.
+ * ---------------------------------------------------------------------- */
+SPUTNIK_HIP_API size_t sputnik_hip_csr_transpose_workspace_bytes(int m, int n, int nonzeros);
+
+SPUTNIK_HIP_API int sputnik_hip_csr_transpose(int m, int n, int nonzeros, int replicas,
+                              const float* values, int64_t values_stride,
+                              const int* row_offsets, const int* column_indices,
+                              float* out_values, int64_t out_values_stride,
+                              int* out_row_offsets, int* out_column_indices,
+                              int* out_permutation, void* workspace,
+                              size_t workspace_bytes,
+                              sputnik_hip_stream_t stream);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+
+#endif /* SPUTNIK_HIP_H_ */

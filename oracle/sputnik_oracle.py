@@ -1,0 +1,244 @@
+"""numpy restatement of the five torch_sputnik ops (TEST INFRASTRUCTURE ONLY).
+
+Every function computes in float64 from the given (normally float32) inputs
+and returns float64, so a float32 device kernel is compared against it with a
+relative tolerance instead of against another float32 summation order.
+
+Citations are to files under the reference checkout (``/root/reference``).
+The arithmetic the reference runs lives in the un-vendored
+``google-research/sputnik`` submodule (``.gitmodules:1-3``, pin unknown) and
+in cuSPARSE; what is restated here is the contract visible at the reference's
+call sites plus the dense definitions the reference's own tests compare with.
+"""
+import numpy as np
+
+
+# --------------------------------------------------------------------------
+# topology helpers
+# --------------------------------------------------------------------------
+def _check_topology(m, row_indices, row_offsets, column_indices):
+    row_offsets = np.asarray(row_offsets).astype(np.int64)
+    column_indices = np.asarray(column_indices).astype(np.int64)
+    assert row_offsets.ndim == 1 and row_offsets.shape[0] == m + 1
+    assert column_indices.ndim == 1
+    assert row_offsets[0] == 0 and row_offsets[-1] == column_indices.shape[0]
+    assert np.all(np.diff(row_offsets) >= 0)
+    if row_indices is not None:
+        row_indices = np.asarray(row_indices).astype(np.int64)
+        assert row_indices.shape == (m,)
+        # row_indices is only a processing order ("row swizzle"); results must
+        # not depend on it.  It has to be a permutation of the rows.
+        assert np.array_equal(np.sort(row_indices), np.arange(m))
+    return row_offsets, column_indices
+
+
+def _rows_of(row_offsets):
+    """row id of every stored element, CSR order."""
+    m = row_offsets.shape[0] - 1
+    return np.repeat(np.arange(m, dtype=np.int64), np.diff(row_offsets))
+
+
+def diffsort(row_offsets):
+    """row_indices as the reference's modules build them.
+
+    modules/spmm.py:4-6 -- ``argsort((offsets - roll(offsets, -1))[:-1],
+    descending=True)``: the differences are minus the row lengths, so the
+    order is by ASCENDING row length.
+    """
+    row_offsets = np.asarray(row_offsets).astype(np.int64)
+    diffs = (row_offsets - np.roll(row_offsets, -1))[:-1]
+    return np.argsort(-diffs, kind="stable").astype(np.int32)
+
+
+def dense_to_csr(matrix):
+    """Dense 2-D array -> (values, row_indices, row_offsets, column_indices).
+
+    Restates tests/sparse_matrix.py:9-41 without the ``.cuda()`` calls:
+    values in row-major order, ``row_indices = argsort(-row_length)``
+    (descending lengths, :22), column indices ascending within a row.
+    """
+    matrix = np.asarray(matrix)
+    assert matrix.ndim == 2
+    mask = matrix != 0
+    values = matrix[mask].astype(np.float32)
+    row_offsets = np.concatenate(([0], np.cumsum(mask.sum(axis=1)))).astype(np.int32)
+    row_indices = np.argsort(-np.diff(row_offsets), kind="stable").astype(np.int32)
+    column_indices = np.nonzero(mask)[1].astype(np.int32)
+    return values, row_indices, row_offsets, column_indices
+
+
+def random_mask(m, n, sparsity, round_to=1, rng=None):
+    """0/1 mask with the distribution of tests/connectors.py:34-59.
+
+    ``num_dormant = round(sparsity * size)`` positions chosen uniformly
+    without replacement are zero; with ``round_to > 1`` the number of
+    nonzeros is rounded UP to a multiple of it (:49-52).
+    """
+    rng = np.random.default_rng(0) if rng is None else rng
+    size = m * n
+    if sparsity == 0.0:
+        return np.ones((m, n), dtype=np.float32)
+    num_dormant = int(round(sparsity * size))
+    if round_to > 1:
+        nnz = size - num_dormant
+        nnz = (nnz + round_to - 1) // round_to * round_to
+        num_dormant = size - nnz
+    mask = np.ones(size, dtype=np.float32)
+    mask[rng.choice(size, num_dormant, replace=False)] = 0.0
+    return mask.reshape(m, n)
+
+
+# --------------------------------------------------------------------------
+# the five ops
+# --------------------------------------------------------------------------
+def _spmm_one(m, n, values, rows, column_indices, dense):
+    out = np.zeros((m, n), dtype=np.float64)
+    if values.shape[0]:
+        # accumulate a_ij * B[j, :] into C[i, :] in CSR order
+        np.add.at(out, rows, values[:, None] * dense[column_indices])
+    return out
+
+
+def spmm(m, k, values, row_indices, row_offsets, column_indices, dense):
+    """C = A_csr @ B.  src/spmm_cuda.cu:9-60; definition tests/test_spmm.py:9-10.
+
+    ``values`` [nnz] with ``dense`` [k,n] -> [m,n]; or ``values`` [R,nnz] with
+    ``dense`` [R,k,n] -> [R,m,n] (topology shared, values per replica,
+    src/spmm_cuda.cu:48-57).
+    """
+    row_offsets, column_indices = _check_topology(m, row_indices, row_offsets, column_indices)
+    values = np.asarray(values, dtype=np.float64)
+    dense = np.asarray(dense, dtype=np.float64)
+    assert values.ndim in (1, 2) and dense.ndim == values.ndim + 1
+    assert values.shape[-1] == column_indices.shape[0]
+    assert dense.shape[-2] == k
+    assert column_indices.size == 0 or (column_indices.min() >= 0 and column_indices.max() < k)
+    n = dense.shape[-1]
+    rows = _rows_of(row_offsets)
+    if values.ndim == 1:
+        return _spmm_one(m, n, values, rows, column_indices, dense)
+    assert values.shape[0] == dense.shape[0]
+    return np.stack([_spmm_one(m, n, values[r], rows, column_indices, dense[r])
+                     for r in range(values.shape[0])])
+
+
+def left_spmm(m, k, values, row_indices, row_offsets, column_indices, dense):
+    """C_r = A_csr @ B_r with ONE sparse matrix.  src/left_replicated_spmm.cu:8-44.
+
+    ``values`` [nnz] is shared by all replicas (pointer not offset, :35);
+    ``dense`` [R,k,n] or [k,n]; the output is ALWAYS 3-D [R,m,n] (:30).
+    """
+    row_offsets, column_indices = _check_topology(m, row_indices, row_offsets, column_indices)
+    values = np.asarray(values, dtype=np.float64)
+    dense = np.asarray(dense, dtype=np.float64)
+    assert values.ndim == 1
+    if dense.ndim == 2:
+        dense = dense[None]
+    assert dense.shape[-2] == k
+    n = dense.shape[-1]
+    rows = _rows_of(row_offsets)
+    return np.stack([_spmm_one(m, n, values, rows, column_indices, dense[r])
+                     for r in range(dense.shape[0])])
+
+
+def sddmm(m, n, row_indices, row_offsets, column_indices, lhs, rhs):
+    """out[p] = <lhs[i_p,:], rhs[j_p,:]> for every stored (i_p, j_p), CSR order.
+
+    src/sddmm_cuda.cu:7-57; definition tests/test_sddmm.py:8-13 and
+    tests/test_sddmm_3d.py:9-14 (``lhs @ rhs^T`` sampled at the mask).
+    lhs [m,k] / [R,m,k], rhs [n,k] / [R,n,k] -> [nnz] / [R,nnz].
+    """
+    row_offsets, column_indices = _check_topology(m, row_indices, row_offsets, column_indices)
+    lhs = np.asarray(lhs, dtype=np.float64)
+    rhs = np.asarray(rhs, dtype=np.float64)
+    assert lhs.ndim == rhs.ndim and lhs.ndim in (2, 3)
+    assert lhs.shape[-1] == rhs.shape[-1]
+    assert lhs.shape[-2] == m and rhs.shape[-2] == n
+    assert column_indices.size == 0 or (column_indices.min() >= 0 and column_indices.max() < n)
+    rows = _rows_of(row_offsets)
+
+    def one(l, r):
+        return np.einsum("pk,pk->p", l[rows], r[column_indices])
+
+    if lhs.ndim == 2:
+        return one(lhs, rhs)
+    assert lhs.shape[0] == rhs.shape[0]
+    return np.stack([one(lhs[r], rhs[r]) for r in range(lhs.shape[0])])
+
+
+def sparse_softmax(values, row_indices, row_offsets, column_indices):
+    """Row-wise softmax over the STORED entries only.
+
+    src/softmax_cuda.cu:7-46; dense definition tests/test_softmax.py:9-22
+    (zeros replaced by -1e9 before a dense softmax).  values [nnz] / [R,nnz].
+    Empty rows contribute nothing.
+    """
+    m = np.asarray(row_offsets).shape[0] - 1
+    row_offsets, column_indices = _check_topology(m, row_indices, row_offsets, column_indices)
+    values = np.asarray(values, dtype=np.float64)
+    assert values.ndim in (1, 2) and values.shape[-1] == column_indices.shape[0]
+    rows = _rows_of(row_offsets)
+
+    def one(x):
+        row_max = np.full(m, -np.inf)
+        np.maximum.at(row_max, rows, x)
+        e = np.exp(x - row_max[rows])
+        row_sum = np.zeros(m)
+        np.add.at(row_sum, rows, e)
+        return e / row_sum[rows]
+
+    if values.ndim == 1:
+        return one(values)
+    return np.stack([one(values[r]) for r in range(values.shape[0])])
+
+
+def csr_transpose(m, n, values, row_offsets, column_indices):
+    """CSR(m x n) -> CSR of the transpose (n x m).
+
+    src/transpose_cuda.cu:45-102 (cusparseCsr2cscEx2, CSR2CSC_ALG1, :90-99):
+    returns (values_t [nnz], row_offsets_t [n+1], column_indices_t [nnz]).
+    ALG1 is a stable counting sort by column, so within each output row the
+    original row ids ascend.  ``values`` may also be [R,nnz] (extension,
+    SURVEY.md section 8f rank 1): the same permutation is applied per replica.
+    """
+    row_offsets, column_indices = _check_topology(m, None, row_offsets, column_indices)
+    values = np.asarray(values)
+    assert values.shape[-1] == column_indices.shape[0]
+    assert column_indices.size == 0 or (column_indices.min() >= 0 and column_indices.max() < n)
+    rows = _rows_of(row_offsets)
+    order = np.argsort(column_indices, kind="stable")
+    values_t = values[..., order]
+    column_indices_t = rows[order].astype(np.int32)
+    counts = np.bincount(column_indices, minlength=n)
+    row_offsets_t = np.concatenate(([0], np.cumsum(counts))).astype(np.int32)
+    return values_t, row_offsets_t, column_indices_t
+
+
+# --------------------------------------------------------------------------
+# dense definitions, exactly as the reference's tests state them
+# --------------------------------------------------------------------------
+def csr_to_dense(m, n, values, row_offsets, column_indices):
+    row_offsets = np.asarray(row_offsets).astype(np.int64)
+    out = np.zeros((m, n), dtype=np.float64)
+    out[_rows_of(row_offsets), np.asarray(column_indices).astype(np.int64)] = values
+    return out
+
+
+def dense_spmm(sparse_dense, dense):
+    """tests/test_spmm.py:9-10 -- ``torch.matmul(sparse, dense)``."""
+    return np.matmul(np.asarray(sparse_dense, np.float64), np.asarray(dense, np.float64))
+
+
+def dense_sddmm(mask, lhs, rhs):
+    """tests/test_sddmm_3d.py:9-14 -- ``lhs @ rhs^T`` with masked_fill_(mask==0, 0)."""
+    out = np.matmul(np.asarray(lhs, np.float64), np.swapaxes(np.asarray(rhs, np.float64), -2, -1))
+    return np.where(np.asarray(mask) == 0, 0.0, out)
+
+
+def dense_softmax(matrix):
+    """tests/test_softmax.py:9-22 -- zeros -> -1e9, then softmax over the last dim."""
+    x = np.asarray(matrix, np.float64).copy()
+    x[x == 0] = -1e9
+    x = x - x.max(axis=-1, keepdims=True)
+    e = np.exp(x)
+    return e / e.sum(axis=-1, keepdims=True)

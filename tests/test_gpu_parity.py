@@ -1,0 +1,308 @@
+"""GPU: the HIP kernels, called through the C ABI (torch_sputnik_amd.capi) and
+through torch.ops.torch_sputnik, against the oracle and the golden fixtures.
+
+Tolerance: BASELINE.json's north star asks for 1e-4 on fp32 outputs.  The
+oracle is float64, so the comparison is relative: |got - want| <= 1e-4 *
+max(|want|, 1e-3 * max|want|)  (helpers.rel_err).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle
+from oracle import sputnik_oracle as O
+from helpers import make_csr, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from torch_sputnik_amd import capi
+    assert "gfx950" in capi.version()
+    return capi
+
+
+@pytest.fixture(scope="module")
+def ts():
+    import torch_sputnik
+    return torch_sputnik
+
+
+def T(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def topo_t(ri, ro, ci, dev):
+    return T(ri, dev), T(ro, dev), T(ci, dev)
+
+
+# ----------------------------------------------------------------------------
+# SpMM
+# ----------------------------------------------------------------------------
+SPMM_SHAPES = [
+    # m, k, n, sparsity, order, empty_rows
+    (64, 64, 64, 0.5, "descending", ()),          # BASELINE config 1
+    (72, 64, 72, 0.9, "descending", ()),          # tests/test_spmm.py
+    (72, 64, 72, 0.9, "ascending", (0, 71)),
+    (33, 47, 7, 0.6, "random", (5,)),             # n odd -> scalar path
+    (33, 47, 18, 0.6, "identity", ()),            # n % 2 == 0 -> float2 path
+    (257, 300, 260, 0.8, "descending", (256,)),   # two n-tiles, ragged
+    (512, 1024, 512, 0.9, "ascending", ()),
+    (1024, 777, 1024, 0.95, "descending", ()),
+    (100, 4096, 256, 0.98, "random", (1, 2, 3)),
+    (2048, 2048, 64, 0.9, "descending", ()),      # attention-like n
+]
+
+
+@pytest.mark.parametrize("m,k,n,sparsity,order,empty", SPMM_SHAPES)
+def test_spmm_capi_vs_oracle(capi, dev, m, k, n, sparsity, order, empty):
+    _, vals, ri, ro, ci = make_csr(m, k, sparsity, seed=m * 7 + n, empty_rows=empty, order=order)
+    b = np.random.default_rng(n).uniform(-1, 1, size=(k, n)).astype(np.float32)
+    want = c_oracle.spmm(m, k, vals, ro, ci, b)
+    out = torch.full((m, n), float("nan"), device=dev)
+    ws = torch.empty(capi.spmm_workspace_bytes(m, k, n, len(ci)) + 16, dtype=torch.uint8, device=dev)
+    capi.spmm_batched(m, k, n, 1, T(ri, dev), T(vals, dev), 0, T(ro, dev), T(ci, dev), T(b, dev),
+                      out, ws)
+    got = out.cpu().numpy()
+    assert not np.isnan(got).any(), "some output elements were never written"
+    assert rel_err(got, want) < TOL
+    for r in empty:
+        assert np.all(got[r] == 0)
+
+
+@pytest.mark.parametrize("replicas,shared", [(3, False), (5, True), (1, False)])
+def test_spmm_batched_capi(capi, dev, replicas, shared):
+    m, k, n = 130, 96, 136
+    _, vals, ri, ro, ci = make_csr(m, k, 0.85, seed=21)
+    rng = np.random.default_rng(22)
+    b = rng.uniform(-1, 1, size=(replicas, k, n)).astype(np.float32)
+    v = vals if shared else rng.uniform(-1, 1, size=(replicas, len(vals))).astype(np.float32)
+    want = c_oracle.spmm(m, k, v, ro, ci, b)
+    out = torch.full((replicas, m, n), float("nan"), device=dev)
+    capi.spmm_batched(m, k, n, replicas, T(ri, dev), T(v, dev), 0 if shared else len(vals),
+                      T(ro, dev), T(ci, dev), T(b, dev), out, None)
+    assert rel_err(out.cpu().numpy(), want) < TOL
+
+
+def test_spmm_unsorted_columns(capi, dev):
+    """Column indices need not ascend inside a row (the CUDA library does not
+    require it either)."""
+    m, k, n = 96, 200, 128
+    _, vals, ri, ro, ci = make_csr(m, k, 0.8, seed=23)
+    rng = np.random.default_rng(24)
+    vals, ci = vals.copy(), ci.copy()
+    for r in range(m):
+        p = rng.permutation(ro[r + 1] - ro[r]) + ro[r]
+        vals[ro[r]:ro[r + 1]], ci[ro[r]:ro[r + 1]] = vals[p], ci[p]
+    b = rng.uniform(-1, 1, size=(k, n)).astype(np.float32)
+    want = c_oracle.spmm(m, k, vals, ro, ci, b)
+    out = torch.empty((m, n), device=dev)
+    ws = torch.empty(capi.spmm_workspace_bytes(m, k, n, len(ci)) + 16, dtype=torch.uint8, device=dev)
+    capi.spmm_batched(m, k, n, 1, T(ri, dev), T(vals, dev), 0, T(ro, dev), T(ci, dev), T(b, dev),
+                      out, ws)
+    assert rel_err(out.cpu().numpy(), want) < TOL
+
+
+@pytest.mark.parametrize("name", ["spmm_c1_64_d050", "spmm_2d_72x64x72", "spmm_3d_r8_72x64x72"])
+def test_spmm_op_golden(ts, dev, golden, name):
+    g = golden(name)
+    out = ts.spmm(int(g["m"]), int(g["k"]), T(g["values"], dev),
+                  *topo_t(g["row_indices"], g["row_offsets"], g["column_indices"], dev),
+                  T(g["dense"], dev))
+    assert tuple(out.shape) == g["expected"].shape
+    assert rel_err(out.cpu().numpy(), g["expected"]) < TOL
+
+
+def test_left_spmm_op(ts, dev):
+    m, k, n, r = 256, 128, 72, 3   # tests/test_linear_3d.py:105
+    _, vals, ri, ro, ci = make_csr(m, k, 0.9, seed=25, order="ascending")
+    b = np.random.default_rng(26).uniform(-1, 1, size=(r, k, n)).astype(np.float32)
+    # int64 row_indices must be accepted
+    out = ts.left_spmm(m, k, T(vals, dev), T(ri.astype(np.int64), dev), T(ro, dev), T(ci, dev),
+                       T(b, dev))
+    assert tuple(out.shape) == (r, m, n)
+    assert rel_err(out.cpu().numpy(), O.left_spmm(m, k, vals, ri, ro, ci, b)) < TOL
+    out2 = ts.left_spmm(m, k, T(vals, dev), T(ri, dev), T(ro, dev), T(ci, dev), T(b[0], dev))
+    assert tuple(out2.shape) == (1, m, n)
+    assert torch.equal(out2[0], out[0])
+
+
+# ----------------------------------------------------------------------------
+# SDDMM
+# ----------------------------------------------------------------------------
+SDDMM_SHAPES = [
+    # m, k, n, sparsity, replicas
+    (72, 64, 72, 0.0, 1),      # tests/test_sddmm.py: dense mask
+    (72, 64, 72, 0.9, 4),      # tests/test_sddmm_3d.py (r reduced)
+    (50, 7, 60, 0.7, 2),       # odd k -> scalar path
+    (50, 10, 60, 0.7, 1),      # k % 2 == 0 -> float2
+    (128, 32, 128, 0.9, 3),
+    (1024, 64, 1024, 0.9, 2),  # attention block geometry (config 3)
+    (200, 300, 150, 0.8, 1),   # k > 256: panels
+    (64, 1100, 96, 0.9, 2),    # k > 1024: several panels, out accumulation
+]
+
+
+@pytest.mark.parametrize("m,k,n,sparsity,replicas", SDDMM_SHAPES)
+def test_sddmm_capi_vs_oracle(capi, dev, m, k, n, sparsity, replicas):
+    _, _, ri, ro, ci = make_csr(m, n, sparsity, seed=m + k + n, round_to=1, empty_rows=(m // 2,))
+    rng = np.random.default_rng(k)
+    lhs = rng.uniform(-1, 1, size=(replicas, m, k)).astype(np.float32)
+    rhs = rng.uniform(-1, 1, size=(replicas, n, k)).astype(np.float32)
+    want = c_oracle.sddmm(m, n, ro, ci, lhs, rhs)
+    out = torch.full((replicas, len(ci)), float("nan"), device=dev)
+    capi.sddmm_batched(m, k, n, replicas, T(ri, dev), T(ro, dev), T(ci, dev), T(lhs, dev),
+                       T(rhs, dev), out)
+    got = out.cpu().numpy()
+    assert not np.isnan(got).any()
+    # inner products of k terms in [-1,1]: scale the tolerance by sqrt(k)-ish magnitude
+    assert np.max(np.abs(got - want)) < TOL * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("name", ["sddmm_2d_dense_mask", "sddmm_3d_r8"])
+def test_sddmm_op_golden(ts, dev, golden, name):
+    g = golden(name)
+    out = ts.sddmm(int(g["m"]), int(g["n"]),
+                   *topo_t(g["row_indices"], g["row_offsets"], g["column_indices"], dev),
+                   T(g["lhs"], dev), T(g["rhs"], dev))
+    assert tuple(out.shape) == g["expected"].shape
+    assert rel_err(out.cpu().numpy(), g["expected"]) < TOL
+
+
+# ----------------------------------------------------------------------------
+# sparse softmax
+# ----------------------------------------------------------------------------
+@pytest.mark.parametrize("m,n,sparsity,replicas", [
+    (72, 72, 0.9, 1), (72, 72, 0.0, 2), (1024, 1024, 0.9, 3), (64, 4096, 0.5, 2),
+    (300, 700, 0.3, 1), (17, 5000, 0.1, 1)])
+def test_softmax_capi_vs_oracle(capi, dev, m, n, sparsity, replicas):
+    _, vals, ri, ro, ci = make_csr(m, n, sparsity, seed=m + n, round_to=1, empty_rows=(0, m - 1))
+    rng = np.random.default_rng(m)
+    v = rng.uniform(-8, 8, size=(replicas, len(vals))).astype(np.float32)
+    want = c_oracle.sparse_softmax(v, ro, ci)
+    out = torch.full((replicas, len(vals)), float("nan"), device=dev)
+    capi.sparse_softmax_batched(m, replicas, T(v, dev), T(ri, dev), T(ro, dev), T(ci, dev), out)
+    got = out.cpu().numpy()
+    assert not np.isnan(got).any()
+    assert np.max(np.abs(got - want)) < TOL * max(1e-3, want.max())
+    assert rel_err(got, want) < 10 * TOL
+
+
+def test_softmax_op_golden(ts, dev, golden):
+    g = golden("softmax_72x72")
+    out = ts.sparse_softmax(T(g["values"], dev),
+                            *topo_t(g["row_indices"], g["row_offsets"], g["column_indices"], dev))
+    assert rel_err(out.cpu().numpy(), g["expected"]) < TOL
+
+
+def test_softmax_large_magnitudes(ts, dev):
+    """max-subtraction: huge scores must not overflow."""
+    _, vals, ri, ro, ci = make_csr(40, 90, 0.5, seed=31, round_to=1)
+    v = (vals * 2000 - 1000).astype(np.float32)
+    out = ts.sparse_softmax(T(v, dev), T(ri, dev), T(ro, dev), T(ci, dev)).cpu().numpy()
+    assert np.isfinite(out).all()
+    assert np.max(np.abs(out - O.sparse_softmax(v, ri, ro, ci))) < TOL
+
+
+# ----------------------------------------------------------------------------
+# CSR transpose (bit-exact)
+# ----------------------------------------------------------------------------
+@pytest.mark.parametrize("m,n,sparsity,replicas,empty", [
+    (4, 4, 0.0, 1, (0,)),                 # tests/test_transpose.py
+    (72, 64, 0.8, 1, ()),
+    (257, 1000, 0.9, 1, (0, 256)),
+    (2048, 2048, 0.8, 1, ()),             # config 5 geometry
+    (1500, 300, 0.5, 3, (7,)),            # batched values (extension)
+    (64, 20000, 0.99, 1, ()),             # n > 16384: global-counter path
+    (3000, 64, 0.3, 2, ()),               # rows_per_chunk > 1
+])
+def test_transpose_capi_bit_exact(capi, dev, m, n, sparsity, replicas, empty):
+    _, vals, _, ro, ci = make_csr(m, n, sparsity, seed=m + 3 * n, round_to=1, empty_rows=empty)
+    rng = np.random.default_rng(n)
+    v = vals if replicas == 1 else rng.uniform(size=(replicas, len(vals))).astype(np.float32)
+    want = O.csr_transpose(m, n, v, ro, ci)
+    nnz = len(ci)
+    out_v = torch.full(v.shape, float("nan"), device=dev)
+    out_ro = torch.full((n + 1,), -1, dtype=torch.int32, device=dev)
+    out_ci = torch.full((nnz,), -1, dtype=torch.int32, device=dev)
+    perm = torch.full((nnz,), -1, dtype=torch.int32, device=dev)
+    ws = torch.empty(capi.csr_transpose_workspace_bytes(m, n, nnz), dtype=torch.uint8, device=dev)
+    capi.csr_transpose(m, n, replicas, T(v, dev), T(ro, dev), T(ci, dev), out_v, out_ro, out_ci,
+                       perm, ws)
+    assert np.array_equal(out_ro.cpu().numpy(), want[1])
+    assert np.array_equal(out_ci.cpu().numpy(), want[2])
+    assert np.array_equal(out_v.cpu().numpy(), want[0])
+    assert np.array_equal(np.asarray(v)[..., perm.cpu().numpy()], want[0])
+
+
+@pytest.mark.parametrize("name", ["transpose_4x4_row0_zero", "transpose_72x64"])
+def test_transpose_op_golden(ts, dev, golden, name):
+    g = golden(name)
+    vt, rot, cit = ts.csr_transpose(int(g["m"]), int(g["n"]), T(g["values"], dev),
+                                    T(g["row_offsets"], dev), T(g["column_indices"], dev))
+    assert np.array_equal(vt.cpu().numpy(), g["values_t"])
+    assert np.array_equal(rot.cpu().numpy(), g["row_offsets_t"])
+    assert np.array_equal(cit.cpu().numpy(), g["column_indices_t"])
+    assert rot.dtype == torch.int32 and cit.dtype == torch.int32
+
+
+def test_transpose_round_trip_full_size(ts, dev):
+    """Size-independent property at config-5 size: transposing twice is the identity."""
+    m = n = 2048
+    _, vals, _, ro, ci = make_csr(m, n, 0.8, seed=41)
+    v, r, c = T(vals, dev), T(ro, dev), T(ci, dev)
+    vt, rot, cit = ts.csr_transpose(m, n, v, r, c)
+    vtt, rott, citt = ts.csr_transpose(n, m, vt, rot, cit)
+    assert torch.equal(vtt, v) and torch.equal(rott, r) and torch.equal(citt, c)
+
+
+# ----------------------------------------------------------------------------
+# determinism, empty inputs, errors
+# ----------------------------------------------------------------------------
+def test_bitwise_reproducible(ts, dev):
+    m, k, n = 512, 512, 512
+    _, vals, ri, ro, ci = make_csr(m, k, 0.9, seed=51)
+    b = np.random.default_rng(52).uniform(-1, 1, size=(k, n)).astype(np.float32)
+    args = (m, k, T(vals, dev), T(ri, dev), T(ro, dev), T(ci, dev), T(b, dev))
+    first = ts.spmm(*args)
+    for _ in range(3):
+        assert torch.equal(ts.spmm(*args), first)
+
+
+def test_empty_topology(ts, dev):
+    m, k, n = 5, 4, 8
+    ro = torch.zeros(m + 1, dtype=torch.int32, device=dev)
+    ci = torch.zeros(0, dtype=torch.int32, device=dev)
+    ri = torch.arange(m, dtype=torch.int32, device=dev)
+    vals = torch.zeros(0, device=dev)
+    out = ts.spmm(m, k, vals, ri, ro, ci, torch.ones(k, n, device=dev))
+    assert tuple(out.shape) == (m, n) and torch.all(out == 0)
+    assert ts.sddmm(m, k, ri, ro, ci, torch.ones(m, 3, device=dev),
+                    torch.ones(k, 3, device=dev)).numel() == 0
+    assert ts.sparse_softmax(vals, ri, ro, ci).numel() == 0
+    vt, rot, cit = ts.csr_transpose(m, k, vals, ro, ci)
+    assert rot.cpu().tolist() == [0] * (k + 1) and vt.numel() == 0 and cit.numel() == 0
+
+
+def test_shape_errors_raise(ts, dev):
+    _, vals, ri, ro, ci = make_csr(8, 8, 0.5, seed=61)
+    v, r, o, c = T(vals, dev), T(ri, dev), T(ro, dev), T(ci, dev)
+    with pytest.raises(RuntimeError):
+        ts.spmm(8, 8, v, r, o, c, torch.ones(9, 4, device=dev))      # k mismatch
+    with pytest.raises(RuntimeError):
+        ts.spmm(8, 8, v[:-1], r, o, c, torch.ones(8, 4, device=dev))  # nnz mismatch
+    with pytest.raises(RuntimeError):
+        ts.spmm(8, 8, v.double(), r, o, c, torch.ones(8, 4, device=dev))  # dtype
+    with pytest.raises(RuntimeError):
+        ts.sddmm(8, 8, r, o, c, torch.ones(8, 4, device=dev), torch.ones(8, 5, device=dev))
+    with pytest.raises((RuntimeError, NotImplementedError)):
+        ts.spmm(8, 8, v.cpu(), r.cpu(), o.cpu(), c.cpu(), torch.ones(8, 4))  # no CPU path

@@ -1,0 +1,68 @@
+"""In-tree build of the two native pieces (gfx950 only):
+
+  lib/libsputnik_hip.so        HIP kernels behind the C ABI (include/sputnik_hip.h)
+  lib/libtorch_sputnik_ops.so  TORCH_LIBRARY registration on top of it (g++, no device code)
+
+Run as ``python -m torch_sputnik_amd.build``; ``__graft_entry__.build()`` calls
+``build_all()``.  hipcc cross-compiles without a GPU.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "lib")
+KERNEL_LIB = os.path.join(LIB, "libsputnik_hip.so")
+OPS_LIB = os.path.join(LIB, "libtorch_sputnik_ops.so")
+
+
+def _run(cmd):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(s) <= t for s in sources)
+
+
+def build_kernels(jobs=6):
+    _run(["make", "-C", CSRC, f"-j{jobs}", "all"])
+    return KERNEL_LIB
+
+
+def build_torch_ops():
+    import torch
+    from torch.utils import cpp_extension
+
+    src = os.path.join(CSRC, "torch_binding.cpp")
+    header = os.path.join(HERE, "..", "include", "sputnik_hip.h")
+    if _newer(OPS_LIB, [src, header, KERNEL_LIB]):
+        return OPS_LIB
+    torch_lib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall",
+           "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}"]
+    for inc in cpp_extension.include_paths("cuda"):
+        cmd += ["-isystem", inc]
+    cmd += [src, "-o", OPS_LIB,
+            f"-L{LIB}", "-lsputnik_hip",
+            f"-L{torch_lib}", "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch",
+            "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{torch_lib}"]
+    _run(cmd)
+    return OPS_LIB
+
+
+def build_all():
+    os.makedirs(LIB, exist_ok=True)
+    build_kernels()
+    build_torch_ops()
+
+
+if __name__ == "__main__":
+    build_all()
+    print("built:", KERNEL_LIB, OPS_LIB)
+    sys.exit(0)

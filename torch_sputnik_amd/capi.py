@@ -1,0 +1,156 @@
+"""ctypes view of the C ABI (include/sputnik_hip.h) for callers that hold raw
+device memory: the parity tests and bench.py call the kernels through this, on
+torch-allocated HIP buffers, without going through the TORCH_LIBRARY layer.
+
+Every wrapper takes already-valid int32 / float32 contiguous GPU tensors,
+passes their pointers plus the current HIP stream, and raises on a nonzero
+status.  No shape inference or casting happens here (that is the op layer's
+job, csrc/torch_binding.cpp).
+"""
+import ctypes
+
+import torch
+
+from ._native import kernel_lib
+
+_c_int = ctypes.c_int
+_c_i64 = ctypes.c_int64
+_c_ptr = ctypes.c_void_p
+_c_size = ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/sputnik_hip.h declares.
+SIGNATURES = {
+    "sputnik_hip_version": (ctypes.c_char_p, []),
+    "sputnik_hip_spmm": (_c_int, [_c_int] * 4 + [_c_ptr] * 7),
+    "sputnik_hip_spmm_workspace_bytes": (_c_size, [_c_int] * 4),
+    "sputnik_hip_spmm_batched": (_c_int, [_c_int] * 5 + [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr,
+                                                        _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr,
+                                                        _c_size, _c_ptr]),
+    "sputnik_hip_sddmm": (_c_int, [_c_int] * 4 + [_c_ptr] * 7),
+    "sputnik_hip_sddmm_batched": (_c_int, [_c_int] * 5 + [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64,
+                                                         _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr]),
+    "sputnik_hip_sparse_softmax": (_c_int, [_c_int] * 3 + [_c_ptr] * 6),
+    "sputnik_hip_sparse_softmax_batched": (_c_int, [_c_int] * 4 + [_c_ptr, _c_i64, _c_ptr, _c_ptr,
+                                                                  _c_ptr, _c_ptr, _c_i64, _c_ptr]),
+    "sputnik_hip_csr_transpose_workspace_bytes": (_c_size, [_c_int] * 3),
+    "sputnik_hip_csr_transpose": (_c_int, [_c_int] * 4 + [_c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr,
+                                                         _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
+                                                         _c_size, _c_ptr]),
+}
+
+_bound = None
+
+
+def lib():
+    global _bound
+    if _bound is None:
+        L = kernel_lib()
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the library lacks the symbol
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _bound = L
+    return _bound
+
+
+def version():
+    return lib().sputnik_hip_version().decode()
+
+
+def _ptr(t):
+    return None if t is None else _c_ptr(t.data_ptr())
+
+
+def _stream(t):
+    return _c_ptr(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _check(status, what):
+    if status != 0:
+        raise RuntimeError(f"{what} failed with status {status}")
+
+
+def _require(t, dtype, name):
+    if not (t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+        raise ValueError(f"{name}: expected a contiguous {dtype} GPU tensor, got "
+                         f"{t.dtype} on {t.device}, contiguous={t.is_contiguous()}")
+
+
+def spmm_workspace_bytes(m, k, n, nonzeros):
+    return lib().sputnik_hip_spmm_workspace_bytes(m, k, n, nonzeros)
+
+
+def spmm(m, k, n, row_indices, values, row_offsets, column_indices, dense, out):
+    """sputnik_hip_spmm: one 2-D SpMM, arguments in sputnik::CudaSpmm order."""
+    nonzeros = column_indices.numel()
+    _check(lib().sputnik_hip_spmm(m, k, n, nonzeros, _ptr(row_indices), _ptr(values),
+                                  _ptr(row_offsets), _ptr(column_indices), _ptr(dense),
+                                  _ptr(out), _stream(out)), "sputnik_hip_spmm")
+    return out
+
+
+def spmm_batched(m, k, n, replicas, row_indices, values, values_stride, row_offsets,
+                 column_indices, dense, out, workspace=None):
+    nonzeros = column_indices.numel()
+    for t, d, nm in ((row_indices, torch.int32, "row_indices"), (values, torch.float32, "values"),
+                     (row_offsets, torch.int32, "row_offsets"),
+                     (column_indices, torch.int32, "column_indices"),
+                     (dense, torch.float32, "dense"), (out, torch.float32, "out")):
+        _require(t, d, nm)
+    ws_bytes = 0 if workspace is None else workspace.numel() * workspace.element_size()
+    _check(lib().sputnik_hip_spmm_batched(
+        m, k, n, nonzeros, replicas, _ptr(row_indices), _ptr(values), values_stride,
+        _ptr(row_offsets), _ptr(column_indices), _ptr(dense), k * n, _ptr(out), m * n,
+        _ptr(workspace), ws_bytes, _stream(out)), "sputnik_hip_spmm_batched")
+    return out
+
+
+def sddmm_batched(m, k, n, replicas, row_indices, row_offsets, column_indices, lhs, rhs, out):
+    nonzeros = column_indices.numel()
+    for t, d, nm in ((row_indices, torch.int32, "row_indices"),
+                     (row_offsets, torch.int32, "row_offsets"),
+                     (column_indices, torch.int32, "column_indices"),
+                     (lhs, torch.float32, "lhs"), (rhs, torch.float32, "rhs"),
+                     (out, torch.float32, "out")):
+        _require(t, d, nm)
+    _check(lib().sputnik_hip_sddmm_batched(
+        m, k, n, nonzeros, replicas, _ptr(row_indices), _ptr(row_offsets), _ptr(column_indices),
+        _ptr(lhs), m * k, _ptr(rhs), n * k, _ptr(out), nonzeros, _stream(out)),
+        "sputnik_hip_sddmm_batched")
+    return out
+
+
+def sparse_softmax_batched(m, replicas, values, row_indices, row_offsets, column_indices, out):
+    nonzeros = column_indices.numel()
+    for t, d, nm in ((values, torch.float32, "values"), (row_indices, torch.int32, "row_indices"),
+                     (row_offsets, torch.int32, "row_offsets"),
+                     (column_indices, torch.int32, "column_indices"),
+                     (out, torch.float32, "out")):
+        _require(t, d, nm)
+    _check(lib().sputnik_hip_sparse_softmax_batched(
+        m, -1, nonzeros, replicas, _ptr(values), nonzeros, _ptr(row_indices), _ptr(row_offsets),
+        _ptr(column_indices), _ptr(out), nonzeros, _stream(out)),
+        "sputnik_hip_sparse_softmax_batched")
+    return out
+
+
+def csr_transpose_workspace_bytes(m, n, nonzeros):
+    return lib().sputnik_hip_csr_transpose_workspace_bytes(m, n, nonzeros)
+
+
+def csr_transpose(m, n, replicas, values, row_offsets, column_indices, out_values,
+                  out_row_offsets, out_column_indices, out_permutation, workspace):
+    nonzeros = column_indices.numel()
+    for t, d, nm in ((values, torch.float32, "values"), (row_offsets, torch.int32, "row_offsets"),
+                     (column_indices, torch.int32, "column_indices"),
+                     (out_values, torch.float32, "out_values"),
+                     (out_row_offsets, torch.int32, "out_row_offsets"),
+                     (out_column_indices, torch.int32, "out_column_indices")):
+        _require(t, d, nm)
+    ws_bytes = 0 if workspace is None else workspace.numel() * workspace.element_size()
+    _check(lib().sputnik_hip_csr_transpose(
+        m, n, nonzeros, replicas, _ptr(values), nonzeros, _ptr(row_offsets), _ptr(column_indices),
+        _ptr(out_values), nonzeros, _ptr(out_row_offsets), _ptr(out_column_indices),
+        _ptr(out_permutation), _ptr(workspace), ws_bytes, _stream(out_values)),
+        "sputnik_hip_csr_transpose")
+    return out_values, out_row_offsets, out_column_indices

@@ -1,0 +1,75 @@
+// Shared host/device helpers for libsputnik_hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sputnik_hip.h"
+
+namespace sputnik_hip {
+
+// Largest gridDim.y / gridDim.z HIP accepts.
+constexpr int kMaxGridYZ = 65535;
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+inline bool aligned_to(const void* p, size_t bytes) {
+  return (reinterpret_cast<uintptr_t>(p) % bytes) == 0;
+}
+
+// Widest float vector (4, 2 or 1) that every row start of a row-major
+// [rows, width] operand with base `p` and replica stride `stride` supports.
+inline int vector_width(const void* p, int64_t width, int64_t stride) {
+  if (width % 4 == 0 && stride % 4 == 0 && aligned_to(p, 16)) return 4;
+  if (width % 2 == 0 && stride % 2 == 0 && aligned_to(p, 8)) return 2;
+  return 1;
+}
+
+inline int launch_status() { return static_cast<int>(hipGetLastError()); }
+
+template <int VEC>
+struct FloatVec;
+template <>
+struct FloatVec<1> {
+  using type = float;
+};
+template <>
+struct FloatVec<2> {
+  using type = float2;
+};
+template <>
+struct FloatVec<4> {
+  using type = float4;
+};
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(float (&dst)[VEC], const float* __restrict__ src) {
+  using V = typename FloatVec<VEC>::type;
+  const V v = *reinterpret_cast<const V*>(src);
+  if constexpr (VEC == 1) {
+    dst[0] = v;
+  } else if constexpr (VEC == 2) {
+    dst[0] = v.x;
+    dst[1] = v.y;
+  } else {
+    dst[0] = v.x;
+    dst[1] = v.y;
+    dst[2] = v.z;
+    dst[3] = v.w;
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* __restrict__ dst, const float (&src)[VEC]) {
+  using V = typename FloatVec<VEC>::type;
+  if constexpr (VEC == 1) {
+    *dst = src[0];
+  } else if constexpr (VEC == 2) {
+    *reinterpret_cast<V*>(dst) = make_float2(src[0], src[1]);
+  } else {
+    *reinterpret_cast<V*>(dst) = make_float4(src[0], src[1], src[2], src[3]);
+  }
+}
+
+}  // namespace sputnik_hip

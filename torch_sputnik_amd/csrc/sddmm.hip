@@ -1,0 +1,176 @@
+// SDDMM  out[p] = <lhs[i_p,:], rhs[j_p,:]>  for gfx950.
+//
+// Replaces sputnik::CudaSddmm as driven by src/sddmm_cuda.cu:45-54.
+//
+// One wave owns one output row (rows dealt in `row_indices` order).  The
+// wave is cut into groups of LPN lanes; a group takes LPN consecutive
+// nonzeros of the row at a time: lane t loads column index t (coalesced),
+// then for each of the LPN nonzeros the whole group reads the matching rhs
+// row with VEC-wide loads (one contiguous LPN*VEC*4-byte segment), multiplies
+// with the lhs row fragment it keeps in registers and reduces with DPP
+// (no LDS crossbar up to 16 lanes).  Lane t keeps result t, so the LPN
+// results leave as one coalesced store.  Long inner dimensions are walked in
+// panels of LPN*VEC*KSL elements; later panels add into the output.
+#include "common.h"
+#include "wave_utils.h"
+
+namespace sputnik_hip {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / kWave;
+
+template <int VEC, int LPN, int KSL>
+__global__ __launch_bounds__(kBlock) void sddmm_rowwave_kernel(
+    int m, int k, const int* __restrict__ row_indices, const int* __restrict__ row_offsets,
+    const int* __restrict__ column_indices, const float* __restrict__ lhs, int64_t lhs_stride,
+    const float* __restrict__ rhs, int64_t rhs_stride, float* __restrict__ out,
+    int64_t out_stride) {
+  constexpr int kGroups = kWave / LPN;
+  constexpr int kPanel = LPN * VEC * KSL;
+  const int wave = threadIdx.x / kWave;
+  const int lane = threadIdx.x % kWave;
+  const int g = lane / LPN;
+  const int l = lane % LPN;
+  const int slot = blockIdx.x * kWavesPerBlock + wave;
+  if (slot >= m) return;  // wave-uniform
+  const int replica = blockIdx.y;
+  lhs += replica * lhs_stride;
+  rhs += replica * rhs_stride;
+  out += replica * out_stride;
+
+  const int row = row_indices[slot];
+  const int p0 = row_offsets[row];
+  const int p1 = row_offsets[row + 1];
+  const int nblocks = (p1 - p0 + LPN - 1) / LPN;
+  const float* __restrict__ lhs_row = lhs + static_cast<int64_t>(row) * k;
+
+  for (int kp = 0; kp < k; kp += kPanel) {
+    // lhs fragment of this panel: slice s covers columns kp + (s*LPN + l)*VEC.
+    float a[KSL][VEC];
+#pragma unroll
+    for (int s = 0; s < KSL; ++s) {
+      const int c = kp + (s * LPN + l) * VEC;
+      if (c < k) {
+        load_vec<VEC>(a[s], lhs_row + c);
+      } else {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) a[s][v] = 0.f;
+      }
+    }
+
+    for (int b = g; b < nblocks; b += kGroups) {
+      const int pb = p0 + b * LPN;
+      const int q = pb + l;
+      const int j_mine = (q < p1) ? column_indices[q] : 0;
+      const int cnt = min(LPN, p1 - pb);
+      float result = 0.f;
+#pragma unroll 2
+      for (int t = 0; t < cnt; ++t) {
+        const int j = __shfl(j_mine, t, LPN);
+        const float* __restrict__ rhs_row = rhs + static_cast<int64_t>(j) * k;
+        float partial = 0.f;
+#pragma unroll
+        for (int s = 0; s < KSL; ++s) {
+          const int c = kp + (s * LPN + l) * VEC;
+          if (c < k) {
+            float bv[VEC];
+            load_vec<VEC>(bv, rhs_row + c);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) partial = fmaf(a[s][v], bv[v], partial);
+          }
+        }
+        const float total = group_sum<LPN>(partial);
+        if (l == t) result = total;
+      }
+      if (q < p1) {
+        if (kp == 0) {
+          out[q] = result;
+        } else {
+          out[q] += result;
+        }
+      }
+    }
+  }
+}
+
+template <int VEC, int LPN, int KSL>
+int launch(int m, int k, int replicas, const int* row_indices, const int* row_offsets,
+           const int* column_indices, const float* lhs, int64_t lhs_stride, const float* rhs,
+           int64_t rhs_stride, float* out, int64_t out_stride, hipStream_t stream) {
+  const int gx = ceil_div(m, kWavesPerBlock);
+  for (int r0 = 0; r0 < replicas; r0 += kMaxGridYZ) {
+    const int ry = min(replicas - r0, kMaxGridYZ);
+    hipLaunchKernelGGL((sddmm_rowwave_kernel<VEC, LPN, KSL>), dim3(gx, ry), dim3(kBlock), 0,
+                       stream, m, k, row_indices, row_offsets, column_indices,
+                       lhs + r0 * lhs_stride, lhs_stride, rhs + r0 * rhs_stride, rhs_stride,
+                       out + r0 * out_stride, out_stride);
+    const int st = launch_status();
+    if (st != 0) return st;
+  }
+  return 0;
+}
+
+template <int VEC>
+int launch_vec(int m, int k, int replicas, const int* row_indices, const int* row_offsets,
+               const int* column_indices, const float* lhs, int64_t lhs_stride, const float* rhs,
+               int64_t rhs_stride, float* out, int64_t out_stride, hipStream_t stream) {
+  const int lanes = ceil_div(k, VEC);
+#define SPUTNIK_HIP_SD(LPN, KSL)                                                              \
+  return launch<VEC, LPN, KSL>(m, k, replicas, row_indices, row_offsets, column_indices, lhs, \
+                               lhs_stride, rhs, rhs_stride, out, out_stride, stream)
+  if (lanes <= 4) SPUTNIK_HIP_SD(4, 1);
+  if (lanes <= 8) SPUTNIK_HIP_SD(8, 1);
+  if (lanes <= 16) SPUTNIK_HIP_SD(16, 1);
+  if (lanes <= 32) SPUTNIK_HIP_SD(32, 1);
+  if (lanes <= 64) SPUTNIK_HIP_SD(64, 1);
+  if (lanes <= 128) SPUTNIK_HIP_SD(64, 2);
+  SPUTNIK_HIP_SD(64, 4);
+#undef SPUTNIK_HIP_SD
+}
+
+}  // namespace
+}  // namespace sputnik_hip
+
+using namespace sputnik_hip;
+
+extern "C" {
+
+int sputnik_hip_sddmm_batched(int m, int k, int n, int nonzeros, int replicas,
+                              const int* row_indices, const int* row_offsets,
+                              const int* column_indices, const float* lhs, int64_t lhs_stride,
+                              const float* rhs, int64_t rhs_stride, float* out,
+                              int64_t out_stride, sputnik_hip_stream_t stream) {
+  if (m < 0 || k < 0 || n < 0 || nonzeros < 0 || replicas < 0) return SPUTNIK_HIP_INVALID_ARGUMENT;
+  if (m == 0 || nonzeros == 0 || replicas == 0) return 0;
+  if (k == 0) {
+    for (int r = 0; r < replicas; ++r) {
+      const hipError_t e =
+          hipMemsetAsync(out + r * out_stride, 0, sizeof(float) * static_cast<size_t>(nonzeros), stream);
+      if (e != hipSuccess) return static_cast<int>(e);
+    }
+    return 0;
+  }
+  int vec = vector_width(lhs, k, lhs_stride);
+  vec = min(vec, vector_width(rhs, k, rhs_stride));
+  switch (vec) {
+    case 4:
+      return launch_vec<4>(m, k, replicas, row_indices, row_offsets, column_indices, lhs,
+                           lhs_stride, rhs, rhs_stride, out, out_stride, stream);
+    case 2:
+      return launch_vec<2>(m, k, replicas, row_indices, row_offsets, column_indices, lhs,
+                           lhs_stride, rhs, rhs_stride, out, out_stride, stream);
+    default:
+      return launch_vec<1>(m, k, replicas, row_indices, row_offsets, column_indices, lhs,
+                           lhs_stride, rhs, rhs_stride, out, out_stride, stream);
+  }
+}
+
+int sputnik_hip_sddmm(int m, int k, int n, int nonzeros, const int* row_indices,
+                      const int* row_offsets, const int* column_indices, const float* lhs,
+                      const float* rhs, float* out, sputnik_hip_stream_t stream) {
+  return sputnik_hip_sddmm_batched(m, k, n, nonzeros, 1, row_indices, row_offsets,
+                                   column_indices, lhs, 0, rhs, 0, out, 0, stream);
+}
+
+}  // extern "C"

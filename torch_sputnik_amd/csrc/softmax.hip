@@ -1,0 +1,138 @@
+// Sparse softmax over the stored entries of each CSR row, for gfx950.
+//
+// Replaces sputnik::SparseSoftmax as driven by src/softmax_cuda.cu:35-43.
+//
+// A group of LPR lanes owns one row (rows dealt in `row_indices` order).
+// Rows of up to LPR*kRegs entries are read from HBM exactly once into
+// registers (coalesced, lane-strided), reduced with DPP (max, then sum of
+// exp) and written once: 8 bytes of HBM traffic per entry, the algorithmic
+// minimum.  Longer rows fall back to three streaming passes whose re-reads
+// are served by L2.
+#include "common.h"
+#include "wave_utils.h"
+
+namespace sputnik_hip {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kRegs = 8;
+
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void sparse_softmax_kernel(
+    int m, const float* __restrict__ values, int64_t values_stride,
+    const int* __restrict__ row_indices, const int* __restrict__ row_offsets,
+    float* __restrict__ out, int64_t out_stride) {
+  constexpr int kRowsPerBlock = kBlock / LPR;
+  const int sub = threadIdx.x / LPR;
+  const int l = threadIdx.x % LPR;
+  const int slot = blockIdx.x * kRowsPerBlock + sub;
+  const int replica = blockIdx.y;
+  values += replica * values_stride;
+  out += replica * out_stride;
+
+  // Lanes of out-of-range slots keep an empty row so that every lane of the
+  // wave reaches the (convergent) cross-lane reductions below.
+  const int row = (slot < m) ? row_indices[slot] : 0;
+  const int p0 = (slot < m) ? row_offsets[row] : 0;
+  const int p1 = (slot < m) ? row_offsets[row + 1] : 0;
+  const int len = p1 - p0;
+
+  // Longest row handled by this wave decides the path (wave-uniform branch).
+  int wave_max_len = len;
+  if constexpr (LPR < kWave) {
+#pragma unroll
+    for (int off = LPR; off < kWave; off <<= 1)
+      wave_max_len = max(wave_max_len, __shfl_xor(wave_max_len, off, kWave));
+  }
+  wave_max_len = __builtin_amdgcn_readfirstlane(wave_max_len);
+
+  if (wave_max_len <= LPR * kRegs) {
+    float x[kRegs];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < kRegs; ++i) {
+      const int q = p0 + i * LPR + l;
+      x[i] = (q < p1) ? values[q] : -INFINITY;
+      mx = fmaxf(mx, x[i]);
+    }
+    mx = group_max<LPR>(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < kRegs; ++i) {
+      const int q = p0 + i * LPR + l;
+      x[i] = (q < p1) ? expf(x[i] - mx) : 0.f;
+      sum += x[i];
+    }
+    sum = group_sum<LPR>(sum);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int i = 0; i < kRegs; ++i) {
+      const int q = p0 + i * LPR + l;
+      if (q < p1) out[q] = x[i] * inv;
+    }
+  } else {
+    float mx = -INFINITY;
+    for (int q = p0 + l; q < p1; q += LPR) mx = fmaxf(mx, values[q]);
+    mx = group_max<LPR>(mx);
+    float sum = 0.f;
+    for (int q = p0 + l; q < p1; q += LPR) sum += expf(values[q] - mx);
+    sum = group_sum<LPR>(sum);
+    const float inv = 1.f / sum;
+    for (int q = p0 + l; q < p1; q += LPR) out[q] = expf(values[q] - mx) * inv;
+  }
+}
+
+template <int LPR>
+int launch(int m, int replicas, const float* values, int64_t values_stride,
+           const int* row_indices, const int* row_offsets, float* out, int64_t out_stride,
+           hipStream_t stream) {
+  const int gx = ceil_div(m, kBlock / LPR);
+  for (int r0 = 0; r0 < replicas; r0 += kMaxGridYZ) {
+    const int ry = min(replicas - r0, kMaxGridYZ);
+    hipLaunchKernelGGL((sparse_softmax_kernel<LPR>), dim3(gx, ry), dim3(kBlock), 0, stream, m,
+                       values + r0 * values_stride, values_stride, row_indices, row_offsets,
+                       out + r0 * out_stride, out_stride);
+    const int st = launch_status();
+    if (st != 0) return st;
+  }
+  return 0;
+}
+
+}  // namespace
+}  // namespace sputnik_hip
+
+using namespace sputnik_hip;
+
+extern "C" {
+
+int sputnik_hip_sparse_softmax_batched(int m, int n, int nonzeros, int replicas,
+                                       const float* values, int64_t values_stride,
+                                       const int* row_indices, const int* row_offsets,
+                                       const int* column_indices, float* out,
+                                       int64_t out_stride, sputnik_hip_stream_t stream) {
+  (void)n;
+  (void)column_indices;
+  if (m < 0 || nonzeros < 0 || replicas < 0) return SPUTNIK_HIP_INVALID_ARGUMENT;
+  if (m == 0 || nonzeros == 0 || replicas == 0) return 0;
+  // Mean row length picks the lanes-per-row split (host-side, no sync: m and
+  // nonzeros are arguments).
+  const int mean_len = nonzeros / m;
+  if (mean_len <= 16 * 4)
+    return launch<16>(m, replicas, values, values_stride, row_indices, row_offsets, out,
+                      out_stride, stream);
+  if (mean_len <= 32 * 4)
+    return launch<32>(m, replicas, values, values_stride, row_indices, row_offsets, out,
+                      out_stride, stream);
+  return launch<64>(m, replicas, values, values_stride, row_indices, row_offsets, out, out_stride,
+                    stream);
+}
+
+int sputnik_hip_sparse_softmax(int m, int n, int nonzeros, const float* values,
+                               const int* row_indices, const int* row_offsets,
+                               const int* column_indices, float* out,
+                               sputnik_hip_stream_t stream) {
+  return sputnik_hip_sparse_softmax_batched(m, n, nonzeros, 1, values, 0, row_indices,
+                                            row_offsets, column_indices, out, 0, stream);
+}
+
+}  // extern "C"

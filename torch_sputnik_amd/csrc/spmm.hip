@@ -1,0 +1,187 @@
+// SpMM  C[m,n] = A_csr[m,k] * B[k,n]  for gfx950 -- dispatcher + the
+// workspace-free "row gather" kernel.
+//
+// Replaces sputnik::CudaSpmm as driven by the reference's host wrappers
+// (src/spmm_cuda.cu:48-57, src/left_replicated_spmm.cu:32-41).
+//
+// Row-gather kernel: 1-D row splitting.  A group of LPR lanes owns one output
+// row strip of LPR*VEC columns; groups take rows in `row_indices` order so a
+// 256-thread workgroup holds rows of similar length.  The group streams its
+// row's (column, value) pairs with coalesced loads, broadcasts one pair at a
+// time (v_readlane for full-wave groups) and gathers the matching row of B
+// with one VEC-wide load per lane: every B read is a contiguous
+// LPR*VEC*4-byte segment.  It needs no workspace and places no requirement
+// on the order of column indices inside a row, so it is also the fallback of
+// the LDS-tiled kernel in spmm_tiled.hip.
+#include "common.h"
+#include "wave_utils.h"
+
+namespace sputnik_hip {
+
+int spmm_tiled_launch(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
+                      const float* values, int64_t values_stride, const int* row_offsets,
+                      const int* column_indices, const float* dense, int64_t dense_stride,
+                      float* out, int64_t out_stride, void* workspace, size_t workspace_bytes,
+                      hipStream_t stream, bool* handled);
+size_t spmm_tiled_workspace_bytes(int m, int k, int n, int nonzeros);
+
+namespace {
+
+constexpr int kBlock = 256;
+
+template <int VEC, int LPR>
+__global__ __launch_bounds__(kBlock) void spmm_rowgather_kernel(
+    int m, int n, const int* __restrict__ row_indices, const float* __restrict__ values,
+    int64_t values_stride, const int* __restrict__ row_offsets,
+    const int* __restrict__ column_indices, const float* __restrict__ dense,
+    int64_t dense_stride, float* __restrict__ out, int64_t out_stride,
+    const int* __restrict__ skip_flag) {
+  // The tiled kernel handled this call (see spmm_tiled.hip): nothing to do.
+  if (skip_flag != nullptr && *skip_flag != 0) return;
+
+  constexpr int kRowsPerBlock = kBlock / LPR;
+  const int sub = threadIdx.x / LPR;
+  const int l = threadIdx.x % LPR;
+  const int slot = blockIdx.x * kRowsPerBlock + sub;
+  const int replica = blockIdx.z;
+  const int c0 = (blockIdx.y * LPR + l) * VEC;
+
+  values += replica * values_stride;
+  dense += replica * dense_stride;
+  out += replica * out_stride;
+
+  const bool row_ok = slot < m;
+  const bool col_ok = c0 < n;  // n % VEC == 0, so the whole vector is in range
+  const int row = row_ok ? row_indices[slot] : 0;
+  int p = row_ok ? row_offsets[row] : 0;
+  const int p_end = row_ok ? row_offsets[row + 1] : 0;
+
+  const float* __restrict__ b_col = dense + (col_ok ? c0 : 0);
+  float acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+
+  for (; p < p_end; p += LPR) {
+    const int q = p + l;
+    int j = 0;
+    float a = 0.f;
+    if (q < p_end) {
+      j = column_indices[q];
+      a = values[q];
+    }
+    const int cnt = min(LPR, p_end - p);
+#pragma unroll 4
+    for (int t = 0; t < cnt; ++t) {
+      const int jj = group_broadcast<LPR>(j, t);
+      const float aa = group_broadcast<LPR>(a, t);
+      float b[VEC];
+      load_vec<VEC>(b, b_col + static_cast<int64_t>(jj) * n);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v] = fmaf(aa, b[v], acc[v]);
+    }
+  }
+
+  if (row_ok && col_ok) store_vec<VEC>(out + static_cast<int64_t>(row) * n + c0, acc);
+}
+
+template <int VEC, int LPR>
+int launch_rowgather(int m, int n, int replicas, const int* row_indices, const float* values,
+                     int64_t values_stride, const int* row_offsets, const int* column_indices,
+                     const float* dense, int64_t dense_stride, float* out, int64_t out_stride,
+                     const int* skip_flag, hipStream_t stream) {
+  constexpr int kRowsPerBlock = kBlock / LPR;
+  const int gx = ceil_div(m, kRowsPerBlock);
+  const int gy = ceil_div(n, LPR * VEC);
+  if (gy > kMaxGridYZ) return SPUTNIK_HIP_INVALID_ARGUMENT;
+  for (int r0 = 0; r0 < replicas; r0 += kMaxGridYZ) {
+    const int rz = min(replicas - r0, kMaxGridYZ);
+    hipLaunchKernelGGL((spmm_rowgather_kernel<VEC, LPR>), dim3(gx, gy, rz), dim3(kBlock), 0,
+                       stream, m, n, row_indices, values + r0 * values_stride, values_stride,
+                       row_offsets, column_indices, dense + r0 * dense_stride, dense_stride,
+                       out + r0 * out_stride, out_stride, skip_flag);
+    const int st = launch_status();
+    if (st != 0) return st;
+  }
+  return 0;
+}
+
+template <int VEC>
+int launch_rowgather_vec(int m, int n, int replicas, const int* row_indices, const float* values,
+                         int64_t values_stride, const int* row_offsets,
+                         const int* column_indices, const float* dense, int64_t dense_stride,
+                         float* out, int64_t out_stride, const int* skip_flag,
+                         hipStream_t stream) {
+  const int lanes_needed = ceil_div(n, VEC);
+#define SPUTNIK_HIP_RG(LPR)                                                                  \
+  return launch_rowgather<VEC, LPR>(m, n, replicas, row_indices, values, values_stride,      \
+                                    row_offsets, column_indices, dense, dense_stride, out,   \
+                                    out_stride, skip_flag, stream)
+  if (lanes_needed <= 8) SPUTNIK_HIP_RG(8);
+  if (lanes_needed <= 16) SPUTNIK_HIP_RG(16);
+  if (lanes_needed <= 32) SPUTNIK_HIP_RG(32);
+  SPUTNIK_HIP_RG(64);
+#undef SPUTNIK_HIP_RG
+}
+
+}  // namespace
+
+int spmm_rowgather_launch(int m, int n, int replicas, const int* row_indices,
+                          const float* values, int64_t values_stride, const int* row_offsets,
+                          const int* column_indices, const float* dense, int64_t dense_stride,
+                          float* out, int64_t out_stride, const int* skip_flag,
+                          hipStream_t stream) {
+  int vec = vector_width(dense, n, dense_stride);
+  vec = min(vec, vector_width(out, n, out_stride));
+  switch (vec) {
+    case 4:
+      return launch_rowgather_vec<4>(m, n, replicas, row_indices, values, values_stride,
+                                     row_offsets, column_indices, dense, dense_stride, out,
+                                     out_stride, skip_flag, stream);
+    case 2:
+      return launch_rowgather_vec<2>(m, n, replicas, row_indices, values, values_stride,
+                                     row_offsets, column_indices, dense, dense_stride, out,
+                                     out_stride, skip_flag, stream);
+    default:
+      return launch_rowgather_vec<1>(m, n, replicas, row_indices, values, values_stride,
+                                     row_offsets, column_indices, dense, dense_stride, out,
+                                     out_stride, skip_flag, stream);
+  }
+}
+
+}  // namespace sputnik_hip
+
+using namespace sputnik_hip;
+
+extern "C" {
+
+size_t sputnik_hip_spmm_workspace_bytes(int m, int k, int n, int nonzeros) {
+  return spmm_tiled_workspace_bytes(m, k, n, nonzeros);
+}
+
+int sputnik_hip_spmm_batched(int m, int k, int n, int nonzeros, int replicas,
+                             const int* row_indices, const float* values,
+                             int64_t values_stride, const int* row_offsets,
+                             const int* column_indices, const float* dense,
+                             int64_t dense_stride, float* out, int64_t out_stride,
+                             void* workspace, size_t workspace_bytes,
+                             sputnik_hip_stream_t stream) {
+  if (m < 0 || k < 0 || n < 0 || nonzeros < 0 || replicas < 0) return SPUTNIK_HIP_INVALID_ARGUMENT;
+  if (m == 0 || n == 0 || replicas == 0) return 0;
+  bool handled = false;
+  const int st = spmm_tiled_launch(m, k, n, nonzeros, replicas, row_indices, values, values_stride,
+                                   row_offsets, column_indices, dense, dense_stride, out,
+                                   out_stride, workspace, workspace_bytes, stream, &handled);
+  if (st != 0 || handled) return st;
+  return spmm_rowgather_launch(m, n, replicas, row_indices, values, values_stride, row_offsets,
+                               column_indices, dense, dense_stride, out, out_stride, nullptr,
+                               stream);
+}
+
+int sputnik_hip_spmm(int m, int k, int n, int nonzeros, const int* row_indices,
+                     const float* values, const int* row_offsets, const int* column_indices,
+                     const float* dense, float* out, sputnik_hip_stream_t stream) {
+  return sputnik_hip_spmm_batched(m, k, n, nonzeros, 1, row_indices, values, 0, row_offsets,
+                                  column_indices, dense, 0, out, 0, nullptr, 0, stream);
+}
+
+}  // extern "C"

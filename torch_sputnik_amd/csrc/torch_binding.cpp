@@ -1,0 +1,298 @@
+// Host side of the drop-in: the reference's five operators
+// (src/sputnik.cpp:36-42) registered with TORCH_LIBRARY as
+// torch.ops.torch_sputnik.{spmm,left_spmm,sddmm,sparse_softmax,csr_transpose}
+// for HIP tensors only, on top of the C ABI in include/sputnik_hip.h.
+//
+// Each op mirrors one host wrapper of the reference:
+//   spmm            src/spmm_cuda.cu:9-60
+//   left_spmm       src/left_replicated_spmm.cu:8-44
+//   sddmm           src/sddmm_cuda.cu:7-57
+//   sparse_softmax  src/softmax_cuda.cu:7-46
+//   csr_transpose   src/transpose_cuda.cu:45-102
+// Same argument order and meaning; differences, all on purpose:
+//   - the reference's shape `assert`s (no-ops under NDEBUG) are TORCH_CHECKs,
+//     so a bad call raises RuntimeError instead of being undefined;
+//   - the replica loop is one launch, outputs are at::empty (every element is
+//     written by the kernels) instead of torch::zeros;
+//   - integer tensors may be int64 (the reference's own SparseLinear backward
+//     hands an int64 row_indices to left_spmm, modules/sparse_linear.py:57-65)
+//     and are cast to int32 here; non-contiguous inputs are made contiguous;
+//   - a device guard on the inputs' device (the reference has none).
+// There is no CPU kernel: CPU tensors raise from the dispatcher.  Autograd is
+// not registered here; the Python autograd.Functions stay the callers.
+#include <ATen/ATen.h>
+#include <c10/core/DeviceGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/library.h>
+
+#include <vector>
+
+#include "../../include/sputnik_hip.h"
+
+namespace {
+
+using at::Tensor;
+
+void check_status(int status, const char* what) {
+  TORCH_CHECK(status == 0, "torch_sputnik::", what, ": kernel library returned error ", status,
+              status == SPUTNIK_HIP_INVALID_ARGUMENT ? " (invalid argument)" : " (hipError_t)");
+}
+
+sputnik_hip_stream_t current_stream(const Tensor& t) {
+  return reinterpret_cast<sputnik_hip_stream_t>(
+      c10::hip::getCurrentHIPStream(t.device().index()).stream());
+}
+
+Tensor as_index(const Tensor& t, const char* name, const Tensor& like) {
+  TORCH_CHECK(t.scalar_type() == at::kInt || t.scalar_type() == at::kLong, name,
+              " must be an int32 (or int64) tensor, got ", t.scalar_type());
+  TORCH_CHECK(t.device() == like.device(), name, " must be on ", like.device(), ", got ",
+              t.device());
+  TORCH_CHECK(t.dim() == 1, name, " should have 1 dimension, got ", t.dim());
+  return t.to(at::kInt).contiguous();
+}
+
+Tensor as_float(const Tensor& t, const char* name) {
+  TORCH_CHECK(t.is_cuda(), name, " must be a GPU (HIP) tensor, got ", t.device());
+  TORCH_CHECK(t.scalar_type() == at::kFloat, name, " must be float32, got ", t.scalar_type());
+  return t.contiguous();
+}
+
+struct Topology {
+  Tensor row_indices, row_offsets, column_indices;
+  int nonzeros;
+};
+
+Topology check_topology(int64_t m, const Tensor& row_indices, const Tensor& row_offsets,
+                        const Tensor& column_indices, const Tensor& like) {
+  Topology t;
+  t.row_indices = as_index(row_indices, "row_indices", like);
+  t.row_offsets = as_index(row_offsets, "row_offsets", like);
+  t.column_indices = as_index(column_indices, "column_indices", like);
+  TORCH_CHECK(t.row_indices.size(0) + 1 == t.row_offsets.size(0),
+              "row_offsets should have one more entry than row_indices, got ",
+              t.row_offsets.size(0), " and ", t.row_indices.size(0));
+  TORCH_CHECK(t.row_indices.size(0) == m, "number of row_indices (", t.row_indices.size(0),
+              ") and m (", m, ") must match");
+  TORCH_CHECK(t.column_indices.size(0) < (int64_t{1} << 31), "too many nonzeros");
+  t.nonzeros = static_cast<int>(t.column_indices.size(0));
+  return t;
+}
+
+int to_int(int64_t v, const char* name) {
+  TORCH_CHECK(v >= 0 && v < (int64_t{1} << 31), name, " out of range: ", v);
+  return static_cast<int>(v);
+}
+
+// Shared by spmm (values [nnz] / [R,nnz]) and left_spmm (values [nnz], shared).
+Tensor spmm_impl(int64_t m64, int64_t k64, const Tensor& values_in, const Tensor& row_indices,
+                 const Tensor& row_offsets, const Tensor& column_indices, const Tensor& dense_in,
+                 bool left, const char* what) {
+  const int m = to_int(m64, "m"), k = to_int(k64, "k");
+  const Tensor values = as_float(values_in, "values");
+  const Tensor dense = as_float(dense_in, "dense");
+  TORCH_CHECK(dense.device() == values.device(), "values and dense must be on one device");
+  TORCH_CHECK(dense.dim() == 2 || dense.dim() == 3, "dense should have 2 or 3 dimensions, got ",
+              dense.dim());
+  if (left) {
+    TORCH_CHECK(values.dim() == 1, "left_spmm: values should have 1 dimension, got ",
+                values.dim());
+  } else {
+    TORCH_CHECK(values.dim() == 1 || values.dim() == 2,
+                "values should have 1 or 2 dimensions, got ", values.dim());
+    TORCH_CHECK(values.dim() == dense.dim() - 1,
+                "values and dense must be replicated the same: values.dim()=", values.dim(),
+                ", dense.dim()=", dense.dim());
+  }
+  const c10::DeviceGuard guard(values.device());
+  const Topology topo = check_topology(m, row_indices, row_offsets, column_indices, values);
+
+  const int dim_offset = static_cast<int>(dense.dim()) - 2;
+  const int replicas = dim_offset == 1 ? to_int(dense.size(0), "replicas") : 1;
+  const int n = to_int(dense.size(dim_offset + 1), "n");
+  TORCH_CHECK(values.size(-1) == topo.nonzeros, "number of values (", values.size(-1),
+              ") must equal the number of column_indices (", topo.nonzeros, ")");
+  TORCH_CHECK(dense.size(dim_offset) == k, "inner matrix dimensions must match: dense has ",
+              dense.size(dim_offset), " rows, k = ", k);
+  if (!left && values.dim() == 2) {
+    TORCH_CHECK(values.size(0) == replicas, "first dim of values (", values.size(0),
+                ") and dense (", replicas, ") must match");
+  }
+
+  const auto options = values.options();
+  Tensor out = (replicas == 1 && !left) ? at::empty({m, n}, options)
+                                        : at::empty({replicas, m, n}, options);
+  const int64_t values_stride = (left || values.dim() == 1) ? 0 : topo.nonzeros;
+  const size_t ws_bytes = sputnik_hip_spmm_workspace_bytes(m, k, n, topo.nonzeros);
+  Tensor workspace;
+  if (ws_bytes > 0)
+    workspace = at::empty({static_cast<int64_t>(ws_bytes)}, options.dtype(at::kByte));
+
+  check_status(sputnik_hip_spmm_batched(
+                   m, k, n, topo.nonzeros, replicas, topo.row_indices.data_ptr<int>(),
+                   values.data_ptr<float>(), values_stride, topo.row_offsets.data_ptr<int>(),
+                   topo.column_indices.data_ptr<int>(), dense.data_ptr<float>(),
+                   static_cast<int64_t>(k) * n, out.data_ptr<float>(),
+                   static_cast<int64_t>(m) * n, ws_bytes ? workspace.data_ptr() : nullptr,
+                   ws_bytes, current_stream(values)),
+               what);
+  return out;
+}
+
+Tensor spmm(int64_t m, int64_t k, const Tensor& values, const Tensor& row_indices,
+            const Tensor& row_offsets, const Tensor& column_indices, const Tensor& dense) {
+  return spmm_impl(m, k, values, row_indices, row_offsets, column_indices, dense, false, "spmm");
+}
+
+Tensor left_spmm(int64_t m, int64_t k, const Tensor& values, const Tensor& row_indices,
+                 const Tensor& row_offsets, const Tensor& column_indices, const Tensor& dense) {
+  return spmm_impl(m, k, values, row_indices, row_offsets, column_indices, dense, true,
+                   "left_spmm");
+}
+
+Tensor sddmm(int64_t m64, int64_t n64, const Tensor& row_indices, const Tensor& row_offsets,
+             const Tensor& column_indices, const Tensor& lhs_in, const Tensor& rhs_in) {
+  const int m = to_int(m64, "m"), n = to_int(n64, "n");
+  const Tensor lhs = as_float(lhs_in, "lhs_matrix");
+  const Tensor rhs = as_float(rhs_in, "rhs_matrix");
+  TORCH_CHECK(lhs.device() == rhs.device(), "lhs_matrix and rhs_matrix must be on one device");
+  TORCH_CHECK(lhs.dim() == 2 || lhs.dim() == 3, "expected 2-dim or 3-dim lhs_matrix, got ",
+              lhs.dim());
+  TORCH_CHECK(rhs.dim() == lhs.dim(), "rhs_matrix and lhs_matrix must match number of dims");
+  TORCH_CHECK(lhs.size(-1) == rhs.size(-1), "last dim of input matrices must match: ",
+              lhs.size(-1), " vs ", rhs.size(-1));
+  const c10::DeviceGuard guard(lhs.device());
+  const Topology topo = check_topology(m, row_indices, row_offsets, column_indices, lhs);
+
+  const int dim_offset = static_cast<int>(lhs.dim()) - 2;
+  const int replicas = dim_offset == 1 ? to_int(lhs.size(0), "replicas") : 1;
+  const int k = to_int(lhs.size(dim_offset + 1), "k");
+  TORCH_CHECK(lhs.size(dim_offset) == m, "first dim of lhs_matrix (", lhs.size(dim_offset),
+              ") must match output rows m = ", m);
+  TORCH_CHECK(rhs.size(dim_offset) == n, "first dim of rhs_matrix (", rhs.size(dim_offset),
+              ") must match output cols n = ", n);
+  TORCH_CHECK(replicas == 1 || rhs.size(0) == replicas,
+              "first dim of lhs_matrix and rhs_matrix must match");
+
+  // 1-D whenever there is a single replica, as src/sddmm_cuda.cu:43 does.
+  Tensor out = replicas == 1 ? at::empty({topo.nonzeros}, lhs.options())
+                             : at::empty({replicas, topo.nonzeros}, lhs.options());
+  check_status(sputnik_hip_sddmm_batched(
+                   m, k, n, topo.nonzeros, replicas, topo.row_indices.data_ptr<int>(),
+                   topo.row_offsets.data_ptr<int>(), topo.column_indices.data_ptr<int>(),
+                   lhs.data_ptr<float>(), static_cast<int64_t>(m) * k, rhs.data_ptr<float>(),
+                   static_cast<int64_t>(n) * k, out.data_ptr<float>(), topo.nonzeros,
+                   current_stream(lhs)),
+               "sddmm");
+  return out;
+}
+
+Tensor sparse_softmax(const Tensor& values_in, const Tensor& row_indices,
+                      const Tensor& row_offsets, const Tensor& column_indices) {
+  const Tensor values = as_float(values_in, "values");
+  TORCH_CHECK(values.dim() == 1 || values.dim() == 2,
+              "values should have 1 or 2 dimensions, got ", values.dim());
+  const c10::DeviceGuard guard(values.device());
+  const int m = to_int(row_indices.size(0), "m");
+  const Topology topo = check_topology(m, row_indices, row_offsets, column_indices, values);
+  TORCH_CHECK(values.size(-1) == topo.nonzeros, "number of values (", values.size(-1),
+              ") must equal the number of column_indices (", topo.nonzeros, ")");
+  const int replicas = values.dim() == 2 ? to_int(values.size(0), "replicas") : 1;
+
+  Tensor out = at::empty_like(values);
+  check_status(sputnik_hip_sparse_softmax_batched(
+                   m, /*n=*/-1, topo.nonzeros, replicas, values.data_ptr<float>(), topo.nonzeros,
+                   topo.row_indices.data_ptr<int>(), topo.row_offsets.data_ptr<int>(),
+                   topo.column_indices.data_ptr<int>(), out.data_ptr<float>(), topo.nonzeros,
+                   current_stream(values)),
+               "sparse_softmax");
+  return out;
+}
+
+// Returns {values_t, row_offsets_t, column_indices_t} (+ {permutation} when
+// asked).  values may be [nnz] (reference contract) or [R,nnz] (extension).
+std::vector<Tensor> csr_transpose_impl(int64_t m64, int64_t n64, const Tensor& values_in,
+                                       const Tensor& row_offsets_in,
+                                       const Tensor& column_indices_in, bool want_permutation) {
+  const int m = to_int(m64, "m"), n = to_int(n64, "n");
+  const Tensor values = as_float(values_in, "values");
+  TORCH_CHECK(values.dim() == 1 || values.dim() == 2,
+              "values should have 1 (or, as an extension, 2) dimensions, got ", values.dim());
+  const c10::DeviceGuard guard(values.device());
+  const Tensor row_offsets = as_index(row_offsets_in, "row_offsets", values);
+  const Tensor column_indices = as_index(column_indices_in, "column_indices", values);
+  TORCH_CHECK(values.size(-1) == column_indices.size(0),
+              "expected same number of values and indices, got ", values.size(-1), " and ",
+              column_indices.size(0));
+  TORCH_CHECK(row_offsets.size(0) == m + 1, "expected m+1 row offsets, got ",
+              row_offsets.size(0), " for m = ", m);
+  const int nonzeros = to_int(column_indices.size(0), "nonzeros");
+  const int replicas = values.dim() == 2 ? to_int(values.size(0), "replicas") : 1;
+
+  const auto index_options = values.options().dtype(at::kInt);
+  Tensor out_values = at::empty_like(values);
+  Tensor out_row_offsets = at::empty({n + 1}, index_options);
+  Tensor out_column_indices = at::empty({nonzeros}, index_options);
+  Tensor permutation;
+  if (want_permutation) permutation = at::empty({nonzeros}, index_options);
+
+  const size_t ws_bytes = sputnik_hip_csr_transpose_workspace_bytes(m, n, nonzeros);
+  Tensor workspace =
+      at::empty({static_cast<int64_t>(ws_bytes)}, values.options().dtype(at::kByte));
+  check_status(
+      sputnik_hip_csr_transpose(m, n, nonzeros, replicas, values.data_ptr<float>(), nonzeros,
+                                row_offsets.data_ptr<int>(), column_indices.data_ptr<int>(),
+                                out_values.data_ptr<float>(), nonzeros,
+                                out_row_offsets.data_ptr<int>(),
+                                out_column_indices.data_ptr<int>(),
+                                want_permutation ? permutation.data_ptr<int>() : nullptr,
+                                workspace.data_ptr(), ws_bytes, current_stream(values)),
+      "csr_transpose");
+  std::vector<Tensor> out{out_values, out_row_offsets, out_column_indices};
+  if (want_permutation) out.push_back(permutation);
+  return out;
+}
+
+std::vector<Tensor> csr_transpose(int64_t m, int64_t n, const Tensor& values,
+                                  const Tensor& row_offsets, const Tensor& column_indices) {
+  return csr_transpose_impl(m, n, values, row_offsets, column_indices, false);
+}
+
+std::vector<Tensor> csr_transpose_with_permutation(int64_t m, int64_t n, const Tensor& values,
+                                                   const Tensor& row_offsets,
+                                                   const Tensor& column_indices) {
+  return csr_transpose_impl(m, n, values, row_offsets, column_indices, true);
+}
+
+}  // namespace
+
+TORCH_LIBRARY(torch_sputnik, m) {
+  m.def(
+      "spmm(int m, int k, Tensor values, Tensor row_indices, Tensor row_offsets, "
+      "Tensor column_indices, Tensor dense_matrix) -> Tensor");
+  m.def(
+      "left_spmm(int m, int k, Tensor values, Tensor row_indices, Tensor row_offsets, "
+      "Tensor column_indices, Tensor dense_matrix) -> Tensor");
+  m.def(
+      "sddmm(int m, int n, Tensor row_indices, Tensor row_offsets, Tensor column_indices, "
+      "Tensor lhs_matrix, Tensor rhs_matrix) -> Tensor");
+  m.def(
+      "sparse_softmax(Tensor values, Tensor row_indices, Tensor row_offsets, "
+      "Tensor column_indices) -> Tensor");
+  m.def(
+      "csr_transpose(int m, int n, Tensor values, Tensor row_offsets, Tensor column_indices) "
+      "-> Tensor[]");
+  m.def(
+      "csr_transpose_with_permutation(int m, int n, Tensor values, Tensor row_offsets, "
+      "Tensor column_indices) -> Tensor[]");
+}
+
+// "CUDA" is the dispatch key of HIP tensors in a ROCm build of PyTorch.
+TORCH_LIBRARY_IMPL(torch_sputnik, CUDA, m) {
+  m.impl("spmm", &spmm);
+  m.impl("left_spmm", &left_spmm);
+  m.impl("sddmm", &sddmm);
+  m.impl("sparse_softmax", &sparse_softmax);
+  m.impl("csr_transpose", &csr_transpose);
+  m.impl("csr_transpose_with_permutation", &csr_transpose_with_permutation);
+}
