@@ -93,10 +93,11 @@ def test_spmm_batched_capi(capi, dev, replicas, shared):
     assert rel_err(out.cpu().numpy(), want) < TOL
 
 
-def test_spmm_unsorted_columns(capi, dev):
+@pytest.mark.parametrize("m,k,n", [(96, 200, 128), (256, 512, 256), (300, 1000, 512)])
+def test_spmm_unsorted_columns(capi, dev, m, k, n):
     """Column indices need not ascend inside a row (the CUDA library does not
-    require it either)."""
-    m, k, n = 96, 200, 128
+    require it either).  The larger shapes qualify for the LDS-tiled kernel,
+    whose pre-pass must notice the order and hand over to the row-gather kernel."""
     _, vals, ri, ro, ci = make_csr(m, k, 0.8, seed=23)
     rng = np.random.default_rng(24)
     vals, ci = vals.copy(), ci.copy()

@@ -1,0 +1,245 @@
+// Instruction-cost microbenchmarks for gfx950 (developer tool, not shipped).
+// Each kernel runs ITERS iterations of a 16-instruction block on every wave of
+// a 256-workgroup grid and reports shader cycles per instruction per SIMD for
+// 1, 2 and 4 waves per SIMD.
+//
+//   hipcc --offload-arch=gfx950 -O2 tools/ubench.hip -o /tmp/ubench && /tmp/ubench
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x)                                                        \
+  do {                                                                  \
+    hipError_t e_ = (x);                                                \
+    if (e_ != hipSuccess) {                                             \
+      printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      exit(1);                                                          \
+    }                                                                   \
+  } while (0)
+
+#define REP16(X) X X X X X X X X X X X X X X X X
+
+#define LOOP_BEGIN "s_mov_b32 s20, %1\n1:\n"
+#define LOOP_END "s_sub_u32 s20, s20, 1\ns_cmp_lg_u32 s20, 0\ns_cbranch_scc1 1b\n"
+
+#define DEF_KERNEL(NAME, BODY, CLOBBERS...)                                          \
+  __global__ void NAME(unsigned long long* out, int iters) {                          \
+    __shared__ float lds[16384];                                                      \
+    for (int i = threadIdx.x; i < 16384; i += blockDim.x) lds[i] = i;                 \
+    __syncthreads();                                                                  \
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();                             \
+    unsigned int base = (threadIdx.x % 64) * 16;                                      \
+    asm volatile("v_mov_b32 v40, %0\n"                                                \
+                 "s_mov_b32 s30, 0x3f800000\ns_mov_b32 s31, 0x3f800000\n"             \
+                 "s_mov_b32 s38, 5\nv_mov_b32 v5, 0\nv_mov_b32 v6, 0\n"                                                 \
+                 LOOP_BEGIN BODY BODY BODY BODY LOOP_END                                             \
+                 "s_waitcnt lgkmcnt(0)\n"                                             \
+                 : : "v"(base), "s"(iters)                                            \
+                 : "memory", "s20", "s30", "s31", "s38", "s33", "s34", "s35", "s36", "v40", "v5", "v6", CLOBBERS); \
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();                             \
+    if (threadIdx.x % 64 == 0) out[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0; \
+    if (lds[threadIdx.x] < -1.f) out[0] = 0;                                          \
+  }
+
+#define V16 "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25"
+#define V32 V16, "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v42", "v43"
+
+// a) v_fma_f32, all-VGPR operands, 16 independent accumulators
+DEF_KERNEL(k_fma_vgpr,
+           "v_fma_f32 v10, v2, v3, v10\nv_fma_f32 v11, v2, v3, v11\nv_fma_f32 v12, v2, v3, v12\nv_fma_f32 v13, v2, v3, v13\n"
+           "v_fma_f32 v14, v2, v3, v14\nv_fma_f32 v15, v2, v3, v15\nv_fma_f32 v16, v2, v3, v16\nv_fma_f32 v17, v2, v3, v17\n"
+           "v_fma_f32 v18, v2, v3, v18\nv_fma_f32 v19, v2, v3, v19\nv_fma_f32 v20, v2, v3, v20\nv_fma_f32 v21, v2, v3, v21\n"
+           "v_fma_f32 v22, v2, v3, v22\nv_fma_f32 v23, v2, v3, v23\nv_fma_f32 v24, v2, v3, v24\nv_fma_f32 v25, v2, v3, v25\n",
+           V16)
+
+// b) v_fma_f32 with an SGPR multiplier
+DEF_KERNEL(k_fma_sgpr,
+           "v_fma_f32 v10, s30, v3, v10\nv_fma_f32 v11, s30, v3, v11\nv_fma_f32 v12, s30, v3, v12\nv_fma_f32 v13, s30, v3, v13\n"
+           "v_fma_f32 v14, s30, v3, v14\nv_fma_f32 v15, s30, v3, v15\nv_fma_f32 v16, s30, v3, v16\nv_fma_f32 v17, s30, v3, v17\n"
+           "v_fma_f32 v18, s30, v3, v18\nv_fma_f32 v19, s30, v3, v19\nv_fma_f32 v20, s30, v3, v20\nv_fma_f32 v21, s30, v3, v21\n"
+           "v_fma_f32 v22, s30, v3, v22\nv_fma_f32 v23, s30, v3, v23\nv_fma_f32 v24, s30, v3, v24\nv_fma_f32 v25, s30, v3, v25\n",
+           V16)
+
+// c) v_pk_fma_f32, all-VGPR
+DEF_KERNEL(k_pkfma_vgpr,
+           "v_pk_fma_f32 v[10:11], v[2:3], v[4:5], v[10:11]\nv_pk_fma_f32 v[12:13], v[2:3], v[4:5], v[12:13]\n"
+           "v_pk_fma_f32 v[14:15], v[2:3], v[4:5], v[14:15]\nv_pk_fma_f32 v[16:17], v[2:3], v[4:5], v[16:17]\n"
+           "v_pk_fma_f32 v[18:19], v[2:3], v[4:5], v[18:19]\nv_pk_fma_f32 v[20:21], v[2:3], v[4:5], v[20:21]\n"
+           "v_pk_fma_f32 v[22:23], v[2:3], v[4:5], v[22:23]\nv_pk_fma_f32 v[24:25], v[2:3], v[4:5], v[24:25]\n"
+           "v_pk_fma_f32 v[26:27], v[2:3], v[4:5], v[26:27]\nv_pk_fma_f32 v[28:29], v[2:3], v[4:5], v[28:29]\n"
+           "v_pk_fma_f32 v[30:31], v[2:3], v[4:5], v[30:31]\nv_pk_fma_f32 v[32:33], v[2:3], v[4:5], v[32:33]\n"
+           "v_pk_fma_f32 v[34:35], v[2:3], v[4:5], v[34:35]\nv_pk_fma_f32 v[36:37], v[2:3], v[4:5], v[36:37]\n"
+           "v_pk_fma_f32 v[38:39], v[2:3], v[4:5], v[38:39]\nv_pk_fma_f32 v[42:43], v[2:3], v[4:5], v[42:43]\n",
+           V32)
+
+// d) v_pk_fma_f32 with an SGPR pair broadcast (the form hipcc emits for a*b+c with scalar a)
+DEF_KERNEL(k_pkfma_sgpr,
+           "v_pk_fma_f32 v[10:11], s[30:31], v[4:5], v[10:11] op_sel_hi:[0,1,1]\nv_pk_fma_f32 v[12:13], s[30:31], v[4:5], v[12:13] op_sel_hi:[0,1,1]\n"
+           "v_pk_fma_f32 v[14:15], s[30:31], v[4:5], v[14:15] op_sel_hi:[0,1,1]\nv_pk_fma_f32 v[16:17], s[30:31], v[4:5], v[16:17] op_sel_hi:[0,1,1]\n"
+           "v_pk_fma_f32 v[18:19], s[30:31], v[4:5], v[18:19] op_sel_hi:[0,1,1]\nv_pk_fma_f32 v[20:21], s[30:31], v[4:5], v[20:21] op_sel_hi:[0,1,1]\n"
+           "v_pk_fma_f32 v[22:23], s[30:31], v[4:5], v[22:23] op_sel_hi:[0,1,1]\nv_pk_fma_f32 v[24:25], s[30:31], v[4:5], v[24:25] op_sel_hi:[0,1,1]\n"
+           "v_pk_fma_f32 v[26:27], s[30:31], v[4:5], v[26:27] op_sel_hi:[0,1,1]\nv_pk_fma_f32 v[28:29], s[30:31], v[4:5], v[28:29] op_sel_hi:[0,1,1]\n"
+           "v_pk_fma_f32 v[30:31], s[30:31], v[4:5], v[30:31] op_sel_hi:[0,1,1]\nv_pk_fma_f32 v[32:33], s[30:31], v[4:5], v[32:33] op_sel_hi:[0,1,1]\n"
+           "v_pk_fma_f32 v[34:35], s[30:31], v[4:5], v[34:35] op_sel_hi:[0,1,1]\nv_pk_fma_f32 v[36:37], s[30:31], v[4:5], v[36:37] op_sel_hi:[0,1,1]\n"
+           "v_pk_fma_f32 v[38:39], s[30:31], v[4:5], v[38:39] op_sel_hi:[0,1,1]\nv_pk_fma_f32 v[42:43], s[30:31], v[4:5], v[42:43] op_sel_hi:[0,1,1]\n",
+           V32)
+
+// e) v_readlane_b32 with an SGPR lane select
+DEF_KERNEL(k_readlane,
+           REP16("v_readlane_b32 s33, v3, s38\n"), "v10")
+
+// f) v_lshl_add_u32 v, s, 10, v
+DEF_KERNEL(k_lshl_add,
+           "v_lshl_add_u32 v10, s38, 10, v40\nv_lshl_add_u32 v11, s38, 10, v40\nv_lshl_add_u32 v12, s38, 10, v40\nv_lshl_add_u32 v13, s38, 10, v40\n"
+           "v_lshl_add_u32 v14, s38, 10, v40\nv_lshl_add_u32 v15, s38, 10, v40\nv_lshl_add_u32 v16, s38, 10, v40\nv_lshl_add_u32 v17, s38, 10, v40\n"
+           "v_lshl_add_u32 v18, s38, 10, v40\nv_lshl_add_u32 v19, s38, 10, v40\nv_lshl_add_u32 v20, s38, 10, v40\nv_lshl_add_u32 v21, s38, 10, v40\n"
+           "v_lshl_add_u32 v22, s38, 10, v40\nv_lshl_add_u32 v23, s38, 10, v40\nv_lshl_add_u32 v24, s38, 10, v40\nv_lshl_add_u32 v25, s38, 10, v40\n",
+           V16)
+
+// g) ds_read_b128 stream: 8 reads (32 VGPRs) then wait; block = 16 "instructions" = 2 x this
+DEF_KERNEL(k_ds_read_b128,
+           "ds_read_b128 v[10:13], v40\nds_read_b128 v[14:17], v40 offset:1024\nds_read_b128 v[18:21], v40 offset:2048\nds_read_b128 v[22:25], v40 offset:3072\n"
+           "ds_read_b128 v[26:29], v40 offset:4096\nds_read_b128 v[30:33], v40 offset:5120\nds_read_b128 v[34:37], v40 offset:6144\nds_read_b128 v[10:13], v40 offset:7168\n"
+           "ds_read_b128 v[14:17], v40 offset:8192\nds_read_b128 v[18:21], v40 offset:9216\nds_read_b128 v[22:25], v40 offset:10240\nds_read_b128 v[26:29], v40 offset:11264\n"
+           "ds_read_b128 v[30:33], v40 offset:12288\nds_read_b128 v[34:37], v40 offset:13312\nds_read_b128 v[10:13], v40 offset:14336\nds_read_b128 v[14:17], v40 offset:15360\n"
+           "s_waitcnt lgkmcnt(0)\n",
+           V32)
+
+// h) the SpMM inner step as compiled: per nonzero 2 readlane, s_sub, lshl_add, ds_read_b128,
+//    2 pk_fma (4 nonzeros per block -> counts as 16 "instructions" = 4 nonzeros x 4 FMA-lanes)
+#define NZ(J, A, ADDR, B0, B1, B2, B3)                                     \
+  "v_readlane_b32 " J ", v3, s38\n"                                          \
+  "v_readlane_b32 " A ", v4, s38\n"                                          \
+  "s_and_b32 " J ", " J ", 15\n"                                             \
+  "v_lshl_add_u32 " ADDR ", " J ", 10, v40\n"                                \
+  "ds_read_b128 v[" B0 ":" B3 "], " ADDR "\n"
+DEF_KERNEL(k_spmm_step,
+           NZ("s33", "s34", "v44", "10", "11", "12", "13")
+           NZ("s35", "s36", "v45", "14", "15", "16", "17")
+           "s_waitcnt lgkmcnt(1)\n"
+           "v_pk_fma_f32 v[26:27], s[34:35], v[10:11], v[26:27] op_sel_hi:[0,1,1]\n"
+           "v_pk_fma_f32 v[28:29], s[34:35], v[12:13], v[28:29] op_sel_hi:[0,1,1]\n"
+           "s_waitcnt lgkmcnt(0)\n"
+           "v_pk_fma_f32 v[26:27], s[36:37], v[14:15], v[26:27] op_sel_hi:[0,1,1]\n"
+           "v_pk_fma_f32 v[28:29], s[36:37], v[16:17], v[28:29] op_sel_hi:[0,1,1]\n"
+           NZ("s33", "s34", "v44", "18", "19", "20", "21")
+           NZ("s35", "s36", "v45", "22", "23", "24", "25")
+           "s_waitcnt lgkmcnt(1)\n"
+           "v_pk_fma_f32 v[30:31], s[34:35], v[18:19], v[30:31] op_sel_hi:[0,1,1]\n"
+           "v_pk_fma_f32 v[32:33], s[34:35], v[20:21], v[32:33] op_sel_hi:[0,1,1]\n"
+           "s_waitcnt lgkmcnt(0)\n"
+           "v_pk_fma_f32 v[30:31], s[36:37], v[22:23], v[30:31] op_sel_hi:[0,1,1]\n"
+           "v_pk_fma_f32 v[32:33], s[36:37], v[24:25], v[32:33] op_sel_hi:[0,1,1]\n",
+           V32, "v44", "v45", "s37")
+
+// i) same step with plain v_fma_f32 (4 per nonzero) instead of v_pk_fma_f32
+DEF_KERNEL(k_spmm_step_fma,
+           NZ("s33", "s34", "v44", "10", "11", "12", "13")
+           NZ("s35", "s36", "v45", "14", "15", "16", "17")
+           "s_waitcnt lgkmcnt(1)\n"
+           "v_fma_f32 v26, s34, v10, v26\nv_fma_f32 v27, s34, v11, v27\nv_fma_f32 v28, s34, v12, v28\nv_fma_f32 v29, s34, v13, v29\n"
+           "s_waitcnt lgkmcnt(0)\n"
+           "v_fma_f32 v26, s36, v14, v26\nv_fma_f32 v27, s36, v15, v27\nv_fma_f32 v28, s36, v16, v28\nv_fma_f32 v29, s36, v17, v29\n"
+           NZ("s33", "s34", "v44", "18", "19", "20", "21")
+           NZ("s35", "s36", "v45", "22", "23", "24", "25")
+           "s_waitcnt lgkmcnt(1)\n"
+           "v_fma_f32 v30, s34, v18, v30\nv_fma_f32 v31, s34, v19, v31\nv_fma_f32 v32, s34, v20, v32\nv_fma_f32 v33, s34, v21, v33\n"
+           "s_waitcnt lgkmcnt(0)\n"
+           "v_fma_f32 v30, s36, v22, v30\nv_fma_f32 v31, s36, v23, v31\nv_fma_f32 v32, s36, v24, v32\nv_fma_f32 v33, s36, v25, v33\n",
+           V32, "v44", "v45", "s37")
+
+// j) v_fmac_f32 with a DPP row_newbcast source (value broadcast inside each 16-lane row)
+DEF_KERNEL(k_fmac_dpp,
+           "v_fmac_f32_dpp v10, v3, v4 row_newbcast:0 row_mask:0xf bank_mask:0xf\nv_fmac_f32_dpp v11, v3, v4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+           "v_fmac_f32_dpp v12, v3, v4 row_newbcast:2 row_mask:0xf bank_mask:0xf\nv_fmac_f32_dpp v13, v3, v4 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+           "v_fmac_f32_dpp v14, v3, v4 row_newbcast:4 row_mask:0xf bank_mask:0xf\nv_fmac_f32_dpp v15, v3, v4 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+           "v_fmac_f32_dpp v16, v3, v4 row_newbcast:6 row_mask:0xf bank_mask:0xf\nv_fmac_f32_dpp v17, v3, v4 row_newbcast:7 row_mask:0xf bank_mask:0xf\n"
+           "v_fmac_f32_dpp v18, v3, v4 row_newbcast:8 row_mask:0xf bank_mask:0xf\nv_fmac_f32_dpp v19, v3, v4 row_newbcast:9 row_mask:0xf bank_mask:0xf\n"
+           "v_fmac_f32_dpp v20, v3, v4 row_newbcast:10 row_mask:0xf bank_mask:0xf\nv_fmac_f32_dpp v21, v3, v4 row_newbcast:11 row_mask:0xf bank_mask:0xf\n"
+           "v_fmac_f32_dpp v22, v3, v4 row_newbcast:12 row_mask:0xf bank_mask:0xf\nv_fmac_f32_dpp v23, v3, v4 row_newbcast:13 row_mask:0xf bank_mask:0xf\n"
+           "v_fmac_f32_dpp v24, v3, v4 row_newbcast:14 row_mask:0xf bank_mask:0xf\nv_fmac_f32_dpp v25, v3, v4 row_newbcast:15 row_mask:0xf bank_mask:0xf\n",
+           V16)
+
+// k) plain v_fmac_f32 (VOP2, 4-byte encoding)
+DEF_KERNEL(k_fmac_vop2,
+           "v_fmac_f32 v10, v3, v4\nv_fmac_f32 v11, v3, v4\nv_fmac_f32 v12, v3, v4\nv_fmac_f32 v13, v3, v4\n"
+           "v_fmac_f32 v14, v3, v4\nv_fmac_f32 v15, v3, v4\nv_fmac_f32 v16, v3, v4\nv_fmac_f32 v17, v3, v4\n"
+           "v_fmac_f32 v18, v3, v4\nv_fmac_f32 v19, v3, v4\nv_fmac_f32 v20, v3, v4\nv_fmac_f32 v21, v3, v4\n"
+           "v_fmac_f32 v22, v3, v4\nv_fmac_f32 v23, v3, v4\nv_fmac_f32 v24, v3, v4\nv_fmac_f32 v25, v3, v4\n",
+           V16)
+
+// l) SpMM step, DPP form: per nonzero v_add_u32_dpp (address) + ds_read_b128 + 4 v_fmac_f32_dpp
+#define NZD(U, ADDR, B0, B3) \
+  "v_and_b32_dpp " ADDR ", v5, v6 row_newbcast:" U " row_mask:0xf bank_mask:0xf\n" \
+  "v_add_u32 " ADDR ", " ADDR ", v40\n" \
+  "ds_read_b128 v[" B0 ":" B3 "], " ADDR "\n"
+#define FMD(U, ACC, B) "v_fmac_f32_dpp " ACC ", v4, " B " row_newbcast:" U " row_mask:0xf bank_mask:0xf\n"
+DEF_KERNEL(k_spmm_step_dpp,
+           NZD("0", "v44", "10", "13") NZD("1", "v45", "14", "17") NZD("2", "v46", "18", "21") NZD("3", "v47", "22", "25")
+           "s_waitcnt lgkmcnt(3)\n" FMD("0", "v26", "v10") FMD("0", "v27", "v11") FMD("0", "v28", "v12") FMD("0", "v29", "v13")
+           "s_waitcnt lgkmcnt(2)\n" FMD("1", "v26", "v14") FMD("1", "v27", "v15") FMD("1", "v28", "v16") FMD("1", "v29", "v17")
+           "s_waitcnt lgkmcnt(1)\n" FMD("2", "v26", "v18") FMD("2", "v27", "v19") FMD("2", "v28", "v20") FMD("2", "v29", "v21")
+           "s_waitcnt lgkmcnt(0)\n" FMD("3", "v26", "v22") FMD("3", "v27", "v23") FMD("3", "v28", "v24") FMD("3", "v29", "v25"),
+           V32, "v44", "v45", "v46", "v47")
+
+// m) same, address formed by ONE v_add_u32_dpp (lane offset + broadcast row offset)
+#define NZE(U, ADDR, B0, B3) \
+  "v_add_u32_dpp " ADDR ", v5, v40 row_newbcast:" U " row_mask:0xf bank_mask:0xf\n" \
+  "ds_read_b128 v[" B0 ":" B3 "], " ADDR "\n"
+DEF_KERNEL(k_spmm_step_dpp1,
+           NZE("0", "v44", "10", "13") NZE("1", "v45", "14", "17") NZE("2", "v46", "18", "21") NZE("3", "v47", "22", "25")
+           "s_waitcnt lgkmcnt(3)\n" FMD("0", "v26", "v10") FMD("0", "v27", "v11") FMD("0", "v28", "v12") FMD("0", "v29", "v13")
+           "s_waitcnt lgkmcnt(2)\n" FMD("1", "v26", "v14") FMD("1", "v27", "v15") FMD("1", "v28", "v16") FMD("1", "v29", "v17")
+           "s_waitcnt lgkmcnt(1)\n" FMD("2", "v26", "v18") FMD("2", "v27", "v19") FMD("2", "v28", "v20") FMD("2", "v29", "v21")
+           "s_waitcnt lgkmcnt(0)\n" FMD("3", "v26", "v22") FMD("3", "v27", "v23") FMD("3", "v28", "v24") FMD("3", "v29", "v25"),
+           V32, "v44", "v45", "v46", "v47")
+
+typedef void (*kern_t)(unsigned long long*, int);
+
+static void run(const char* name, kern_t k, int per_block_insts) {
+  const int iters = 5000;
+  unsigned long long* d;
+  CHECK(hipMalloc(&d, sizeof(unsigned long long) * 256 * 16));
+  for (int waves : {4, 8, 16}) {
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k, dim3(256), dim3(waves * 64), 0, 0, d, 1000);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k, dim3(256), dim3(waves * 64), 0, 0, d, iters);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipDeviceSynchronize());
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<unsigned long long> h(256 * waves);
+    CHECK(hipMemcpy(h.data(), d, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+    double avg = 0;
+    for (auto v : h) avg += double(v);
+    avg /= h.size();
+    // s_memtime ticks at 100 MHz on this part; report both tick- and wall-derived figures
+    const double insts_per_simd = double(iters) * 4 * per_block_insts * (waves / 4.0);
+    printf("%-18s waves/SIMD=%d  wall=%.3f ms  ns/inst/SIMD=%.3f  memtime_ticks/wave=%.0f\n", name,
+           waves / 4, ms, ms * 1e6 / insts_per_simd, avg);
+  }
+  CHECK(hipFree(d));
+}
+
+int main() {
+  run("fma_vgpr", k_fma_vgpr, 16);
+  run("fma_sgpr", k_fma_sgpr, 16);
+  run("pkfma_vgpr", k_pkfma_vgpr, 16);
+  run("pkfma_sgpr", k_pkfma_sgpr, 16);
+  run("readlane", k_readlane, 16);
+  run("lshl_add", k_lshl_add, 16);
+  run("ds_read_b128", k_ds_read_b128, 16);
+  run("spmm_step(4nz)", k_spmm_step, 4);
+  run("spmm_step_fma(4nz)", k_spmm_step_fma, 4);
+  run("fmac_dpp", k_fmac_dpp, 16);
+  run("fmac_vop2", k_fmac_vop2, 16);
+  run("spmm_step_dpp(4nz)", k_spmm_step_dpp, 4);
+  run("spmm_step_dpp1(4nz)", k_spmm_step_dpp1, 4);
+  return 0;
+}
