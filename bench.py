@@ -1,0 +1,308 @@
+#!/usr/bin/env python3
+"""Headline benchmark: SpMM effective GFLOP/s (+ algorithmic HBM GB/s) at
+M=N=K=4096, fp32, on MI355X -- BASELINE.json's metric.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path (the C-ABI entry sputnik_hip_spmm_batched:
+topology pre-pass + LDS-tiled SpMM kernel) over one batch of synthetic input
+that is already resident in HBM.
+
+  N = 1  workload "C2": 2-D SpMM 4096^3, density 0.1 (BASELINE.json configs[1];
+         the other densities of the sweep are reported in `sweep`).
+  N > 1  workload "C4": batched SpMM, 16 replicas of the same problem per GPU
+         (128 replicas at 8 GPUs), replica dimension sharded over the ranks,
+         one launch per rank per step.  Per-GPU work is fixed -> "weak".
+         The shards are independent: no collective is on the data path.
+         `--allgather` adds the RCCL all-gather of C (north star's optional
+         exchange step) inside the timed step.
+
+value = 2*nnz*N*replicas_total / time  (effective GFLOP/s of the whole job).
+Rank 0 prints ONE JSON line.  Extra keys: `roofline` (HBM roof, algorithmic
+bytes / dominant kernel time), `roofline_valu` (the roof that actually binds
+fp32 SpMM at this size), `cpu_baseline`, `sweep`, `other_ops`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+VALU_PEAK_TFLOPS = 157.3     # fp32 vector FMA peak (spec); MFMA is excluded by the north star
+M = K = N = 4096
+DENSITIES = [0.5, 0.25, 0.2, 0.15, 0.1, 0.05]
+HEADLINE_DENSITY = 0.1
+REPLICAS_PER_GPU_MULTI = 16
+
+
+def spmm_bytes(nnz, m, k, n, replicas=1):
+    """Algorithmic bytes: values + column ids, B once, C once per
+    replica; offsets + row_indices once."""
+    return replicas * (8.0 * nnz + 4.0 * k * n + 4.0 * m * n) + 4.0 * (2 * m + 1)
+
+
+def event_time_ms(fn, iters):
+    start = torch.cuda.Event(enable_timing=True)
+    end = torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    start.record()
+    for _ in range(iters):
+        fn()
+    end.record()
+    torch.cuda.synchronize()
+    return start.elapsed_time(end) / iters
+
+
+class SpmmProblem:
+    def __init__(self, dev, density, replicas, seed):
+        from torch_sputnik_amd import capi
+        from torch_sputnik_amd.synthetic import random_csr, uniform
+        self.capi = capi
+        self.replicas = replicas
+        self.ri, self.ro, self.ci, self.nnz = random_csr(M, K, density, dev, seed=seed)
+        vshape = (replicas, self.nnz) if replicas > 1 else (self.nnz,)
+        bshape = (replicas, K, N) if replicas > 1 else (K, N)
+        self.values = uniform(vshape, dev, seed + 1)
+        self.dense = uniform(bshape, dev, seed + 2)
+        self.out = torch.empty((replicas, M, N) if replicas > 1 else (M, N), device=dev)
+        self.ws = torch.empty(capi.spmm_workspace_bytes(M, K, N, self.nnz) + 16,
+                              dtype=torch.uint8, device=dev)
+        self.flops = 2.0 * self.nnz * N * replicas
+        self.bytes = spmm_bytes(self.nnz, M, K, N, replicas)
+
+    def step(self):
+        """The whole hot path: pre-pass + kernel (what the torch op does per call)."""
+        self.capi.spmm_batched(M, K, N, self.replicas, self.ri, self.values,
+                               self.nnz if self.replicas > 1 else 0, self.ro, self.ci,
+                               self.dense, self.out, self.ws)
+
+    def kernel_only(self):
+        """Dominant kernel alone, on an already planned workspace."""
+        self.capi.spmm_batched_planned(M, K, N, self.replicas, self.ri, self.values,
+                                       self.nnz if self.replicas > 1 else 0, self.ro, self.ci,
+                                       self.dense, self.out, self.ws)
+
+
+def cpu_baseline(problem):
+    """Oracle (C restatement, CSR, OpenMP) timed on the host cores; bounded sample."""
+    import numpy as np
+    from oracle import c_oracle
+    if not c_oracle.available():
+        return None
+    vals = problem.values.reshape(-1)[:problem.nnz].cpu().numpy()
+    ro, ci = problem.ro.cpu().numpy(), problem.ci.cpu().numpy()
+    dense = problem.dense.reshape(-1, K, N)[0].cpu().numpy()
+    threads = c_oracle.num_threads()
+    c_oracle.spmm(M, K, vals, ro, ci, dense, f32_accumulate=True)  # warm-up
+    times = []
+    t_all = time.perf_counter()
+    while len(times) < 5 and time.perf_counter() - t_all < 25.0:
+        t0 = time.perf_counter()
+        c_oracle.spmm(M, K, vals, ro, ci, dense, f32_accumulate=True)
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    base = {"value": 2.0 * problem.nnz * N / med / 1e9, "unit": "GFLOP/s", "cores": threads,
+            "kind": "port",
+            "sample": f"{len(times)} runs of the full C2 d={HEADLINE_DENSITY} SpMM "
+                      f"(oracle/csrc/sputnik_oracle.c oracle_spmm_f32, OpenMP over rows), median",
+            "ms": med * 1e3}
+    # The reference's own "CPU path" is the dense matmul its tests compare with
+    # (tests/test_spmm.py:9-10): time that too, same A (zeros included) and B.
+    try:
+        torch.set_num_threads(threads)
+        a = torch.zeros(M, K)
+        rows = torch.repeat_interleave(torch.arange(M), torch.from_numpy(np.diff(ro)).long())
+        a[rows, torch.from_numpy(ci).long()] = torch.from_numpy(vals)
+        b = torch.from_numpy(dense)
+        torch.matmul(a, b)
+        dt = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            torch.matmul(a, b)
+            dt.append(time.perf_counter() - t0)
+        dmed = sorted(dt)[1]
+        base["dense_torch_matmul"] = {"ms": dmed * 1e3, "effective_gflops": 2.0 * problem.nnz * N / dmed / 1e9,
+                                      "dense_gflops": 2.0 * M * K * N / dmed / 1e9, "threads": threads}
+    except Exception as e:  # noqa: BLE001 - baseline is best effort
+        base["dense_torch_matmul"] = {"error": str(e)}
+    return base
+
+
+def other_ops(dev):
+    """Kernel times of the rest of the path at BASELINE.json configs 3 and 5."""
+    from torch_sputnik_amd import capi
+    from torch_sputnik_amd.synthetic import random_csr, uniform
+    res = {}
+    s, d, reps = 1024, 64, 64  # config 3: seq 1024, 8 heads x batch 8, head_dim 64
+    ri, ro, ci, nnz = random_csr(s, s, 0.1, dev, seed=7)
+    q, kk, v = (uniform((reps, s, d), dev, 11 + i) for i in range(3))
+    scores = torch.empty(reps, nnz, device=dev)
+    probs = torch.empty_like(scores)
+    ctx = torch.empty(reps, s, d, device=dev)
+    t = event_time_ms(lambda: capi.sddmm_batched(s, d, s, reps, ri, ro, ci, q, kk, scores), 20)
+    by = reps * (8.0 * s * d + 4.0 * nnz) + 4.0 * nnz + 4.0 * (2 * s + 1)
+    res["sddmm_c3"] = {"ms": t, "gflops": 2.0 * nnz * d * reps / t / 1e6, "alg_gbs": by / t / 1e6}
+    t = event_time_ms(lambda: capi.sparse_softmax_batched(s, reps, scores, ri, ro, ci, probs), 20)
+    by = reps * 8.0 * nnz + 4.0 * (2 * s + 1)
+    res["softmax_c3"] = {"ms": t, "alg_gbs": by / t / 1e6, "hbm_frac": by / t / 1e6 / HBM_PEAK_GBS}
+    t = event_time_ms(lambda: capi.spmm_batched(s, s, d, reps, ri, probs, nnz, ro, ci, v, ctx, None), 20)
+    by = reps * (4.0 * nnz + 8.0 * s * d) + 4.0 * nnz + 4.0 * (2 * s + 1)
+    res["spmm_c3"] = {"ms": t, "gflops": 2.0 * nnz * d * reps / t / 1e6, "alg_gbs": by / t / 1e6}
+    m = n = 2048  # config 5: transpose of a 2048^2, density 0.2 weight
+    ri, ro, ci, nnz = random_csr(m, n, 0.2, dev, seed=9)
+    vals = uniform((nnz,), dev, 10)
+    ov, oro = torch.empty_like(vals), torch.empty(n + 1, dtype=torch.int32, device=dev)
+    oci = torch.empty(nnz, dtype=torch.int32, device=dev)
+    ws = torch.empty(capi.csr_transpose_workspace_bytes(m, n, nnz), dtype=torch.uint8, device=dev)
+    t = event_time_ms(lambda: capi.csr_transpose(m, n, 1, vals, ro, ci, ov, oro, oci, None, ws), 20)
+    by = 16.0 * nnz + 4.0 * (m + n + 2)
+    res["csr_transpose_c5"] = {"ms": t, "alg_gbs": by / t / 1e6, "hbm_frac": by / t / 1e6 / HBM_PEAK_GBS}
+    return res
+
+
+def load_pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3
+    PMC passes (profiles/*.json, collected as MI355X_MICROARCH.md prescribes);
+    None when no such file exists for this build."""
+    path = os.path.join(REPO, "profiles", "spmm_c2_d010_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get("traffic_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--allgather", action="store_true",
+                    help="N>1: all-gather C over RCCL inside the timed step")
+    ap.add_argument("--replicas-per-gpu", type=int, default=0,
+                    help="override (default 1 at --gpus 1, 16 otherwise)")
+    ap.add_argument("--no-extras", action="store_true", help="skip sweep / cpu baseline / other ops")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    n_gpus = world if distributed else 1
+    if args.gpus != n_gpus and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {n_gpus}", file=sys.stderr)
+
+    replicas = args.replicas_per_gpu or (1 if n_gpus == 1 else REPLICAS_PER_GPU_MULTI)
+    problem = SpmmProblem(dev, HEADLINE_DENSITY, replicas, seed=1234 + 1000 * DENSITIES.index(HEADLINE_DENSITY) + rank)
+
+    gathered = None
+    if distributed and args.allgather:
+        gathered = torch.empty((world,) + tuple(problem.out.reshape(replicas, M, N).shape), device=dev)
+
+    def step():
+        problem.step()
+        if gathered is not None:
+            dist.all_gather_into_tensor(gathered, problem.out.reshape(replicas, M, N))
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    total_flops = problem.flops * n_gpus
+    value = total_flops / (ms_per_step * 1e-3) / 1e9
+
+    result = None
+    if rank == 0:
+        # Dominant kernel alone (HIP events on the launch stream = torch's current stream).
+        problem.step()
+        kernel_ms = event_time_ms(problem.kernel_only, max(10, args.steps))
+        achieved_gbs = problem.bytes / (kernel_ms * 1e-3) / 1e9
+        result = {
+            "metric": "SpMM effective GFLOP/s (2*nnz*N/t), M=N=K=4096 fp32, density 0.1",
+            "value": value, "unit": "GFLOP/s", "n_gpus": n_gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": ("C2: 2-D SpMM M=N=K=4096 density 0.1 (nnz=%d), 1 replica" % problem.nnz)
+                if n_gpus == 1 else
+                ("C4: batched SpMM M=N=K=4096 density 0.1, %d replicas per GPU, %d total, replica-sharded"
+                 % (replicas, replicas * n_gpus)),
+                "replicas_per_gpu": replicas, "nnz": problem.nnz,
+                "step": "sputnik_hip_spmm_batched (pre-pass + kernel) via the C ABI",
+                "collective": "all_gather(C) over RCCL" if gathered is not None else "none (independent shards)",
+                "inputs": "uniform-random sparsity (tests/connectors.py distribution), U[0,1) values, resident in HBM",
+            },
+            "algorithmic_gbs": problem.bytes * n_gpus / (ms_per_step * 1e-3) / 1e9,
+            "roofline": {
+                "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": load_pmc_traffic(),
+                "kernel": "spmm_tiled_kernel", "kernel_ms": kernel_ms,
+                "algorithmic_bytes_per_launch": problem.bytes,
+                "note": "fp32 SpMM at this size is above the HBM ridge (93 flop/B vs 19.7): see roofline_valu",
+            },
+            "roofline_valu": {
+                "bound": "valu_fp32+lds", "achieved": problem.flops / (kernel_ms * 1e-3) / 1e12,
+                "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": problem.flops / (kernel_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
+                "lds_operand_bound_tflops": 78.6,
+            },
+            "a100_reference_sputnik_gflops": 3416.0,  # README.md:54 of the reference (other hardware)
+        }
+        if not args.no_extras and n_gpus == 1:
+            sweep = []
+            for d in DENSITIES:
+                p = problem if d == HEADLINE_DENSITY else SpmmProblem(dev, d, 1, seed=1234 + 1000 * DENSITIES.index(d))
+                p.step()
+                ms_full = event_time_ms(p.step, 10)
+                ms_kern = event_time_ms(p.kernel_only, 10)
+                sweep.append({"density": d, "nnz": p.nnz, "ms": ms_full, "kernel_ms": ms_kern,
+                              "gflops": p.flops / ms_full / 1e6, "alg_gbs": p.bytes / ms_full / 1e6,
+                              "hbm_frac": p.bytes / ms_kern / 1e6 / HBM_PEAK_GBS,
+                              "valu_frac": p.flops / ms_kern / 1e9 / VALU_PEAK_TFLOPS})
+                if p is not problem:
+                    del p
+            result["sweep"] = sweep
+            result["other_ops"] = other_ops(dev)
+            result["cpu_baseline"] = cpu_baseline(problem)
+        elif n_gpus == 1:
+            result["cpu_baseline"] = None
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

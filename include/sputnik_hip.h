@@ -81,6 +81,27 @@ SPUTNIK_HIP_API int sputnik_hip_spmm_batched(int m, int k, int n, int nonzeros, 
                              size_t workspace_bytes,
                              sputnik_hip_stream_t stream);
 
+/*
+ * The same in two steps, for callers whose sparsity pattern is static (layer
+ * weights, attention masks): `plan` runs the topology-only pre-pass into the
+ * workspace once, `batched_planned` may then be called any number of times
+ * with that workspace (values, dense and out may change between calls; the
+ * three index arrays, m, k and n may not).  No counterpart in the reference,
+ * which re-derives everything per call (src/spmm_cuda.cu:48-57).
+ */
+SPUTNIK_HIP_API int sputnik_hip_spmm_plan(int m, int k, int n, int nonzeros,
+                          const int* row_indices, const int* row_offsets,
+                          const int* column_indices, void* workspace,
+                          size_t workspace_bytes, sputnik_hip_stream_t stream);
+
+SPUTNIK_HIP_API int sputnik_hip_spmm_batched_planned(int m, int k, int n, int nonzeros,
+                             int replicas, const int* row_indices,
+                             const float* values, int64_t values_stride,
+                             const int* row_offsets, const int* column_indices,
+                             const float* dense, int64_t dense_stride, float* out,
+                             int64_t out_stride, const void* workspace,
+                             size_t workspace_bytes, sputnik_hip_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * SDDMM  out[p] = < lhs[i_p, 0:k], rhs[j_p, 0:k] >  for each stored (i_p,j_p)
  * lhs is [m,k], rhs is [n,k] (row-major, i.e. already "transposed").

@@ -118,6 +118,8 @@ def spmm(m, k, values, row_indices, row_offsets, column_indices, dense):
     if values.ndim == 1:
         return _spmm_one(m, n, values, rows, column_indices, dense)
     assert values.shape[0] == dense.shape[0]
+    if values.shape[0] == 0:
+        return np.zeros((0, m, n))
     return np.stack([_spmm_one(m, n, values[r], rows, column_indices, dense[r])
                      for r in range(values.shape[0])])
 
@@ -137,6 +139,8 @@ def left_spmm(m, k, values, row_indices, row_offsets, column_indices, dense):
     assert dense.shape[-2] == k
     n = dense.shape[-1]
     rows = _rows_of(row_offsets)
+    if dense.shape[0] == 0:
+        return np.zeros((0, m, n))
     return np.stack([_spmm_one(m, n, values, rows, column_indices, dense[r])
                      for r in range(dense.shape[0])])
 
@@ -163,6 +167,8 @@ def sddmm(m, n, row_indices, row_offsets, column_indices, lhs, rhs):
     if lhs.ndim == 2:
         return one(lhs, rhs)
     assert lhs.shape[0] == rhs.shape[0]
+    if lhs.shape[0] == 0:
+        return np.zeros((0, column_indices.shape[0]))
     return np.stack([one(lhs[r], rhs[r]) for r in range(lhs.shape[0])])
 
 
@@ -189,6 +195,8 @@ def sparse_softmax(values, row_indices, row_offsets, column_indices):
 
     if values.ndim == 1:
         return one(values)
+    if values.shape[0] == 0:
+        return np.zeros((0, column_indices.shape[0]))
     return np.stack([one(values[r]) for r in range(values.shape[0])])
 
 

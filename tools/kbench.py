@@ -19,22 +19,8 @@ from torch_sputnik_amd import capi  # noqa: E402
 
 
 def gpu_csr(m, n, density, dev, seed=0, round_to=4):
-    """Random CSR pattern built on the GPU (same nonzero count as
-    tests/connectors.py Uniform(1-density, round_to))."""
-    g = torch.Generator(device=dev)
-    g.manual_seed(seed)
-    size = m * n
-    num_dormant = int(round((1.0 - density) * size))
-    nnz = size - num_dormant
-    nnz = (nnz + round_to - 1) // round_to * round_to
-    idx = torch.sort(torch.randperm(size, device=dev, generator=g)[:nnz]).values
-    rows = torch.div(idx, n, rounding_mode="floor")
-    cols = (idx - rows * n).to(torch.int32)
-    counts = torch.bincount(rows, minlength=m)
-    row_offsets = torch.zeros(m + 1, dtype=torch.int64, device=dev)
-    row_offsets[1:] = torch.cumsum(counts, 0)
-    row_indices = torch.argsort(counts, descending=True, stable=True).to(torch.int32)
-    return row_indices, row_offsets.to(torch.int32), cols.contiguous(), nnz
+    from torch_sputnik_amd.synthetic import random_csr
+    return random_csr(m, n, density, dev, seed=seed, round_to=round_to)
 
 
 def timeit(fn, iters, warmup=5):

@@ -26,6 +26,10 @@ SIGNATURES = {
     "sputnik_hip_spmm_batched": (_c_int, [_c_int] * 5 + [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr,
                                                         _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr,
                                                         _c_size, _c_ptr]),
+    "sputnik_hip_spmm_plan": (_c_int, [_c_int] * 4 + [_c_ptr] * 4 + [_c_size, _c_ptr]),
+    "sputnik_hip_spmm_batched_planned": (_c_int, [_c_int] * 5 + [_c_ptr, _c_ptr, _c_i64, _c_ptr,
+                                                                _c_ptr, _c_ptr, _c_i64, _c_ptr,
+                                                                _c_i64, _c_ptr, _c_size, _c_ptr]),
     "sputnik_hip_sddmm": (_c_int, [_c_int] * 4 + [_c_ptr] * 7),
     "sputnik_hip_sddmm_batched": (_c_int, [_c_int] * 5 + [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64,
                                                          _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr]),
@@ -102,6 +106,27 @@ def spmm_batched(m, k, n, replicas, row_indices, values, values_stride, row_offs
         m, k, n, nonzeros, replicas, _ptr(row_indices), _ptr(values), values_stride,
         _ptr(row_offsets), _ptr(column_indices), _ptr(dense), k * n, _ptr(out), m * n,
         _ptr(workspace), ws_bytes, _stream(out)), "sputnik_hip_spmm_batched")
+    return out
+
+
+def spmm_plan(m, k, n, row_indices, row_offsets, column_indices, workspace):
+    """Topology-only pre-pass into `workspace` (reusable by spmm_batched_planned)."""
+    nonzeros = column_indices.numel()
+    ws_bytes = 0 if workspace is None else workspace.numel() * workspace.element_size()
+    _check(lib().sputnik_hip_spmm_plan(m, k, n, nonzeros, _ptr(row_indices), _ptr(row_offsets),
+                                       _ptr(column_indices), _ptr(workspace), ws_bytes,
+                                       _stream(row_offsets)), "sputnik_hip_spmm_plan")
+    return workspace
+
+
+def spmm_batched_planned(m, k, n, replicas, row_indices, values, values_stride, row_offsets,
+                         column_indices, dense, out, workspace):
+    nonzeros = column_indices.numel()
+    ws_bytes = 0 if workspace is None else workspace.numel() * workspace.element_size()
+    _check(lib().sputnik_hip_spmm_batched_planned(
+        m, k, n, nonzeros, replicas, _ptr(row_indices), _ptr(values), values_stride,
+        _ptr(row_offsets), _ptr(column_indices), _ptr(dense), k * n, _ptr(out), m * n,
+        _ptr(workspace), ws_bytes, _stream(out)), "sputnik_hip_spmm_batched_planned")
     return out
 
 

@@ -18,11 +18,14 @@
 
 namespace sputnik_hip {
 
-int spmm_tiled_launch(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
-                      const float* values, int64_t values_stride, const int* row_offsets,
-                      const int* column_indices, const float* dense, int64_t dense_stride,
-                      float* out, int64_t out_stride, void* workspace, size_t workspace_bytes,
-                      hipStream_t stream, bool* handled);
+int spmm_tiled_plan(int m, int k, int n, int nonzeros, const int* row_indices,
+                    const int* row_offsets, const int* column_indices, void* workspace,
+                    size_t workspace_bytes, hipStream_t stream, bool* planned);
+int spmm_tiled_exec(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
+                    const float* values, int64_t values_stride, const int* row_offsets,
+                    const int* column_indices, const float* dense, int64_t dense_stride,
+                    float* out, int64_t out_stride, const void* workspace,
+                    size_t workspace_bytes, hipStream_t stream, bool* handled);
 size_t spmm_tiled_workspace_bytes(int m, int k, int n, int nonzeros);
 
 namespace {
@@ -158,6 +161,35 @@ size_t sputnik_hip_spmm_workspace_bytes(int m, int k, int n, int nonzeros) {
   return spmm_tiled_workspace_bytes(m, k, n, nonzeros);
 }
 
+int sputnik_hip_spmm_plan(int m, int k, int n, int nonzeros, const int* row_indices,
+                          const int* row_offsets, const int* column_indices, void* workspace,
+                          size_t workspace_bytes, sputnik_hip_stream_t stream) {
+  if (m < 0 || k < 0 || n < 0 || nonzeros < 0) return SPUTNIK_HIP_INVALID_ARGUMENT;
+  if (m == 0 || n == 0) return 0;
+  bool planned = false;
+  return spmm_tiled_plan(m, k, n, nonzeros, row_indices, row_offsets, column_indices, workspace,
+                         workspace_bytes, stream, &planned);
+}
+
+int sputnik_hip_spmm_batched_planned(int m, int k, int n, int nonzeros, int replicas,
+                                     const int* row_indices, const float* values,
+                                     int64_t values_stride, const int* row_offsets,
+                                     const int* column_indices, const float* dense,
+                                     int64_t dense_stride, float* out, int64_t out_stride,
+                                     const void* workspace, size_t workspace_bytes,
+                                     sputnik_hip_stream_t stream) {
+  if (m < 0 || k < 0 || n < 0 || nonzeros < 0 || replicas < 0) return SPUTNIK_HIP_INVALID_ARGUMENT;
+  if (m == 0 || n == 0 || replicas == 0) return 0;
+  bool handled = false;
+  const int st = spmm_tiled_exec(m, k, n, nonzeros, replicas, row_indices, values, values_stride,
+                                 row_offsets, column_indices, dense, dense_stride, out,
+                                 out_stride, workspace, workspace_bytes, stream, &handled);
+  if (st != 0 || handled) return st;
+  return spmm_rowgather_launch(m, n, replicas, row_indices, values, values_stride, row_offsets,
+                               column_indices, dense, dense_stride, out, out_stride, nullptr,
+                               stream);
+}
+
 int sputnik_hip_spmm_batched(int m, int k, int n, int nonzeros, int replicas,
                              const int* row_indices, const float* values,
                              int64_t values_stride, const int* row_offsets,
@@ -165,16 +197,13 @@ int sputnik_hip_spmm_batched(int m, int k, int n, int nonzeros, int replicas,
                              int64_t dense_stride, float* out, int64_t out_stride,
                              void* workspace, size_t workspace_bytes,
                              sputnik_hip_stream_t stream) {
-  if (m < 0 || k < 0 || n < 0 || nonzeros < 0 || replicas < 0) return SPUTNIK_HIP_INVALID_ARGUMENT;
-  if (m == 0 || n == 0 || replicas == 0) return 0;
-  bool handled = false;
-  const int st = spmm_tiled_launch(m, k, n, nonzeros, replicas, row_indices, values, values_stride,
-                                   row_offsets, column_indices, dense, dense_stride, out,
-                                   out_stride, workspace, workspace_bytes, stream, &handled);
-  if (st != 0 || handled) return st;
-  return spmm_rowgather_launch(m, n, replicas, row_indices, values, values_stride, row_offsets,
-                               column_indices, dense, dense_stride, out, out_stride, nullptr,
-                               stream);
+  const int st = sputnik_hip_spmm_plan(m, k, n, nonzeros, row_indices, row_offsets,
+                                       column_indices, workspace, workspace_bytes, stream);
+  if (st != 0) return st;
+  return sputnik_hip_spmm_batched_planned(m, k, n, nonzeros, replicas, row_indices, values,
+                                          values_stride, row_offsets, column_indices, dense,
+                                          dense_stride, out, out_stride, workspace,
+                                          workspace_bytes, stream);
 }
 
 int sputnik_hip_spmm(int m, int k, int n, int nonzeros, const int* row_indices,

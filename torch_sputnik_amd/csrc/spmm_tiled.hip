@@ -379,31 +379,49 @@ size_t spmm_tiled_workspace_bytes(int m, int k, int n, int nonzeros) {
   return kFlagBytes + make_plan<CfgLarge>(m, k, n).table_bytes;
 }
 
-int spmm_tiled_launch(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
-                      const float* values, int64_t values_stride, const int* row_offsets,
-                      const int* column_indices, const float* dense, int64_t dense_stride,
-                      float* out, int64_t out_stride, void* workspace, size_t workspace_bytes,
-                      hipStream_t stream, bool* handled) {
-  *handled = false;
+// Pre-pass only: topology -> chunk table + order flag in `workspace`.  Depends
+// on the topology alone, so a caller with a static pattern can run it once and
+// reuse the workspace for any number of spmm_tiled_exec calls.
+int spmm_tiled_plan(int m, int k, int n, int nonzeros, const int* row_indices,
+                    const int* row_offsets, const int* column_indices, void* workspace,
+                    size_t workspace_bytes, hipStream_t stream, bool* planned) {
+  *planned = false;
   if (!tiled_applicable(m, k, n, nonzeros)) return 0;
   using Cfg = CfgLarge;
   const Plan plan = make_plan<Cfg>(m, k, n);
-  if (workspace == nullptr || workspace_bytes < kFlagBytes + plan.table_bytes) return 0;
-  if (!aligned_to(dense, 16) || !aligned_to(out, 16) || dense_stride % 4 != 0 ||
-      out_stride % 4 != 0 || !aligned_to(workspace, 16))
+  if (workspace == nullptr || workspace_bytes < kFlagBytes + plan.table_bytes ||
+      !aligned_to(workspace, 16))
     return 0;
-  if (replicas > kMaxGridYZ) return 0;
-
   int* flag = static_cast<int*>(workspace);
   int* table = reinterpret_cast<int*>(static_cast<char*>(workspace) + kFlagBytes);
-
-  hipError_t e = hipMemsetAsync(flag, 1, sizeof(int), stream);  // nonzero = "sorted so far"
+  const hipError_t e = hipMemsetAsync(flag, 1, sizeof(int), stream);  // nonzero = "sorted so far"
   if (e != hipSuccess) return static_cast<int>(e);
   hipLaunchKernelGGL((spmm_chunk_table_kernel<ilog2(Cfg::kBK)>), dim3(ceil_div(plan.slots, 4)),
                      dim3(256), 0, stream, m, k, plan.slots, plan.nchunks, row_indices,
                      row_offsets, column_indices, table, flag);
-  int st = launch_status();
-  if (st != 0) return st;
+  *planned = true;
+  return launch_status();
+}
+
+// Main kernel (+ the flag-gated row-gather fallback) on a planned workspace.
+int spmm_tiled_exec(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
+                    const float* values, int64_t values_stride, const int* row_offsets,
+                    const int* column_indices, const float* dense, int64_t dense_stride,
+                    float* out, int64_t out_stride, const void* workspace,
+                    size_t workspace_bytes, hipStream_t stream, bool* handled) {
+  *handled = false;
+  if (!tiled_applicable(m, k, n, nonzeros)) return 0;
+  using Cfg = CfgLarge;
+  const Plan plan = make_plan<Cfg>(m, k, n);
+  if (workspace == nullptr || workspace_bytes < kFlagBytes + plan.table_bytes ||
+      !aligned_to(workspace, 16))
+    return 0;
+  if (!aligned_to(dense, 16) || !aligned_to(out, 16) || dense_stride % 4 != 0 ||
+      out_stride % 4 != 0 || replicas > kMaxGridYZ)
+    return 0;
+  const int* flag = static_cast<const int*>(workspace);
+  const int* table =
+      reinterpret_cast<const int*>(static_cast<const char*>(workspace) + kFlagBytes);
 
   const int blocks = (plan.slots / Cfg::kBM) * plan.n_tiles;
   static const int mode = [] {
@@ -421,11 +439,11 @@ int spmm_tiled_launch(int m, int k, int n, int nonzeros, int replicas, const int
                        row_indices, values, values_stride, column_indices, table, dense,
                        dense_stride, out, out_stride, flag);
   }
-  st = launch_status();
+  int st = launch_status();
   if (st != 0) return st;
 
-  // Fallback for unsorted column indices: runs only when the pre-pass cleared the flag...
-  // its skip test is "flag != 0", i.e. it exits when the tiled kernel did the work.
+  // Fallback for unsorted column indices: its skip test is "flag != 0", i.e. it
+  // exits at once when the tiled kernel did the work.
   st = spmm_rowgather_launch(m, n, replicas, row_indices, values, values_stride, row_offsets,
                              column_indices, dense, dense_stride, out, out_stride, flag, stream);
   *handled = true;
