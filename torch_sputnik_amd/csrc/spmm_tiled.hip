@@ -118,15 +118,16 @@ struct TileConfig {
 // following ds_read, which would serialise the prefetch of the next stage
 // with the compute on the current one.  The waits are placed by hand instead
 // (wait_stage() before the barrier that publishes a stage).
-__device__ __forceinline__ void lds_dma_row(const float* src, const float* lds_dst) {
+__device__ __forceinline__ void lds_dma_row(const float* row_base /* wave-uniform */,
+                                            unsigned lane_byte_offset, const float* lds_dst) {
   const unsigned lds_addr =
       static_cast<unsigned>(reinterpret_cast<uintptr_t>(AS_LDS(const_cast<float*>(lds_dst))));
   asm volatile(
       "s_mov_b32 m0, %0\n\t"
       "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, off"
+      "global_load_lds_dwordx4 %1, %2"
       :
-      : "s"(lds_addr), "v"(src)
+      : "s"(lds_addr), "v"(lane_byte_offset), "s"(row_base)
       : "memory", "m0");
 }
 
@@ -134,18 +135,49 @@ __device__ __forceinline__ void wait_stage() { asm volatile("s_waitcnt vmcnt(0)"
 
 template <typename Cfg>
 __device__ __forceinline__ void stage_chunk(float* __restrict__ tile, const float* __restrict__ dense,
-                                            int n, int k, int n0, int kc, int wave, int lane) {
+                                            int n, int k, int kc, int wave,
+                                            unsigned lane_byte_offset) {
   // Wave w copies B rows kc + w, kc + w + WAVES, ...; one wave instruction
-  // moves one row segment straight into the row-major tile row.
+  // moves one row segment (lane_byte_offset = (n0 + lane*4) * 4 selects the
+  // workgroup's column tile and the lane's 16 bytes) straight into the
+  // row-major tile row.  Rows past the end of B (last, partial chunk) re-read
+  // row k-1: no nonzero refers to them, and every wave then issues exactly
+  // kStageRowsPerWave copies per stage, which the counted vmcnt waits of
+  // MODE 2 rely on.
 #pragma unroll
   for (int i = 0; i < Cfg::kStageRowsPerWave; ++i) {
     const int r = wave + i * Cfg::kWaves;
-    if (kc + r < k)
-      lds_dma_row(dense + static_cast<int64_t>(kc + r) * n + n0 + lane * 4, tile + r * Cfg::kBN);
+    const int src_row = min(kc + r, k - 1);
+    lds_dma_row(dense + static_cast<int64_t>(src_row) * n, lane_byte_offset, tile + r * Cfg::kBN);
   }
 }
 
-// One nonzero against the staged tile: acc[0..3] += a * tile[j - kc][lane*4 .. +3].
+// Vector load whose completion the compiler does not track (MODE 2 counts
+// vmcnt by hand, see the kernel).
+// (wave-uniform base in SGPRs + 32-bit per-lane byte offset: no 64-bit VGPR
+// address arithmetic, no VGPR pairs to keep alive.)
+__device__ __forceinline__ int untracked_load_i32(const int* base, unsigned byte_offset) {
+  int v;
+  asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(byte_offset), "s"(base) : "memory");
+  return v;
+}
+__device__ __forceinline__ float untracked_load_f32(const float* base, unsigned byte_offset) {
+  float v;
+  asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(byte_offset), "s"(base) : "memory");
+  return v;
+}
+// Wait until at most N vector-memory operations of this wave are in flight;
+// the operands tie later uses of the loaded registers to the wait.
+template <int N>
+__device__ __forceinline__ void wait_vm(int& a, float& b, int& c) {
+  asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+}
+
+// One nonzero against the staged tile: acc[0..3] += a * (float4 read from the tile).
 #define SPUTNIK_HIP_FMA4(ACC, A, B)          \
   do {                                       \
     (ACC)[0] = fmaf((A), (B).x, (ACC)[0]);   \
@@ -154,19 +186,172 @@ __device__ __forceinline__ void stage_chunk(float* __restrict__ tile, const floa
     (ACC)[3] = fmaf((A), (B).w, (ACC)[3]);   \
   } while (0)
 
+// DPP row_newbcast: every lane of a 16-lane row reads lane U of ITS row.  With
+// the same 16 entries replicated in all four rows this is a wave-wide
+// broadcast of entry U that costs one VALU op and no SGPR round trip.
+template <int U>
+__device__ __forceinline__ int row_bcast_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, 0x150 + U, 0xF, 0xF, true);
+}
+template <int U>
+__device__ __forceinline__ float row_bcast_f(float v) {
+  return __builtin_bit_cast(float, row_bcast_i<U>(__builtin_bit_cast(int, v)));
+}
+
+// Four nonzeros G..G+3 of the replicated 16-entry set (roff = byte offset of
+// the B row inside the staged tile, rval = value; both per entry lane).
+template <int G>
+__device__ __forceinline__ void dpp_group4(float (&acc)[4], int roff, float rval,
+                                           const char* __restrict__ lane_base) {
+  const int o0 = row_bcast_i<G + 0>(roff), o1 = row_bcast_i<G + 1>(roff);
+  const int o2 = row_bcast_i<G + 2>(roff), o3 = row_bcast_i<G + 3>(roff);
+  const float4 b0 = *reinterpret_cast<const float4*>(lane_base + o0);
+  const float4 b1 = *reinterpret_cast<const float4*>(lane_base + o1);
+  const float4 b2 = *reinterpret_cast<const float4*>(lane_base + o2);
+  const float4 b3 = *reinterpret_cast<const float4*>(lane_base + o3);
+  const float a0 = row_bcast_f<G + 0>(rval), a1 = row_bcast_f<G + 1>(rval);
+  const float a2 = row_bcast_f<G + 2>(rval), a3 = row_bcast_f<G + 3>(rval);
+  SPUTNIK_HIP_FMA4(acc, a0, b0);
+  SPUTNIK_HIP_FMA4(acc, a1, b1);
+  SPUTNIK_HIP_FMA4(acc, a2, b2);
+  SPUTNIK_HIP_FMA4(acc, a3, b3);
+}
+
+// MODE 2 main loop (see the kernel's header comment).
+//
+// Every vector-memory operation inside the loop is issued from inline asm, in
+// a fixed order and number per chunk, so the waits can be counted by hand:
+//   A  kStageRowsPerWave (S) LDS-DMA copies of B rows for chunk c+1
+//   B  1 load of the rows' stream positions two chunks ahead
+//   C  after each row r: 2 loads = the entry window of the row that is D rows
+//      further down the walk (row r+D of this chunk, or row r+D-RPW of the
+//      next one); D windows (2*D VGPRs) are live at any time.
+// A window is consumed D rows after it was requested.  In between exactly
+// D-1 other windows were requested (2*(D-1) operations), plus A and B if the
+// chunk boundary was crossed (rows r < D): `vmcnt` with that count retires it
+// and nothing newer.  At the end of a chunk `vmcnt(2*RPW+1)` retires A (the B
+// tile of the next chunk) and leaves B and C in flight across the barrier.
+// The last chunk issues the same (clamped, unused) operations so that the
+// counts hold for every iteration; the first one starts from a full drain.
+template <typename Cfg>
+__device__ __forceinline__ void spmm_tiled_body_dpp(
+    float (&acc)[Cfg::kRPW][Cfg::kVec], float* __restrict__ tile0, int lane, int wave, int slot0,
+    int slots, int nchunks, int nonzeros, int n, int k, int n0, const float* __restrict__ values,
+    const int* __restrict__ column_indices, const int* __restrict__ table,
+    const float* __restrict__ dense, bool dbg_no_compute, bool dbg_no_stage) {
+  constexpr int BN = Cfg::kBN, BK = Cfg::kBK, RPW = Cfg::kRPW, VEC = Cfg::kVec;
+  constexpr int S = Cfg::kStageRowsPerWave;
+  constexpr int D = 8;  // windows in flight
+  static_assert(RPW % D == 0 && D <= RPW, "window ring");
+  constexpr int kWaitSameChunk = 2 * (D - 1);
+  constexpr int kWaitCrossChunk = 2 * (D - 1) + S + 1;
+  constexpr int kWaitStage = 2 * RPW + 1;
+  static_assert(kWaitStage <= 63, "vmcnt is a 6-bit counter");
+
+  const unsigned ptr_off = static_cast<unsigned>(min(lane, RPW - 1)) * 4u;
+  const int* __restrict__ my_table = table + slot0;  // wave-uniform
+  const int last = nonzeros - 1;
+  const int e16 = lane & 15;
+  const float* lane_tile = tile0 + lane * VEC;
+  const unsigned b_lane_off = static_cast<unsigned>(n0 + lane * 4) * 4u;
+
+  // lane r: stream position of row r at the start of chunk c / at its end
+  int v_ps = untracked_load_i32(my_table, ptr_off);
+  int v_pe = untracked_load_i32(my_table + slots, ptr_off);
+  wait_vm<0>();
+  asm volatile("" : "+v"(v_ps), "+v"(v_pe));
+
+  int vcol[D];
+  float vval[D];
+#pragma unroll
+  for (int r = 0; r < D; ++r) {
+    const unsigned off =
+        static_cast<unsigned>(min(__builtin_amdgcn_readlane(v_ps, r) + lane, last)) * 4u;
+    vcol[r] = untracked_load_i32(column_indices, off);
+    vval[r] = untracked_load_f32(values, off);
+  }
+  stage_chunk<Cfg>(tile0, dense, n, k, 0, wave, b_lane_off);
+  int v_pe_next = untracked_load_i32(my_table + static_cast<int64_t>(min(2, nchunks)) * slots, ptr_off);
+  wait_vm<0>();
+  __syncthreads();
+
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    // A (the timing experiment without staging still issues the copies, from
+    // chunk 0, so that the operation count the waits assume is unchanged)
+    stage_chunk<Cfg>(tile0 + (buf ^ 1) * (BK * BN), dense, n, k,
+                     dbg_no_stage ? 0 : min(c + 1, nchunks - 1) * BK, wave, b_lane_off);
+    // B
+    int v_pe_after =
+        untracked_load_i32(my_table + static_cast<int64_t>(min(c + 3, nchunks)) * slots, ptr_off);
+    const char* __restrict__ lane_base =
+        reinterpret_cast<const char*>(lane_tile + buf * (BK * BN));
+    const int kc = c * BK;
+
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      constexpr int kDummy = 0;
+      (void)kDummy;
+      int& wcol = vcol[r % D];
+      float& wval = vval[r % D];
+      if (r < D) {
+        wait_vm<kWaitCrossChunk>(wcol, wval, v_pe);
+      } else {
+        wait_vm<kWaitSameChunk>(wcol, wval, v_pe);
+      }
+      const int cnt = dbg_no_compute ? 0
+                                     : __builtin_amdgcn_readlane(v_pe, r) -
+                                           __builtin_amdgcn_readlane(v_ps, r);
+      for (int q0 = 0; q0 < cnt; q0 += 16) {
+        const int e = e16 + q0;  // entry this lane stands for
+        const int rcol = __builtin_amdgcn_ds_bpermute(e << 2, wcol);
+        const float rval_all = __builtin_bit_cast(
+            float, __builtin_amdgcn_ds_bpermute(e << 2, __builtin_bit_cast(int, wval)));
+        const bool valid = e < cnt;
+        const int roff = valid ? ((rcol - kc) * (BN * 4)) : 0;
+        const float rval = valid ? rval_all : 0.f;
+        const int n16 = cnt - q0;
+        dpp_group4<0>(acc[r], roff, rval, lane_base);
+        if (n16 > 4) dpp_group4<4>(acc[r], roff, rval, lane_base);
+        if (n16 > 8) dpp_group4<8>(acc[r], roff, rval, lane_base);
+        if (n16 > 12) dpp_group4<12>(acc[r], roff, rval, lane_base);
+      }
+      // C: request the window that will be consumed D rows from now.
+      const int start = (r + D < RPW) ? __builtin_amdgcn_readlane(v_ps, (r + D) % RPW)
+                                      : __builtin_amdgcn_readlane(v_pe, (r + D) % RPW);
+      const unsigned off = static_cast<unsigned>(min(start + lane, last)) * 4u;
+      wcol = untracked_load_i32(column_indices, off);
+      wval = untracked_load_f32(values, off);
+    }
+    v_ps = v_pe;
+    v_pe = v_pe_next;
+    v_pe_next = v_pe_after;
+    wait_vm<kWaitStage>();  // next B tile landed; windows and positions stay in flight
+    __syncthreads();
+  }
+  wait_vm<0>();  // nothing may be in flight (LDS-DMA!) when the wave ends
+}
+
 // MODE 0: the row's (column, value) stream is read with scalar loads.
 // MODE 1: each row keeps the next 64 entries of its stream in two VGPRs
 //         (lane u = entry u), prefetched one K chunk ahead with vector loads
 //         and handed out with v_readlane; per (row, chunk) this costs two
 //         vector loads instead of a chain of dependent scalar loads.
+// MODE 2: same windows, but entries are handed out with DPP row broadcasts
+//         (16 entries at a time, replicated into every 16-lane row with one
+//         ds_bpermute pair): no VGPR->SGPR traffic at all.  Entries are
+//         processed four at a time, the last group padded with zero values.
 template <typename Cfg, int MODE>
 __global__ __launch_bounds__(Cfg::kThreads) void spmm_tiled_kernel(
     int m, int k, int n, int nonzeros, int slots, int nchunks, int n_tiles,
     const int* __restrict__ row_indices, const float* __restrict__ values,
     int64_t values_stride, const int* __restrict__ column_indices,
     const int* __restrict__ table, const float* __restrict__ dense, int64_t dense_stride,
-    float* __restrict__ out, int64_t out_stride, const int* __restrict__ sorted_flag) {
+    float* __restrict__ out, int64_t out_stride, const int* __restrict__ sorted_flag,
+    int debug) {
   if (*sorted_flag == 0) return;  // unsorted columns: the row-gather kernel runs instead
+  // Timing experiments only (SPUTNIK_HIP_SPMM_DEBUG): 1 = no compute, 2 = no staging.
+  const bool dbg_no_compute = debug & 1, dbg_no_stage = debug & 2;
 
   constexpr int BN = Cfg::kBN, BK = Cfg::kBK, RPW = Cfg::kRPW, VEC = Cfg::kVec;
   static_assert(BK <= kWave, "a row has at most BK <= 64 entries per chunk (MODE 1 window)");
@@ -204,20 +389,25 @@ __global__ __launch_bounds__(Cfg::kThreads) void spmm_tiled_kernel(
     for (int v = 0; v < VEC; ++v) acc[r][v] = 0.f;
 
   const float* lane_tile = &tile[0][0] + lane * VEC;
+  const unsigned b_lane_off = static_cast<unsigned>(n0 + lane * 4) * 4u;
 
-  if constexpr (MODE == 0) {
+  if constexpr (MODE == 2) {
+    spmm_tiled_body_dpp<Cfg>(acc, &tile[0][0], lane, wave, slot0, slots, nchunks, nonzeros, n, k,
+                             n0, values, column_indices, table, dense, dbg_no_compute,
+                             dbg_no_stage);
+  } else if constexpr (MODE == 0) {
     int ps[RPW];
 #pragma unroll
     for (int r = 0; r < RPW; ++r) ps[r] = table[slot0 + r];
 
-    stage_chunk<Cfg>(tile[0], dense, n, k, n0, 0, wave, lane);
+    stage_chunk<Cfg>(tile[0], dense, n, k, 0, wave, b_lane_off);
     wait_stage();
     __syncthreads();
 
     for (int c = 0; c < nchunks; ++c) {
       const int buf = c & 1;
-      if (c + 1 < nchunks)
-        stage_chunk<Cfg>(tile[buf ^ 1], dense, n, k, n0, (c + 1) * BK, wave, lane);
+      if (c + 1 < nchunks && !dbg_no_stage)
+        stage_chunk<Cfg>(tile[buf ^ 1], dense, n, k, (c + 1) * BK, wave, b_lane_off);
       const int* __restrict__ next_ptr = table + static_cast<int64_t>(c + 1) * slots + slot0;
       const float* __restrict__ btile = lane_tile + buf * (BK * BN);
       const int kc = c * BK;
@@ -269,14 +459,14 @@ __global__ __launch_bounds__(Cfg::kThreads) void spmm_tiled_kernel(
       vval[r] = values[idx];
     }
 
-    stage_chunk<Cfg>(tile[0], dense, n, k, n0, 0, wave, lane);
+    stage_chunk<Cfg>(tile[0], dense, n, k, 0, wave, b_lane_off);
     wait_stage();
     __syncthreads();
 
     for (int c = 0; c < nchunks; ++c) {
       const int buf = c & 1;
-      if (c + 1 < nchunks)
-        stage_chunk<Cfg>(tile[buf ^ 1], dense, n, k, n0, (c + 1) * BK, wave, lane);
+      if (c + 1 < nchunks && !dbg_no_stage)
+        stage_chunk<Cfg>(tile[buf ^ 1], dense, n, k, (c + 1) * BK, wave, b_lane_off);
       const int v_pe_next =
           (c + 2 <= nchunks) ? my_table[static_cast<int64_t>(c + 2) * slots] : 0;
       const float* __restrict__ btile = lane_tile + buf * (BK * BN);
@@ -284,8 +474,8 @@ __global__ __launch_bounds__(Cfg::kThreads) void spmm_tiled_kernel(
 #pragma unroll
       for (int r = 0; r < RPW; ++r) {
         const int s_pe = __builtin_amdgcn_readlane(v_pe, r);
-        const int cnt = s_pe - __builtin_amdgcn_readlane(v_ps, r);
-        int u = 0;
+        const int cnt = dbg_no_compute ? 0 : s_pe - __builtin_amdgcn_readlane(v_ps, r);
+      int u = 0;
         for (; u + 4 <= cnt; u += 4) {
           int j[4];
           float a[4];
@@ -426,18 +616,27 @@ int spmm_tiled_exec(int m, int k, int n, int nonzeros, int replicas, const int* 
   const int blocks = (plan.slots / Cfg::kBM) * plan.n_tiles;
   static const int mode = [] {
     const char* e = getenv("SPUTNIK_HIP_SPMM_MODE");  // developer knob, see DESIGN.md
-    return e ? atoi(e) : 1;
+    return e ? atoi(e) : 2;
+  }();
+  static const int debug = [] {
+    const char* e = getenv("SPUTNIK_HIP_SPMM_DEBUG");
+    return e ? atoi(e) : 0;
   }();
   if (mode == 0) {
     hipLaunchKernelGGL((spmm_tiled_kernel<Cfg, 0>), dim3(blocks, replicas), dim3(Cfg::kThreads),
                        0, stream, m, k, n, nonzeros, plan.slots, plan.nchunks, plan.n_tiles,
                        row_indices, values, values_stride, column_indices, table, dense,
-                       dense_stride, out, out_stride, flag);
-  } else {
+                       dense_stride, out, out_stride, flag, debug);
+  } else if (mode == 1) {
     hipLaunchKernelGGL((spmm_tiled_kernel<Cfg, 1>), dim3(blocks, replicas), dim3(Cfg::kThreads),
                        0, stream, m, k, n, nonzeros, plan.slots, plan.nchunks, plan.n_tiles,
                        row_indices, values, values_stride, column_indices, table, dense,
-                       dense_stride, out, out_stride, flag);
+                       dense_stride, out, out_stride, flag, debug);
+  } else {
+    hipLaunchKernelGGL((spmm_tiled_kernel<Cfg, 2>), dim3(blocks, replicas), dim3(Cfg::kThreads),
+                       0, stream, m, k, n, nonzeros, plan.slots, plan.nchunks, plan.n_tiles,
+                       row_indices, values, values_stride, column_indices, table, dense,
+                       dense_stride, out, out_stride, flag, debug);
   }
   int st = launch_status();
   if (st != 0) return st;
