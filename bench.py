@@ -99,7 +99,10 @@ def cpu_baseline(problem):
     vals = problem.values.reshape(-1)[:problem.nnz].cpu().numpy()
     ro, ci = problem.ro.cpu().numpy(), problem.ci.cpu().numpy()
     dense = problem.dense.reshape(-1, K, N)[0].cpu().numpy()
-    threads = c_oracle.num_threads()
+    # Threads = the cores this process may run on (the GPU box gives one GPU's
+    # share of the host, not all of its cores).
+    threads = max(1, min(c_oracle.num_threads(), len(os.sched_getaffinity(0))))
+    c_oracle.set_num_threads(threads)
     c_oracle.spmm(M, K, vals, ro, ci, dense, f32_accumulate=True)  # warm-up
     times = []
     t_all = time.perf_counter()
