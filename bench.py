@@ -155,7 +155,8 @@ def other_ops(dev):
     t = event_time_ms(lambda: capi.sparse_softmax_batched(s, reps, scores, ri, ro, ci, probs), 20)
     by = reps * 8.0 * nnz + 4.0 * (2 * s + 1)
     res["softmax_c3"] = {"ms": t, "alg_gbs": by / t / 1e6, "hbm_frac": by / t / 1e6 / HBM_PEAK_GBS}
-    t = event_time_ms(lambda: capi.spmm_batched(s, s, d, reps, ri, probs, nnz, ro, ci, v, ctx, None), 20)
+    ws3 = torch.empty(capi.spmm_workspace_bytes(s, s, d, nnz) + 16, dtype=torch.uint8, device=dev)
+    t = event_time_ms(lambda: capi.spmm_batched(s, s, d, reps, ri, probs, nnz, ro, ci, v, ctx, ws3), 20)
     by = reps * (4.0 * nnz + 8.0 * s * d) + 4.0 * nnz + 4.0 * (2 * s + 1)
     res["spmm_c3"] = {"ms": t, "gflops": 2.0 * nnz * d * reps / t / 1e6, "alg_gbs": by / t / 1e6}
     m = n = 2048  # config 5: transpose of a 2048^2, density 0.2 weight
@@ -197,7 +198,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # BENCH_FORCE_DIST=1 exercises the torch.distributed path with one rank.
+    distributed = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (the hot path has no CPU fallback)")
     torch.cuda.set_device(local_rank)

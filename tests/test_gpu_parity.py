@@ -59,7 +59,11 @@ SPMM_SHAPES = [
     (512, 1024, 512, 0.9, "ascending", ()),
     (1024, 777, 1024, 0.95, "descending", ()),
     (100, 4096, 256, 0.98, "random", (1, 2, 3)),
-    (2048, 2048, 64, 0.9, "descending", ()),      # attention-like n
+    (2048, 2048, 64, 0.9, "descending", ()),      # attention-like n: 64-column tiled kernel
+    (512, 300, 128, 0.8, "ascending", (17,)),     # two 64-column tiles, partial last K chunk
+    (100, 1000, 192, 0.9, "random", (0,)),        # padded row slots, three tiles
+    (128, 256, 64, 0.3, "descending", ()),        # > 16 entries per row and chunk: extra windows
+    (64, 128, 64, 0.0, "identity", ()),           # dense "sparse" matrix
 ]
 
 
@@ -79,21 +83,26 @@ def test_spmm_capi_vs_oracle(capi, dev, m, k, n, sparsity, order, empty):
         assert np.all(got[r] == 0)
 
 
-@pytest.mark.parametrize("replicas,shared", [(3, False), (5, True), (1, False)])
-def test_spmm_batched_capi(capi, dev, replicas, shared):
-    m, k, n = 130, 96, 136
+@pytest.mark.parametrize("replicas,shared,m,k,n", [
+    (3, False, 130, 96, 136), (5, True, 130, 96, 136), (1, False, 130, 96, 136),
+    (4, False, 512, 512, 64), (3, True, 300, 256, 128),       # 64-column tiled kernel
+    (2, False, 512, 512, 256), (3, True, 256, 1024, 512)])    # 256-column tiled kernel
+def test_spmm_batched_capi(capi, dev, replicas, shared, m, k, n):
     _, vals, ri, ro, ci = make_csr(m, k, 0.85, seed=21)
     rng = np.random.default_rng(22)
     b = rng.uniform(-1, 1, size=(replicas, k, n)).astype(np.float32)
     v = vals if shared else rng.uniform(-1, 1, size=(replicas, len(vals))).astype(np.float32)
     want = c_oracle.spmm(m, k, v, ro, ci, b)
     out = torch.full((replicas, m, n), float("nan"), device=dev)
+    ws = torch.empty(capi.spmm_workspace_bytes(m, k, n, len(ci)) + 16, dtype=torch.uint8, device=dev)
     capi.spmm_batched(m, k, n, replicas, T(ri, dev), T(v, dev), 0 if shared else len(vals),
-                      T(ro, dev), T(ci, dev), T(b, dev), out, None)
-    assert rel_err(out.cpu().numpy(), want) < TOL
+                      T(ro, dev), T(ci, dev), T(b, dev), out, ws)
+    got = out.cpu().numpy()
+    assert not np.isnan(got).any()
+    assert rel_err(got, want) < TOL
 
 
-@pytest.mark.parametrize("m,k,n", [(96, 200, 128), (256, 512, 256), (300, 1000, 512)])
+@pytest.mark.parametrize("m,k,n", [(96, 200, 128), (256, 512, 256), (300, 1000, 512), (200, 300, 64)])
 def test_spmm_unsorted_columns(capi, dev, m, k, n):
     """Column indices need not ascend inside a row (the CUDA library does not
     require it either).  The larger shapes qualify for the LDS-tiled kernel,

@@ -79,7 +79,8 @@ def bench_attention_ops(dev, iters, s=1024, d=64, replicas=64, density=0.1):
     rows.append(dict(op="softmax", s=s, replicas=replicas, nnz=nnz, ms=med * 1e3, ms_min=best * 1e3,
                      alg_gbs=by / med / 1e9, hbm_frac=by / med / 8e12))
     print(json.dumps(rows[-1]), flush=True)
-    med, best = timeit(lambda: capi.spmm_batched(s, s, d, replicas, ri, probs, nnz, ro, ci, v, ctx, None), iters)
+    ws = torch.empty(capi.spmm_workspace_bytes(s, s, d, nnz) + 16, dtype=torch.uint8, device=dev)
+    med, best = timeit(lambda: capi.spmm_batched(s, s, d, replicas, ri, probs, nnz, ro, ci, v, ctx, ws), iters)
     by = replicas * (4.0 * nnz + 4 * 2 * s * d) + 4 * nnz + 4 * (2 * s + 1)
     rows.append(dict(op="spmm_attn", s=s, d=d, replicas=replicas, nnz=nnz, ms=med * 1e3, ms_min=best * 1e3,
                      gflops=2.0 * nnz * d * replicas / med / 1e9, alg_gbs=by / med / 1e9,

@@ -1,0 +1,224 @@
+// LDS-tiled SpMM for NARROW dense operands (n a multiple of 64 that the
+// 256-column kernel of spmm_tiled.hip does not take): attention heads
+// (n = head_dim), SparseLinear with short sequences.
+//
+// Same decomposition as spmm_tiled.hip -- B staged per K chunk into LDS by
+// direct global->LDS copies, C accumulators in registers for the whole K walk,
+// rows dealt in row_indices order, chunk table pre-pass -- but a wavefront
+// works on FOUR rows at a time: each 16-lane row of the wave owns one matrix
+// row and its 64 output columns (4 per lane).  That is exactly the shape DPP
+// `row_newbcast` serves: the 16 lanes of a row group hold 16 consecutive
+// entries of THEIR row's (column, value) stream, and entry u is broadcast
+// inside the group by the DPP modifier -- four different nonzeros, one per
+// group, are processed by every wave instruction (one ds_read_b128 fetches four
+// different 256-byte B rows; since the tile's row stride is one full LDS bank
+// row, this is conflict-free).  Groups whose row has fewer entries in the
+// chunk run the extra steps with a zero value.
+//
+// Register budget is small here (32 accumulators), so the entry windows of the
+// NEXT chunk are requested at the start of the current one into a second
+// register set: they have a whole chunk to land and the end-of-chunk
+// `vmcnt(0)` (needed for the B copy) costs nothing.
+#include "spmm_tiled_common.h"
+
+namespace sputnik_hip {
+
+int spmm_rowgather_launch(int m, int n, int replicas, const int* row_indices,
+                          const float* values, int64_t values_stride, const int* row_offsets,
+                          const int* column_indices, const float* dense, int64_t dense_stride,
+                          float* out, int64_t out_stride, const int* skip_flag,
+                          hipStream_t stream);
+
+namespace {
+
+using namespace tiled;
+
+constexpr int kBN = 64;     // columns of C per workgroup
+constexpr int kWaves = 8;   // waves per workgroup
+constexpr int kRQ = 8;      // row quads per wave (4 rows each)
+constexpr int kBK = 128;    // rows of B per LDS stage
+constexpr int kBM = kWaves * kRQ * 4;
+constexpr int kThreads = kWaves * kWave;
+constexpr int kTileFloats = kBK * kBN;                 // 32 KiB
+constexpr int kCopiesPerStage = kBK / 4;               // one wave instruction moves 4 tile rows
+constexpr int kCopiesPerWave = kCopiesPerStage / kWaves;
+static_assert(kCopiesPerStage % kWaves == 0, "stage copies split evenly over the waves");
+
+// One wave instruction copies tile rows 4j .. 4j+3 (4 x 256 B, lane l -> row
+// l/16, bytes (l%16)*16) from B rows kc+4j .. kc+4j+3 into LDS.
+__device__ __forceinline__ void stage_chunk64(float* __restrict__ tile,
+                                              const float* __restrict__ dense, int n, int k,
+                                              int n0, int kc, int wave, int lane) {
+  const int g = lane >> 4, i = lane & 15;
+#pragma unroll
+  for (int j = 0; j < kCopiesPerWave; ++j) {
+    const int r0 = (wave + j * kWaves) * 4;
+    const int src_row = min(kc + r0 + g, k - 1);  // past the end of B: re-read the last row
+    const unsigned off = static_cast<unsigned>(src_row) * static_cast<unsigned>(n) * 4u +
+                         static_cast<unsigned>(n0 + i * 4) * 4u;
+    lds_dma_row(dense, off, tile + r0 * kBN);
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void spmm_tiled64_kernel(
+    int m, int k, int n, int nonzeros, int slots, int nchunks, int n_tiles,
+    const int* __restrict__ row_indices, const float* __restrict__ values,
+    int64_t values_stride, const int* __restrict__ column_indices,
+    const int* __restrict__ table, const float* __restrict__ dense, int64_t dense_stride,
+    float* __restrict__ out, int64_t out_stride, const int* __restrict__ sorted_flag) {
+  if (*sorted_flag == 0) return;  // unsorted columns: the row-gather kernel runs instead
+  __shared__ float tile[2][kTileFloats];
+
+  const int lane = threadIdx.x % kWave;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int g = lane >> 4, i = lane & 15;
+
+  const int ntile = blockIdx.x % n_tiles;
+  const int mblock = blockIdx.x / n_tiles;
+  const int replica = blockIdx.y;
+  values += replica * values_stride;
+  dense += replica * dense_stride;
+  out += replica * out_stride;
+  const int n0 = ntile * kBN;
+  const int slot0 = mblock * kBM + wave * (kRQ * 4);  // this wave's first row slot
+  const int last = nonzeros - 1;
+
+  float acc[kRQ][4];
+#pragma unroll
+  for (int t = 0; t < kRQ; ++t)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[t][v] = 0.f;
+
+  // Per quad t, this lane's row is slot0 + 4t + g: stream position at the start
+  // / end of the current chunk, and its first 16 entries (lane i = entry i).
+  const int* __restrict__ my_table = table + slot0 + g;
+  int ps[kRQ], pe[kRQ], wcol[kRQ];
+  float wval[kRQ];
+#pragma unroll
+  for (int t = 0; t < kRQ; ++t) {
+    ps[t] = my_table[4 * t];
+    pe[t] = my_table[slots + 4 * t];
+    const int idx = min(ps[t] + i, last);
+    wcol[t] = column_indices[idx];
+    wval[t] = values[idx];
+  }
+
+  stage_chunk64(tile[0], dense, n, k, n0, 0, wave, lane);
+  wait_vm<0>();
+  __syncthreads();
+
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    const bool more = c + 1 < nchunks;
+    if (more) stage_chunk64(tile[buf ^ 1], dense, n, k, n0, (c + 1) * kBK, wave, lane);
+
+    // Next chunk's positions and entry windows: requested now, used after the barrier.
+    int pe_next[kRQ], ncol[kRQ];
+    float nval[kRQ];
+#pragma unroll
+    for (int t = 0; t < kRQ; ++t) {
+      pe_next[t] = more ? my_table[static_cast<int64_t>(c + 2) * slots + 4 * t] : pe[t];
+      const int idx = min(pe[t] + i, last);
+      ncol[t] = more ? column_indices[idx] : 0;
+      nval[t] = more ? values[idx] : 0.f;
+    }
+
+    const char* __restrict__ lane_base = reinterpret_cast<const char*>(&tile[buf][0] + i * 4);
+    const int kc = c * kBK;
+
+#pragma unroll
+    for (int t = 0; t < kRQ; ++t) {
+      const int cnt = pe[t] - ps[t];  // this group's row; same in its 16 lanes
+      // longest of the four rows decides the number of steps (wave-uniform)
+      const int steps = max(max(__builtin_amdgcn_readlane(cnt, 0), __builtin_amdgcn_readlane(cnt, 16)),
+                            max(__builtin_amdgcn_readlane(cnt, 32), __builtin_amdgcn_readlane(cnt, 48)));
+      for (int w0 = 0; w0 < steps; w0 += 16) {
+        int ecol = wcol[t];
+        float eval = wval[t];
+        if (w0 > 0) {  // rows longer than one window inside a chunk: fetch on demand
+          const int idx = min(ps[t] + w0 + i, last);
+          ecol = column_indices[idx];
+          eval = values[idx];
+        }
+        const bool valid = w0 + i < cnt;
+        const int roff = valid ? ((ecol - kc) * (kBN * 4)) : 0;
+        const float rval = valid ? eval : 0.f;
+        const int n16 = steps - w0;
+        dpp_group4<0>(acc[t], roff, rval, lane_base);
+        if (n16 > 4) dpp_group4<4>(acc[t], roff, rval, lane_base);
+        if (n16 > 8) dpp_group4<8>(acc[t], roff, rval, lane_base);
+        if (n16 > 12) dpp_group4<12>(acc[t], roff, rval, lane_base);
+      }
+    }
+
+#pragma unroll
+    for (int t = 0; t < kRQ; ++t) {
+      ps[t] = pe[t];
+      pe[t] = pe_next[t];
+      wcol[t] = ncol[t];
+      wval[t] = nval[t];
+    }
+    wait_vm<0>();     // the next B tile has landed (the windows landed long ago)
+    __syncthreads();  // ... for every wave, and the current buffer is free
+  }
+
+#pragma unroll
+  for (int t = 0; t < kRQ; ++t) {
+    const int slot = slot0 + 4 * t + g;
+    if (slot < m) {
+      const int row = row_indices[slot];
+      *reinterpret_cast<float4*>(out + static_cast<int64_t>(row) * n + n0 + i * 4) =
+          make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+    }
+  }
+}
+
+inline int slots_of(int m) { return ceil_div(m, kBM) * kBM; }
+inline int chunks_of(int k) { return ceil_div(k, kBK); }
+
+}  // namespace
+
+bool spmm_tiled64_applicable(int m, int k, int n, int nonzeros) {
+  // B rows are addressed with 32-bit byte offsets; enough work per staged tile.
+  return n % kBN == 0 && k >= 32 && m >= 16 && nonzeros >= 4 * static_cast<int64_t>(m) &&
+         static_cast<int64_t>(k) * n * 4 < (int64_t{1} << 32);
+}
+
+size_t spmm_tiled64_workspace_bytes(int m, int k) {
+  return kFlagBytes + sizeof(int) * static_cast<size_t>(chunks_of(k) + 1) * slots_of(m);
+}
+
+int spmm_tiled64_plan(int m, int k, const int* row_indices, const int* row_offsets,
+                      const int* column_indices, void* workspace, hipStream_t stream) {
+  int* flag = static_cast<int*>(workspace);
+  int* table = reinterpret_cast<int*>(static_cast<char*>(workspace) + kFlagBytes);
+  const hipError_t e = hipMemsetAsync(flag, 1, sizeof(int), stream);  // nonzero = "sorted so far"
+  if (e != hipSuccess) return static_cast<int>(e);
+  const int slots = slots_of(m);
+  hipLaunchKernelGGL((spmm_chunk_table_kernel<ilog2(kBK)>), dim3(ceil_div(slots, 4)), dim3(256),
+                     0, stream, m, k, slots, chunks_of(k), row_indices, row_offsets,
+                     column_indices, table, flag);
+  return launch_status();
+}
+
+int spmm_tiled64_exec(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
+                      const float* values, int64_t values_stride, const int* row_offsets,
+                      const int* column_indices, const float* dense, int64_t dense_stride,
+                      float* out, int64_t out_stride, const void* workspace,
+                      hipStream_t stream) {
+  const int* flag = static_cast<const int*>(workspace);
+  const int* table =
+      reinterpret_cast<const int*>(static_cast<const char*>(workspace) + kFlagBytes);
+  const int slots = slots_of(m);
+  const int n_tiles = n / kBN;
+  hipLaunchKernelGGL(spmm_tiled64_kernel, dim3((slots / kBM) * n_tiles, replicas), dim3(kThreads),
+                     0, stream, m, k, n, nonzeros, slots, chunks_of(k), n_tiles, row_indices,
+                     values, values_stride, column_indices, table, dense, dense_stride, out,
+                     out_stride, flag);
+  const int st = launch_status();
+  if (st != 0) return st;
+  return spmm_rowgather_launch(m, n, replicas, row_indices, values, values_stride, row_offsets,
+                               column_indices, dense, dense_stride, out, out_stride, flag, stream);
+}
+
+}  // namespace sputnik_hip

@@ -1,0 +1,153 @@
+// Pieces shared by the LDS-tiled SpMM kernels (spmm_tiled.hip: 256-column
+// tiles, spmm_tiled64.hip: 64-column tiles): the chunk-table pre-pass, the
+// direct global->LDS copy, hand-counted waits and the DPP broadcast helpers.
+#pragma once
+
+#include "common.h"
+#include "wave_utils.h"
+
+namespace sputnik_hip {
+namespace tiled {
+
+constexpr int kFlagBytes = 256;  // flag word + padding so the table stays aligned
+
+#define AS_GLOBAL(p) ((__attribute__((address_space(1))) void*)(p))
+#define AS_LDS(p) ((__attribute__((address_space(3))) void*)(p))
+
+// ---------------------------------------------------------------------------
+// Pre-pass: chunk table + order check.  One wave per row slot.
+// table[c * slots + slot], c in [0, nchunks]: index of the first nonzero of
+// row row_indices[slot] whose column is >= c*BK (row end if none).  Padding
+// slots (slot >= m) get 0 everywhere, i.e. empty rows.
+// ---------------------------------------------------------------------------
+template <int BK_LOG2>
+__global__ __launch_bounds__(256) void spmm_chunk_table_kernel(
+    int m, int k, int slots, int nchunks, const int* __restrict__ row_indices,
+    const int* __restrict__ row_offsets, const int* __restrict__ column_indices,
+    int* __restrict__ table, int* __restrict__ sorted_flag) {
+  const int lane = threadIdx.x % kWave;
+  const int slot = blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
+  if (slot >= slots) return;
+  if (slot >= m) {
+    for (int c = lane; c <= nchunks; c += kWave) table[static_cast<int64_t>(c) * slots + slot] = 0;
+    return;
+  }
+  const int row = row_indices[slot];
+  const int p0 = row_offsets[row];
+  const int p1 = row_offsets[row + 1];
+  bool ok = true;
+  for (int base = p0; base < p1; base += kWave) {
+    const int p = base + lane;
+    if (p < p1) {
+      const int cur = column_indices[p];
+      const int prev = (p > p0) ? column_indices[p - 1] : -1;
+      if (cur <= prev || cur >= k) {
+        ok = false;
+      } else {
+        const int cb = cur >> BK_LOG2;
+        const int pb = (prev < 0) ? -1 : (prev >> BK_LOG2);
+        for (int c = pb + 1; c <= cb; ++c) table[static_cast<int64_t>(c) * slots + slot] = p;
+      }
+    }
+  }
+  int last = -1;
+  if (p1 > p0) {
+    const int lc = column_indices[p1 - 1];
+    last = (lc >= 0 && lc < k) ? (lc >> BK_LOG2) : nchunks;
+  }
+  for (int c = last + 1 + lane; c <= nchunks; c += kWave)
+    table[static_cast<int64_t>(c) * slots + slot] = p1;
+  if (!ok) *sorted_flag = 0;
+}
+
+// Direct global->LDS copy of one 1 KiB row segment (64 lanes x 16 B):
+// LDS destination = M0 + lane*16, global source = per-lane address.
+// Written as inline asm on purpose: for the builtin form hipcc treats the
+// copy as a pending LDS write and puts `s_waitcnt vmcnt(0)` in front of every
+// following ds_read, which would serialise the prefetch of the next stage
+// with the compute on the current one.  The waits are placed by hand instead
+// (wait_stage() before the barrier that publishes a stage).
+__device__ __forceinline__ void lds_dma_row(const float* row_base /* wave-uniform */,
+                                            unsigned lane_byte_offset, const float* lds_dst) {
+  const unsigned lds_addr =
+      static_cast<unsigned>(reinterpret_cast<uintptr_t>(AS_LDS(const_cast<float*>(lds_dst))));
+  asm volatile(
+      "s_mov_b32 m0, %0\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2"
+      :
+      : "s"(lds_addr), "v"(lane_byte_offset), "s"(row_base)
+      : "memory", "m0");
+}
+
+__device__ __forceinline__ void wait_stage() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Vector load whose completion the compiler does not track (MODE 2 counts
+// vmcnt by hand, see the kernel).
+// (wave-uniform base in SGPRs + 32-bit per-lane byte offset: no 64-bit VGPR
+// address arithmetic, no VGPR pairs to keep alive.)
+__device__ __forceinline__ int untracked_load_i32(const int* base, unsigned byte_offset) {
+  int v;
+  asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(byte_offset), "s"(base) : "memory");
+  return v;
+}
+__device__ __forceinline__ float untracked_load_f32(const float* base, unsigned byte_offset) {
+  float v;
+  asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(byte_offset), "s"(base) : "memory");
+  return v;
+}
+// Wait until at most N vector-memory operations of this wave are in flight;
+// the operands tie later uses of the loaded registers to the wait.
+template <int N>
+__device__ __forceinline__ void wait_vm(int& a, float& b, int& c) {
+  asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+}
+
+// One nonzero against the staged tile: acc[0..3] += a * (float4 read from the tile).
+#define SPUTNIK_HIP_FMA4(ACC, A, B)          \
+  do {                                       \
+    (ACC)[0] = fmaf((A), (B).x, (ACC)[0]);   \
+    (ACC)[1] = fmaf((A), (B).y, (ACC)[1]);   \
+    (ACC)[2] = fmaf((A), (B).z, (ACC)[2]);   \
+    (ACC)[3] = fmaf((A), (B).w, (ACC)[3]);   \
+  } while (0)
+
+// DPP row_newbcast: every lane of a 16-lane row reads lane U of ITS row.  With
+// the same 16 entries replicated in all four rows this is a wave-wide
+// broadcast of entry U that costs one VALU op and no SGPR round trip.
+template <int U>
+__device__ __forceinline__ int row_bcast_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, 0x150 + U, 0xF, 0xF, true);
+}
+template <int U>
+__device__ __forceinline__ float row_bcast_f(float v) {
+  return __builtin_bit_cast(float, row_bcast_i<U>(__builtin_bit_cast(int, v)));
+}
+
+// Four nonzeros G..G+3 of the replicated 16-entry set (roff = byte offset of
+// the B row inside the staged tile, rval = value; both per entry lane).
+template <int G>
+__device__ __forceinline__ void dpp_group4(float (&acc)[4], int roff, float rval,
+                                           const char* __restrict__ lane_base) {
+  const int o0 = row_bcast_i<G + 0>(roff), o1 = row_bcast_i<G + 1>(roff);
+  const int o2 = row_bcast_i<G + 2>(roff), o3 = row_bcast_i<G + 3>(roff);
+  const float4 b0 = *reinterpret_cast<const float4*>(lane_base + o0);
+  const float4 b1 = *reinterpret_cast<const float4*>(lane_base + o1);
+  const float4 b2 = *reinterpret_cast<const float4*>(lane_base + o2);
+  const float4 b3 = *reinterpret_cast<const float4*>(lane_base + o3);
+  const float a0 = row_bcast_f<G + 0>(rval), a1 = row_bcast_f<G + 1>(rval);
+  const float a2 = row_bcast_f<G + 2>(rval), a3 = row_bcast_f<G + 3>(rval);
+  SPUTNIK_HIP_FMA4(acc, a0, b0);
+  SPUTNIK_HIP_FMA4(acc, a1, b1);
+  SPUTNIK_HIP_FMA4(acc, a2, b2);
+  SPUTNIK_HIP_FMA4(acc, a3, b3);
+}
+
+constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v / 2); }
+
+}  // namespace tiled
+}  // namespace sputnik_hip
