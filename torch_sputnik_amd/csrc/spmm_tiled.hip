@@ -220,9 +220,8 @@ __global__ __launch_bounds__(Cfg::kThreads) void spmm_tiled_kernel(
     const int* __restrict__ row_indices, const float* __restrict__ values,
     int64_t values_stride, const int* __restrict__ column_indices,
     const int* __restrict__ table, const float* __restrict__ dense, int64_t dense_stride,
-    float* __restrict__ out, int64_t out_stride, const int* __restrict__ sorted_flag,
-    int debug) {
-  if (*sorted_flag == 0) return;  // unsorted columns: the row-gather kernel runs instead
+    float* __restrict__ out, int64_t out_stride, const int* __restrict__ row_ok,
+    const int* __restrict__ row_offsets, int debug) {
   // Timing experiments only (SPUTNIK_HIP_SPMM_DEBUG): 1 = no compute, 2 = no staging.
   const bool dbg_no_compute = debug & 1, dbg_no_stage = debug & 2;
 
@@ -254,6 +253,20 @@ __global__ __launch_bounds__(Cfg::kThreads) void spmm_tiled_kernel(
 
   const int n0 = ntile * BN;
   const int slot0 = mblock * Cfg::kBM + wave * RPW;
+
+  // Row blocks whose column indices do not ascend inside rows cannot be cut by
+  // K chunk: they take the order-independent path (B gathered from L2).
+  if (!block_rows_ok(row_ok, mblock * Cfg::kBM, Cfg::kBM)) {
+    for (int r = 0; r < RPW; ++r) {
+      const int slot = slot0 + r;
+      if (slot >= m) break;
+      const int row = row_indices[slot];
+      const float4 acc4 = gather_row_strip(values, column_indices, row_offsets[row],
+                                           row_offsets[row + 1], dense + n0 + lane * VEC, n);
+      *reinterpret_cast<float4*>(out + static_cast<int64_t>(row) * n + n0 + lane * VEC) = acc4;
+    }
+    return;
+  }
 
   float acc[RPW][VEC];
 #pragma unroll
@@ -436,7 +449,10 @@ inline bool tiled_applicable(int m, int k, int n, int nonzeros) {
 }  // namespace
 
 size_t spmm_tiled_workspace_bytes(int m, int k, int n, int nonzeros) {
-  if (tiled_applicable(m, k, n, nonzeros)) return kFlagBytes + make_plan<CfgLarge>(m, k, n).table_bytes;
+  if (tiled_applicable(m, k, n, nonzeros)) {
+    const Plan plan = make_plan<CfgLarge>(m, k, n);
+    return row_ok_bytes(plan.slots) + plan.table_bytes;
+  }
   if (spmm_tiled64_applicable(m, k, n, nonzeros)) return spmm_tiled64_workspace_bytes(m, k);
   return 0;
 }
@@ -457,16 +473,14 @@ int spmm_tiled_plan(int m, int k, int n, int nonzeros, const int* row_indices,
   }
   using Cfg = CfgLarge;
   const Plan plan = make_plan<Cfg>(m, k, n);
-  if (workspace == nullptr || workspace_bytes < kFlagBytes + plan.table_bytes ||
+  if (workspace == nullptr || workspace_bytes < row_ok_bytes(plan.slots) + plan.table_bytes ||
       !aligned_to(workspace, 16))
     return 0;
-  int* flag = static_cast<int*>(workspace);
-  int* table = reinterpret_cast<int*>(static_cast<char*>(workspace) + kFlagBytes);
-  const hipError_t e = hipMemsetAsync(flag, 1, sizeof(int), stream);  // nonzero = "sorted so far"
-  if (e != hipSuccess) return static_cast<int>(e);
+  int* row_ok = static_cast<int*>(workspace);
+  int* table = reinterpret_cast<int*>(static_cast<char*>(workspace) + row_ok_bytes(plan.slots));
   hipLaunchKernelGGL((spmm_chunk_table_kernel<ilog2(Cfg::kBK)>), dim3(ceil_div(plan.slots, 4)),
                      dim3(256), 0, stream, m, k, plan.slots, plan.nchunks, row_indices,
-                     row_offsets, column_indices, table, flag);
+                     row_offsets, column_indices, table, row_ok);
   *planned = true;
   return launch_status();
 }
@@ -491,15 +505,15 @@ int spmm_tiled_exec(int m, int k, int n, int nonzeros, int replicas, const int* 
   }
   using Cfg = CfgLarge;
   const Plan plan = make_plan<Cfg>(m, k, n);
-  if (workspace == nullptr || workspace_bytes < kFlagBytes + plan.table_bytes ||
+  if (workspace == nullptr || workspace_bytes < row_ok_bytes(plan.slots) + plan.table_bytes ||
       !aligned_to(workspace, 16))
     return 0;
   if (!aligned_to(dense, 16) || !aligned_to(out, 16) || dense_stride % 4 != 0 ||
       out_stride % 4 != 0 || replicas > kMaxGridYZ)
     return 0;
-  const int* flag = static_cast<const int*>(workspace);
-  const int* table =
-      reinterpret_cast<const int*>(static_cast<const char*>(workspace) + kFlagBytes);
+  const int* row_ok = static_cast<const int*>(workspace);
+  const int* table = reinterpret_cast<const int*>(static_cast<const char*>(workspace) +
+                                                  row_ok_bytes(plan.slots));
 
   const int blocks = (plan.slots / Cfg::kBM) * plan.n_tiles;
   static const int mode = [] {
@@ -514,27 +528,20 @@ int spmm_tiled_exec(int m, int k, int n, int nonzeros, int replicas, const int* 
     hipLaunchKernelGGL((spmm_tiled_kernel<Cfg, 0>), dim3(blocks, replicas), dim3(Cfg::kThreads),
                        0, stream, m, k, n, nonzeros, plan.slots, plan.nchunks, plan.n_tiles,
                        row_indices, values, values_stride, column_indices, table, dense,
-                       dense_stride, out, out_stride, flag, debug);
+                       dense_stride, out, out_stride, row_ok, row_offsets, debug);
   } else if (mode == 1) {
     hipLaunchKernelGGL((spmm_tiled_kernel<Cfg, 1>), dim3(blocks, replicas), dim3(Cfg::kThreads),
                        0, stream, m, k, n, nonzeros, plan.slots, plan.nchunks, plan.n_tiles,
                        row_indices, values, values_stride, column_indices, table, dense,
-                       dense_stride, out, out_stride, flag, debug);
+                       dense_stride, out, out_stride, row_ok, row_offsets, debug);
   } else {
     hipLaunchKernelGGL((spmm_tiled_kernel<Cfg, 2>), dim3(blocks, replicas), dim3(Cfg::kThreads),
                        0, stream, m, k, n, nonzeros, plan.slots, plan.nchunks, plan.n_tiles,
                        row_indices, values, values_stride, column_indices, table, dense,
-                       dense_stride, out, out_stride, flag, debug);
+                       dense_stride, out, out_stride, row_ok, row_offsets, debug);
   }
-  int st = launch_status();
-  if (st != 0) return st;
-
-  // Fallback for unsorted column indices: its skip test is "flag != 0", i.e. it
-  // exits at once when the tiled kernel did the work.
-  st = spmm_rowgather_launch(m, n, replicas, row_indices, values, values_stride, row_offsets,
-                             column_indices, dense, dense_stride, out, out_stride, flag, stream);
   *handled = true;
-  return st;
+  return launch_status();
 }
 
 }  // namespace sputnik_hip

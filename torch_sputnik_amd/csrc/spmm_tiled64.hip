@@ -15,10 +15,13 @@
 // row, this is conflict-free).  Groups whose row has fewer entries in the
 // chunk run the extra steps with a zero value.
 //
-// Register budget is small here (32 accumulators), so the entry windows of the
-// NEXT chunk are requested at the start of the current one into a second
-// register set: they have a whole chunk to land and the end-of-chunk
-// `vmcnt(0)` (needed for the B copy) costs nothing.
+// Register budget is small here (16 accumulators), so every row keeps TWO
+// 16-entry windows per chunk, and the windows of the NEXT chunk are requested
+// at the start of the current one into a second register set: they have a
+// whole chunk to land and the end-of-chunk `vmcnt(0)` (needed for the B copy)
+// costs nothing.  Rows with more than 32 entries in one chunk fetch the rest on
+// demand.  The four row groups of a wave run their own number of steps
+// (EXEC-masked), so no LDS traffic is spent on the shorter rows' padding.
 #include "spmm_tiled_common.h"
 
 namespace sputnik_hip {
@@ -35,7 +38,7 @@ using namespace tiled;
 
 constexpr int kBN = 64;     // columns of C per workgroup
 constexpr int kWaves = 8;   // waves per workgroup
-constexpr int kRQ = 8;      // row quads per wave (4 rows each)
+constexpr int kRQ = 4;      // row quads per wave (4 rows each)
 constexpr int kBK = 128;    // rows of B per LDS stage
 constexpr int kBM = kWaves * kRQ * 4;
 constexpr int kThreads = kWaves * kWave;
@@ -65,8 +68,8 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled64_kernel(
     const int* __restrict__ row_indices, const float* __restrict__ values,
     int64_t values_stride, const int* __restrict__ column_indices,
     const int* __restrict__ table, const float* __restrict__ dense, int64_t dense_stride,
-    float* __restrict__ out, int64_t out_stride, const int* __restrict__ sorted_flag) {
-  if (*sorted_flag == 0) return;  // unsorted columns: the row-gather kernel runs instead
+    float* __restrict__ out, int64_t out_stride, const int* __restrict__ row_ok,
+    const int* __restrict__ row_offsets) {
   __shared__ float tile[2][kTileFloats];
 
   const int lane = threadIdx.x % kWave;
@@ -83,6 +86,21 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled64_kernel(
   const int slot0 = mblock * kBM + wave * (kRQ * 4);  // this wave's first row slot
   const int last = nonzeros - 1;
 
+  // Row blocks whose column indices do not ascend inside rows take the
+  // order-independent path (B gathered from L2), one row per 16-lane group.
+  if (!block_rows_ok(row_ok, mblock * kBM, kBM)) {
+    for (int t = 0; t < kRQ; ++t) {
+      const int slot = slot0 + 4 * t + g;
+      if (slot < m) {
+        const int row = row_indices[slot];
+        const float4 acc4 = gather_row_strip(values, column_indices, row_offsets[row],
+                                             row_offsets[row + 1], dense + n0 + i * 4, n);
+        *reinterpret_cast<float4*>(out + static_cast<int64_t>(row) * n + n0 + i * 4) = acc4;
+      }
+    }
+    return;
+  }
+
   float acc[kRQ][4];
 #pragma unroll
   for (int t = 0; t < kRQ; ++t)
@@ -90,17 +108,22 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled64_kernel(
     for (int v = 0; v < 4; ++v) acc[t][v] = 0.f;
 
   // Per quad t, this lane's row is slot0 + 4t + g: stream position at the start
-  // / end of the current chunk, and its first 16 entries (lane i = entry i).
+  // / end of the current chunk, and its first 32 entries (window w, lane i =
+  // entry 16w + i).
+  constexpr int kWin = 2;
   const int* __restrict__ my_table = table + slot0 + g;
-  int ps[kRQ], pe[kRQ], wcol[kRQ];
-  float wval[kRQ];
+  int ps[kRQ], pe[kRQ], wcol[kRQ][kWin];
+  float wval[kRQ][kWin];
 #pragma unroll
   for (int t = 0; t < kRQ; ++t) {
     ps[t] = my_table[4 * t];
     pe[t] = my_table[slots + 4 * t];
-    const int idx = min(ps[t] + i, last);
-    wcol[t] = column_indices[idx];
-    wval[t] = values[idx];
+#pragma unroll
+    for (int w = 0; w < kWin; ++w) {
+      const int idx = min(ps[t] + 16 * w + i, last);
+      wcol[t][w] = column_indices[idx];
+      wval[t][w] = values[idx];
+    }
   }
 
   stage_chunk64(tile[0], dense, n, k, n0, 0, wave, lane);
@@ -113,14 +136,17 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled64_kernel(
     if (more) stage_chunk64(tile[buf ^ 1], dense, n, k, n0, (c + 1) * kBK, wave, lane);
 
     // Next chunk's positions and entry windows: requested now, used after the barrier.
-    int pe_next[kRQ], ncol[kRQ];
-    float nval[kRQ];
+    int pe_next[kRQ], ncol[kRQ][kWin];
+    float nval[kRQ][kWin];
 #pragma unroll
     for (int t = 0; t < kRQ; ++t) {
       pe_next[t] = more ? my_table[static_cast<int64_t>(c + 2) * slots + 4 * t] : pe[t];
-      const int idx = min(pe[t] + i, last);
-      ncol[t] = more ? column_indices[idx] : 0;
-      nval[t] = more ? values[idx] : 0.f;
+#pragma unroll
+      for (int w = 0; w < kWin; ++w) {
+        const int idx = min(pe[t] + 16 * w + i, last);
+        ncol[t][w] = more ? column_indices[idx] : 0;
+        nval[t][w] = more ? values[idx] : 0.f;
+      }
     }
 
     const char* __restrict__ lane_base = reinterpret_cast<const char*>(&tile[buf][0] + i * 4);
@@ -128,26 +154,27 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled64_kernel(
 
 #pragma unroll
     for (int t = 0; t < kRQ; ++t) {
-      const int cnt = pe[t] - ps[t];  // this group's row; same in its 16 lanes
-      // longest of the four rows decides the number of steps (wave-uniform)
-      const int steps = max(max(__builtin_amdgcn_readlane(cnt, 0), __builtin_amdgcn_readlane(cnt, 16)),
-                            max(__builtin_amdgcn_readlane(cnt, 32), __builtin_amdgcn_readlane(cnt, 48)));
-      for (int w0 = 0; w0 < steps; w0 += 16) {
-        int ecol = wcol[t];
-        float eval = wval[t];
-        if (w0 > 0) {  // rows longer than one window inside a chunk: fetch on demand
-          const int idx = min(ps[t] + w0 + i, last);
-          ecol = column_indices[idx];
-          eval = values[idx];
-        }
-        const bool valid = w0 + i < cnt;
+      const int cnt = pe[t] - ps[t];  // this group's row; the same in its 16 lanes
+      // One 16-entry window of this group's row: groups of four entries, each
+      // group of lanes stopping at its own row's count (EXEC-masked).
+      auto window = [&](int ecol, float eval, int w0) {
+        const int left = cnt - w0;  // entries of this row at or after the window start
+        const bool valid = i < left;
         const int roff = valid ? ((ecol - kc) * (kBN * 4)) : 0;
         const float rval = valid ? eval : 0.f;
-        const int n16 = steps - w0;
-        dpp_group4<0>(acc[t], roff, rval, lane_base);
-        if (n16 > 4) dpp_group4<4>(acc[t], roff, rval, lane_base);
-        if (n16 > 8) dpp_group4<8>(acc[t], roff, rval, lane_base);
-        if (n16 > 12) dpp_group4<12>(acc[t], roff, rval, lane_base);
+        if (left > 0) dpp_group4<0>(acc[t], roff, rval, lane_base);
+        if (left > 4) dpp_group4<4>(acc[t], roff, rval, lane_base);
+        if (left > 8) dpp_group4<8>(acc[t], roff, rval, lane_base);
+        if (left > 12) dpp_group4<12>(acc[t], roff, rval, lane_base);
+      };
+#pragma unroll
+      for (int w = 0; w < kWin; ++w) window(wcol[t][w], wval[t][w], 16 * w);
+      // longer rows (more than 32 entries inside one chunk): fetch on demand
+      const int longest = max(max(__builtin_amdgcn_readlane(cnt, 0), __builtin_amdgcn_readlane(cnt, 16)),
+                              max(__builtin_amdgcn_readlane(cnt, 32), __builtin_amdgcn_readlane(cnt, 48)));
+      for (int w0 = 16 * kWin; w0 < longest; w0 += 16) {
+        const int idx = min(ps[t] + w0 + i, last);
+        window(column_indices[idx], values[idx], w0);
       }
     }
 
@@ -155,8 +182,11 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled64_kernel(
     for (int t = 0; t < kRQ; ++t) {
       ps[t] = pe[t];
       pe[t] = pe_next[t];
-      wcol[t] = ncol[t];
-      wval[t] = nval[t];
+#pragma unroll
+      for (int w = 0; w < kWin; ++w) {
+        wcol[t][w] = ncol[t][w];
+        wval[t][w] = nval[t][w];
+      }
     }
     wait_vm<0>();     // the next B tile has landed (the windows landed long ago)
     __syncthreads();  // ... for every wave, and the current buffer is free
@@ -185,19 +215,18 @@ bool spmm_tiled64_applicable(int m, int k, int n, int nonzeros) {
 }
 
 size_t spmm_tiled64_workspace_bytes(int m, int k) {
-  return kFlagBytes + sizeof(int) * static_cast<size_t>(chunks_of(k) + 1) * slots_of(m);
+  return row_ok_bytes(slots_of(m)) +
+         sizeof(int) * static_cast<size_t>(chunks_of(k) + 1) * slots_of(m);
 }
 
 int spmm_tiled64_plan(int m, int k, const int* row_indices, const int* row_offsets,
                       const int* column_indices, void* workspace, hipStream_t stream) {
-  int* flag = static_cast<int*>(workspace);
-  int* table = reinterpret_cast<int*>(static_cast<char*>(workspace) + kFlagBytes);
-  const hipError_t e = hipMemsetAsync(flag, 1, sizeof(int), stream);  // nonzero = "sorted so far"
-  if (e != hipSuccess) return static_cast<int>(e);
   const int slots = slots_of(m);
+  int* row_ok = static_cast<int*>(workspace);
+  int* table = reinterpret_cast<int*>(static_cast<char*>(workspace) + row_ok_bytes(slots));
   hipLaunchKernelGGL((spmm_chunk_table_kernel<ilog2(kBK)>), dim3(ceil_div(slots, 4)), dim3(256),
                      0, stream, m, k, slots, chunks_of(k), row_indices, row_offsets,
-                     column_indices, table, flag);
+                     column_indices, table, row_ok);
   return launch_status();
 }
 
@@ -206,19 +235,16 @@ int spmm_tiled64_exec(int m, int k, int n, int nonzeros, int replicas, const int
                       const int* column_indices, const float* dense, int64_t dense_stride,
                       float* out, int64_t out_stride, const void* workspace,
                       hipStream_t stream) {
-  const int* flag = static_cast<const int*>(workspace);
-  const int* table =
-      reinterpret_cast<const int*>(static_cast<const char*>(workspace) + kFlagBytes);
   const int slots = slots_of(m);
+  const int* row_ok = static_cast<const int*>(workspace);
+  const int* table =
+      reinterpret_cast<const int*>(static_cast<const char*>(workspace) + row_ok_bytes(slots));
   const int n_tiles = n / kBN;
   hipLaunchKernelGGL(spmm_tiled64_kernel, dim3((slots / kBM) * n_tiles, replicas), dim3(kThreads),
                      0, stream, m, k, n, nonzeros, slots, chunks_of(k), n_tiles, row_indices,
                      values, values_stride, column_indices, table, dense, dense_stride, out,
-                     out_stride, flag);
-  const int st = launch_status();
-  if (st != 0) return st;
-  return spmm_rowgather_launch(m, n, replicas, row_indices, values, values_stride, row_offsets,
-                               column_indices, dense, dense_stride, out, out_stride, flag, stream);
+                     out_stride, row_ok, row_offsets);
+  return launch_status();
 }
 
 }  // namespace sputnik_hip

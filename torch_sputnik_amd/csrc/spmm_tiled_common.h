@@ -9,13 +9,14 @@
 namespace sputnik_hip {
 namespace tiled {
 
-constexpr int kFlagBytes = 256;  // flag word + padding so the table stays aligned
+// Workspace layout: [row_ok: one int per row slot][chunk table].
+inline size_t row_ok_bytes(int slots) { return (sizeof(int) * static_cast<size_t>(slots) + 255) / 256 * 256; }
 
 #define AS_GLOBAL(p) ((__attribute__((address_space(1))) void*)(p))
 #define AS_LDS(p) ((__attribute__((address_space(3))) void*)(p))
 
 // ---------------------------------------------------------------------------
-// Pre-pass: chunk table + order check.  One wave per row slot.
+// Pre-pass: chunk table + per-row order check.  One wave per row slot.
 // table[c * slots + slot], c in [0, nchunks]: index of the first nonzero of
 // row row_indices[slot] whose column is >= c*BK (row end if none).  Padding
 // slots (slot >= m) get 0 everywhere, i.e. empty rows.
@@ -24,12 +25,13 @@ template <int BK_LOG2>
 __global__ __launch_bounds__(256) void spmm_chunk_table_kernel(
     int m, int k, int slots, int nchunks, const int* __restrict__ row_indices,
     const int* __restrict__ row_offsets, const int* __restrict__ column_indices,
-    int* __restrict__ table, int* __restrict__ sorted_flag) {
+    int* __restrict__ table, int* __restrict__ row_ok) {
   const int lane = threadIdx.x % kWave;
   const int slot = blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
   if (slot >= slots) return;
   if (slot >= m) {
     for (int c = lane; c <= nchunks; c += kWave) table[static_cast<int64_t>(c) * slots + slot] = 0;
+    if (lane == 0) row_ok[slot] = 1;
     return;
   }
   const int row = row_indices[slot];
@@ -57,7 +59,10 @@ __global__ __launch_bounds__(256) void spmm_chunk_table_kernel(
   }
   for (int c = last + 1 + lane; c <= nchunks; c += kWave)
     table[static_cast<int64_t>(c) * slots + slot] = p1;
-  if (!ok) *sorted_flag = 0;
+  // 1 = this row's columns ascend and are in range (the tiled kernels rely on
+  // it); every slot writes its own word, so the array needs no initialisation.
+  const bool wave_ok = __builtin_amdgcn_ballot_w64(!ok) == 0;
+  if (lane == 0) row_ok[slot] = wave_ok ? 1 : 0;
 }
 
 // Direct global->LDS copy of one 1 KiB row segment (64 lanes x 16 B):
@@ -145,6 +150,35 @@ __device__ __forceinline__ void dpp_group4(float (&acc)[4], int roff, float rval
   SPUTNIK_HIP_FMA4(acc, a1, b1);
   SPUTNIK_HIP_FMA4(acc, a2, b2);
   SPUTNIK_HIP_FMA4(acc, a3, b3);
+}
+
+// True iff every one of the workgroup's `rows` row slots (starting at
+// block_slot0) passed the pre-pass check.  Contains a workgroup barrier.
+__device__ __forceinline__ bool block_rows_ok(const int* __restrict__ row_ok, int block_slot0,
+                                              int rows) {
+  int ok = 1;
+  for (int s = threadIdx.x; s < rows; s += blockDim.x) ok &= row_ok[block_slot0 + s];
+  return __syncthreads_and(ok) != 0;
+}
+
+// Order-independent path for ONE row strip of 4 columns per lane: walks the
+// row's nonzeros in storage order and gathers B from global memory.  Used by
+// the tiled kernels for row blocks whose columns do not ascend.
+__device__ __forceinline__ float4 gather_row_strip(const float* __restrict__ values,
+                                                   const int* __restrict__ column_indices,
+                                                   int p0, int p1,
+                                                   const float* __restrict__ dense_col, int n) {
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int p = p0; p < p1; ++p) {
+    const float a = values[p];
+    const float4 b =
+        *reinterpret_cast<const float4*>(dense_col + static_cast<int64_t>(column_indices[p]) * n);
+    acc.x = fmaf(a, b.x, acc.x);
+    acc.y = fmaf(a, b.y, acc.y);
+    acc.z = fmaf(a, b.z, acc.z);
+    acc.w = fmaf(a, b.w, acc.w);
+  }
+  return acc;
 }
 
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v / 2); }
