@@ -147,9 +147,10 @@ def other_ops(dev):
     ri, ro, ci, nnz = random_csr(s, s, 0.1, dev, seed=7)
     q, kk, v = (uniform((reps, s, d), dev, 11 + i) for i in range(3))
     scores = torch.empty(reps, nnz, device=dev)
+    sd_ws = torch.empty(capi.sddmm_workspace_bytes(s, d, s, nnz) + 16, dtype=torch.uint8, device=dev)
     probs = torch.empty_like(scores)
     ctx = torch.empty(reps, s, d, device=dev)
-    t = event_time_ms(lambda: capi.sddmm_batched(s, d, s, reps, ri, ro, ci, q, kk, scores), 20)
+    t = event_time_ms(lambda: capi.sddmm_batched(s, d, s, reps, ri, ro, ci, q, kk, scores, sd_ws), 20)
     by = reps * (8.0 * s * d + 4.0 * nnz) + 4.0 * nnz + 4.0 * (2 * s + 1)
     res["sddmm_c3"] = {"ms": t, "gflops": 2.0 * nnz * d * reps / t / 1e6, "alg_gbs": by / t / 1e6}
     t = event_time_ms(lambda: capi.sparse_softmax_batched(s, reps, scores, ri, ro, ci, probs), 20)

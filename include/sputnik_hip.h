@@ -115,12 +115,17 @@ SPUTNIK_HIP_API int sputnik_hip_sddmm(int m, int k, int n, int nonzeros,
                       const float* rhs, float* out,
                       sputnik_hip_stream_t stream);
 
+/* `workspace` may be NULL (workspace-free kernel only); otherwise it must hold
+ * sputnik_hip_sddmm_workspace_bytes(m,k,n,nonzeros) (0 = none needed). */
+SPUTNIK_HIP_API size_t sputnik_hip_sddmm_workspace_bytes(int m, int k, int n, int nonzeros);
+
 SPUTNIK_HIP_API int sputnik_hip_sddmm_batched(int m, int k, int n, int nonzeros, int replicas,
                               const int* row_indices, const int* row_offsets,
                               const int* column_indices, const float* lhs,
                               int64_t lhs_stride, const float* rhs,
                               int64_t rhs_stride, float* out,
-                              int64_t out_stride, sputnik_hip_stream_t stream);
+                              int64_t out_stride, void* workspace,
+                              size_t workspace_bytes, sputnik_hip_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Sparse softmax: per CSR row, exp(x - max) / sum(exp(x - max)) over the

@@ -159,6 +159,9 @@ SDDMM_SHAPES = [
     (1024, 64, 1024, 0.9, 2),  # attention block geometry (config 3)
     (200, 300, 150, 0.8, 1),   # k > 256: panels
     (64, 1100, 96, 0.9, 2),    # k > 1024: several panels, out accumulation
+    (300, 64, 500, 0.8, 3),    # tiled kernel, ragged row / column blocks
+    (256, 128, 256, 0.5, 2),   # tiled kernel, k = 128, > 32 entries per row and chunk
+    (64, 64, 64, 0.0, 1),      # tiled kernel, dense mask
 ]
 
 
@@ -170,8 +173,9 @@ def test_sddmm_capi_vs_oracle(capi, dev, m, k, n, sparsity, replicas):
     rhs = rng.uniform(-1, 1, size=(replicas, n, k)).astype(np.float32)
     want = c_oracle.sddmm(m, n, ro, ci, lhs, rhs)
     out = torch.full((replicas, len(ci)), float("nan"), device=dev)
+    ws = torch.empty(capi.sddmm_workspace_bytes(m, k, n, len(ci)) + 16, dtype=torch.uint8, device=dev)
     capi.sddmm_batched(m, k, n, replicas, T(ri, dev), T(ro, dev), T(ci, dev), T(lhs, dev),
-                       T(rhs, dev), out)
+                       T(rhs, dev), out, ws)
     got = out.cpu().numpy()
     assert not np.isnan(got).any()
     # inner products of k terms in [-1,1]: scale the tolerance by sqrt(k)-ish magnitude

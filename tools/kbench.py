@@ -65,10 +65,11 @@ def bench_attention_ops(dev, iters, s=1024, d=64, replicas=64, density=0.1):
     kk = torch.rand(replicas, s, d, device=dev)
     v = torch.rand(replicas, s, d, device=dev)
     scores = torch.empty(replicas, nnz, device=dev)
+    sd_ws = torch.empty(capi.sddmm_workspace_bytes(s, d, s, nnz) + 16, dtype=torch.uint8, device=dev)
     probs = torch.empty(replicas, nnz, device=dev)
     ctx = torch.empty(replicas, s, d, device=dev)
     rows = []
-    med, best = timeit(lambda: capi.sddmm_batched(s, d, s, replicas, ri, ro, ci, q, kk, scores), iters)
+    med, best = timeit(lambda: capi.sddmm_batched(s, d, s, replicas, ri, ro, ci, q, kk, scores, sd_ws), iters)
     by = replicas * (4.0 * (2 * s * d) + 4 * nnz) + 4 * nnz + 4 * (2 * s + 1)
     rows.append(dict(op="sddmm", s=s, d=d, replicas=replicas, nnz=nnz, ms=med * 1e3, ms_min=best * 1e3,
                      gflops=2.0 * nnz * d * replicas / med / 1e9, alg_gbs=by / med / 1e9,

@@ -31,8 +31,10 @@ SIGNATURES = {
                                                                 _c_ptr, _c_ptr, _c_i64, _c_ptr,
                                                                 _c_i64, _c_ptr, _c_size, _c_ptr]),
     "sputnik_hip_sddmm": (_c_int, [_c_int] * 4 + [_c_ptr] * 7),
+    "sputnik_hip_sddmm_workspace_bytes": (_c_size, [_c_int] * 4),
     "sputnik_hip_sddmm_batched": (_c_int, [_c_int] * 5 + [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64,
-                                                         _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr]),
+                                                         _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr,
+                                                         _c_size, _c_ptr]),
     "sputnik_hip_sparse_softmax": (_c_int, [_c_int] * 3 + [_c_ptr] * 6),
     "sputnik_hip_sparse_softmax_batched": (_c_int, [_c_int] * 4 + [_c_ptr, _c_i64, _c_ptr, _c_ptr,
                                                                   _c_ptr, _c_ptr, _c_i64, _c_ptr]),
@@ -130,7 +132,12 @@ def spmm_batched_planned(m, k, n, replicas, row_indices, values, values_stride, 
     return out
 
 
-def sddmm_batched(m, k, n, replicas, row_indices, row_offsets, column_indices, lhs, rhs, out):
+def sddmm_workspace_bytes(m, k, n, nonzeros):
+    return lib().sputnik_hip_sddmm_workspace_bytes(m, k, n, nonzeros)
+
+
+def sddmm_batched(m, k, n, replicas, row_indices, row_offsets, column_indices, lhs, rhs, out,
+                  workspace=None):
     nonzeros = column_indices.numel()
     for t, d, nm in ((row_indices, torch.int32, "row_indices"),
                      (row_offsets, torch.int32, "row_offsets"),
@@ -140,7 +147,8 @@ def sddmm_batched(m, k, n, replicas, row_indices, row_offsets, column_indices, l
         _require(t, d, nm)
     _check(lib().sputnik_hip_sddmm_batched(
         m, k, n, nonzeros, replicas, _ptr(row_indices), _ptr(row_offsets), _ptr(column_indices),
-        _ptr(lhs), m * k, _ptr(rhs), n * k, _ptr(out), nonzeros, _stream(out)),
+        _ptr(lhs), m * k, _ptr(rhs), n * k, _ptr(out), nonzeros, _ptr(workspace),
+        0 if workspace is None else workspace.numel() * workspace.element_size(), _stream(out)),
         "sputnik_hip_sddmm_batched")
     return out
 

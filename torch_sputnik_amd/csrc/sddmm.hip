@@ -15,6 +15,15 @@
 #include "wave_utils.h"
 
 namespace sputnik_hip {
+
+bool sddmm_tiled_applicable(int m, int k, int n, int nonzeros, const float* lhs,
+                            int64_t lhs_stride, const float* rhs, int64_t rhs_stride);
+size_t sddmm_tiled_workspace_bytes(int m, int k, int n, int nonzeros);
+int sddmm_tiled_launch(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
+                       const int* row_offsets, const int* column_indices, const float* lhs,
+                       int64_t lhs_stride, const float* rhs, int64_t rhs_stride, float* out,
+                       int64_t out_stride, void* workspace, hipStream_t stream);
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -136,11 +145,17 @@ using namespace sputnik_hip;
 
 extern "C" {
 
+size_t sputnik_hip_sddmm_workspace_bytes(int m, int k, int n, int nonzeros) {
+  if (m <= 0 || k <= 0 || n <= 0 || nonzeros <= 0) return 0;
+  return sddmm_tiled_workspace_bytes(m, k, n, nonzeros);
+}
+
 int sputnik_hip_sddmm_batched(int m, int k, int n, int nonzeros, int replicas,
                               const int* row_indices, const int* row_offsets,
                               const int* column_indices, const float* lhs, int64_t lhs_stride,
                               const float* rhs, int64_t rhs_stride, float* out,
-                              int64_t out_stride, sputnik_hip_stream_t stream) {
+                              int64_t out_stride, void* workspace, size_t workspace_bytes,
+                              sputnik_hip_stream_t stream) {
   if (m < 0 || k < 0 || n < 0 || nonzeros < 0 || replicas < 0) return SPUTNIK_HIP_INVALID_ARGUMENT;
   if (m == 0 || nonzeros == 0 || replicas == 0) return 0;
   if (k == 0) {
@@ -151,6 +166,12 @@ int sputnik_hip_sddmm_batched(int m, int k, int n, int nonzeros, int replicas,
     }
     return 0;
   }
+  if (workspace != nullptr && aligned_to(workspace, 16) &&
+      sddmm_tiled_applicable(m, k, n, nonzeros, lhs, lhs_stride, rhs, rhs_stride) &&
+      workspace_bytes >= sddmm_tiled_workspace_bytes(m, k, n, nonzeros))
+    return sddmm_tiled_launch(m, k, n, nonzeros, replicas, row_indices, row_offsets,
+                              column_indices, lhs, lhs_stride, rhs, rhs_stride, out, out_stride,
+                              workspace, stream);
   int vec = vector_width(lhs, k, lhs_stride);
   vec = min(vec, vector_width(rhs, k, rhs_stride));
   switch (vec) {
@@ -170,7 +191,7 @@ int sputnik_hip_sddmm(int m, int k, int n, int nonzeros, const int* row_indices,
                       const int* row_offsets, const int* column_indices, const float* lhs,
                       const float* rhs, float* out, sputnik_hip_stream_t stream) {
   return sputnik_hip_sddmm_batched(m, k, n, nonzeros, 1, row_indices, row_offsets,
-                                   column_indices, lhs, 0, rhs, 0, out, 0, stream);
+                                   column_indices, lhs, 0, rhs, 0, out, 0, nullptr, 0, stream);
 }
 
 }  // extern "C"

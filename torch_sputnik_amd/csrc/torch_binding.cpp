@@ -177,12 +177,16 @@ Tensor sddmm(int64_t m64, int64_t n64, const Tensor& row_indices, const Tensor& 
   // 1-D whenever there is a single replica, as src/sddmm_cuda.cu:43 does.
   Tensor out = replicas == 1 ? at::empty({topo.nonzeros}, lhs.options())
                              : at::empty({replicas, topo.nonzeros}, lhs.options());
+  const size_t ws_bytes = sputnik_hip_sddmm_workspace_bytes(m, k, n, topo.nonzeros);
+  Tensor workspace;
+  if (ws_bytes > 0)
+    workspace = at::empty({static_cast<int64_t>(ws_bytes)}, lhs.options().dtype(at::kByte));
   check_status(sputnik_hip_sddmm_batched(
                    m, k, n, topo.nonzeros, replicas, topo.row_indices.data_ptr<int>(),
                    topo.row_offsets.data_ptr<int>(), topo.column_indices.data_ptr<int>(),
                    lhs.data_ptr<float>(), static_cast<int64_t>(m) * k, rhs.data_ptr<float>(),
                    static_cast<int64_t>(n) * k, out.data_ptr<float>(), topo.nonzeros,
-                   current_stream(lhs)),
+                   ws_bytes ? workspace.data_ptr() : nullptr, ws_bytes, current_stream(lhs)),
                "sddmm");
   return out;
 }
