@@ -6,71 +6,70 @@
 // source row ids ascend, which is the order ALG1 produces and what makes
 // values_t line up with column_indices_t deterministically.
 //
-// The source rows are cut into `chunks` contiguous row ranges; one wave owns
-// one chunk and walks its rows IN ORDER, 64 nonzeros of one row at a time (a
-// valid CSR row holds each column at most once, so the lanes of one step never
-// meet on a counter and the order of two entries of one column is the order
-// of their rows):
-//   1. count    per-chunk histogram of column ids (counters in LDS)
-//                 -> table[chunk][column]
-//   2. scan     table[:, column] made exclusive down the chunks, column
-//               totals scanned into out_row_offsets
-//   3. scatter  every chunk reloads its base offsets into LDS and walks its
-//               rows again, handing out slots with returning LDS adds.
-// Workspace: chunks*n + n int32 (table + column totals).  HBM traffic is
-// 16 B per nonzero (values and indices read and written once) + 8 B per
-// nonzero for the second read of the column ids + the table passes.
+// The slot of a nonzero (row r, column c) in the output is
+//     row_offsets_t[c] + #{nonzeros (r', c) with r' < r}.
+// The second term is split by chunks of R (8..32) consecutive source rows:
+// whole earlier chunks come from a [chunks][n] count table (scanned down the
+// chunks), and inside a chunk the rank is a popcount: a workgroup builds, in
+// LDS, one 32-bit mask per column with bit r-r0 set iff row r holds that
+// column (a CSR row holds a column at most once), so
+//     rank inside chunk = popc(mask[c] & ((1 << (r - r0)) - 1)).
+// All nonzeros of a chunk are therefore independent: no ordered walk, no
+// returning atomics -- every phase is flat data-parallel work.
+//   1. count    masks in LDS (ds_or_b32), table[chunk][c] = popc(mask[c])
+//   2. scan     table[:, c] made exclusive down the chunks; column totals
+//               scanned into out_row_offsets
+//   3. scatter  masks rebuilt in LDS, every nonzero computes its slot and
+//               moves (value(s), row id, optionally its source index)
+// Matrices with more than 8192 columns are processed in column ranges of 8192
+// (64 KiB of masks + slot bases) by separate workgroups.  R is chosen so that
+// a few hundred workgroups exist (m/R >= 256 where m allows).
+// HBM traffic: 16 B per nonzero (values and indices read and written once)
+// + 12 B per nonzero of repeated column-index reads + the small table.
 #include "common.h"
 #include "wave_utils.h"
 
 namespace sputnik_hip {
 namespace {
 
-constexpr int kMaxChunks = 1024;
-constexpr int kLdsColumns = 16384;  // 64 KiB of counters per wave
-constexpr int kScanGroups = 16;     // chunk groups per column in the table scan
+constexpr int kMaxRowsPerChunk = 32;  // one mask bit per row
+constexpr int kColsPerRange = 8192;   // 32 KiB of masks + 32 KiB of slot bases
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / kWave;
+constexpr int kScanGroups = 16;  // chunk groups per column in the table scan
 
-struct ChunkPlan {
-  int chunks;
-  int rows_per_chunk;
-};
+typedef unsigned int mask_t;
 
-inline ChunkPlan plan_chunks(int m) {
-  ChunkPlan p;
-  p.rows_per_chunk = max(1, ceil_div(m, kMaxChunks));
-  p.chunks = max(1, ceil_div(m, p.rows_per_chunk));
-  return p;
+// Builds mask[c - c0] for the columns [c0, c1) of the rows [row0, row1).
+// One wave per row at a time, lanes over the row's nonzeros (coalesced).
+__device__ __forceinline__ void build_masks(mask_t* __restrict__ masks, int row0, int row1, int c0,
+                                            int c1, const int* __restrict__ row_offsets,
+                                            const int* __restrict__ column_indices) {
+  const int lane = threadIdx.x % kWave;
+  const int wave = threadIdx.x / kWave;
+  for (int c = threadIdx.x; c < c1 - c0; c += kBlock) masks[c] = 0;
+  __syncthreads();
+  for (int row = row0 + wave; row < row1; row += kWaves) {
+    const mask_t bit = mask_t{1} << (row - row0);
+    const int p1 = row_offsets[row + 1];
+    for (int p = row_offsets[row] + lane; p < p1; p += kWave) {
+      const int c = column_indices[p];
+      if (c >= c0 && c < c1) atomicOr(&masks[c - c0], bit);
+    }
+  }
+  __syncthreads();
 }
 
-// One wave per chunk.  LDS_COUNTERS: counters live in LDS (n <= kLdsColumns),
-// otherwise in this chunk's row of the global table.
-template <bool LDS_COUNTERS>
-__global__ __launch_bounds__(kWave) void transpose_count_kernel(
+__global__ __launch_bounds__(kBlock) void transpose_count_kernel(
     int m, int n, int rows_per_chunk, const int* __restrict__ row_offsets,
     const int* __restrict__ column_indices, int* __restrict__ table) {
-  extern __shared__ int lds_counters[];
+  extern __shared__ mask_t masks[];
   const int chunk = blockIdx.x;
-  const int lane = threadIdx.x;
-  int* __restrict__ my_table = table + static_cast<int64_t>(chunk) * n;
-  int* counters = LDS_COUNTERS ? lds_counters : my_table;
-  for (int c = lane; c < n; c += kWave) counters[c] = 0;
-  if constexpr (LDS_COUNTERS) {
-    __syncthreads();
-  } else {
-    __threadfence();
-  }
-
-  const int row0 = chunk * rows_per_chunk;
-  const int row1 = min(m, row0 + rows_per_chunk);
-  // Counting does not need the row order: sweep the chunk's nonzeros flat.
-  const int p0 = row_offsets[row0];
-  const int p1 = row_offsets[row1];
-  for (int p = p0 + lane; p < p1; p += kWave) atomicAdd(&counters[column_indices[p]], 1);
-
-  if constexpr (LDS_COUNTERS) {
-    __syncthreads();
-    for (int c = lane; c < n; c += kWave) my_table[c] = lds_counters[c];
-  }
+  const int c0 = blockIdx.y * kColsPerRange, c1 = min(n, c0 + kColsPerRange);
+  const int row0 = chunk * rows_per_chunk, row1 = min(m, row0 + rows_per_chunk);
+  build_masks(masks, row0, row1, c0, c1, row_offsets, column_indices);
+  int* __restrict__ my_table = table + static_cast<int64_t>(chunk) * n + c0;
+  for (int c = threadIdx.x; c < c1 - c0; c += kBlock) my_table[c] = __popc(masks[c]);
 }
 
 // table[:, c] -> exclusive prefix down the chunks; totals[c] = column count.
@@ -117,8 +116,7 @@ __global__ __launch_bounds__(kScanBlock) void transpose_scan_totals_kernel(
   const int c1 = min(n, c0 + per);
   int mine = 0;
   for (int c = c0; c < c1; ++c) mine += totals[c];
-  // inclusive scan of `mine` over the wave
-  int incl = mine;
+  int incl = mine;  // inclusive scan of `mine` over the wave
 #pragma unroll
   for (int off = 1; off < kWave; off <<= 1) {
     const int up = __shfl_up(incl, off, kWave);
@@ -136,46 +134,50 @@ __global__ __launch_bounds__(kScanBlock) void transpose_scan_totals_kernel(
   if (tid == kScanBlock - 1) offsets[n] = running;
 }
 
-template <bool LDS_COUNTERS>
-__global__ __launch_bounds__(kWave) void transpose_scatter_kernel(
-    int m, int n, int nonzeros, int replicas, int rows_per_chunk,
-    const float* __restrict__ values, int64_t values_stride,
+__global__ __launch_bounds__(kBlock) void transpose_scatter_kernel(
+    int m, int n, int rows_per_chunk, int replicas, const float* __restrict__ values,
+    int64_t values_stride,
     const int* __restrict__ row_offsets, const int* __restrict__ column_indices,
-    int* __restrict__ table, const int* __restrict__ out_row_offsets,
+    const int* __restrict__ table, const int* __restrict__ out_row_offsets,
     float* __restrict__ out_values, int64_t out_values_stride,
     int* __restrict__ out_column_indices, int* __restrict__ out_permutation) {
-  extern __shared__ int lds_counters[];
+  extern __shared__ mask_t masks[];
   const int chunk = blockIdx.x;
-  const int lane = threadIdx.x;
-  int* __restrict__ my_table = table + static_cast<int64_t>(chunk) * n;
-  int* counters = LDS_COUNTERS ? lds_counters : my_table;
-  for (int c = lane; c < n; c += kWave) counters[c] = my_table[c] + out_row_offsets[c];
-  if constexpr (LDS_COUNTERS) {
-    __syncthreads();
-  } else {
-    __threadfence();
-  }
+  const int c0 = blockIdx.y * kColsPerRange, c1 = min(n, c0 + kColsPerRange);
+  const int row0 = chunk * rows_per_chunk, row1 = min(m, row0 + rows_per_chunk);
+  build_masks(masks, row0, row1, c0, c1, row_offsets, column_indices);
 
-  const int row0 = chunk * rows_per_chunk;
-  const int row1 = min(m, row0 + rows_per_chunk);
-  for (int row = row0; row < row1; ++row) {
-    const int p0 = row_offsets[row];
+  // Slot base of every column of the range for this chunk (coalesced reads,
+  // instead of two dependent gathers per nonzero).
+  int* __restrict__ base = reinterpret_cast<int*>(masks + (c1 - c0));
+  const int* __restrict__ my_table = table + static_cast<int64_t>(chunk) * n + c0;
+  for (int c = threadIdx.x; c < c1 - c0; c += kBlock) base[c] = out_row_offsets[c0 + c] + my_table[c];
+  __syncthreads();
+
+  const int lane = threadIdx.x % kWave;
+  const int wave = threadIdx.x / kWave;
+  for (int row = row0 + wave; row < row1; row += kWaves) {
+    const mask_t below = (mask_t{1} << (row - row0)) - 1;
     const int p1 = row_offsets[row + 1];
-    for (int p = p0 + lane; p < p1; p += kWave) {
-      const int pos = atomicAdd(&counters[column_indices[p]], 1);
+    for (int p = row_offsets[row] + lane; p < p1; p += kWave) {
+      const int c = column_indices[p];
+      if (c < c0 || c >= c1) continue;
+      const int pos = base[c - c0] + __popc(masks[c - c0] & below);
       out_column_indices[pos] = row;
       if (out_permutation != nullptr) out_permutation[pos] = p;
       for (int r = 0; r < replicas; ++r)
         out_values[r * out_values_stride + pos] = values[r * values_stride + p];
     }
-    // The next row's adds must come after this row's.  One wave issues its
-    // LDS instructions in order and the LDS executes them in order, so the
-    // LDS path needs nothing; the global-counter path drains its returning
-    // atomics before it starts the next row.
-    if constexpr (!LDS_COUNTERS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
-  (void)nonzeros;
 }
+
+// Rows per chunk: 8, 16 or 32, the largest that still leaves >= 256 chunks.
+inline int rows_per_chunk_of(int m) {
+  int r = kMaxRowsPerChunk;
+  while (r > 8 && m / r < 256) r /= 2;
+  return r;
+}
+inline int chunks_of(int m) { return ceil_div(m, rows_per_chunk_of(m)); }
 
 }  // namespace
 }  // namespace sputnik_hip
@@ -187,8 +189,7 @@ extern "C" {
 size_t sputnik_hip_csr_transpose_workspace_bytes(int m, int n, int nonzeros) {
   (void)nonzeros;
   if (m <= 0 || n <= 0) return 0;
-  const ChunkPlan plan = plan_chunks(m);
-  return sizeof(int) * (static_cast<size_t>(plan.chunks) * n + n);
+  return sizeof(int) * (static_cast<size_t>(chunks_of(m)) * n + n);
 }
 
 int sputnik_hip_csr_transpose(int m, int n, int nonzeros, int replicas, const float* values,
@@ -209,43 +210,32 @@ int sputnik_hip_csr_transpose(int m, int n, int nonzeros, int replicas, const fl
       workspace_bytes < sputnik_hip_csr_transpose_workspace_bytes(m, n, nonzeros))
     return SPUTNIK_HIP_INVALID_ARGUMENT;
 
-  const ChunkPlan plan = plan_chunks(m);
+  const int rows_per_chunk = rows_per_chunk_of(m);
+  const int chunks = chunks_of(m);
+  const int ranges = ceil_div(n, kColsPerRange);
+  if (ranges > kMaxGridYZ) return SPUTNIK_HIP_INVALID_ARGUMENT;
   int* table = static_cast<int*>(workspace);
-  int* totals = table + static_cast<size_t>(plan.chunks) * n;
-  const bool lds = n <= kLdsColumns;
-  const size_t lds_bytes = lds ? sizeof(int) * static_cast<size_t>(n) : 0;
+  int* totals = table + static_cast<size_t>(chunks) * n;
+  const size_t range_cols = static_cast<size_t>(min(n, kColsPerRange));
+  const size_t lds_bytes = sizeof(mask_t) * range_cols;
 
-  if (lds) {
-    hipLaunchKernelGGL(transpose_count_kernel<true>, dim3(plan.chunks), dim3(kWave), lds_bytes,
-                       stream, m, n, plan.rows_per_chunk, row_offsets, column_indices, table);
-  } else {
-    hipLaunchKernelGGL(transpose_count_kernel<false>, dim3(plan.chunks), dim3(kWave), 0, stream,
-                       m, n, plan.rows_per_chunk, row_offsets, column_indices, table);
-  }
+  hipLaunchKernelGGL(transpose_count_kernel, dim3(chunks, ranges), dim3(kBlock), lds_bytes, stream,
+                     m, n, rows_per_chunk, row_offsets, column_indices, table);
   int st = launch_status();
   if (st != 0) return st;
-
   hipLaunchKernelGGL(transpose_scan_table_kernel, dim3(ceil_div(n, kWave)),
-                     dim3(kWave * kScanGroups), 0, stream, n, plan.chunks, table, totals);
+                     dim3(kWave * kScanGroups), 0, stream, n, chunks, table, totals);
   st = launch_status();
   if (st != 0) return st;
-
   hipLaunchKernelGGL(transpose_scan_totals_kernel, dim3(1), dim3(kScanBlock), 0, stream, n,
                      totals, out_row_offsets);
   st = launch_status();
   if (st != 0) return st;
-
-  if (lds) {
-    hipLaunchKernelGGL(transpose_scatter_kernel<true>, dim3(plan.chunks), dim3(kWave), lds_bytes,
-                       stream, m, n, nonzeros, replicas, plan.rows_per_chunk, values,
-                       values_stride, row_offsets, column_indices, table, out_row_offsets,
-                       out_values, out_values_stride, out_column_indices, out_permutation);
-  } else {
-    hipLaunchKernelGGL(transpose_scatter_kernel<false>, dim3(plan.chunks), dim3(kWave), 0,
-                       stream, m, n, nonzeros, replicas, plan.rows_per_chunk, values,
-                       values_stride, row_offsets, column_indices, table, out_row_offsets,
-                       out_values, out_values_stride, out_column_indices, out_permutation);
-  }
+  hipLaunchKernelGGL(transpose_scatter_kernel, dim3(chunks, ranges), dim3(kBlock),
+                     lds_bytes + sizeof(int) * range_cols, stream, m, n, rows_per_chunk, replicas,
+                     values, values_stride, row_offsets, column_indices,
+                     table, out_row_offsets, out_values, out_values_stride, out_column_indices,
+                     out_permutation);
   return launch_status();
 }
 
