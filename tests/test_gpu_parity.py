@@ -307,6 +307,18 @@ def test_empty_topology(ts, dev):
     assert rot.cpu().tolist() == [0] * (k + 1) and vt.numel() == 0 and cit.numel() == 0
 
 
+def test_half_storage_is_widened(ts, dev):
+    """fp16 storage (BASELINE config 5): operands widened once, fp32 math and output."""
+    m, k, n, r = 128, 96, 64, 2
+    _, vals, ri, ro, ci = make_csr(m, k, 0.8, seed=71)
+    b = np.random.default_rng(72).uniform(-1, 1, size=(r, k, n)).astype(np.float32)
+    v16, b16 = T(vals, dev).half(), T(b, dev).half()
+    out = ts.left_spmm(m, k, v16, T(ri, dev), T(ro, dev), T(ci, dev), b16)
+    assert out.dtype == torch.float32
+    want = O.left_spmm(m, k, v16.float().cpu().numpy(), ri, ro, ci, b16.float().cpu().numpy())
+    assert rel_err(out.cpu().numpy(), want) < TOL
+
+
 def test_shape_errors_raise(ts, dev):
     _, vals, ri, ro, ci = make_csr(8, 8, 0.5, seed=61)
     v, r, o, c = T(vals, dev), T(ri, dev), T(ro, dev), T(ci, dev)

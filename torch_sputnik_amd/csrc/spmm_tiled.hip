@@ -123,8 +123,9 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
 
   const unsigned ptr_off = static_cast<unsigned>(min(lane, RPW - 1)) * 4u;
   const int* __restrict__ my_table = table + slot0;  // wave-uniform
-  const int last = nonzeros - 1;
-  const int e16 = lane & 15;
+  const int e16x4 = (lane & 15) * 4;
+  const unsigned lane4 = static_cast<unsigned>(lane) * 4u;
+  const int last_window = nonzeros - kWave;  // >= 0: the dispatcher requires >= 1024 nonzeros
   const float* lane_tile = tile0 + lane * VEC;
   const unsigned b_lane_off = static_cast<unsigned>(n0 + lane * 4) * 4u;
 
@@ -134,15 +135,22 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
   wait_vm<0>();
   asm volatile("" : "+v"(v_ps), "+v"(v_pe));
 
+  // Entry window of a row: 64 consecutive stream entries (lane = entry)
+  // starting at `start`, loaded with a wave-uniform base and a constant lane
+  // offset.  Near the end of the arrays the window is moved back so that it
+  // never reads past them; `shift` is then the position of the row's first
+  // entry inside the window.
   int vcol[D];
   float vval[D];
+  int shift[D];
+  auto request = [&](int slot, int start) {
+    const int base = min(start, last_window);
+    shift[slot] = start - base;
+    vcol[slot] = untracked_load_i32(column_indices + base, lane4);
+    vval[slot] = untracked_load_f32(values + base, lane4);
+  };
 #pragma unroll
-  for (int r = 0; r < D; ++r) {
-    const unsigned off =
-        static_cast<unsigned>(min(__builtin_amdgcn_readlane(v_ps, r) + lane, last)) * 4u;
-    vcol[r] = untracked_load_i32(column_indices, off);
-    vval[r] = untracked_load_f32(values, off);
-  }
+  for (int r = 0; r < D; ++r) request(r, __builtin_amdgcn_readlane(v_ps, r));
   stage_chunk<Cfg>(tile0, dense, n, k, 0, wave, b_lane_off);
   int v_pe_next = untracked_load_i32(my_table + static_cast<int64_t>(min(2, nchunks)) * slots, ptr_off);
   wait_vm<0>();
@@ -157,44 +165,38 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
     // B
     int v_pe_after =
         untracked_load_i32(my_table + static_cast<int64_t>(min(c + 3, nchunks)) * slots, ptr_off);
-    const char* __restrict__ lane_base =
-        reinterpret_cast<const char*>(lane_tile + buf * (BK * BN));
-    const int kc = c * BK;
+    // Tile row of column j starts at (j - c*BK) * BN floats: fold the chunk's
+    // first column into the lane's base address once per chunk.
+    const char* __restrict__ lane_base = reinterpret_cast<const char*>(
+        lane_tile + buf * (BK * BN) - static_cast<int64_t>(c) * (BK * BN));
+    int v_cnt = v_pe - v_ps;
+    const int kc_off = c * (BK * BN * 4);  // byte offset that lane_base turns into tile row 0
 
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
-      constexpr int kDummy = 0;
-      (void)kDummy;
       int& wcol = vcol[r % D];
       float& wval = vval[r % D];
       if (r < D) {
-        wait_vm<kWaitCrossChunk>(wcol, wval, v_pe);
+        wait_vm<kWaitCrossChunk>(wcol, wval, v_cnt);
       } else {
-        wait_vm<kWaitSameChunk>(wcol, wval, v_pe);
+        wait_vm<kWaitSameChunk>(wcol, wval, v_cnt);
       }
-      const int cnt = dbg_no_compute ? 0
-                                     : __builtin_amdgcn_readlane(v_pe, r) -
-                                           __builtin_amdgcn_readlane(v_ps, r);
+      const int cnt = dbg_no_compute ? 0 : __builtin_amdgcn_readlane(v_cnt, r);
       for (int q0 = 0; q0 < cnt; q0 += 16) {
-        const int e = e16 + q0;  // entry this lane stands for
-        const int rcol = __builtin_amdgcn_ds_bpermute(e << 2, wcol);
+        // replicate entries q0 .. q0+15 of the row into every 16-lane row
+        const int idx = e16x4 + ((q0 + shift[r % D]) << 2);
+        const int rcol = __builtin_amdgcn_ds_bpermute(idx, wcol);
         const float rval_all = __builtin_bit_cast(
-            float, __builtin_amdgcn_ds_bpermute(e << 2, __builtin_bit_cast(int, wval)));
-        const bool valid = e < cnt;
-        const int roff = valid ? ((rcol - kc) * (BN * 4)) : 0;
+            float, __builtin_amdgcn_ds_bpermute(idx, __builtin_bit_cast(int, wval)));
+        // lanes standing for entries past the row's count: zero value, tile row 0
+        const bool valid = e16x4 < ((cnt - q0) << 2);
+        const int roff = valid ? rcol * (BN * 4) : kc_off;
         const float rval = valid ? rval_all : 0.f;
-        const int n16 = cnt - q0;
-        dpp_group4<0>(acc[r], roff, rval, lane_base);
-        if (n16 > 4) dpp_group4<4>(acc[r], roff, rval, lane_base);
-        if (n16 > 8) dpp_group4<8>(acc[r], roff, rval, lane_base);
-        if (n16 > 12) dpp_group4<12>(acc[r], roff, rval, lane_base);
+        dpp_entries(acc[r], min(16, cnt - q0), roff, rval, lane_base);
       }
       // C: request the window that will be consumed D rows from now.
-      const int start = (r + D < RPW) ? __builtin_amdgcn_readlane(v_ps, (r + D) % RPW)
-                                      : __builtin_amdgcn_readlane(v_pe, (r + D) % RPW);
-      const unsigned off = static_cast<unsigned>(min(start + lane, last)) * 4u;
-      wcol = untracked_load_i32(column_indices, off);
-      wval = untracked_load_f32(values, off);
+      request(r % D, (r + D < RPW) ? __builtin_amdgcn_readlane(v_ps, (r + D) % RPW)
+                                   : __builtin_amdgcn_readlane(v_pe, (r + D) % RPW));
     }
     v_ps = v_pe;
     v_pe = v_pe_next;

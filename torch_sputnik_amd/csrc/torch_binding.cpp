@@ -52,10 +52,17 @@ Tensor as_index(const Tensor& t, const char* name, const Tensor& like) {
   return t.to(at::kInt).contiguous();
 }
 
+// float32 is the reference's only dtype (data_ptr<float>(), src/spmm_cuda.cu:51).
+// float16 / bfloat16 storage is accepted as an extension (BASELINE.json config 5
+// names fp16): such operands are widened once here, all arithmetic and every
+// output stay float32, exactly as the reference's outputs always are
+// (src/spmm_cuda.cu:42).
 Tensor as_float(const Tensor& t, const char* name) {
   TORCH_CHECK(t.is_cuda(), name, " must be a GPU (HIP) tensor, got ", t.device());
-  TORCH_CHECK(t.scalar_type() == at::kFloat, name, " must be float32, got ", t.scalar_type());
-  return t.contiguous();
+  const auto st = t.scalar_type();
+  TORCH_CHECK(st == at::kFloat || st == at::kHalf || st == at::kBFloat16, name,
+              " must be float32 (or float16 / bfloat16 storage), got ", st);
+  return t.to(at::kFloat).contiguous();
 }
 
 struct Topology {
