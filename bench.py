@@ -48,16 +48,21 @@ def spmm_bytes(nnz, m, k, n, replicas=1):
     return replicas * (8.0 * nnz + 4.0 * k * n + 4.0 * m * n) + 4.0 * (2 * m + 1)
 
 
-def event_time_ms(fn, iters):
-    start = torch.cuda.Event(enable_timing=True)
-    end = torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    start.record()
-    for _ in range(iters):
+def event_time_ms(fn, iters, warmup=3):
+    """Median GPU time of one call: one HIP event pair per call on torch's current
+    stream (= the stream the C ABI launches on), so host launch gaps are not counted."""
+    for _ in range(warmup):
         fn()
-    end.record()
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
     torch.cuda.synchronize()
-    return start.elapsed_time(end) / iters
+    for s, e in zip(starts, ends):
+        s.record()
+        fn()
+        e.record()
+    torch.cuda.synchronize()
+    times = sorted(s.elapsed_time(e) for s, e in zip(starts, ends))
+    return times[len(times) // 2]
 
 
 class SpmmProblem:
@@ -260,7 +265,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": ("C2: 2-D SpMM M=N=K=4096 density 0.1 (nnz=%d), 1 replica" % problem.nnz)
+                "workload": ("C2: 2-D SpMM M=N=K=4096 density 0.1 (nnz=%d), %d replica(s)" % (problem.nnz, replicas))
                 if n_gpus == 1 else
                 ("C4: batched SpMM M=N=K=4096 density 0.1, %d replicas per GPU, %d total, replica-sharded"
                  % (replicas, replicas * n_gpus)),

@@ -196,6 +196,39 @@ DEF_KERNEL(k_spmm_step_dpp1,
            "s_waitcnt lgkmcnt(0)\n" FMD("3", "v26", "v22") FMD("3", "v27", "v23") FMD("3", "v28", "v24") FMD("3", "v29", "v25"),
            V32, "v44", "v45", "v46", "v47")
 
+// n) SALU throughput: 16 independent s_and_b32
+DEF_KERNEL(k_salu,
+           "s_and_b32 s33, s38, 63\ns_and_b32 s34, s38, 63\ns_and_b32 s35, s38, 63\ns_and_b32 s36, s38, 63\n"
+           "s_and_b32 s33, s38, 63\ns_and_b32 s34, s38, 63\ns_and_b32 s35, s38, 63\ns_and_b32 s36, s38, 63\n"
+           "s_and_b32 s33, s38, 63\ns_and_b32 s34, s38, 63\ns_and_b32 s35, s38, 63\ns_and_b32 s36, s38, 63\n"
+           "s_and_b32 s33, s38, 63\ns_and_b32 s34, s38, 63\ns_and_b32 s35, s38, 63\ns_and_b32 s36, s38, 63\n",
+           "v10")
+
+// o) SALU next to VALU: 8 v_fmac + 8 s_and interleaved (do they overlap?)
+DEF_KERNEL(k_salu_valu,
+           "v_fmac_f32 v10, v3, v4\ns_and_b32 s33, s38, 63\nv_fmac_f32 v11, v3, v4\ns_and_b32 s34, s38, 63\n"
+           "v_fmac_f32 v12, v3, v4\ns_and_b32 s35, s38, 63\nv_fmac_f32 v13, v3, v4\ns_and_b32 s36, s38, 63\n"
+           "v_fmac_f32 v14, v3, v4\ns_and_b32 s33, s38, 63\nv_fmac_f32 v15, v3, v4\ns_and_b32 s34, s38, 63\n"
+           "v_fmac_f32 v16, v3, v4\ns_and_b32 s35, s38, 63\nv_fmac_f32 v17, v3, v4\ns_and_b32 s36, s38, 63\n",
+           V16)
+
+// p) scalar-operand SpMM step: per nonzero s_and, v_lshl_add_u32 (SGPR), ds_read_b128, 2 v_pk_fma (SGPR pair)
+#define NZS(J, ADDR, B0, B3) \
+  "s_and_b32 " J ", s38, 15\n" \
+  "v_lshl_add_u32 " ADDR ", " J ", 10, v40\n" \
+  "ds_read_b128 v[" B0 ":" B3 "], " ADDR "\n"
+DEF_KERNEL(k_spmm_step_scalar,
+           NZS("s33", "v44", "10", "13") NZS("s34", "v45", "14", "17") NZS("s35", "v46", "18", "21") NZS("s36", "v47", "22", "25")
+           "s_waitcnt lgkmcnt(3)\n"
+           "v_pk_fma_f32 v[26:27], s[30:31], v[10:11], v[26:27] op_sel_hi:[0,1,1]\nv_pk_fma_f32 v[28:29], s[30:31], v[12:13], v[28:29] op_sel_hi:[0,1,1]\n"
+           "s_waitcnt lgkmcnt(2)\n"
+           "v_pk_fma_f32 v[26:27], s[30:31], v[14:15], v[26:27] op_sel:[1,0,0]\nv_pk_fma_f32 v[28:29], s[30:31], v[16:17], v[28:29] op_sel:[1,0,0]\n"
+           "s_waitcnt lgkmcnt(1)\n"
+           "v_pk_fma_f32 v[26:27], s[30:31], v[18:19], v[26:27] op_sel_hi:[0,1,1]\nv_pk_fma_f32 v[28:29], s[30:31], v[20:21], v[28:29] op_sel_hi:[0,1,1]\n"
+           "s_waitcnt lgkmcnt(0)\n"
+           "v_pk_fma_f32 v[26:27], s[30:31], v[22:23], v[26:27] op_sel:[1,0,0]\nv_pk_fma_f32 v[28:29], s[30:31], v[24:25], v[28:29] op_sel:[1,0,0]\n",
+           V32, "v44", "v45", "v46", "v47")
+
 typedef void (*kern_t)(unsigned long long*, int);
 
 static void run(const char* name, kern_t k, int per_block_insts) {
@@ -241,5 +274,8 @@ int main() {
   run("fmac_vop2", k_fmac_vop2, 16);
   run("spmm_step_dpp(4nz)", k_spmm_step_dpp, 4);
   run("spmm_step_dpp1(4nz)", k_spmm_step_dpp1, 4);
+  run("salu", k_salu, 16);
+  run("salu+valu(16)", k_salu_valu, 16);
+  run("spmm_step_scalar(4nz)", k_spmm_step_scalar, 4);
   return 0;
 }
