@@ -83,6 +83,66 @@ def test_spmm_capi_vs_oracle(capi, dev, m, k, n, sparsity, order, empty):
         assert np.all(got[r] == 0)
 
 
+STRESS = [
+    # m, k, n, sparsity: corners of the tiled kernels' bookkeeping
+    (256, 64, 256, 0.05),     # one chunk, nearly dense rows (up to 64 entries per row and chunk)
+    (300, 200, 256, 0.1),     # dense rows, ragged m and k, entry windows clamped at the array end
+    (64, 4096, 256, 0.995),   # most (row, chunk) segments empty
+    (1000, 130, 512, 0.5),    # k % 64 = 2: last chunk almost empty
+    (257, 65, 768, 0.7),      # three column tiles (n_tiles % 8 != 0), 1 padded chunk row
+    (2048, 2048, 256, 0.8),   # medium-tile configuration
+    (512, 96, 64, 0.2),       # 64-column kernel, > 32 entries per row and chunk
+    (90, 1000, 320, 0.9),     # 64-column kernel, five tiles, padded row slots
+]
+
+
+@pytest.mark.parametrize("m,k,n,sparsity", STRESS)
+@pytest.mark.parametrize("order", ["descending", "random"])
+def test_spmm_tiled_stress(capi, dev, m, k, n, sparsity, order):
+    _, vals, ri, ro, ci = make_csr(m, k, sparsity, seed=3 * m + k + n, round_to=1, order=order,
+                                   empty_rows=(m - 1,) if sparsity > 0.5 else ())
+    b = np.random.default_rng(m + n).uniform(-1, 1, size=(k, n)).astype(np.float32)
+    want = c_oracle.spmm(m, k, vals, ro, ci, b)
+    out = torch.full((m, n), float("nan"), device=dev)
+    ws = torch.empty(capi.spmm_workspace_bytes(m, k, n, len(ci)) + 16, dtype=torch.uint8, device=dev)
+    capi.spmm_batched(m, k, n, 1, T(ri, dev), T(vals, dev), 0, T(ro, dev), T(ci, dev), T(b, dev),
+                      out, ws)
+    got = out.cpu().numpy()
+    assert not np.isnan(got).any()
+    assert rel_err(got, want) < TOL
+
+
+def test_spmm_full_size_linearity(capi, dev):
+    """BASELINE.json's headline size (4096^3, density 0.1), checked through
+    size-independent properties: linearity in the values, agreement of the planned
+    and unplanned entry points, and exact rows against the oracle on a sample."""
+    from torch_sputnik_amd.synthetic import random_csr, uniform
+    m = k = n = 4096
+    ri, ro, ci, nnz = random_csr(m, k, 0.1, dev, seed=5234)
+    v1, v2 = uniform((nnz,), dev, 1), uniform((nnz,), dev, 2)
+    b = uniform((k, n), dev, 3) - 0.5
+    ws = torch.empty(capi.spmm_workspace_bytes(m, k, n, nnz) + 16, dtype=torch.uint8, device=dev)
+
+    def run(v):
+        out = torch.empty(m, n, device=dev)
+        capi.spmm_batched(m, k, n, 1, ri, v, 0, ro, ci, b, out, ws)
+        return out
+
+    c1, c2, c12 = run(v1), run(v2), run(v1 + 2 * v2)
+    assert torch.allclose(c12, c1 + 2 * c2, rtol=1e-4, atol=1e-3)
+    planned = torch.empty(m, n, device=dev)
+    capi.spmm_plan(m, k, n, ri, ro, ci, ws)
+    capi.spmm_batched_planned(m, k, n, 1, ri, v1, 0, ro, ci, b, planned, ws)
+    assert torch.equal(planned, c1)
+    # 16 sampled rows, float64 on the host
+    rows = torch.randint(0, m, (16,), generator=torch.Generator().manual_seed(0)).tolist()
+    ro_h, ci_h, v_h, b_h = ro.cpu().numpy(), ci.cpu().numpy(), v1.cpu().numpy(), b.cpu().double().numpy()
+    for r in rows:
+        p0, p1 = ro_h[r], ro_h[r + 1]
+        want = v_h[p0:p1].astype(np.float64) @ b_h[ci_h[p0:p1]]
+        assert rel_err(c1[r].cpu().numpy(), want) < TOL
+
+
 @pytest.mark.parametrize("replicas,shared,m,k,n", [
     (3, False, 130, 96, 136), (5, True, 130, 96, 136), (1, False, 130, 96, 136),
     (4, False, 512, 512, 64), (3, True, 300, 256, 128),       # 64-column tiled kernel

@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--densities", default="0.5,0.25,0.2,0.15,0.1,0.05")
     ap.add_argument("--replicas", type=int, default=1)
+    ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -120,7 +121,7 @@ def main():
     t0 = time.time()
     if "spmm" in ops:
         rows += bench_spmm(dev, args.iters, [float(x) for x in args.densities.split(",")],
-                           replicas=args.replicas)
+                           m=args.size, k=args.size, n=args.size, replicas=args.replicas)
     if "attn" in ops:
         rows += bench_attention_ops(dev, args.iters)
     if "transpose" in ops:

@@ -440,6 +440,10 @@ Plan make_plan(int m, int k, int n) {
 }
 
 using CfgLarge = TileConfig<256, 16, 16, 64>;  // 256 x 256 tile of C per workgroup
+// Same kernel with 8 rows per wave (128 x 256 tiles): twice the workgroups, for
+// problems whose 256-row blocks would leave most of the 256 CUs idle (e.g. one
+// 2048^3 product is only 64 large tiles).  Same workspace layout.
+using CfgMedium = TileConfig<256, 16, 8, 64>;
 
 inline bool tiled_applicable(int m, int k, int n, int nonzeros) {
   // Needs full column tiles, and enough work per row block to amortise staging
@@ -536,11 +540,18 @@ int spmm_tiled_exec(int m, int k, int n, int nonzeros, int replicas, const int* 
                        0, stream, m, k, n, nonzeros, plan.slots, plan.nchunks, plan.n_tiles,
                        row_indices, values, values_stride, column_indices, table, dense,
                        dense_stride, out, out_stride, row_ok, row_offsets, debug);
-  } else {
+  } else if (static_cast<int64_t>(blocks) * replicas >= 192) {
     hipLaunchKernelGGL((spmm_tiled_kernel<Cfg, 2>), dim3(blocks, replicas), dim3(Cfg::kThreads),
                        0, stream, m, k, n, nonzeros, plan.slots, plan.nchunks, plan.n_tiles,
                        row_indices, values, values_stride, column_indices, table, dense,
                        dense_stride, out, out_stride, row_ok, row_offsets, debug);
+  } else {
+    const int blocks_medium = (plan.slots / CfgMedium::kBM) * plan.n_tiles;
+    hipLaunchKernelGGL((spmm_tiled_kernel<CfgMedium, 2>), dim3(blocks_medium, replicas),
+                       dim3(CfgMedium::kThreads), 0, stream, m, k, n, nonzeros, plan.slots,
+                       plan.nchunks, plan.n_tiles, row_indices, values, values_stride,
+                       column_indices, table, dense, dense_stride, out, out_stride, row_ok,
+                       row_offsets, debug);
   }
   *handled = true;
   return launch_status();
