@@ -367,6 +367,44 @@ def test_empty_topology(ts, dev):
     assert rot.cpu().tolist() == [0] * (k + 1) and vt.numel() == 0 and cit.numel() == 0
 
 
+def test_hip_graph_capture_of_attention_ops(ts, dev):
+    """The ops neither synchronise nor allocate outside torch's allocator, so a
+    launch-bound chain (SDDMM -> softmax -> SpMM) can be captured into a HIP graph
+    and replayed on new data."""
+    s_len, d, r = 256, 64, 4
+    mask, _, ri, ro, ci = make_csr(s_len, s_len, 0.9, seed=81, round_to=1)
+    topo = (T(ri, dev), T(ro, dev), T(ci, dev))
+    q = torch.randn(r, s_len, d, device=dev)
+    k = torch.randn(r, s_len, d, device=dev)
+    v = torch.randn(r, s_len, d, device=dev)
+
+    def block():
+        scores = ts.sddmm(s_len, s_len, *topo, q, k) / 8.0
+        probs = ts.sparse_softmax(scores, *topo)
+        return ts.spmm(s_len, s_len, probs, *topo, v)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            block()  # warm-up outside capture
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        captured = block()
+    q.copy_(torch.randn_like(q))
+    v.copy_(torch.randn_like(v))
+    graph.replay()
+    torch.cuda.synchronize()
+    eager = block()
+    assert torch.equal(captured, eager)
+    # and against the dense definition
+    dense_scores = torch.matmul(q.double(), k.double().transpose(1, 2)) / 8.0
+    dense_scores = dense_scores.masked_fill(T(mask, dev) == 0, float("-inf"))
+    want = torch.matmul(torch.nan_to_num(torch.softmax(dense_scores, -1)), v.double())
+    assert rel_err(captured.cpu().numpy(), want.cpu().numpy()) < TOL
+
+
 def test_half_storage_is_widened(ts, dev):
     """fp16 storage (BASELINE config 5): operands widened once, fp32 math and output."""
     m, k, n, r = 128, 96, 64, 2

@@ -12,10 +12,13 @@
 //   * each wave owns RPW rows whose accumulators stay in registers for the
 //     whole K walk (RPW*BN/64 VGPRs), so C is written exactly once and no
 //     atomics or partial sums exist -> bitwise reproducible;
-//   * a row's (column, value) stream is wave-uniform, so it is read with
-//     SCALAR loads (s_load through the scalar cache) and the value enters
-//     v_fma_f32 as an SGPR operand: the vector memory path and LDS carry
-//     only B.  Per nonzero and lane: one ds_read_b128 + 4 FMA.
+//   * a row's (column, value) stream is wave-uniform.  Its next 64 entries are
+//     prefetched into two VGPRs (lane = entry) and handed out with DPP
+//     row_newbcast after one ds_bpermute pair per 16 entries: per nonzero one
+//     v_add_u32_dpp (LDS address), one ds_read_b128, one v_mov_b32_dpp (value)
+//     and two v_pk_fma_f32 -- no VGPR->SGPR traffic, no scalar loads (MODE 2;
+//     MODE 0 = scalar loads and MODE 1 = v_readlane hand-out are kept for A/B
+//     measurements).
 //
 // The binding limit is LDS bandwidth: one B dword per FMA, 256 B/clk/CU
 // -> 64 FMA/clk/CU = 78.6 TFLOP/s chip-wide (= the plain v_fma_f32 rate).
@@ -24,10 +27,10 @@
 // Splitting a row's nonzeros by K chunk needs the column indices of a row to
 // ascend; a small pre-pass builds, per row and chunk boundary, the position
 // of the first nonzero at or past the boundary (the "chunk table", in the
-// caller's workspace) and verifies the order.  If any row is not ascending
-// the pre-pass clears a device flag: this kernel then exits at once and the
-// row-gather kernel, launched behind it with the opposite test, does the work.
-// No host synchronisation is involved.
+// caller's workspace) and records per row whether its columns ascend.  A
+// workgroup that finds a non-ascending row in its block takes an
+// order-independent path (B gathered from L2) inside the same launch: no host
+// synchronisation, no second kernel.
 #include <stdlib.h>
 
 #include "spmm_tiled_common.h"
@@ -463,7 +466,7 @@ size_t spmm_tiled_workspace_bytes(int m, int k, int n, int nonzeros) {
   return 0;
 }
 
-// Pre-pass only: topology -> chunk table + order flag in `workspace`.  Depends
+// Pre-pass only: topology -> per-row order status + chunk table in `workspace`.  Depends
 // on the topology alone, so a caller with a static pattern can run it once and
 // reuse the workspace for any number of spmm_tiled_exec calls.
 int spmm_tiled_plan(int m, int k, int n, int nonzeros, const int* row_indices,
@@ -491,7 +494,7 @@ int spmm_tiled_plan(int m, int k, int n, int nonzeros, const int* row_indices,
   return launch_status();
 }
 
-// Main kernel (+ the flag-gated row-gather fallback) on a planned workspace.
+// Main kernel on a planned workspace.
 int spmm_tiled_exec(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
                     const float* values, int64_t values_stride, const int* row_offsets,
                     const int* column_indices, const float* dense, int64_t dense_stride,
