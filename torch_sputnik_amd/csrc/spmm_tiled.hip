@@ -109,7 +109,7 @@ __device__ __forceinline__ void stage_chunk(float* __restrict__ tile, const floa
 // tile of the next chunk) and leaves B and C in flight across the barrier.
 // The last chunk issues the same (clamped, unused) operations so that the
 // counts hold for every iteration; the first one starts from a full drain.
-template <typename Cfg>
+template <typename Cfg, bool EXACT>
 __device__ __forceinline__ void spmm_tiled_body_dpp(
     float (&acc)[Cfg::kRPW][Cfg::kVec], float* __restrict__ tile0, int lane, int wave, int slot0,
     int slots, int nchunks, int nonzeros, int n, int k, int n0, const float* __restrict__ values,
@@ -191,11 +191,15 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
         const int rcol = __builtin_amdgcn_ds_bpermute(idx, wcol);
         const float rval_all = __builtin_bit_cast(
             float, __builtin_amdgcn_ds_bpermute(idx, __builtin_bit_cast(int, wval)));
-        // lanes standing for entries past the row's count: zero value, tile row 0
-        const bool valid = e16x4 < ((cnt - q0) << 2);
-        const int roff = valid ? rcol * (BN * 4) : kc_off;
-        const float rval = valid ? rval_all : 0.f;
-        dpp_entries(acc[r], min(16, cnt - q0), roff, rval, lane_base);
+        if constexpr (EXACT) {
+          dpp_entries_exact(acc[r], min(16, cnt - q0), rcol * (BN * 4), rval_all, lane_base);
+        } else {
+          // lanes standing for entries past the row's count: zero value, tile row 0
+          const bool valid = e16x4 < ((cnt - q0) << 2);
+          const int roff = valid ? rcol * (BN * 4) : kc_off;
+          const float rval = valid ? rval_all : 0.f;
+          dpp_entries(acc[r], min(16, cnt - q0), roff, rval, lane_base);
+        }
       }
       // C: request the window that will be consumed D rows from now.
       request(r % D, (r + D < RPW) ? __builtin_amdgcn_readlane(v_ps, (r + D) % RPW)
@@ -282,8 +286,8 @@ __global__ __launch_bounds__(Cfg::kThreads) void spmm_tiled_kernel(
   const float* lane_tile = &tile[0][0] + lane * VEC;
   const unsigned b_lane_off = static_cast<unsigned>(n0 + lane * 4) * 4u;
 
-  if constexpr (MODE == 2) {
-    spmm_tiled_body_dpp<Cfg>(acc, &tile[0][0], lane, wave, slot0, slots, nchunks, nonzeros, n, k,
+  if constexpr (MODE == 2 || MODE == 3) {
+    spmm_tiled_body_dpp<Cfg, MODE == 3>(acc, &tile[0][0], lane, wave, slot0, slots, nchunks, nonzeros, n, k,
                              n0, values, column_indices, table, dense, dbg_no_compute,
                              dbg_no_stage);
   } else if constexpr (MODE == 0) {
@@ -527,8 +531,11 @@ int spmm_tiled_exec(int m, int k, int n, int nonzeros, int replicas, const int* 
   const int blocks = (plan.slots / Cfg::kBM) * plan.n_tiles;
   static const int mode = [] {
     const char* e = getenv("SPUTNIK_HIP_SPMM_MODE");  // developer knob, see DESIGN.md
-    return e ? atoi(e) : 2;
+    return e ? atoi(e) : -1;  // -1: choose between 2 and 3 from the mean segment length
   }();
+  // mean number of entries of a row inside one K chunk
+  const bool short_segments =
+      static_cast<int64_t>(nonzeros) < int64_t{12} * m * plan.nchunks;
   static const int debug = [] {
     const char* e = getenv("SPUTNIK_HIP_SPMM_DEBUG");
     return e ? atoi(e) : 0;
@@ -543,6 +550,13 @@ int spmm_tiled_exec(int m, int k, int n, int nonzeros, int replicas, const int* 
                        0, stream, m, k, n, nonzeros, plan.slots, plan.nchunks, plan.n_tiles,
                        row_indices, values, values_stride, column_indices, table, dense,
                        dense_stride, out, out_stride, row_ok, row_offsets, debug);
+  } else if (static_cast<int64_t>(blocks) * replicas >= 192 &&
+             (mode == 3 || (mode != 2 && short_segments))) {
+    // MODE 3 = MODE 2 with exact (rotating) processing of short segments
+    hipLaunchKernelGGL((spmm_tiled_kernel<Cfg, 3>), dim3(blocks, replicas), dim3(Cfg::kThreads),
+                       0, stream, m, k, n, nonzeros, plan.slots, plan.nchunks, plan.n_tiles,
+                       row_indices, values, values_stride, column_indices, table, dense,
+                       dense_stride, out, out_stride, row_ok, row_offsets, debug);
   } else if (static_cast<int64_t>(blocks) * replicas >= 192) {
     hipLaunchKernelGGL((spmm_tiled_kernel<Cfg, 2>), dim3(blocks, replicas), dim3(Cfg::kThreads),
                        0, stream, m, k, n, nonzeros, plan.slots, plan.nchunks, plan.n_tiles,
@@ -550,11 +564,19 @@ int spmm_tiled_exec(int m, int k, int n, int nonzeros, int replicas, const int* 
                        dense_stride, out, out_stride, row_ok, row_offsets, debug);
   } else {
     const int blocks_medium = (plan.slots / CfgMedium::kBM) * plan.n_tiles;
-    hipLaunchKernelGGL((spmm_tiled_kernel<CfgMedium, 2>), dim3(blocks_medium, replicas),
-                       dim3(CfgMedium::kThreads), 0, stream, m, k, n, nonzeros, plan.slots,
-                       plan.nchunks, plan.n_tiles, row_indices, values, values_stride,
-                       column_indices, table, dense, dense_stride, out, out_stride, row_ok,
-                       row_offsets, debug);
+    if (mode == 3 || (mode != 2 && short_segments)) {
+      hipLaunchKernelGGL((spmm_tiled_kernel<CfgMedium, 3>), dim3(blocks_medium, replicas),
+                         dim3(CfgMedium::kThreads), 0, stream, m, k, n, nonzeros, plan.slots,
+                         plan.nchunks, plan.n_tiles, row_indices, values, values_stride,
+                         column_indices, table, dense, dense_stride, out, out_stride, row_ok,
+                         row_offsets, debug);
+    } else {
+      hipLaunchKernelGGL((spmm_tiled_kernel<CfgMedium, 2>), dim3(blocks_medium, replicas),
+                         dim3(CfgMedium::kThreads), 0, stream, m, k, n, nonzeros, plan.slots,
+                         plan.nchunks, plan.n_tiles, row_indices, values, values_stride,
+                         column_indices, table, dense, dense_stride, out, out_stride, row_ok,
+                         row_offsets, debug);
+    }
   }
   *handled = true;
   return launch_status();

@@ -194,6 +194,53 @@ __device__ __forceinline__ void dpp_entries(float (&acc)[4], int n16, int roff, 
   if (n16 > 12) dpp_group4<12>(acc, roff, rval, lane_base);
 }
 
+// Exact variant for short segments: always work on entries 0..3 of the
+// replicated set and rotate the set by four lanes (DPP row_ror) after each
+// group, so every position is the static position 0: one group body instead of
+// four, and the last 1-3 entries are processed exactly (no padded entry), at
+// the price of two extra DPP moves per group of four.
+// lane i of every 16-lane row <- lane (i + N) mod 16.  (DPP row_ror:R moves
+// data towards HIGHER lanes, lane i <- lane i - R, so this is row_ror:16-N.)
+template <int N>
+__device__ __forceinline__ int row_rotate_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, 0x120 + (16 - N), 0xF, 0xF, true);
+}
+template <int N>
+__device__ __forceinline__ float row_rotate_f(float v) {
+  return __builtin_bit_cast(float, row_rotate_i<N>(__builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ void dpp_group2_at0(float (&acc)[4], int roff, float rval,
+                                               const char* __restrict__ lane_base) {
+  const int o0 = row_bcast_i<0>(roff), o1 = row_bcast_i<1>(roff);
+  const float4 b0 = *reinterpret_cast<const float4*>(lane_base + o0);
+  const float4 b1 = *reinterpret_cast<const float4*>(lane_base + o1);
+  const float a0 = row_bcast_f<0>(rval), a1 = row_bcast_f<1>(rval);
+  SPUTNIK_HIP_FMA4(acc, a0, b0);
+  SPUTNIK_HIP_FMA4(acc, a1, b1);
+}
+__device__ __forceinline__ void dpp_group1_at0(float (&acc)[4], int roff, float rval,
+                                               const char* __restrict__ lane_base) {
+  const int o0 = row_bcast_i<0>(roff);
+  const float4 b0 = *reinterpret_cast<const float4*>(lane_base + o0);
+  const float a0 = row_bcast_f<0>(rval);
+  SPUTNIK_HIP_FMA4(acc, a0, b0);
+}
+__device__ __forceinline__ void dpp_entries_exact(float (&acc)[4], int n16, int roff, float rval,
+                                                  const char* __restrict__ lane_base) {
+  int left = n16;
+  for (; left >= 4; left -= 4) {
+    dpp_group4<0>(acc, roff, rval, lane_base);
+    roff = row_rotate_i<4>(roff);
+    rval = row_rotate_f<4>(rval);
+  }
+  if (left & 2) {
+    dpp_group2_at0(acc, roff, rval, lane_base);
+    roff = row_rotate_i<2>(roff);
+    rval = row_rotate_f<2>(rval);
+  }
+  if (left & 1) dpp_group1_at0(acc, roff, rval, lane_base);
+}
+
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v / 2); }
 
 }  // namespace tiled
