@@ -165,6 +165,27 @@ def other_ops(dev):
     t = event_time_ms(lambda: capi.spmm_batched(s, s, d, reps, ri, probs, nnz, ro, ci, v, ctx, ws3), 20)
     by = reps * (4.0 * nnz + 8.0 * s * d) + 4.0 * nnz + 4.0 * (2 * s + 1)
     res["spmm_c3"] = {"ms": t, "gflops": 2.0 * nnz * d * reps / t / 1e6, "alg_gbs": by / t / 1e6}
+    # Whole SparseAttention.forward (modules/sparse_attention.py:105-128) through the
+    # torch ops: 4 SparseLinear (left_spmm) + SDDMM + scale + softmax + SpMM, B=8, H=8, D=64.
+    try:
+        import numpy as np
+        from torch_sputnik_amd import SparseAttention
+        torch.manual_seed(0)
+        emb, heads, batch = 512, 8, 8
+        attn = SparseAttention(heads, emb, max_sequence_length=s, device=dev, sparsity=0.9,
+                               mask_generator=np.random.default_rng(0))
+        for lin in attn.linears:
+            w = torch.randn(emb, emb, device=dev) * (torch.rand(emb, emb, device=dev) < 0.1)
+            lin.weight = torch.nn.Parameter(w)
+            lin.setup_sparse_tensors()
+        x = torch.randn(batch, s, emb, device=dev)
+        with torch.no_grad():
+            t = event_time_ms(lambda: attn(x, x, x, None), 10)
+        res["sparse_attention_forward_c3"] = {"ms": t, "batch": batch, "heads": heads, "seq": s,
+                                              "head_dim": emb // heads, "mask_density": 0.1,
+                                              "projection_density": 0.1}
+    except Exception as e:  # noqa: BLE001 - extra metric, best effort
+        res["sparse_attention_forward_c3"] = {"error": str(e)[:200]}
     m = n = 2048  # config 5: transpose of a 2048^2, density 0.2 weight
     ri, ro, ci, nnz = random_csr(m, n, 0.2, dev, seed=9)
     vals = uniform((nnz,), dev, 10)
