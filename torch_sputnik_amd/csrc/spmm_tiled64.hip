@@ -22,6 +22,8 @@
 // costs nothing.  Rows with more than 32 entries in one chunk fetch the rest on
 // demand.  The four row groups of a wave run their own number of steps
 // (EXEC-masked), so no LDS traffic is spent on the shorter rows' padding.
+#include <stdlib.h>
+
 #include "spmm_tiled_common.h"
 
 namespace sputnik_hip {
@@ -69,8 +71,9 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled64_kernel(
     int64_t values_stride, const int* __restrict__ column_indices,
     const int* __restrict__ table, const float* __restrict__ dense, int64_t dense_stride,
     float* __restrict__ out, int64_t out_stride, const int* __restrict__ row_ok,
-    const int* __restrict__ row_offsets) {
+    const int* __restrict__ row_offsets, int debug) {
   __shared__ float tile[2][kTileFloats];
+  const bool dbg_no_compute = debug & 1, dbg_no_stage = debug & 2;
 
   const int lane = threadIdx.x % kWave;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled64_kernel(
   for (int c = 0; c < nchunks; ++c) {
     const int buf = c & 1;
     const bool more = c + 1 < nchunks;
-    if (more) stage_chunk64(tile[buf ^ 1], dense, n, k, n0, (c + 1) * kBK, wave, lane);
+    if (more && !dbg_no_stage) stage_chunk64(tile[buf ^ 1], dense, n, k, n0, (c + 1) * kBK, wave, lane);
 
     // Next chunk's positions and entry windows: requested now, used after the barrier.
     int pe_next[kRQ], ncol[kRQ][kWin];
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled64_kernel(
 
 #pragma unroll
     for (int t = 0; t < kRQ; ++t) {
-      const int cnt = pe[t] - ps[t];  // this group's row; the same in its 16 lanes
+      const int cnt = dbg_no_compute ? 0 : pe[t] - ps[t];  // this group's row; the same in its 16 lanes
       // One 16-entry window of this group's row: groups of four entries, each
       // group of lanes stopping at its own row's count (EXEC-masked).
       auto window = [&](int ecol, float eval, int w0) {
@@ -240,10 +243,14 @@ int spmm_tiled64_exec(int m, int k, int n, int nonzeros, int replicas, const int
   const int* table =
       reinterpret_cast<const int*>(static_cast<const char*>(workspace) + row_ok_bytes(slots));
   const int n_tiles = n / kBN;
+  static const int debug = [] {
+    const char* e = getenv("SPUTNIK_HIP_SPMM_DEBUG");  // timing experiments only
+    return e ? atoi(e) : 0;
+  }();
   hipLaunchKernelGGL(spmm_tiled64_kernel, dim3((slots / kBM) * n_tiles, replicas), dim3(kThreads),
                      0, stream, m, k, n, nonzeros, slots, chunks_of(k), n_tiles, row_indices,
                      values, values_stride, column_indices, table, dense, dense_stride, out,
-                     out_stride, row_ok, row_offsets);
+                     out_stride, row_ok, row_offsets, debug);
   return launch_status();
 }
 
