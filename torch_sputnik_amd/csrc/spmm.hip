@@ -11,8 +11,7 @@
 // time (v_readlane for full-wave groups) and gathers the matching row of B
 // with one VEC-wide load per lane: every B read is a contiguous
 // LPR*VEC*4-byte segment.  It needs no workspace and places no requirement
-// on the order of column indices inside a row, so it is also the fallback of
-// the LDS-tiled kernel in spmm_tiled.hip.
+// on the order of column indices inside a row.
 #include "common.h"
 #include "wave_utils.h"
 
@@ -37,11 +36,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rowgather_kernel(
     int m, int n, const int* __restrict__ row_indices, const float* __restrict__ values,
     int64_t values_stride, const int* __restrict__ row_offsets,
     const int* __restrict__ column_indices, const float* __restrict__ dense,
-    int64_t dense_stride, float* __restrict__ out, int64_t out_stride,
-    const int* __restrict__ skip_flag) {
-  // The tiled kernel handled this call (see spmm_tiled.hip): nothing to do.
-  if (skip_flag != nullptr && *skip_flag != 0) return;
-
+    int64_t dense_stride, float* __restrict__ out, int64_t out_stride) {
   constexpr int kRowsPerBlock = kBlock / LPR;
   const int sub = threadIdx.x / LPR;
   const int l = threadIdx.x % LPR;
@@ -91,7 +86,7 @@ template <int VEC, int LPR>
 int launch_rowgather(int m, int n, int replicas, const int* row_indices, const float* values,
                      int64_t values_stride, const int* row_offsets, const int* column_indices,
                      const float* dense, int64_t dense_stride, float* out, int64_t out_stride,
-                     const int* skip_flag, hipStream_t stream) {
+                     hipStream_t stream) {
   constexpr int kRowsPerBlock = kBlock / LPR;
   const int gx = ceil_div(m, kRowsPerBlock);
   const int gy = ceil_div(n, LPR * VEC);
@@ -101,7 +96,7 @@ int launch_rowgather(int m, int n, int replicas, const int* row_indices, const f
     hipLaunchKernelGGL((spmm_rowgather_kernel<VEC, LPR>), dim3(gx, gy, rz), dim3(kBlock), 0,
                        stream, m, n, row_indices, values + r0 * values_stride, values_stride,
                        row_offsets, column_indices, dense + r0 * dense_stride, dense_stride,
-                       out + r0 * out_stride, out_stride, skip_flag);
+                       out + r0 * out_stride, out_stride);
     const int st = launch_status();
     if (st != 0) return st;
   }
@@ -112,13 +107,12 @@ template <int VEC>
 int launch_rowgather_vec(int m, int n, int replicas, const int* row_indices, const float* values,
                          int64_t values_stride, const int* row_offsets,
                          const int* column_indices, const float* dense, int64_t dense_stride,
-                         float* out, int64_t out_stride, const int* skip_flag,
-                         hipStream_t stream) {
+                         float* out, int64_t out_stride, hipStream_t stream) {
   const int lanes_needed = ceil_div(n, VEC);
 #define SPUTNIK_HIP_RG(LPR)                                                                  \
   return launch_rowgather<VEC, LPR>(m, n, replicas, row_indices, values, values_stride,      \
                                     row_offsets, column_indices, dense, dense_stride, out,   \
-                                    out_stride, skip_flag, stream)
+                                    out_stride, stream)
   if (lanes_needed <= 8) SPUTNIK_HIP_RG(8);
   if (lanes_needed <= 16) SPUTNIK_HIP_RG(16);
   if (lanes_needed <= 32) SPUTNIK_HIP_RG(32);
@@ -131,23 +125,22 @@ int launch_rowgather_vec(int m, int n, int replicas, const int* row_indices, con
 int spmm_rowgather_launch(int m, int n, int replicas, const int* row_indices,
                           const float* values, int64_t values_stride, const int* row_offsets,
                           const int* column_indices, const float* dense, int64_t dense_stride,
-                          float* out, int64_t out_stride, const int* skip_flag,
-                          hipStream_t stream) {
+                          float* out, int64_t out_stride, hipStream_t stream) {
   int vec = vector_width(dense, n, dense_stride);
   vec = min(vec, vector_width(out, n, out_stride));
   switch (vec) {
     case 4:
       return launch_rowgather_vec<4>(m, n, replicas, row_indices, values, values_stride,
                                      row_offsets, column_indices, dense, dense_stride, out,
-                                     out_stride, skip_flag, stream);
+                                     out_stride, stream);
     case 2:
       return launch_rowgather_vec<2>(m, n, replicas, row_indices, values, values_stride,
                                      row_offsets, column_indices, dense, dense_stride, out,
-                                     out_stride, skip_flag, stream);
+                                     out_stride, stream);
     default:
       return launch_rowgather_vec<1>(m, n, replicas, row_indices, values, values_stride,
                                      row_offsets, column_indices, dense, dense_stride, out,
-                                     out_stride, skip_flag, stream);
+                                     out_stride, stream);
   }
 }
 
@@ -186,8 +179,7 @@ int sputnik_hip_spmm_batched_planned(int m, int k, int n, int nonzeros, int repl
                                  out_stride, workspace, workspace_bytes, stream, &handled);
   if (st != 0 || handled) return st;
   return spmm_rowgather_launch(m, n, replicas, row_indices, values, values_stride, row_offsets,
-                               column_indices, dense, dense_stride, out, out_stride, nullptr,
-                               stream);
+                               column_indices, dense, dense_stride, out, out_stride, stream);
 }
 
 int sputnik_hip_spmm_batched(int m, int k, int n, int nonzeros, int replicas,

@@ -28,12 +28,6 @@
 
 namespace sputnik_hip {
 
-int spmm_rowgather_launch(int m, int n, int replicas, const int* row_indices,
-                          const float* values, int64_t values_stride, const int* row_offsets,
-                          const int* column_indices, const float* dense, int64_t dense_stride,
-                          float* out, int64_t out_stride, const int* skip_flag,
-                          hipStream_t stream);
-
 namespace {
 
 using namespace tiled;
