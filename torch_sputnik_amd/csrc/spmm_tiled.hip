@@ -16,9 +16,9 @@
 //     prefetched into two VGPRs (lane = entry) and handed out with DPP
 //     row_newbcast after one ds_bpermute pair per 16 entries: per nonzero one
 //     v_add_u32_dpp (LDS address), one ds_read_b128, one v_mov_b32_dpp (value)
-//     and two v_pk_fma_f32 -- no VGPR->SGPR traffic, no scalar loads (MODE 2;
-//     MODE 0 = scalar loads and MODE 1 = v_readlane hand-out are kept for A/B
-//     measurements).
+//     and two v_pk_fma_f32 -- no VGPR->SGPR traffic, no scalar loads.  (Two
+//     earlier forms, scalar loads of the stream and v_readlane hand-out, were
+//     measured slower and removed: DESIGN.md section 3.1.)
 //
 // The binding limit is LDS bandwidth: one B dword per FMA, 256 B/clk/CU
 // -> 64 FMA/clk/CU = 78.6 TFLOP/s chip-wide (= the plain v_fma_f32 rate).
@@ -78,7 +78,7 @@ __device__ __forceinline__ void stage_chunk(float* __restrict__ tile, const floa
   // row-major tile row.  Rows past the end of B (last, partial chunk) re-read
   // row k-1: no nonzero refers to them, and every wave then issues exactly
   // kStageRowsPerWave copies per stage, which the counted vmcnt waits of
-  // MODE 2 rely on.
+  // main loop rely on.
 #pragma unroll
   for (int i = 0; i < Cfg::kStageRowsPerWave; ++i) {
     const int r = wave + i * Cfg::kWaves;
@@ -87,7 +87,7 @@ __device__ __forceinline__ void stage_chunk(float* __restrict__ tile, const floa
   }
 }
 
-// MODE 2 main loop (see the kernel's header comment).
+// Main loop (see the file header).
 //
 // Every vector-memory operation inside the loop is issued from inline asm, in
 // a fixed order and number per chunk, so the waits can be counted by hand:
@@ -208,16 +208,9 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
   wait_vm<0>();  // nothing may be in flight (LDS-DMA!) when the wave ends
 }
 
-// MODE 0: the row's (column, value) stream is read with scalar loads.
-// MODE 1: each row keeps the next 64 entries of its stream in two VGPRs
-//         (lane u = entry u), prefetched one K chunk ahead with vector loads
-//         and handed out with v_readlane; per (row, chunk) this costs two
-//         vector loads instead of a chain of dependent scalar loads.
-// MODE 2: same windows, but entries are handed out with DPP row broadcasts
-//         (16 entries at a time, replicated into every 16-lane row with one
-//         ds_bpermute pair): no VGPR->SGPR traffic at all.  Entries are
-//         processed four at a time, the last group padded with zero values.
-template <typename Cfg, int MODE>
+// EXACT = false: groups of four entries, the last one padded ("MODE 2" in
+//         DESIGN.md); EXACT = true: rotating groups, exact tails ("MODE 3").
+template <typename Cfg, bool EXACT>
 __global__ __launch_bounds__(Cfg::kThreads) void spmm_tiled_kernel(
     int m, int k, int n, int nonzeros, int slots, int nchunks, int n_tiles,
     const int* __restrict__ row_indices, const float* __restrict__ values,
@@ -229,7 +222,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void spmm_tiled_kernel(
   const bool dbg_no_compute = debug & 1, dbg_no_stage = debug & 2;
 
   constexpr int BN = Cfg::kBN, BK = Cfg::kBK, RPW = Cfg::kRPW, VEC = Cfg::kVec;
-  static_assert(BK <= kWave, "a row has at most BK <= 64 entries per chunk (MODE 1 window)");
+  static_assert(BK <= kWave, "a row has at most BK <= 64 entries per chunk (one window)");
   __shared__ float tile[2][BK * BN];
 
   const int lane = threadIdx.x % kWave;
@@ -277,137 +270,10 @@ __global__ __launch_bounds__(Cfg::kThreads) void spmm_tiled_kernel(
 #pragma unroll
     for (int v = 0; v < VEC; ++v) acc[r][v] = 0.f;
 
-  const float* lane_tile = &tile[0][0] + lane * VEC;
-  const unsigned b_lane_off = static_cast<unsigned>(n0 + lane * 4) * 4u;
-
-  if constexpr (MODE == 2 || MODE == 3) {
-    spmm_tiled_body_dpp<Cfg, MODE == 3>(acc, &tile[0][0], lane, wave, slot0, slots, nchunks, nonzeros, n, k,
+  {
+    spmm_tiled_body_dpp<Cfg, EXACT>(acc, &tile[0][0], lane, wave, slot0, slots, nchunks, nonzeros, n, k,
                              n0, values, column_indices, table, dense, dbg_no_compute,
                              dbg_no_stage);
-  } else if constexpr (MODE == 0) {
-    int ps[RPW];
-#pragma unroll
-    for (int r = 0; r < RPW; ++r) ps[r] = table[slot0 + r];
-
-    stage_chunk<Cfg>(tile[0], dense, n, k, 0, wave, b_lane_off);
-    wait_stage();
-    __syncthreads();
-
-    for (int c = 0; c < nchunks; ++c) {
-      const int buf = c & 1;
-      if (c + 1 < nchunks && !dbg_no_stage)
-        stage_chunk<Cfg>(tile[buf ^ 1], dense, n, k, (c + 1) * BK, wave, b_lane_off);
-      const int* __restrict__ next_ptr = table + static_cast<int64_t>(c + 1) * slots + slot0;
-      const float* __restrict__ btile = lane_tile + buf * (BK * BN);
-      const int kc = c * BK;
-#pragma unroll
-      for (int r = 0; r < RPW; ++r) {
-        const int pe = next_ptr[r];
-        int p = ps[r];
-        for (; p + 4 <= pe; p += 4) {
-          int j[4];
-          float a[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            j[u] = column_indices[p + u];
-            a[u] = values[p + u];
-          }
-          float4 b[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-            b[u] = *reinterpret_cast<const float4*>(btile + (j[u] - kc) * BN);
-#pragma unroll
-          for (int u = 0; u < 4; ++u) SPUTNIK_HIP_FMA4(acc[r], a[u], b[u]);
-        }
-        for (; p < pe; ++p) {
-          const int j = column_indices[p];
-          const float a = values[p];
-          const float4 b = *reinterpret_cast<const float4*>(btile + (j - kc) * BN);
-          SPUTNIK_HIP_FMA4(acc[r], a, b);
-        }
-        ps[r] = pe;
-      }
-      wait_stage();     // this wave's share of the next stage has landed in LDS
-      __syncthreads();  // everyone's has, and the current buffer is free to overwrite
-    }
-  } else {
-    // Lane r (< RPW) of these holds the stream position of row r at the
-    // start of the current chunk / of the next chunk / of the one after.
-    const int ptr_lane = min(lane, RPW - 1);
-    const int* __restrict__ my_table = table + slot0 + ptr_lane;
-    int v_ps = my_table[0];
-    int v_pe = my_table[slots];
-    const int last = nonzeros - 1;
-
-    int vcol[RPW];
-    float vval[RPW];
-#pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-      const int idx = min(__builtin_amdgcn_readlane(v_ps, r) + lane, last);
-      vcol[r] = column_indices[idx];
-      vval[r] = values[idx];
-    }
-
-    stage_chunk<Cfg>(tile[0], dense, n, k, 0, wave, b_lane_off);
-    wait_stage();
-    __syncthreads();
-
-    for (int c = 0; c < nchunks; ++c) {
-      const int buf = c & 1;
-      if (c + 1 < nchunks && !dbg_no_stage)
-        stage_chunk<Cfg>(tile[buf ^ 1], dense, n, k, (c + 1) * BK, wave, b_lane_off);
-      const int v_pe_next =
-          (c + 2 <= nchunks) ? my_table[static_cast<int64_t>(c + 2) * slots] : 0;
-      const float* __restrict__ btile = lane_tile + buf * (BK * BN);
-      const int kc = c * BK;
-#pragma unroll
-      for (int r = 0; r < RPW; ++r) {
-        const int s_pe = __builtin_amdgcn_readlane(v_pe, r);
-        const int cnt = dbg_no_compute ? 0 : s_pe - __builtin_amdgcn_readlane(v_ps, r);
-      int u = 0;
-        for (; u + 4 <= cnt; u += 4) {
-          int j[4];
-          float a[4];
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            j[t] = __builtin_amdgcn_readlane(vcol[r], u + t);
-            a[t] = readlane_f32(vval[r], u + t);
-          }
-          float4 b[4];
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-            b[t] = *reinterpret_cast<const float4*>(btile + (j[t] - kc) * BN);
-#pragma unroll
-          for (int t = 0; t < 4; ++t) SPUTNIK_HIP_FMA4(acc[r], a[t], b[t]);
-        }
-        if (cnt & 2) {
-          const int j0 = __builtin_amdgcn_readlane(vcol[r], u);
-          const int j1 = __builtin_amdgcn_readlane(vcol[r], u + 1);
-          const float a0 = readlane_f32(vval[r], u), a1 = readlane_f32(vval[r], u + 1);
-          const float4 b0 = *reinterpret_cast<const float4*>(btile + (j0 - kc) * BN);
-          const float4 b1 = *reinterpret_cast<const float4*>(btile + (j1 - kc) * BN);
-          SPUTNIK_HIP_FMA4(acc[r], a0, b0);
-          SPUTNIK_HIP_FMA4(acc[r], a1, b1);
-          u += 2;
-        }
-        if (cnt & 1) {
-          const int j0 = __builtin_amdgcn_readlane(vcol[r], u);
-          const float a0 = readlane_f32(vval[r], u);
-          const float4 b0 = *reinterpret_cast<const float4*>(btile + (j0 - kc) * BN);
-          SPUTNIK_HIP_FMA4(acc[r], a0, b0);
-        }
-        // This row's window for the next chunk (in flight until the barrier).
-        if (c + 1 < nchunks) {
-          const int idx = min(s_pe + lane, last);
-          vcol[r] = column_indices[idx];
-          vval[r] = values[idx];
-        }
-      }
-      v_ps = v_pe;
-      v_pe = v_pe_next;
-      wait_stage();     // next stage of B and the next entry windows have landed
-      __syncthreads();  // ... for every wave, and the current buffer is free
-    }
   }
 
 #pragma unroll
@@ -523,55 +389,33 @@ int spmm_tiled_exec(int m, int k, int n, int nonzeros, int replicas, const int* 
                                                   row_ok_bytes(plan.slots));
 
   const int blocks = (plan.slots / Cfg::kBM) * plan.n_tiles;
-  static const int mode = [] {
-    const char* e = getenv("SPUTNIK_HIP_SPMM_MODE");  // developer knob, see DESIGN.md
-    return e ? atoi(e) : -1;  // -1: choose between 2 and 3 from the mean segment length
+  static const int forced = [] {
+    const char* e = getenv("SPUTNIK_HIP_SPMM_EXACT");  // developer knob: 0 / 1 forces the variant
+    return e ? atoi(e) : -1;
   }();
-  // mean number of entries of a row inside one K chunk
-  const bool short_segments =
-      static_cast<int64_t>(nonzeros) < int64_t{12} * m * plan.nchunks;
   static const int debug = [] {
-    const char* e = getenv("SPUTNIK_HIP_SPMM_DEBUG");
+    const char* e = getenv("SPUTNIK_HIP_SPMM_DEBUG");  // timing experiments only
     return e ? atoi(e) : 0;
   }();
-  if (mode == 0) {
-    hipLaunchKernelGGL((spmm_tiled_kernel<Cfg, 0>), dim3(blocks, replicas), dim3(Cfg::kThreads),
-                       0, stream, m, k, n, nonzeros, plan.slots, plan.nchunks, plan.n_tiles,
-                       row_indices, values, values_stride, column_indices, table, dense,
-                       dense_stride, out, out_stride, row_ok, row_offsets, debug);
-  } else if (mode == 1) {
-    hipLaunchKernelGGL((spmm_tiled_kernel<Cfg, 1>), dim3(blocks, replicas), dim3(Cfg::kThreads),
-                       0, stream, m, k, n, nonzeros, plan.slots, plan.nchunks, plan.n_tiles,
-                       row_indices, values, values_stride, column_indices, table, dense,
-                       dense_stride, out, out_stride, row_ok, row_offsets, debug);
-  } else if (static_cast<int64_t>(blocks) * replicas >= 192 &&
-             (mode == 3 || (mode != 2 && short_segments))) {
-    // MODE 3 = MODE 2 with exact (rotating) processing of short segments
-    hipLaunchKernelGGL((spmm_tiled_kernel<Cfg, 3>), dim3(blocks, replicas), dim3(Cfg::kThreads),
-                       0, stream, m, k, n, nonzeros, plan.slots, plan.nchunks, plan.n_tiles,
-                       row_indices, values, values_stride, column_indices, table, dense,
-                       dense_stride, out, out_stride, row_ok, row_offsets, debug);
-  } else if (static_cast<int64_t>(blocks) * replicas >= 192) {
-    hipLaunchKernelGGL((spmm_tiled_kernel<Cfg, 2>), dim3(blocks, replicas), dim3(Cfg::kThreads),
-                       0, stream, m, k, n, nonzeros, plan.slots, plan.nchunks, plan.n_tiles,
-                       row_indices, values, values_stride, column_indices, table, dense,
-                       dense_stride, out, out_stride, row_ok, row_offsets, debug);
+  // Short segments (mean number of entries of a row inside one K chunk < 12)
+  // take the rotating, exact variant.
+  const bool exact = forced >= 0 ? forced != 0
+                                 : static_cast<int64_t>(nonzeros) < int64_t{12} * m * plan.nchunks;
+  const bool large = static_cast<int64_t>(blocks) * replicas >= 192;
+#define SPUTNIK_HIP_LAUNCH_TILED(CFG, EXACT_)                                                     \
+  hipLaunchKernelGGL((spmm_tiled_kernel<CFG, EXACT_>),                                            \
+                     dim3((plan.slots / CFG::kBM) * plan.n_tiles, replicas), dim3(CFG::kThreads), \
+                     0, stream, m, k, n, nonzeros, plan.slots, plan.nchunks, plan.n_tiles,        \
+                     row_indices, values, values_stride, column_indices, table, dense,            \
+                     dense_stride, out, out_stride, row_ok, row_offsets, debug)
+  if (large) {
+    if (exact) SPUTNIK_HIP_LAUNCH_TILED(CfgLarge, true);
+    else SPUTNIK_HIP_LAUNCH_TILED(CfgLarge, false);
   } else {
-    const int blocks_medium = (plan.slots / CfgMedium::kBM) * plan.n_tiles;
-    if (mode == 3 || (mode != 2 && short_segments)) {
-      hipLaunchKernelGGL((spmm_tiled_kernel<CfgMedium, 3>), dim3(blocks_medium, replicas),
-                         dim3(CfgMedium::kThreads), 0, stream, m, k, n, nonzeros, plan.slots,
-                         plan.nchunks, plan.n_tiles, row_indices, values, values_stride,
-                         column_indices, table, dense, dense_stride, out, out_stride, row_ok,
-                         row_offsets, debug);
-    } else {
-      hipLaunchKernelGGL((spmm_tiled_kernel<CfgMedium, 2>), dim3(blocks_medium, replicas),
-                         dim3(CfgMedium::kThreads), 0, stream, m, k, n, nonzeros, plan.slots,
-                         plan.nchunks, plan.n_tiles, row_indices, values, values_stride,
-                         column_indices, table, dense, dense_stride, out, out_stride, row_ok,
-                         row_offsets, debug);
-    }
+    if (exact) SPUTNIK_HIP_LAUNCH_TILED(CfgMedium, true);
+    else SPUTNIK_HIP_LAUNCH_TILED(CfgMedium, false);
   }
+#undef SPUTNIK_HIP_LAUNCH_TILED
   *handled = true;
   return launch_status();
 }

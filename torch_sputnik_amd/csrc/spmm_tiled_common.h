@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void spmm_chunk_table_kernel(
 // copy as a pending LDS write and puts `s_waitcnt vmcnt(0)` in front of every
 // following ds_read, which would serialise the prefetch of the next stage
 // with the compute on the current one.  The waits are placed by hand instead
-// (wait_stage() before the barrier that publishes a stage).
+// (wait_vm<N>() before the barrier that publishes a stage).
 __device__ __forceinline__ void lds_dma_row(const float* row_base /* wave-uniform */,
                                             unsigned lane_byte_offset, const float* lds_dst) {
   const unsigned lds_addr =
@@ -85,9 +85,8 @@ __device__ __forceinline__ void lds_dma_row(const float* row_base /* wave-unifor
       : "memory", "m0");
 }
 
-__device__ __forceinline__ void wait_stage() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// Vector load whose completion the compiler does not track (MODE 2 counts
+// Vector load whose completion the compiler does not track (the main loop counts
 // vmcnt by hand, see the kernel).
 // (wave-uniform base in SGPRs + 32-bit per-lane byte offset: no 64-bit VGPR
 // address arithmetic, no VGPR pairs to keep alive.)
