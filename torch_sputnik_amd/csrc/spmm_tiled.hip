@@ -103,7 +103,7 @@ __device__ __forceinline__ void stage_chunk(float* __restrict__ tile, const floa
 // tile of the next chunk) and leaves B and C in flight across the barrier.
 // The last chunk issues the same (clamped, unused) operations so that the
 // counts hold for every iteration; the first one starts from a full drain.
-template <typename Cfg, bool EXACT>
+template <typename Cfg, bool SPARSE>
 __device__ __forceinline__ void spmm_tiled_body_dpp(
     float (&acc)[Cfg::kRPW][Cfg::kVec], float* __restrict__ tile0, int lane, int wave, int slot0,
     int slots, int nchunks, int nonzeros, int n, int k, int n0, const float* __restrict__ values,
@@ -118,11 +118,17 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
   constexpr int kWaitStage = 2 * RPW + 1;
   static_assert(kWaitStage <= 63, "vmcnt is a 6-bit counter");
 
+  // SPARSE: the window holds 16 entries, already replicated in every 16-lane
+  // row by the load itself (lane l reads entry l % 16): no ds_bpermute step, a
+  // quarter of the window traffic, and the entries are processed exactly
+  // (rotating groups).  For short segments only: the rare segment with more
+  // than 16 entries fetches the rest on demand, draining the wave's loads.
+  constexpr int kWindow = SPARSE ? 16 : kWave;
   const unsigned ptr_off = static_cast<unsigned>(min(lane, RPW - 1)) * 4u;
   const int* __restrict__ my_table = table + slot0;  // wave-uniform
   const int e16x4 = (lane & 15) * 4;
-  const unsigned lane4 = static_cast<unsigned>(lane) * 4u;
-  const int last_window = nonzeros - kWave;  // >= 0: the dispatcher requires >= 1024 nonzeros
+  const unsigned lane4 = static_cast<unsigned>(SPARSE ? (lane & 15) : lane) * 4u;
+  const int last_window = nonzeros - kWindow;  // >= 0: the dispatcher requires >= 1024 nonzeros
   const float* lane_tile = tile0 + lane * VEC;
   const unsigned b_lane_off = static_cast<unsigned>(n0 + lane * 4) * 4u;
 
@@ -179,21 +185,49 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
         wait_vm<kWaitSameChunk>(wcol, wval, v_cnt);
       }
       const int cnt = dbg_no_compute ? 0 : __builtin_amdgcn_readlane(v_cnt, r);
+      if constexpr (SPARSE) {
+        if (cnt > 0) {
+          int rcol = wcol;
+          float rval = wval;
+          if (shift[r % D] != 0) {  // window moved back at the end of the arrays: realign
+            const int idx = ((lane & 48) << 2) + ((e16x4 + (shift[r % D] << 2)) & 60);
+            rcol = __builtin_amdgcn_ds_bpermute(idx, rcol);
+            rval = __builtin_bit_cast(
+                float, __builtin_amdgcn_ds_bpermute(idx, __builtin_bit_cast(int, rval)));
+          }
+          dpp_entries_exact(acc[r], min(16, cnt), rcol * (BN * 4), rval, lane_base);
+          if (cnt > 16) {  // rare: the rest of a long segment, 16 entries at a time
+            const int start = __builtin_amdgcn_readlane(v_ps, r);
+            for (int q0 = 16; q0 < cnt; q0 += 16) {
+              const int base = min(start + q0, last_window);
+              const int sh = start + q0 - base;
+              int c2 = untracked_load_i32(column_indices + base, lane4);
+              float v2 = untracked_load_f32(values + base, lane4);
+              wait_vm<0>();
+              asm volatile("" : "+v"(c2), "+v"(v2));
+              if (sh != 0) {
+                const int idx = ((lane & 48) << 2) + ((e16x4 + (sh << 2)) & 60);
+                c2 = __builtin_amdgcn_ds_bpermute(idx, c2);
+                v2 = __builtin_bit_cast(
+                    float, __builtin_amdgcn_ds_bpermute(idx, __builtin_bit_cast(int, v2)));
+              }
+              dpp_entries_exact(acc[r], min(16, cnt - q0), c2 * (BN * 4), v2, lane_base);
+            }
+          }
+        }
+      } else {
       for (int q0 = 0; q0 < cnt; q0 += 16) {
         // replicate entries q0 .. q0+15 of the row into every 16-lane row
         const int idx = e16x4 + ((q0 + shift[r % D]) << 2);
         const int rcol = __builtin_amdgcn_ds_bpermute(idx, wcol);
         const float rval_all = __builtin_bit_cast(
             float, __builtin_amdgcn_ds_bpermute(idx, __builtin_bit_cast(int, wval)));
-        if constexpr (EXACT) {
-          dpp_entries_exact(acc[r], min(16, cnt - q0), rcol * (BN * 4), rval_all, lane_base);
-        } else {
-          // lanes standing for entries past the row's count: zero value, tile row 0
-          const bool valid = e16x4 < ((cnt - q0) << 2);
-          const int roff = valid ? rcol * (BN * 4) : kc_off;
-          const float rval = valid ? rval_all : 0.f;
-          dpp_entries(acc[r], min(16, cnt - q0), roff, rval, lane_base);
-        }
+        // lanes standing for entries past the row's count: zero value, tile row 0
+        const bool valid = e16x4 < ((cnt - q0) << 2);
+        const int roff = valid ? rcol * (BN * 4) : kc_off;
+        const float rval = valid ? rval_all : 0.f;
+        dpp_entries(acc[r], min(16, cnt - q0), roff, rval, lane_base);
+      }
       }
       // C: request the window that will be consumed D rows from now.
       request(r % D, (r + D < RPW) ? __builtin_amdgcn_readlane(v_ps, (r + D) % RPW)
@@ -208,9 +242,10 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
   wait_vm<0>();  // nothing may be in flight (LDS-DMA!) when the wave ends
 }
 
-// EXACT = false: groups of four entries, the last one padded ("MODE 2" in
-//         DESIGN.md); EXACT = true: rotating groups, exact tails ("MODE 3").
-template <typename Cfg, bool EXACT>
+// SPARSE = false: 64-entry windows, groups of four entries with a padded last
+// group (long segments).  SPARSE = true: 16-entry windows replicated by the
+// load itself, rotating groups with exact tails (short segments).
+template <typename Cfg, bool SPARSE>
 __global__ __launch_bounds__(Cfg::kThreads) void spmm_tiled_kernel(
     int m, int k, int n, int nonzeros, int slots, int nchunks, int n_tiles,
     const int* __restrict__ row_indices, const float* __restrict__ values,
@@ -271,7 +306,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void spmm_tiled_kernel(
     for (int v = 0; v < VEC; ++v) acc[r][v] = 0.f;
 
   {
-    spmm_tiled_body_dpp<Cfg, EXACT>(acc, &tile[0][0], lane, wave, slot0, slots, nchunks, nonzeros, n, k,
+    spmm_tiled_body_dpp<Cfg, SPARSE>(acc, &tile[0][0], lane, wave, slot0, slots, nchunks, nonzeros, n, k,
                              n0, values, column_indices, table, dense, dbg_no_compute,
                              dbg_no_stage);
   }
@@ -390,29 +425,30 @@ int spmm_tiled_exec(int m, int k, int n, int nonzeros, int replicas, const int* 
 
   const int blocks = (plan.slots / Cfg::kBM) * plan.n_tiles;
   static const int forced = [] {
-    const char* e = getenv("SPUTNIK_HIP_SPMM_EXACT");  // developer knob: 0 / 1 forces the variant
+    const char* e = getenv("SPUTNIK_HIP_SPMM_SPARSE");  // developer knob: 0 / 1 forces the variant
     return e ? atoi(e) : -1;
   }();
   static const int debug = [] {
     const char* e = getenv("SPUTNIK_HIP_SPMM_DEBUG");  // timing experiments only
     return e ? atoi(e) : 0;
   }();
-  // Short segments (mean number of entries of a row inside one K chunk < 12)
-  // take the rotating, exact variant.
-  const bool exact = forced >= 0 ? forced != 0
-                                 : static_cast<int64_t>(nonzeros) < int64_t{12} * m * plan.nchunks;
+  // Mean number of entries of a row inside one K chunk picks the variant
+  // (measured cross-over at 4096^3: between density 0.15 and 0.2).
+  const bool sparse = forced >= 0
+                          ? forced != 0
+                          : static_cast<int64_t>(nonzeros) < int64_t{12} * m * plan.nchunks;
   const bool large = static_cast<int64_t>(blocks) * replicas >= 192;
-#define SPUTNIK_HIP_LAUNCH_TILED(CFG, EXACT_)                                                     \
-  hipLaunchKernelGGL((spmm_tiled_kernel<CFG, EXACT_>),                                            \
+#define SPUTNIK_HIP_LAUNCH_TILED(CFG, SPARSE_)                                                    \
+  hipLaunchKernelGGL((spmm_tiled_kernel<CFG, SPARSE_>),                                           \
                      dim3((plan.slots / CFG::kBM) * plan.n_tiles, replicas), dim3(CFG::kThreads), \
                      0, stream, m, k, n, nonzeros, plan.slots, plan.nchunks, plan.n_tiles,        \
                      row_indices, values, values_stride, column_indices, table, dense,            \
                      dense_stride, out, out_stride, row_ok, row_offsets, debug)
   if (large) {
-    if (exact) SPUTNIK_HIP_LAUNCH_TILED(CfgLarge, true);
+    if (sparse) SPUTNIK_HIP_LAUNCH_TILED(CfgLarge, true);
     else SPUTNIK_HIP_LAUNCH_TILED(CfgLarge, false);
   } else {
-    if (exact) SPUTNIK_HIP_LAUNCH_TILED(CfgMedium, true);
+    if (sparse) SPUTNIK_HIP_LAUNCH_TILED(CfgMedium, true);
     else SPUTNIK_HIP_LAUNCH_TILED(CfgMedium, false);
   }
 #undef SPUTNIK_HIP_LAUNCH_TILED
