@@ -437,7 +437,11 @@ int spmm_tiled_exec(int m, int k, int n, int nonzeros, int replicas, const int* 
   const bool sparse = forced >= 0
                           ? forced != 0
                           : static_cast<int64_t>(nonzeros) < int64_t{12} * m * plan.nchunks;
-  const bool large = static_cast<int64_t>(blocks) * replicas >= 192;
+  static const int force_medium = [] {
+    const char* e = getenv("SPUTNIK_HIP_SPMM_MEDIUM");  // developer knob
+    return e ? atoi(e) : 0;
+  }();
+  const bool large = !force_medium && static_cast<int64_t>(blocks) * replicas >= 192;
 #define SPUTNIK_HIP_LAUNCH_TILED(CFG, SPARSE_)                                                    \
   hipLaunchKernelGGL((spmm_tiled_kernel<CFG, SPARSE_>),                                           \
                      dim3((plan.slots / CFG::kBM) * plan.n_tiles, replicas), dim3(CFG::kThreads), \
