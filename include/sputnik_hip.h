@@ -169,6 +169,110 @@ SPUTNIK_HIP_API int sputnik_hip_csr_transpose(int m, int n, int nonzeros, int re
                               size_t workspace_bytes,
                               sputnik_hip_stream_t stream);
 
+/* ========================================================================
+ * Extensions around the five operators.  The reference binding
+ * as committed (src/sputnik.cpp:36-42) has none of these; the call sites that
+ * fix their meaning are cited per entry.
+ * ====================================================================== */
+
+/*
+ * SpMM with a fused epilogue: out[i, :] = act(sum + bias[i]); `bias` ([m],
+ * indexed by output row, may be NULL) and relu (0/1) are both optional.
+ * Call site: torch_sputnik.spmm_bias(m, k, values, row_indices, row_offsets,
+ * column_indices, bias, dense), tests/test_spmm_bias_relu.py:35-37; the
+ * SparseLinear callers add the bias in a separate pass
+ * (tests/test_linear_3d.py:47).
+ */
+SPUTNIK_HIP_API int sputnik_hip_spmm_bias_batched(int m, int k, int n, int nonzeros,
+                             int replicas, const int* row_indices,
+                             const float* values, int64_t values_stride,
+                             const int* row_offsets, const int* column_indices,
+                             const float* dense, int64_t dense_stride,
+                             const float* bias, int relu, float* out,
+                             int64_t out_stride, void* workspace,
+                             size_t workspace_bytes, sputnik_hip_stream_t stream);
+
+/*
+ * softmax(scale * x) per CSR row: folds the 1/sqrt(d) of
+ * modules/sparse_attention.py:72 into the softmax pass.
+ */
+SPUTNIK_HIP_API int sputnik_hip_sparse_softmax_scaled_batched(int m, int n, int nonzeros,
+                             int replicas, const float* values, int64_t values_stride,
+                             const int* row_indices, const int* row_offsets,
+                             const int* column_indices, float scale, float* out,
+                             int64_t out_stride, sputnik_hip_stream_t stream);
+
+/*
+ * Gradient of y = softmax(scale * x):
+ *   grad_values = scale * y * (grad_out - rowsum(grad_out * y)),
+ * row sums over the stored entries.  The reference calls the raw op inside
+ * attention (modules/sparse_attention.py:76), which cuts the gradient; the
+ * intended autograd wrapper is tests/transformer/functions.py:70-120.
+ */
+SPUTNIK_HIP_API int sputnik_hip_sparse_softmax_backward_batched(int m, int nonzeros,
+                             int replicas, const float* softmax_out, int64_t out_stride,
+                             const float* grad_out, int64_t grad_out_stride,
+                             const int* row_offsets, float scale, float* grad_values,
+                             int64_t grad_values_stride, sputnik_hip_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * "many mask" family: `masks` topologies of the same m x n shape, laid out
+ * as tests/transformer/utils.py:17-38 builds them:
+ *   row_indices    [masks * m]        local row ids of mask i at i*m
+ *   row_offsets    [masks * (m + 1)]  each mask's offsets start at 0
+ *   column_indices [sum nonzeros[i]]  concatenated
+ *   nonzeros       [masks]            HOST array
+ * `replicas` (a multiple of `masks`) value / dense slices; replica r uses
+ * mask r / (replicas / masks), i.e. the heads of one batch element share its
+ * mask (tests/test_attention_many_masks.py:107-150).  Replica r keeps its
+ * nonzeros[mask] values at values + r * values_stride; the stride is
+ * normally max(nonzeros) and anything past a replica's own count is never
+ * read or written.
+ * Call sites: torch_sputnik.{sddmm,sparse_softmax,spmm,csr_transpose}_many_mask,
+ * tests/transformer/functions.py:20,41,50,59,81,135,156,165,177.
+ * Workspaces: the single-mask query at max(nonzeros).
+ * ---------------------------------------------------------------------- */
+SPUTNIK_HIP_API int sputnik_hip_spmm_many_mask(int masks, int m, int k, int n,
+                             const int* nonzeros, int replicas, const int* row_indices,
+                             const float* values, int64_t values_stride,
+                             const int* row_offsets, const int* column_indices,
+                             const float* dense, int64_t dense_stride, float* out,
+                             int64_t out_stride, void* workspace,
+                             size_t workspace_bytes, sputnik_hip_stream_t stream);
+
+SPUTNIK_HIP_API int sputnik_hip_sddmm_many_mask(int masks, int m, int k, int n,
+                             const int* nonzeros, int replicas, const int* row_indices,
+                             const int* row_offsets, const int* column_indices,
+                             const float* lhs, int64_t lhs_stride, const float* rhs,
+                             int64_t rhs_stride, float* out, int64_t out_stride,
+                             void* workspace, size_t workspace_bytes,
+                             sputnik_hip_stream_t stream);
+
+SPUTNIK_HIP_API int sputnik_hip_sparse_softmax_many_mask(int masks, int m,
+                             const int* nonzeros, int replicas, const float* values,
+                             int64_t values_stride, const int* row_indices,
+                             const int* row_offsets, const int* column_indices,
+                             float scale, float* out, int64_t out_stride,
+                             sputnik_hip_stream_t stream);
+
+SPUTNIK_HIP_API int sputnik_hip_sparse_softmax_backward_many_mask(int masks, int m,
+                             const int* nonzeros, int replicas, const float* softmax_out,
+                             int64_t out_stride, const float* grad_out,
+                             int64_t grad_out_stride, const int* row_offsets, float scale,
+                             float* grad_values, int64_t grad_values_stride,
+                             sputnik_hip_stream_t stream);
+
+/* out_row_offsets [masks][n + 1], out_column_indices / out_permutation
+ * (may be NULL) laid out like column_indices. */
+SPUTNIK_HIP_API int sputnik_hip_csr_transpose_many_mask(int masks, int m, int n,
+                             const int* nonzeros, int replicas, const float* values,
+                             int64_t values_stride, const int* row_offsets,
+                             const int* column_indices, float* out_values,
+                             int64_t out_values_stride, int* out_row_offsets,
+                             int* out_column_indices, int* out_permutation,
+                             void* workspace, size_t workspace_bytes,
+                             sputnik_hip_stream_t stream);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

@@ -225,6 +225,166 @@ def autograd_cases():
           grad_x=xd.grad.numpy(), grad_values=wd.grad.numpy()[weight != 0])
 
 
+def spmm_bias_cases():
+    """tests/test_spmm_bias_relu.py:19-45: m,k,n = 72,64,72, sparsity 0, bias = ones(m),
+    expected ``dense_result + 1``; plus a signed case that makes the ReLU visible."""
+    seed = 5101
+    np.random.seed(seed)
+    m, k, n = 72, 64, 72
+    lhs = _f32(connectors.Uniform(0.0, round_to=4)(initializers.Uniform()([m, k])))
+    rhs = _f32(initializers.Uniform()([k, n]))
+    values, row_indices, row_offsets, column_indices = O.dense_to_csr(lhs)
+    bias = np.ones(m, dtype=np.float32)
+    expected = O.dense_spmm(lhs, rhs) + 1.0
+    _close(O.spmm_bias(m, k, values, row_indices, row_offsets, column_indices, bias, rhs),
+           expected, "spmm_bias")
+    _save("spmm_bias_72x64x72", seed=seed, m=m, k=k, n=n, values=values, row_indices=row_indices,
+          row_offsets=row_offsets, column_indices=column_indices, dense=rhs, bias=bias,
+          relu=0, expected=expected)
+
+    seed = 5102
+    np.random.seed(seed)
+    m, k, n = 40, 48, 36
+    lhs = _f32(connectors.Uniform(0.8, round_to=4)(initializers.Uniform(-1.0, 1.0)([m, k])))
+    rhs = _f32(initializers.Uniform(-1.0, 1.0)([k, n]))
+    bias = _f32(initializers.Uniform(-0.5, 0.5)([m]))
+    values, row_indices, row_offsets, column_indices = O.dense_to_csr(lhs)
+    expected = np.maximum(O.dense_spmm(lhs, rhs) + bias.astype(np.float64)[:, None], 0.0)
+    _close(O.spmm_bias(m, k, values, row_indices, row_offsets, column_indices, bias, rhs,
+                       relu=True), expected, "spmm_bias_relu")
+    _save("spmm_bias_relu_40x48x36", seed=seed, m=m, k=k, n=n, values=values,
+          row_indices=row_indices, row_offsets=row_offsets, column_indices=column_indices,
+          dense=rhs, bias=bias, relu=1, expected=expected)
+
+
+def softmax_backward_case():
+    """Gradient of the masked dense softmax of tests/test_softmax.py:9-22 (here with a
+    scale), from dense float64 autograd."""
+    seed = 5201
+    np.random.seed(seed)
+    m, n, scale = 48, 40, 0.125
+    mask = connectors.Uniform(0.7)(np.ones([m, n])) != 0
+    mask[5] = False  # an empty row
+    x = _f32(initializers.Uniform(-4.0, 4.0)([m, n]))
+    grad = _f32(initializers.Uniform(-1.0, 1.0)([m, n]))
+    _, row_indices, row_offsets, column_indices = O.dense_to_csr(mask.astype(np.float32))
+    xd = torch.from_numpy(x).double().requires_grad_(True)
+    masked = (xd * scale).masked_fill(~torch.from_numpy(mask), float("-inf"))
+    y = torch.softmax(masked, dim=-1)
+    y = torch.where(torch.from_numpy(mask), y, torch.zeros_like(y))  # empty row: nan -> 0
+    (y * torch.from_numpy(grad).double())[torch.from_numpy(mask)].sum().backward()
+    y_sparse = y.detach().numpy()[mask]
+    grad_sparse = grad[mask]
+    expected = np.nan_to_num(xd.grad.numpy())[mask]
+    _close(O.sparse_softmax_scaled(x[mask], row_indices, row_offsets, column_indices, scale),
+           y_sparse, "softmax scaled")
+    _close(O.sparse_softmax_backward(y_sparse, grad_sparse, row_offsets, scale), expected,
+           "softmax backward")
+    _save("softmax_backward_48x40", seed=seed, m=m, n=n, scale=scale, values=x[mask],
+          row_indices=row_indices, row_offsets=row_offsets, column_indices=column_indices,
+          softmax_out=y_sparse, grad_out=grad_sparse, grad_values=expected)
+
+
+def many_mask_cases():
+    """The many-mask family through the reference's own sketches:
+    tests/transformer/functions.py ``Spmm`` / ``Sddmm`` (forward + backward) and
+    the attention chain of tests/test_attention_many_masks.py:107-150, with the
+    topology built by tests/transformer/utils.py ``dense_to_sparse_3d``.  Expected
+    values are dense float64 autograd per batch element."""
+    torch_cpu_backend.install()
+    sys.path.insert(0, os.path.join(REFERENCE, "tests", "transformer"))
+    import functions as ref_functions  # reference: tests/transformer/functions.py
+    import utils as ref_utils  # reference: tests/transformer/utils.py
+
+    seed = 6101
+    np.random.seed(seed)
+    b, heads, s, hn = 3, 2, 24, 8
+    replicas = b * heads
+    # different sparsity per batch element, as tests/test_attention_many_masks.py:26-36
+    masks = np.stack([connectors.Uniform(sp)(np.ones([s, s])) for sp in (0.2, 0.5, 0.8)])
+    masks = masks.astype(np.float32)
+    mask_t = torch.from_numpy(masks)
+    _, row_indices, row_offsets, column_indices, nnzs = ref_utils.dense_to_sparse_3d(mask_t)
+    ri, ro, ci, nn = O.dense_to_csr_many_mask(masks)
+    assert np.array_equal(row_offsets.numpy().reshape(-1), ro)
+    assert np.array_equal(column_indices.numpy(), ci) and np.array_equal(nnzs.numpy(), nn)
+    # (row_indices: torch.argsort is not stable, ties may order differently; any order is valid)
+    width = int(nn.max())
+
+    q = _f32(initializers.Uniform(-1.0, 1.0)([replicas, s, hn]))
+    kk = _f32(initializers.Uniform(-1.0, 1.0)([replicas, s, hn]))
+    v = _f32(initializers.Uniform(-1.0, 1.0)([replicas, s, hn]))
+    grad_ctx = _f32(initializers.Uniform(-1.0, 1.0)([replicas, s, hn]))
+    scale = 1.0 / np.sqrt(hn)
+
+    # --- reference sketches: Sddmm and Spmm with many masks, forward + backward ------
+    qt = torch.from_numpy(q).requires_grad_(True)
+    kt = torch.from_numpy(kk).requires_grad_(True)
+    scores = ref_functions.Sddmm.apply(b, s, s, nnzs, row_indices, row_offsets, column_indices,
+                                       qt, kt)
+    grad_scores = _f32(initializers.Uniform(-1.0, 1.0)(list(scores.shape)))
+    for i in range(b):  # nothing flows through the padding
+        grad_scores[i * heads:(i + 1) * heads, int(nn[i]):] = 0.0
+    scores.backward(torch.from_numpy(grad_scores))
+
+    rep_mask = np.repeat(masks != 0, heads, axis=0)  # [R, s, s]
+    qd = torch.from_numpy(q).double().requires_grad_(True)
+    kd = torch.from_numpy(kk).double().requires_grad_(True)
+    dense_scores = torch.matmul(qd, kd.transpose(1, 2))
+    expected_scores = np.zeros((replicas, width))
+    dense_grad = np.zeros((replicas, s, s))
+    for r in range(replicas):
+        cnt = int(nn[r // heads])
+        expected_scores[r, :cnt] = dense_scores[r].detach().numpy()[rep_mask[r]]
+        dense_grad[r][rep_mask[r]] = grad_scores[r, :cnt]
+    dense_scores.backward(torch.from_numpy(dense_grad))
+    _close32(scores.detach().numpy(), expected_scores, "Sddmm many-mask fwd")
+    _close32(qt.grad.numpy(), qd.grad.numpy(), "Sddmm many-mask grad_lhs")
+    _close32(kt.grad.numpy(), kd.grad.numpy(), "Sddmm many-mask grad_rhs")
+
+    weights_in = np.zeros((replicas, width), dtype=np.float32)
+    for r in range(replicas):
+        cnt = int(nn[r // heads])
+        weights_in[r, :cnt] = initializers.Uniform(-1.0, 1.0)([cnt])
+    wt = torch.from_numpy(weights_in).requires_grad_(True)
+    vt = torch.from_numpy(v).requires_grad_(True)
+    ctx = ref_functions.Spmm.apply(b, s, s, nnzs, wt, row_indices, row_offsets, column_indices, vt)
+    ctx.backward(torch.from_numpy(grad_ctx))
+    w_dense = np.zeros((replicas, s, s))
+    for r in range(replicas):
+        w_dense[r][rep_mask[r]] = weights_in[r, :int(nn[r // heads])]
+    wd = torch.from_numpy(w_dense).requires_grad_(True)
+    vd = torch.from_numpy(v).double().requires_grad_(True)
+    ctx_d = torch.matmul(wd, vd)
+    ctx_d.backward(torch.from_numpy(grad_ctx).double())
+    expected_gw = np.zeros((replicas, width))
+    for r in range(replicas):
+        expected_gw[r, :int(nn[r // heads])] = wd.grad.numpy()[r][rep_mask[r]]
+    _close32(ctx.detach().numpy(), ctx_d.detach().numpy(), "Spmm many-mask fwd")
+    _close32(vt.grad.numpy(), vd.grad.numpy(), "Spmm many-mask grad_dense")
+    _close32(wt.grad.numpy(), expected_gw, "Spmm many-mask grad_values")
+
+    # --- attention chain, tests/test_attention_many_masks.py:107-150 ---------------
+    import torch_sputnik
+    sc = torch_sputnik.sddmm_many_mask(b, s, s, nnzs, row_indices, row_offsets, column_indices,
+                                       torch.from_numpy(q), torch.from_numpy(kk)) / np.sqrt(hn)
+    we = torch_sputnik.sparse_softmax_many_mask(b, s, nnzs, sc, row_indices, row_offsets,
+                                                column_indices)
+    rep = torch_sputnik.spmm_many_mask(b, s, s, nnzs, we, row_indices, row_offsets,
+                                       column_indices, torch.from_numpy(v))
+    logits = torch.matmul(torch.from_numpy(q).double(), torch.from_numpy(kk).double().transpose(1, 2))
+    logits = (logits / np.sqrt(hn)).masked_fill(~torch.from_numpy(rep_mask), float("-inf"))
+    dense_rep = torch.matmul(torch.softmax(logits, dim=-1), torch.from_numpy(v).double())
+    _close32(rep.numpy(), dense_rep.numpy(), "many-mask attention")
+
+    _save("many_mask_b3_h2_s24", seed=seed, b=b, heads=heads, s=s, hn=hn, masks=masks,
+          row_indices=ri, row_offsets=ro, column_indices=ci, nnzs=nn, q=q, k=kk, v=v,
+          scale=scale, scores=expected_scores, grad_scores=grad_scores, grad_q=qd.grad.numpy(),
+          grad_k=kd.grad.numpy(), weights=weights_in, context=ctx_d.detach().numpy(),
+          grad_context=grad_ctx, grad_weights=expected_gw, grad_v=vd.grad.numpy(),
+          attention=dense_rep.numpy())
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     # BASELINE.json config 1: 64^3, density 0.5
@@ -237,6 +397,9 @@ def main():
     transpose_case("transpose_4x4_row0_zero", 3201, 4, 4, 0.0, zero_first_row=True)
     transpose_case("transpose_72x64", 3202, 72, 64, 0.8)
     autograd_cases()
+    spmm_bias_cases()
+    softmax_backward_case()
+    many_mask_cases()
 
 
 if __name__ == "__main__":

@@ -223,6 +223,167 @@ def csr_transpose(m, n, values, row_offsets, column_indices):
 
 
 # --------------------------------------------------------------------------
+# extensions: epilogues, softmax gradient, many-mask
+# --------------------------------------------------------------------------
+def spmm_bias(m, k, values, row_indices, row_offsets, column_indices, bias, dense, relu=False):
+    """``spmm`` + per-output-row bias (+ ReLU).
+
+    Call site tests/test_spmm_bias_relu.py:35-37 (the check at :43 compares
+    with ``dense_result + 1`` for ``bias = ones(m)``: one bias per output ROW,
+    broadcast over the n columns).
+    """
+    out = spmm(m, k, values, row_indices, row_offsets, column_indices, dense)
+    if bias is not None:
+        bias = np.asarray(bias, dtype=np.float64)
+        assert bias.shape == (m,)
+        out = out + bias[:, None]
+    return np.maximum(out, 0.0) if relu else out
+
+
+def sparse_softmax_scaled(values, row_indices, row_offsets, column_indices, scale):
+    """softmax(scale * x): the ``/ math.sqrt(d)`` of modules/sparse_attention.py:72
+    folded into the softmax."""
+    return sparse_softmax(np.asarray(values, np.float64) * float(scale), row_indices,
+                          row_offsets, column_indices)
+
+
+def sparse_softmax_backward(softmax_out, grad_out, row_offsets, scale=1.0):
+    """dX for Y = softmax(scale * X) over stored entries:
+    ``scale * Y * (dY - rowsum(dY * Y))``.  (tests/transformer/functions.py:70-120
+    sketches the wrapper; its formula is not the softmax Jacobian -- SURVEY.md 8f.)"""
+    row_offsets = np.asarray(row_offsets).astype(np.int64)
+    m = row_offsets.shape[0] - 1
+    y = np.asarray(softmax_out, np.float64)
+    g = np.asarray(grad_out, np.float64)
+    assert y.shape == g.shape and y.shape[-1] == row_offsets[-1]
+    rows = _rows_of(row_offsets)
+
+    def one(y1, g1):
+        dot = np.zeros(m)
+        np.add.at(dot, rows, y1 * g1)
+        return float(scale) * y1 * (g1 - dot[rows])
+
+    if y.ndim == 1:
+        return one(y, g)
+    if y.shape[0] == 0:
+        return np.zeros_like(y)
+    return np.stack([one(y[r], g[r]) for r in range(y.shape[0])])
+
+
+def dense_to_csr_many_mask(masks):
+    """[b, m, n] 0/1 array -> (row_indices [b*m], row_offsets [b*(m+1)],
+    column_indices [sum nnz], nnzs [b]).
+
+    Restates tests/transformer/utils.py:17-38 / tests/test_attention_many_masks.py:54-73:
+    per-mask ``to_sparse_csr`` topologies concatenated, every mask's offsets
+    starting at 0, ``row_indices = diffsort(row_offsets)`` per mask.
+    """
+    masks = np.asarray(masks)
+    assert masks.ndim == 3
+    ri, ro, ci, nnzs = [], [], [], []
+    for mask in masks:
+        _, _, offsets, cols = dense_to_csr(mask)
+        ri.append(diffsort(offsets))
+        ro.append(offsets)
+        ci.append(cols)
+        nnzs.append(cols.shape[0])
+    cat = lambda xs: np.concatenate(xs).astype(np.int32) if xs else np.zeros(0, np.int32)
+    return cat(ri), cat(ro), cat(ci), np.asarray(nnzs, dtype=np.int64)
+
+
+def _split_many_mask(b, m, nnzs, row_indices, row_offsets, column_indices):
+    nnzs = [int(x) for x in np.asarray(nnzs).reshape(-1)]
+    assert len(nnzs) == b
+    row_indices = None if row_indices is None else np.asarray(row_indices).reshape(-1)
+    row_offsets = np.asarray(row_offsets).reshape(-1)
+    column_indices = np.asarray(column_indices).reshape(-1)
+    assert row_offsets.shape[0] == b * (m + 1) and column_indices.shape[0] == sum(nnzs)
+    first = np.concatenate(([0], np.cumsum(nnzs))).astype(np.int64)
+    for i in range(b):
+        yield (i, nnzs[i],
+               None if row_indices is None else row_indices[i * m:(i + 1) * m],
+               row_offsets[i * (m + 1):(i + 1) * (m + 1)],
+               column_indices[first[i]:first[i + 1]])
+
+
+def _heads(b, replicas):
+    assert b > 0 and replicas % b == 0
+    return replicas // b
+
+
+def spmm_many_mask(b, m, k, nnzs, values, row_indices, row_offsets, column_indices, dense):
+    """Replica r multiplies with mask ``r // heads`` (tests/transformer/functions.py:20;
+    tests/test_attention_many_masks.py:143-150).  values [R, >= max nnz] (a
+    replica's own ``nnzs[mask]`` leading entries count), dense [R,k,n] -> [R,m,n]."""
+    values = np.asarray(values, np.float64)
+    dense = np.asarray(dense, np.float64)
+    heads = _heads(b, dense.shape[0])
+    out = np.zeros((dense.shape[0], m, dense.shape[-1]))
+    for i, nnz, ri, ro, ci in _split_many_mask(b, m, nnzs, row_indices, row_offsets, column_indices):
+        sl = slice(i * heads, (i + 1) * heads)
+        out[sl] = spmm(m, k, values[sl, :nnz], ri, ro, ci, dense[sl])
+    return out
+
+
+def sddmm_many_mask(b, m, n, nnzs, row_indices, row_offsets, column_indices, lhs, rhs):
+    """tests/transformer/functions.py:135; tests/test_attention_many_masks.py:120-127.
+    Returns [R, max nnz]; entries past a replica's own count are 0."""
+    lhs = np.asarray(lhs, np.float64)
+    rhs = np.asarray(rhs, np.float64)
+    heads = _heads(b, lhs.shape[0])
+    width = int(max([int(x) for x in np.asarray(nnzs).reshape(-1)] + [0]))
+    out = np.zeros((lhs.shape[0], width))
+    for i, nnz, ri, ro, ci in _split_many_mask(b, m, nnzs, row_indices, row_offsets, column_indices):
+        sl = slice(i * heads, (i + 1) * heads)
+        out[sl, :nnz] = sddmm(m, n, ri, ro, ci, lhs[sl], rhs[sl])
+    return out
+
+
+def sparse_softmax_many_mask(b, m, nnzs, values, row_indices, row_offsets, column_indices,
+                             scale=1.0):
+    """tests/transformer/functions.py:81; tests/test_attention_many_masks.py:132-138."""
+    values = np.asarray(values, np.float64)
+    heads = _heads(b, values.shape[0])
+    out = np.zeros_like(values)
+    for i, nnz, ri, ro, ci in _split_many_mask(b, m, nnzs, row_indices, row_offsets, column_indices):
+        sl = slice(i * heads, (i + 1) * heads)
+        out[sl, :nnz] = sparse_softmax_scaled(values[sl, :nnz], ri, ro, ci, scale)
+    return out
+
+
+def sparse_softmax_backward_many_mask(b, m, nnzs, softmax_out, grad_out, row_offsets, scale=1.0):
+    y = np.asarray(softmax_out, np.float64)
+    g = np.asarray(grad_out, np.float64)
+    heads = _heads(b, y.shape[0])
+    out = np.zeros_like(y)
+    nnz_list = [int(x) for x in np.asarray(nnzs).reshape(-1)]
+    row_offsets = np.asarray(row_offsets).reshape(-1)
+    for i, nnz in enumerate(nnz_list):
+        sl = slice(i * heads, (i + 1) * heads)
+        out[sl, :nnz] = sparse_softmax_backward(y[sl, :nnz], g[sl, :nnz],
+                                                row_offsets[i * (m + 1):(i + 1) * (m + 1)], scale)
+    return out
+
+
+def csr_transpose_many_mask(b, m, n, nnzs, values, row_offsets, column_indices):
+    """tests/transformer/functions.py:50,165 -> (values_t [R, width],
+    row_offsets_t [b, n+1] (indexed per mask by diffsort_many_mask,
+    tests/transformer/utils.py:51-62), column_indices_t [sum nnz])."""
+    values = np.asarray(values)
+    heads = _heads(b, values.shape[0])
+    values_t = np.zeros_like(values)
+    ro_t, ci_t = [], []
+    for i, nnz, _, ro, ci in _split_many_mask(b, m, nnzs, None, row_offsets, column_indices):
+        sl = slice(i * heads, (i + 1) * heads)
+        vt, rt, ct = csr_transpose(m, n, values[sl, :nnz], ro, ci)
+        values_t[sl, :nnz] = vt
+        ro_t.append(rt)
+        ci_t.append(ct)
+    return (values_t, np.stack(ro_t).astype(np.int32),
+            np.concatenate(ci_t).astype(np.int32) if ci_t else np.zeros(0, np.int32))
+
+
+# --------------------------------------------------------------------------
 # dense definitions, exactly as the reference's tests state them
 # --------------------------------------------------------------------------
 def csr_to_dense(m, n, values, row_offsets, column_indices):

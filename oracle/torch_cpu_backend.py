@@ -59,6 +59,64 @@ def _csr_transpose_with_permutation(m, n, values, row_offsets, column_indices):
     return out + [torch.from_numpy(perm)]
 
 
+def _f32(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+
+
+def _spmm_bias(m, k, values, row_indices, row_offsets, column_indices, bias, dense, relu=False):
+    out = O.spmm_bias(m, k, _np(values), _np(row_indices), _np(row_offsets), _np(column_indices),
+                      _np(bias), _np(dense), relu=relu)
+    if out.ndim == 3 and out.shape[0] == 1:
+        out = out[0]
+    return _f32(out)
+
+
+def _spmm_bias_relu(m, k, values, row_indices, row_offsets, column_indices, bias, dense):
+    return _spmm_bias(m, k, values, row_indices, row_offsets, column_indices, bias, dense, True)
+
+
+def _sparse_softmax_scaled(values, row_indices, row_offsets, column_indices, scale):
+    return _f32(O.sparse_softmax_scaled(_np(values), _np(row_indices), _np(row_offsets),
+                                        _np(column_indices), scale))
+
+
+def _sparse_softmax_backward(softmax_out, grad_out, row_offsets, scale):
+    return _f32(O.sparse_softmax_backward(_np(softmax_out), _np(grad_out), _np(row_offsets),
+                                          scale))
+
+
+def _spmm_many_mask(b, m, k, nonzeros, values, row_indices, row_offsets, column_indices, dense):
+    return _f32(O.spmm_many_mask(b, m, k, _np(nonzeros), _np(values), _np(row_indices),
+                                 _np(row_offsets), _np(column_indices), _np(dense)))
+
+
+def _sddmm_many_mask(b, m, n, nonzeros, row_indices, row_offsets, column_indices, lhs, rhs):
+    return _f32(O.sddmm_many_mask(b, m, n, _np(nonzeros), _np(row_indices), _np(row_offsets),
+                                  _np(column_indices), _np(lhs), _np(rhs)))
+
+
+def _sparse_softmax_many_mask_scaled(b, m, nonzeros, values, row_indices, row_offsets,
+                                     column_indices, scale):
+    return _f32(O.sparse_softmax_many_mask(b, m, _np(nonzeros), _np(values), _np(row_indices),
+                                           _np(row_offsets), _np(column_indices), scale))
+
+
+def _sparse_softmax_many_mask(b, m, nonzeros, values, row_indices, row_offsets, column_indices):
+    return _sparse_softmax_many_mask_scaled(b, m, nonzeros, values, row_indices, row_offsets,
+                                            column_indices, 1.0)
+
+
+def _sparse_softmax_backward_many_mask(b, m, nonzeros, softmax_out, grad_out, row_offsets, scale):
+    return _f32(O.sparse_softmax_backward_many_mask(b, m, _np(nonzeros), _np(softmax_out),
+                                                    _np(grad_out), _np(row_offsets), scale))
+
+
+def _csr_transpose_many_mask(b, m, n, nonzeros, values, row_offsets, column_indices):
+    v, ro, ci = O.csr_transpose_many_mask(b, m, n, _np(nonzeros), _np(values), _np(row_offsets),
+                                          _np(column_indices))
+    return [_f32(v), torch.from_numpy(ro), torch.from_numpy(ci)]
+
+
 def install():
     """Idempotent.  Needs the product's op schemas, so it imports the package
     (which loads the native libraries; no GPU is touched)."""
@@ -73,3 +131,13 @@ def install():
     _lib.impl("sparse_softmax", _sparse_softmax, "CPU")
     _lib.impl("csr_transpose", _csr_transpose, "CPU")
     _lib.impl("csr_transpose_with_permutation", _csr_transpose_with_permutation, "CPU")
+    _lib.impl("spmm_bias", _spmm_bias, "CPU")
+    _lib.impl("spmm_bias_relu", _spmm_bias_relu, "CPU")
+    _lib.impl("sparse_softmax_scaled", _sparse_softmax_scaled, "CPU")
+    _lib.impl("sparse_softmax_backward", _sparse_softmax_backward, "CPU")
+    _lib.impl("spmm_many_mask", _spmm_many_mask, "CPU")
+    _lib.impl("sddmm_many_mask", _sddmm_many_mask, "CPU")
+    _lib.impl("sparse_softmax_many_mask", _sparse_softmax_many_mask, "CPU")
+    _lib.impl("sparse_softmax_many_mask_scaled", _sparse_softmax_many_mask_scaled, "CPU")
+    _lib.impl("sparse_softmax_backward_many_mask", _sparse_softmax_backward_many_mask, "CPU")
+    _lib.impl("csr_transpose_many_mask", _csr_transpose_many_mask, "CPU")

@@ -1,0 +1,290 @@
+"""GPU: the extension kernels through the C ABI and through
+torch.ops.torch_sputnik, against the oracle and the golden fixtures.  Same
+tolerance as test_gpu_parity.py (1e-4, helpers.rel_err); index outputs bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle
+from oracle import sputnik_oracle as O
+from helpers import make_csr, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from torch_sputnik_amd import capi
+    return capi
+
+
+@pytest.fixture(scope="module")
+def ts():
+    import torch_sputnik
+    return torch_sputnik
+
+
+def T(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+# ----------------------------------------------------------------------------
+# SpMM + bias (+ ReLU): every kernel family has its own epilogue
+# ----------------------------------------------------------------------------
+BIAS_SHAPES = [
+    # m, k, n, sparsity, replicas
+    (72, 64, 72, 0.0, 1),        # tests/test_spmm_bias_relu.py shape (row-gather kernel)
+    (33, 47, 7, 0.6, 2),         # scalar path
+    (512, 300, 128, 0.8, 3),     # 64-column tiled kernel
+    (1024, 777, 1024, 0.9, 1),   # 256-column tiled kernel, short segments
+    (512, 512, 512, 0.4, 2),     # 256-column tiled kernel, long segments
+]
+
+
+@pytest.mark.parametrize("m,k,n,sparsity,replicas", BIAS_SHAPES)
+@pytest.mark.parametrize("relu", [0, 1])
+def test_spmm_bias_capi_vs_oracle(capi, dev, m, k, n, sparsity, replicas, relu):
+    _, vals, ri, ro, ci = make_csr(m, k, sparsity, seed=m + n + relu, order="ascending")
+    rng = np.random.default_rng(k)
+    vals = (vals * rng.choice([-1.0, 1.0], size=vals.shape)).astype(np.float32)
+    b = rng.uniform(-1, 1, size=(replicas, k, n)).astype(np.float32)
+    bias = rng.uniform(-2, 2, size=m).astype(np.float32)
+    want = np.stack([c_oracle.spmm(m, k, vals, ro, ci, b[r]) for r in range(replicas)])
+    want = want + bias.astype(np.float64)[None, :, None]
+    if relu:
+        want = np.maximum(want, 0.0)
+    out = torch.full((replicas, m, n), float("nan"), device=dev)
+    ws = torch.empty(capi.spmm_workspace_bytes(m, k, n, len(ci)) + 16, dtype=torch.uint8,
+                     device=dev)
+    capi.spmm_bias_batched(m, k, n, replicas, T(ri, dev), T(vals, dev), 0, T(ro, dev), T(ci, dev),
+                           T(b, dev), T(bias, dev), relu, out, ws)
+    got = out.cpu().numpy()
+    assert not np.isnan(got).any()
+    assert rel_err(got, want) < TOL
+    if relu:
+        assert (got >= 0).all() and (got == 0).any()
+
+
+def test_spmm_null_bias_is_plain_spmm(capi, dev):
+    m, k, n = 512, 300, 256
+    _, vals, ri, ro, ci = make_csr(m, k, 0.8, seed=9)
+    b = np.random.default_rng(1).uniform(-1, 1, size=(k, n)).astype(np.float32)
+    args = (T(ri, dev), T(vals, dev), 0, T(ro, dev), T(ci, dev), T(b, dev))
+    ws = torch.empty(capi.spmm_workspace_bytes(m, k, n, len(ci)), dtype=torch.uint8, device=dev)
+    a = capi.spmm_batched(m, k, n, 1, *args, torch.empty(m, n, device=dev), ws)
+    c = capi.spmm_bias_batched(m, k, n, 1, *args, None, 0, torch.empty(m, n, device=dev), ws)
+    assert torch.equal(a, c)
+
+
+def test_spmm_bias_unsorted_columns_take_the_fallback_epilogue(capi, dev):
+    m, k, n = 256, 512, 256
+    _, vals, ri, ro, ci = make_csr(m, k, 0.7, seed=21)
+    rng = np.random.default_rng(3)
+    ci = ci.copy()
+    vals = vals.copy()
+    for r in range(0, m, 3):  # shuffle the entries of every third row
+        p = rng.permutation(ro[r + 1] - ro[r]) + ro[r]
+        ci[ro[r]:ro[r + 1]] = ci[p]
+        vals[ro[r]:ro[r + 1]] = vals[p]
+    b = rng.uniform(-1, 1, size=(k, n)).astype(np.float32)
+    bias = rng.uniform(-1, 1, size=m).astype(np.float32)
+    want = np.maximum(O.spmm(m, k, vals, ri, ro, ci, b) + bias.astype(np.float64)[:, None], 0)
+    ws = torch.empty(capi.spmm_workspace_bytes(m, k, n, len(ci)), dtype=torch.uint8, device=dev)
+    out = capi.spmm_bias_batched(m, k, n, 1, T(ri, dev), T(vals, dev), 0, T(ro, dev), T(ci, dev),
+                                 T(b, dev), T(bias, dev), 1, torch.empty(m, n, device=dev), ws)
+    assert rel_err(out.cpu().numpy(), want) < TOL
+
+
+@pytest.mark.parametrize("name", ["spmm_bias_72x64x72", "spmm_bias_relu_40x48x36"])
+def test_spmm_bias_op_golden(ts, dev, golden, name):
+    g = golden(name)
+    fn = ts.spmm_bias_relu if int(g["relu"]) else ts.spmm_bias
+    out = fn(int(g["m"]), int(g["k"]), T(g["values"], dev), T(g["row_indices"], dev),
+             T(g["row_offsets"], dev), T(g["column_indices"], dev), T(g["bias"], dev),
+             T(g["dense"], dev))
+    assert out.shape == g["expected"].shape
+    assert rel_err(out.cpu().numpy(), g["expected"]) < TOL
+    with pytest.raises(RuntimeError):
+        fn(int(g["m"]), int(g["k"]), T(g["values"], dev), T(g["row_indices"], dev),
+           T(g["row_offsets"], dev), T(g["column_indices"], dev), T(g["bias"][:-1], dev),
+           T(g["dense"], dev))
+
+
+# ----------------------------------------------------------------------------
+# scaled softmax and the softmax gradient
+# ----------------------------------------------------------------------------
+SOFTMAX_SHAPES = [
+    # m, n, sparsity, replicas, scale
+    (72, 72, 0.9, 1, 1.0),
+    (1024, 1024, 0.9, 8, 0.125),      # C3 row lengths: 16 lanes per row
+    (256, 2048, 0.85, 3, 0.5),        # 32 lanes per row
+    (64, 4096, 0.5, 2, 0.25),         # long rows: streaming path
+    (100, 37, 0.3, 5, 2.0),
+]
+
+
+@pytest.mark.parametrize("m,n,sparsity,replicas,scale", SOFTMAX_SHAPES)
+def test_softmax_scaled_and_backward_capi(capi, dev, m, n, sparsity, replicas, scale):
+    _, _, ri, ro, ci = make_csr(m, n, sparsity, seed=m + n, empty_rows=(1,))
+    rng = np.random.default_rng(n)
+    x = rng.uniform(-6, 6, size=(replicas, len(ci))).astype(np.float32)
+    gy = rng.uniform(-1, 1, size=(replicas, len(ci))).astype(np.float32)
+    y = capi.sparse_softmax_scaled_batched(m, replicas, T(x, dev), T(ri, dev), T(ro, dev),
+                                           T(ci, dev), scale, torch.full_like(T(x, dev), np.nan))
+    want_y = O.sparse_softmax_scaled(x, ri, ro, ci, scale)
+    assert rel_err(y.cpu().numpy(), want_y) < TOL
+    dx = capi.sparse_softmax_backward_batched(m, replicas, y, T(gy, dev), T(ro, dev), scale,
+                                              torch.full_like(y, np.nan))
+    want_dx = O.sparse_softmax_backward(y.cpu().numpy(), gy, ro, scale)
+    got = dx.cpu().numpy()
+    assert not np.isnan(got).any()
+    assert rel_err(got, want_dx) < TOL
+
+
+def test_softmax_backward_op_golden_and_autograd(ts, dev, golden):
+    from torch_sputnik_amd.functional import SparseSoftmax
+    g = golden("softmax_backward_48x40")
+    topo = [T(g[x], dev) for x in ("row_indices", "row_offsets", "column_indices")]
+    scale = float(g["scale"])
+    y = ts.sparse_softmax_scaled(T(g["values"], dev), *topo, scale)
+    assert rel_err(y.cpu().numpy(), g["softmax_out"]) < TOL
+    dx = ts.sparse_softmax_backward(T(g["softmax_out"].astype(np.float32), dev),
+                                    T(g["grad_out"], dev), topo[1], scale)
+    with pytest.raises(RuntimeError):  # float64 is not a storage type of this library
+        ts.sparse_softmax_backward(T(g["softmax_out"], dev), T(g["grad_out"], dev), topo[1], scale)
+    assert rel_err(dx.cpu().numpy(), g["grad_values"]) < TOL
+    x = T(g["values"], dev).requires_grad_(True)
+    SparseSoftmax.apply(x, *topo, scale).backward(T(g["grad_out"], dev))
+    assert rel_err(x.grad.cpu().numpy(), g["grad_values"]) < TOL
+
+
+# ----------------------------------------------------------------------------
+# many-mask family
+# ----------------------------------------------------------------------------
+def _many_mask_inputs(b, heads, s, hn, sparsities, seed):
+    rng = np.random.default_rng(seed)
+    masks = np.stack([O.random_mask(s, s, sparsities[i % len(sparsities)], round_to=4, rng=rng)
+                      for i in range(b)])
+    ri, ro, ci, nn = O.dense_to_csr_many_mask(masks)
+    r = b * heads
+    q = rng.uniform(-1, 1, (r, s, hn)).astype(np.float32)
+    k = rng.uniform(-1, 1, (r, s, hn)).astype(np.float32)
+    v = rng.uniform(-1, 1, (r, s, hn)).astype(np.float32)
+    return masks, ri, ro, ci, nn, q, k, v
+
+
+@pytest.mark.parametrize("b,heads,s,hn,sparsities", [
+    (3, 2, 24, 8, (0.2, 0.5, 0.8)),
+    (4, 8, 512, 64, (0.2, 0.5)),      # tests/test_attention_many_masks.py:26-36 sparsities
+    (2, 4, 256, 64, (0.9,)),          # equal counts: no padding anywhere
+])
+def test_many_mask_chain_capi_vs_oracle(capi, dev, b, heads, s, hn, sparsities):
+    masks, ri, ro, ci, nn, q, k, v = _many_mask_inputs(b, heads, s, hn, sparsities, seed=s + b)
+    r, width = b * heads, int(nn.max())
+    scale = 1.0 / np.sqrt(hn)
+    d_ri, d_ro, d_ci = T(ri, dev), T(ro, dev), T(ci, dev)
+    ws = torch.empty(max(capi.sddmm_workspace_bytes(s, hn, s, width),
+                         capi.spmm_workspace_bytes(s, s, hn, width),
+                         capi.csr_transpose_workspace_bytes(s, s, width)) + 16,
+                     dtype=torch.uint8, device=dev)
+    scores = torch.zeros(r, width, device=dev)
+    capi.sddmm_many_mask(b, s, hn, s, nn, r, d_ri, d_ro, d_ci, T(q, dev), T(k, dev), scores, ws)
+    want_scores = O.sddmm_many_mask(b, s, s, nn, ri, ro, ci, q, k)
+    assert rel_err(scores.cpu().numpy(), want_scores) < TOL
+
+    weights = torch.zeros(r, width, device=dev)
+    capi.sparse_softmax_many_mask(b, s, nn, r, scores, d_ri, d_ro, d_ci, scale, weights)
+    want_weights = O.sparse_softmax_many_mask(b, s, nn, scores.cpu().numpy(), ri, ro, ci, scale)
+    assert rel_err(weights.cpu().numpy(), want_weights) < TOL
+
+    ctx = torch.full((r, s, hn), float("nan"), device=dev)
+    capi.spmm_many_mask(b, s, s, hn, nn, r, d_ri, weights, d_ro, d_ci, T(v, dev), ctx, ws)
+    want_ctx = O.spmm_many_mask(b, s, s, nn, weights.cpu().numpy(), ri, ro, ci, v)
+    got = ctx.cpu().numpy()
+    assert not np.isnan(got).any()
+    assert rel_err(got, want_ctx) < TOL
+
+    # transpose: bit-exact, padding untouched
+    vt = torch.zeros(r, width, device=dev)
+    rot = torch.empty(b, s + 1, dtype=torch.int32, device=dev)
+    cit = torch.empty(len(ci), dtype=torch.int32, device=dev)
+    capi.csr_transpose_many_mask(b, s, s, nn, r, weights, d_ro, d_ci, vt, rot, cit, None, ws)
+    w_vt, w_rot, w_cit = O.csr_transpose_many_mask(b, s, s, nn, weights.cpu().numpy(), ro, ci)
+    assert np.array_equal(rot.cpu().numpy(), w_rot)
+    assert np.array_equal(cit.cpu().numpy(), w_cit)
+    assert np.array_equal(vt.cpu().numpy(), w_vt)
+
+    # softmax gradient, many masks
+    gy = np.random.default_rng(1).uniform(-1, 1, (r, width)).astype(np.float32)
+    dx = torch.zeros(r, width, device=dev)
+    capi.sparse_softmax_backward_many_mask(b, s, nn, r, weights, T(gy, dev), d_ro, scale, dx)
+    want_dx = O.sparse_softmax_backward_many_mask(b, s, nn, weights.cpu().numpy(), gy, ro, scale)
+    assert rel_err(dx.cpu().numpy(), want_dx) < TOL
+
+
+def test_many_mask_ops_golden_and_autograd(ts, dev, golden):
+    from torch_sputnik_amd.functional import CsrSoftmaxManyMask, SddmmManyMask, SpmmManyMask
+    g = golden("many_mask_b3_h2_s24")
+    b, s = int(g["b"]), int(g["s"])
+    nn = torch.from_numpy(g["nnzs"])  # host tensor, as tests/transformer/utils.py:36 builds it
+    # stacked [b, s+1] / [b, s] index tensors are accepted like flat ones
+    topo = [T(g["row_indices"].reshape(b, s), dev), T(g["row_offsets"].reshape(b, s + 1), dev),
+            T(g["column_indices"], dev)]
+    scores = ts.sddmm_many_mask(b, s, s, nn, *topo, T(g["q"], dev), T(g["k"], dev))
+    assert scores.shape == g["scores"].shape
+    assert rel_err(scores.cpu().numpy(), g["scores"]) < TOL
+    weights = ts.sparse_softmax_many_mask(b, s, nn, scores * float(g["scale"]), *topo)
+    att = ts.spmm_many_mask(b, s, s, nn, weights, *topo, T(g["v"], dev))
+    assert rel_err(att.cpu().numpy(), g["attention"]) < TOL
+    vt, rot, cit = ts.csr_transpose_many_mask(b, s, s, nn, T(g["weights"], dev), topo[1], topo[2])
+    w_vt, w_rot, w_cit = O.csr_transpose_many_mask(b, s, s, g["nnzs"], g["weights"],
+                                                   g["row_offsets"], g["column_indices"])
+    assert rot.shape == (b, s + 1)
+    assert np.array_equal(vt.cpu().numpy(), w_vt) and np.array_equal(rot.cpu().numpy(), w_rot)
+    assert np.array_equal(cit.cpu().numpy(), w_cit)
+
+    q = T(g["q"], dev).requires_grad_(True)
+    k = T(g["k"], dev).requires_grad_(True)
+    sc = SddmmManyMask.apply(b, s, s, nn, *topo, q, k)
+    sc.backward(T(g["grad_scores"], dev))
+    assert rel_err(q.grad.cpu().numpy(), g["grad_q"]) < TOL
+    assert rel_err(k.grad.cpu().numpy(), g["grad_k"]) < TOL
+    w = T(g["weights"], dev).requires_grad_(True)
+    v = T(g["v"], dev).requires_grad_(True)
+    ctx = SpmmManyMask.apply(b, s, s, nn, w, *topo, v)
+    ctx.backward(T(g["grad_context"], dev))
+    assert rel_err(ctx.detach().cpu().numpy(), g["context"]) < TOL
+    assert rel_err(w.grad.cpu().numpy(), g["grad_weights"]) < TOL
+    assert rel_err(v.grad.cpu().numpy(), g["grad_v"]) < TOL
+    # chain with the fused scale
+    q2 = T(g["q"], dev).requires_grad_(True)
+    out = SpmmManyMask.apply(
+        b, s, s, nn,
+        CsrSoftmaxManyMask.apply(b, s, nn, SddmmManyMask.apply(b, s, s, nn, *topo, q2,
+                                                                T(g["k"], dev)),
+                                 *topo, float(g["scale"])),
+        *topo, T(g["v"], dev))
+    out.sum().backward()
+    assert rel_err(out.detach().cpu().numpy(), g["attention"]) < TOL
+    assert torch.isfinite(q2.grad).all()
+
+
+def test_many_mask_errors(ts, dev, golden):
+    g = golden("many_mask_b3_h2_s24")
+    b, s = int(g["b"]), int(g["s"])
+    nn = torch.from_numpy(g["nnzs"])
+    topo = [T(g[x], dev) for x in ("row_indices", "row_offsets", "column_indices")]
+    with pytest.raises(RuntimeError):  # 5 replicas for 3 masks
+        ts.sddmm_many_mask(b, s, s, nn, *topo, T(g["q"][:5], dev), T(g["k"][:5], dev))
+    with pytest.raises(RuntimeError):  # wrong number of counts
+        ts.sddmm_many_mask(b, s, s, nn[:2], *topo, T(g["q"], dev), T(g["k"], dev))
+    with pytest.raises(RuntimeError):  # value rows shorter than the longest mask
+        ts.spmm_many_mask(b, s, s, nn, T(g["weights"][:, :10], dev), *topo, T(g["v"], dev))

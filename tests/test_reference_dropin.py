@@ -98,3 +98,40 @@ def test_own_functions_agree_with_reference_functions(ref, cpu_ops):
         fn.apply(20, 12, v, T(ri), T(ro), T(ci), d).square().sum().backward()
         outs.append((v.grad.clone(), d.grad.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_reference_many_mask_sketches(cpu_ops, golden):
+    """tests/transformer/functions.py (the reference's many-mask autograd
+    sketches) imported unchanged: forward and backward through this package's
+    ``*_many_mask`` ops, against the golden dense-autograd values."""
+    path = os.path.join(REFERENCE, "tests", "transformer")
+    if not os.path.isfile(os.path.join(path, "functions.py")):
+        pytest.skip("reference sketches not present")
+    saved = {k: sys.modules.pop(k, None) for k in ("functions", "utils")}
+    sys.path.insert(0, path)
+    try:
+        functions = importlib.import_module("functions")
+        utils = importlib.import_module("utils")
+    finally:
+        sys.path.remove(path)
+        for k, v in saved.items():
+            sys.modules.pop(k, None)
+            if v is not None:
+                sys.modules[k] = v
+    g = golden("many_mask_b3_h2_s24")
+    b, s = int(g["b"]), int(g["s"])
+    # topology exactly as the reference builds it (stacked [b, s+1] offsets)
+    _, ri, ro, ci, nnzs = utils.dense_to_sparse_3d(T(g["masks"]))
+    assert ro.shape == (b, s + 1) and np.array_equal(nnzs.numpy(), g["nnzs"])
+    q, k = T(g["q"]).requires_grad_(True), T(g["k"]).requires_grad_(True)
+    scores = functions.Sddmm.apply(b, s, s, nnzs, ri, ro, ci, q, k)
+    scores.backward(T(g["grad_scores"]))
+    assert rel_err(scores.detach().numpy(), g["scores"]) < 2e-5
+    assert rel_err(q.grad.numpy(), g["grad_q"]) < 2e-5
+    assert rel_err(k.grad.numpy(), g["grad_k"]) < 2e-5
+    w, v = T(g["weights"]).requires_grad_(True), T(g["v"]).requires_grad_(True)
+    ctx = functions.Spmm.apply(b, s, s, nnzs, w, ri, ro, ci, v)
+    ctx.backward(T(g["grad_context"]))
+    assert rel_err(ctx.detach().numpy(), g["context"]) < 2e-5
+    assert rel_err(w.grad.numpy(), g["grad_weights"]) < 2e-5
+    assert rel_err(v.grad.numpy(), g["grad_v"]) < 2e-5

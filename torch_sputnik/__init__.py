@@ -3,16 +3,33 @@
 so ``import torch_sputnik`` in modules/spmm.py, modules/sddmm.py,
 modules/sparse_linear.py and modules/sparse_attention.py keeps working
 unchanged on an MI355X.  The implementation lives in ``torch_sputnik_amd``.
+
+Also exported: the functions the reference's test scripts call but its
+committed binding does not define (``spmm_bias``, tests/test_spmm_bias_relu.py:37;
+the ``*_many_mask`` family, tests/transformer/functions.py), and the softmax
+gradient.
 """
 from torch_sputnik_amd.ops import (  # noqa: F401
     csr_transpose,
+    csr_transpose_many_mask,
     csr_transpose_with_permutation,
     left_replicated_spmm,
     left_spmm,
     sddmm,
+    sddmm_many_mask,
     sparse_softmax,
+    sparse_softmax_backward,
+    sparse_softmax_backward_many_mask,
+    sparse_softmax_many_mask,
+    sparse_softmax_scaled,
     spmm,
+    spmm_bias,
+    spmm_bias_relu,
+    spmm_many_mask,
 )
 
 __all__ = ["spmm", "left_spmm", "left_replicated_spmm", "sddmm", "sparse_softmax",
-           "csr_transpose", "csr_transpose_with_permutation"]
+           "csr_transpose", "csr_transpose_with_permutation", "spmm_bias", "spmm_bias_relu",
+           "sparse_softmax_scaled", "sparse_softmax_backward", "spmm_many_mask",
+           "sddmm_many_mask", "sparse_softmax_many_mask", "sparse_softmax_backward_many_mask",
+           "csr_transpose_many_mask"]

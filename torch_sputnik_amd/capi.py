@@ -17,6 +17,7 @@ _c_int = ctypes.c_int
 _c_i64 = ctypes.c_int64
 _c_ptr = ctypes.c_void_p
 _c_size = ctypes.c_size_t
+_c_float = ctypes.c_float
 
 # name -> (restype, argtypes); must list every symbol include/sputnik_hip.h declares.
 SIGNATURES = {
@@ -42,6 +43,27 @@ SIGNATURES = {
     "sputnik_hip_csr_transpose": (_c_int, [_c_int] * 4 + [_c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr,
                                                          _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
                                                          _c_size, _c_ptr]),
+    # extensions
+    "sputnik_hip_spmm_bias_batched": (_c_int, [_c_int] * 5 + [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr,
+                                                             _c_ptr, _c_i64, _c_ptr, _c_int, _c_ptr,
+                                                             _c_i64, _c_ptr, _c_size, _c_ptr]),
+    "sputnik_hip_sparse_softmax_scaled_batched": (_c_int, [_c_int] * 4 + [
+        _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_float, _c_ptr, _c_i64, _c_ptr]),
+    "sputnik_hip_sparse_softmax_backward_batched": (_c_int, [_c_int] * 3 + [
+        _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_float, _c_ptr, _c_i64, _c_ptr]),
+    "sputnik_hip_spmm_many_mask": (_c_int, [_c_int] * 4 + [_c_ptr, _c_int, _c_ptr, _c_ptr, _c_i64,
+                                                          _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr,
+                                                          _c_i64, _c_ptr, _c_size, _c_ptr]),
+    "sputnik_hip_sddmm_many_mask": (_c_int, [_c_int] * 4 + [_c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr,
+                                                           _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr,
+                                                           _c_i64, _c_ptr, _c_size, _c_ptr]),
+    "sputnik_hip_sparse_softmax_many_mask": (_c_int, [_c_int] * 2 + [
+        _c_ptr, _c_int, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_float, _c_ptr, _c_i64, _c_ptr]),
+    "sputnik_hip_sparse_softmax_backward_many_mask": (_c_int, [_c_int] * 2 + [
+        _c_ptr, _c_int, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_float, _c_ptr, _c_i64, _c_ptr]),
+    "sputnik_hip_csr_transpose_many_mask": (_c_int, [_c_int] * 3 + [
+        _c_ptr, _c_int, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr,
+        _c_ptr, _c_size, _c_ptr]),
 }
 
 _bound = None
@@ -186,4 +208,121 @@ def csr_transpose(m, n, replicas, values, row_offsets, column_indices, out_value
         _ptr(out_values), nonzeros, _ptr(out_row_offsets), _ptr(out_column_indices),
         _ptr(out_permutation), _ptr(workspace), ws_bytes, _stream(out_values)),
         "sputnik_hip_csr_transpose")
+    return out_values, out_row_offsets, out_column_indices
+
+
+# ---------------------------------------------------------------------------
+# extensions (SURVEY.md 8f)
+# ---------------------------------------------------------------------------
+def _ws_bytes(workspace):
+    return 0 if workspace is None else workspace.numel() * workspace.element_size()
+
+
+def spmm_bias_batched(m, k, n, replicas, row_indices, values, values_stride, row_offsets,
+                      column_indices, dense, bias, relu, out, workspace=None):
+    nonzeros = column_indices.numel()
+    for t, d, nm in ((row_indices, torch.int32, "row_indices"), (values, torch.float32, "values"),
+                     (row_offsets, torch.int32, "row_offsets"),
+                     (column_indices, torch.int32, "column_indices"),
+                     (dense, torch.float32, "dense"), (out, torch.float32, "out")):
+        _require(t, d, nm)
+    if bias is not None:
+        _require(bias, torch.float32, "bias")
+        if bias.numel() != m:
+            raise ValueError(f"bias: expected {m} elements, got {bias.numel()}")
+    _check(lib().sputnik_hip_spmm_bias_batched(
+        m, k, n, nonzeros, replicas, _ptr(row_indices), _ptr(values), values_stride,
+        _ptr(row_offsets), _ptr(column_indices), _ptr(dense), k * n, _ptr(bias), int(bool(relu)),
+        _ptr(out), m * n, _ptr(workspace), _ws_bytes(workspace), _stream(out)),
+        "sputnik_hip_spmm_bias_batched")
+    return out
+
+
+def sparse_softmax_scaled_batched(m, replicas, values, row_indices, row_offsets, column_indices,
+                                  scale, out):
+    nonzeros = column_indices.numel()
+    for t, d, nm in ((values, torch.float32, "values"), (row_indices, torch.int32, "row_indices"),
+                     (row_offsets, torch.int32, "row_offsets"),
+                     (column_indices, torch.int32, "column_indices"),
+                     (out, torch.float32, "out")):
+        _require(t, d, nm)
+    _check(lib().sputnik_hip_sparse_softmax_scaled_batched(
+        m, -1, nonzeros, replicas, _ptr(values), nonzeros, _ptr(row_indices), _ptr(row_offsets),
+        _ptr(column_indices), float(scale), _ptr(out), nonzeros, _stream(out)),
+        "sputnik_hip_sparse_softmax_scaled_batched")
+    return out
+
+
+def sparse_softmax_backward_batched(m, replicas, softmax_out, grad_out, row_offsets, scale,
+                                    grad_values):
+    nonzeros = softmax_out.shape[-1]
+    for t, d, nm in ((softmax_out, torch.float32, "softmax_out"),
+                     (grad_out, torch.float32, "grad_out"),
+                     (row_offsets, torch.int32, "row_offsets"),
+                     (grad_values, torch.float32, "grad_values")):
+        _require(t, d, nm)
+    _check(lib().sputnik_hip_sparse_softmax_backward_batched(
+        m, nonzeros, replicas, _ptr(softmax_out), nonzeros, _ptr(grad_out), nonzeros,
+        _ptr(row_offsets), float(scale), _ptr(grad_values), nonzeros, _stream(grad_values)),
+        "sputnik_hip_sparse_softmax_backward_batched")
+    return grad_values
+
+
+def _host_counts(nonzeros):
+    """[masks] nonzero counts as a C int array living on the host."""
+    counts = [int(x) for x in (nonzeros.tolist() if torch.is_tensor(nonzeros) else nonzeros)]
+    return (ctypes.c_int * len(counts))(*counts), counts
+
+
+def spmm_many_mask(masks, m, k, n, nonzeros, replicas, row_indices, values, row_offsets,
+                   column_indices, dense, out, workspace=None):
+    arr, _ = _host_counts(nonzeros)
+    _check(lib().sputnik_hip_spmm_many_mask(
+        masks, m, k, n, arr, replicas, _ptr(row_indices), _ptr(values), values.shape[-1],
+        _ptr(row_offsets), _ptr(column_indices), _ptr(dense), k * n, _ptr(out), m * n,
+        _ptr(workspace), _ws_bytes(workspace), _stream(out)), "sputnik_hip_spmm_many_mask")
+    return out
+
+
+def sddmm_many_mask(masks, m, k, n, nonzeros, replicas, row_indices, row_offsets, column_indices,
+                    lhs, rhs, out, workspace=None):
+    arr, _ = _host_counts(nonzeros)
+    _check(lib().sputnik_hip_sddmm_many_mask(
+        masks, m, k, n, arr, replicas, _ptr(row_indices), _ptr(row_offsets), _ptr(column_indices),
+        _ptr(lhs), m * k, _ptr(rhs), n * k, _ptr(out), out.shape[-1], _ptr(workspace),
+        _ws_bytes(workspace), _stream(out)), "sputnik_hip_sddmm_many_mask")
+    return out
+
+
+def sparse_softmax_many_mask(masks, m, nonzeros, replicas, values, row_indices, row_offsets,
+                             column_indices, scale, out):
+    arr, _ = _host_counts(nonzeros)
+    _check(lib().sputnik_hip_sparse_softmax_many_mask(
+        masks, m, arr, replicas, _ptr(values), values.shape[-1], _ptr(row_indices),
+        _ptr(row_offsets), _ptr(column_indices), float(scale), _ptr(out), out.shape[-1],
+        _stream(out)), "sputnik_hip_sparse_softmax_many_mask")
+    return out
+
+
+def sparse_softmax_backward_many_mask(masks, m, nonzeros, replicas, softmax_out, grad_out,
+                                      row_offsets, scale, grad_values):
+    arr, _ = _host_counts(nonzeros)
+    _check(lib().sputnik_hip_sparse_softmax_backward_many_mask(
+        masks, m, arr, replicas, _ptr(softmax_out), softmax_out.shape[-1], _ptr(grad_out),
+        grad_out.shape[-1], _ptr(row_offsets), float(scale), _ptr(grad_values),
+        grad_values.shape[-1], _stream(grad_values)),
+        "sputnik_hip_sparse_softmax_backward_many_mask")
+    return grad_values
+
+
+def csr_transpose_many_mask(masks, m, n, nonzeros, replicas, values, row_offsets, column_indices,
+                            out_values, out_row_offsets, out_column_indices, out_permutation,
+                            workspace):
+    arr, _ = _host_counts(nonzeros)
+    _check(lib().sputnik_hip_csr_transpose_many_mask(
+        masks, m, n, arr, replicas, _ptr(values), 0 if values is None else values.shape[-1],
+        _ptr(row_offsets), _ptr(column_indices), _ptr(out_values),
+        0 if out_values is None else out_values.shape[-1], _ptr(out_row_offsets),
+        _ptr(out_column_indices), _ptr(out_permutation), _ptr(workspace), _ws_bytes(workspace),
+        _stream(out_row_offsets)), "sputnik_hip_csr_transpose_many_mask")
     return out_values, out_row_offsets, out_column_indices

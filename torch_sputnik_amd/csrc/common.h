@@ -28,6 +28,28 @@ inline int vector_width(const void* p, int64_t width, int64_t stride) {
 
 inline int launch_status() { return static_cast<int>(hipGetLastError()); }
 
+// Fused SpMM epilogue: out[i, :] = act(acc + bias[i]) (both optional).
+struct Epilogue {
+  const float* bias = nullptr;  // [m], indexed by output row
+  int relu = 0;
+};
+
+__device__ __forceinline__ float epilogue_scalar(float v, float b, int relu) {
+  v += b;
+  return relu ? fmaxf(v, 0.f) : v;
+}
+
+__device__ __forceinline__ float4 apply_epilogue(float4 v, const Epilogue& e, int row) {
+  if (e.bias != nullptr || e.relu) {
+    const float b = e.bias != nullptr ? e.bias[row] : 0.f;
+    v.x = epilogue_scalar(v.x, b, e.relu);
+    v.y = epilogue_scalar(v.y, b, e.relu);
+    v.z = epilogue_scalar(v.z, b, e.relu);
+    v.w = epilogue_scalar(v.w, b, e.relu);
+  }
+  return v;
+}
+
 template <int VEC>
 struct FloatVec;
 template <>

@@ -24,7 +24,7 @@ int spmm_tiled_exec(int m, int k, int n, int nonzeros, int replicas, const int* 
                     const float* values, int64_t values_stride, const int* row_offsets,
                     const int* column_indices, const float* dense, int64_t dense_stride,
                     float* out, int64_t out_stride, const void* workspace,
-                    size_t workspace_bytes, hipStream_t stream, bool* handled);
+                    size_t workspace_bytes, hipStream_t stream, Epilogue epi, bool* handled);
 size_t spmm_tiled_workspace_bytes(int m, int k, int n, int nonzeros);
 
 namespace {
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rowgather_kernel(
     int m, int n, const int* __restrict__ row_indices, const float* __restrict__ values,
     int64_t values_stride, const int* __restrict__ row_offsets,
     const int* __restrict__ column_indices, const float* __restrict__ dense,
-    int64_t dense_stride, float* __restrict__ out, int64_t out_stride) {
+    int64_t dense_stride, float* __restrict__ out, int64_t out_stride, Epilogue epi) {
   constexpr int kRowsPerBlock = kBlock / LPR;
   const int sub = threadIdx.x / LPR;
   const int l = threadIdx.x % LPR;
@@ -79,14 +79,21 @@ __global__ __launch_bounds__(kBlock) void spmm_rowgather_kernel(
     }
   }
 
-  if (row_ok && col_ok) store_vec<VEC>(out + static_cast<int64_t>(row) * n + c0, acc);
+  if (row_ok && col_ok) {
+    if (epi.bias != nullptr || epi.relu) {
+      const float b = epi.bias != nullptr ? epi.bias[row] : 0.f;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v] = epilogue_scalar(acc[v], b, epi.relu);
+    }
+    store_vec<VEC>(out + static_cast<int64_t>(row) * n + c0, acc);
+  }
 }
 
 template <int VEC, int LPR>
 int launch_rowgather(int m, int n, int replicas, const int* row_indices, const float* values,
                      int64_t values_stride, const int* row_offsets, const int* column_indices,
                      const float* dense, int64_t dense_stride, float* out, int64_t out_stride,
-                     hipStream_t stream) {
+                     hipStream_t stream, Epilogue epi) {
   constexpr int kRowsPerBlock = kBlock / LPR;
   const int gx = ceil_div(m, kRowsPerBlock);
   const int gy = ceil_div(n, LPR * VEC);
@@ -96,7 +103,7 @@ int launch_rowgather(int m, int n, int replicas, const int* row_indices, const f
     hipLaunchKernelGGL((spmm_rowgather_kernel<VEC, LPR>), dim3(gx, gy, rz), dim3(kBlock), 0,
                        stream, m, n, row_indices, values + r0 * values_stride, values_stride,
                        row_offsets, column_indices, dense + r0 * dense_stride, dense_stride,
-                       out + r0 * out_stride, out_stride);
+                       out + r0 * out_stride, out_stride, epi);
     const int st = launch_status();
     if (st != 0) return st;
   }
@@ -107,12 +114,12 @@ template <int VEC>
 int launch_rowgather_vec(int m, int n, int replicas, const int* row_indices, const float* values,
                          int64_t values_stride, const int* row_offsets,
                          const int* column_indices, const float* dense, int64_t dense_stride,
-                         float* out, int64_t out_stride, hipStream_t stream) {
+                         float* out, int64_t out_stride, hipStream_t stream, Epilogue epi) {
   const int lanes_needed = ceil_div(n, VEC);
 #define SPUTNIK_HIP_RG(LPR)                                                                  \
   return launch_rowgather<VEC, LPR>(m, n, replicas, row_indices, values, values_stride,      \
                                     row_offsets, column_indices, dense, dense_stride, out,   \
-                                    out_stride, stream)
+                                    out_stride, stream, epi)
   if (lanes_needed <= 8) SPUTNIK_HIP_RG(8);
   if (lanes_needed <= 16) SPUTNIK_HIP_RG(16);
   if (lanes_needed <= 32) SPUTNIK_HIP_RG(32);
@@ -125,22 +132,22 @@ int launch_rowgather_vec(int m, int n, int replicas, const int* row_indices, con
 int spmm_rowgather_launch(int m, int n, int replicas, const int* row_indices,
                           const float* values, int64_t values_stride, const int* row_offsets,
                           const int* column_indices, const float* dense, int64_t dense_stride,
-                          float* out, int64_t out_stride, hipStream_t stream) {
+                          float* out, int64_t out_stride, hipStream_t stream, Epilogue epi) {
   int vec = vector_width(dense, n, dense_stride);
   vec = min(vec, vector_width(out, n, out_stride));
   switch (vec) {
     case 4:
       return launch_rowgather_vec<4>(m, n, replicas, row_indices, values, values_stride,
                                      row_offsets, column_indices, dense, dense_stride, out,
-                                     out_stride, stream);
+                                     out_stride, stream, epi);
     case 2:
       return launch_rowgather_vec<2>(m, n, replicas, row_indices, values, values_stride,
                                      row_offsets, column_indices, dense, dense_stride, out,
-                                     out_stride, stream);
+                                     out_stride, stream, epi);
     default:
       return launch_rowgather_vec<1>(m, n, replicas, row_indices, values, values_stride,
                                      row_offsets, column_indices, dense, dense_stride, out,
-                                     out_stride, stream);
+                                     out_stride, stream, epi);
   }
 }
 
@@ -164,6 +171,26 @@ int sputnik_hip_spmm_plan(int m, int k, int n, int nonzeros, const int* row_indi
                          workspace_bytes, stream, &planned);
 }
 
+namespace {
+
+int spmm_exec(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
+              const float* values, int64_t values_stride, const int* row_offsets,
+              const int* column_indices, const float* dense, int64_t dense_stride, float* out,
+              int64_t out_stride, const void* workspace, size_t workspace_bytes,
+              hipStream_t stream, Epilogue epi) {
+  if (m < 0 || k < 0 || n < 0 || nonzeros < 0 || replicas < 0) return SPUTNIK_HIP_INVALID_ARGUMENT;
+  if (m == 0 || n == 0 || replicas == 0) return 0;
+  bool handled = false;
+  const int st = spmm_tiled_exec(m, k, n, nonzeros, replicas, row_indices, values, values_stride,
+                                 row_offsets, column_indices, dense, dense_stride, out,
+                                 out_stride, workspace, workspace_bytes, stream, epi, &handled);
+  if (st != 0 || handled) return st;
+  return spmm_rowgather_launch(m, n, replicas, row_indices, values, values_stride, row_offsets,
+                               column_indices, dense, dense_stride, out, out_stride, stream, epi);
+}
+
+}  // namespace
+
 int sputnik_hip_spmm_batched_planned(int m, int k, int n, int nonzeros, int replicas,
                                      const int* row_indices, const float* values,
                                      int64_t values_stride, const int* row_offsets,
@@ -171,15 +198,9 @@ int sputnik_hip_spmm_batched_planned(int m, int k, int n, int nonzeros, int repl
                                      int64_t dense_stride, float* out, int64_t out_stride,
                                      const void* workspace, size_t workspace_bytes,
                                      sputnik_hip_stream_t stream) {
-  if (m < 0 || k < 0 || n < 0 || nonzeros < 0 || replicas < 0) return SPUTNIK_HIP_INVALID_ARGUMENT;
-  if (m == 0 || n == 0 || replicas == 0) return 0;
-  bool handled = false;
-  const int st = spmm_tiled_exec(m, k, n, nonzeros, replicas, row_indices, values, values_stride,
-                                 row_offsets, column_indices, dense, dense_stride, out,
-                                 out_stride, workspace, workspace_bytes, stream, &handled);
-  if (st != 0 || handled) return st;
-  return spmm_rowgather_launch(m, n, replicas, row_indices, values, values_stride, row_offsets,
-                               column_indices, dense, dense_stride, out, out_stride, stream);
+  return spmm_exec(m, k, n, nonzeros, replicas, row_indices, values, values_stride, row_offsets,
+                   column_indices, dense, dense_stride, out, out_stride, workspace,
+                   workspace_bytes, stream, Epilogue{});
 }
 
 int sputnik_hip_spmm_batched(int m, int k, int n, int nonzeros, int replicas,
@@ -189,13 +210,28 @@ int sputnik_hip_spmm_batched(int m, int k, int n, int nonzeros, int replicas,
                              int64_t dense_stride, float* out, int64_t out_stride,
                              void* workspace, size_t workspace_bytes,
                              sputnik_hip_stream_t stream) {
+  return sputnik_hip_spmm_bias_batched(m, k, n, nonzeros, replicas, row_indices, values,
+                                       values_stride, row_offsets, column_indices, dense,
+                                       dense_stride, nullptr, 0, out, out_stride, workspace,
+                                       workspace_bytes, stream);
+}
+
+int sputnik_hip_spmm_bias_batched(int m, int k, int n, int nonzeros, int replicas,
+                                  const int* row_indices, const float* values,
+                                  int64_t values_stride, const int* row_offsets,
+                                  const int* column_indices, const float* dense,
+                                  int64_t dense_stride, const float* bias, int relu, float* out,
+                                  int64_t out_stride, void* workspace, size_t workspace_bytes,
+                                  sputnik_hip_stream_t stream) {
   const int st = sputnik_hip_spmm_plan(m, k, n, nonzeros, row_indices, row_offsets,
                                        column_indices, workspace, workspace_bytes, stream);
   if (st != 0) return st;
-  return sputnik_hip_spmm_batched_planned(m, k, n, nonzeros, replicas, row_indices, values,
-                                          values_stride, row_offsets, column_indices, dense,
-                                          dense_stride, out, out_stride, workspace,
-                                          workspace_bytes, stream);
+  Epilogue epi;
+  epi.bias = bias;
+  epi.relu = relu != 0;
+  return spmm_exec(m, k, n, nonzeros, replicas, row_indices, values, values_stride, row_offsets,
+                   column_indices, dense, dense_stride, out, out_stride, workspace,
+                   workspace_bytes, stream, epi);
 }
 
 int sputnik_hip_spmm(int m, int k, int n, int nonzeros, const int* row_indices,

@@ -45,7 +45,7 @@ int spmm_tiled64_exec(int m, int k, int n, int nonzeros, int replicas, const int
                       const float* values, int64_t values_stride, const int* row_offsets,
                       const int* column_indices, const float* dense, int64_t dense_stride,
                       float* out, int64_t out_stride, const void* workspace,
-                      hipStream_t stream);
+                      hipStream_t stream, Epilogue epi);
 
 namespace {
 
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void spmm_tiled_kernel(
     int64_t values_stride, const int* __restrict__ column_indices,
     const int* __restrict__ table, const float* __restrict__ dense, int64_t dense_stride,
     float* __restrict__ out, int64_t out_stride, const int* __restrict__ row_ok,
-    const int* __restrict__ row_offsets, int debug) {
+    const int* __restrict__ row_offsets, int debug, Epilogue epi) {
   // Timing experiments only (SPUTNIK_HIP_SPMM_DEBUG): 1 = no compute, 2 = no staging.
   const bool dbg_no_compute = debug & 1, dbg_no_stage = debug & 2;
 
@@ -294,7 +294,8 @@ __global__ __launch_bounds__(Cfg::kThreads) void spmm_tiled_kernel(
       const int row = row_indices[slot];
       const float4 acc4 = gather_row_strip(values, column_indices, row_offsets[row],
                                            row_offsets[row + 1], dense + n0 + lane * VEC, n);
-      *reinterpret_cast<float4*>(out + static_cast<int64_t>(row) * n + n0 + lane * VEC) = acc4;
+      *reinterpret_cast<float4*>(out + static_cast<int64_t>(row) * n + n0 + lane * VEC) =
+          apply_epilogue(acc4, epi, row);
     }
     return;
   }
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void spmm_tiled_kernel(
     if (slot < m) {
       const int row = row_indices[slot];
       *reinterpret_cast<float4*>(out + static_cast<int64_t>(row) * n + n0 + lane * VEC) =
-          make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+          apply_epilogue(make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]), epi, row);
     }
   }
 }
@@ -398,7 +399,7 @@ int spmm_tiled_exec(int m, int k, int n, int nonzeros, int replicas, const int* 
                     const float* values, int64_t values_stride, const int* row_offsets,
                     const int* column_indices, const float* dense, int64_t dense_stride,
                     float* out, int64_t out_stride, const void* workspace,
-                    size_t workspace_bytes, hipStream_t stream, bool* handled) {
+                    size_t workspace_bytes, hipStream_t stream, Epilogue epi, bool* handled) {
   *handled = false;
   if (!tiled_applicable(m, k, n, nonzeros)) {
     if (!spmm_tiled64_applicable(m, k, n, nonzeros) || workspace == nullptr ||
@@ -409,7 +410,7 @@ int spmm_tiled_exec(int m, int k, int n, int nonzeros, int replicas, const int* 
     *handled = true;
     return spmm_tiled64_exec(m, k, n, nonzeros, replicas, row_indices, values, values_stride,
                              row_offsets, column_indices, dense, dense_stride, out, out_stride,
-                             workspace, stream);
+                             workspace, stream, epi);
   }
   using Cfg = CfgLarge;
   const Plan plan = make_plan<Cfg>(m, k, n);
@@ -447,7 +448,7 @@ int spmm_tiled_exec(int m, int k, int n, int nonzeros, int replicas, const int* 
                      dim3((plan.slots / CFG::kBM) * plan.n_tiles, replicas), dim3(CFG::kThreads), \
                      0, stream, m, k, n, nonzeros, plan.slots, plan.nchunks, plan.n_tiles,        \
                      row_indices, values, values_stride, column_indices, table, dense,            \
-                     dense_stride, out, out_stride, row_ok, row_offsets, debug)
+                     dense_stride, out, out_stride, row_ok, row_offsets, debug, epi)
   if (large) {
     if (sparse) SPUTNIK_HIP_LAUNCH_TILED(CfgLarge, true);
     else SPUTNIK_HIP_LAUNCH_TILED(CfgLarge, false);

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled64_kernel(
     int64_t values_stride, const int* __restrict__ column_indices,
     const int* __restrict__ table, const float* __restrict__ dense, int64_t dense_stride,
     float* __restrict__ out, int64_t out_stride, const int* __restrict__ row_ok,
-    const int* __restrict__ row_offsets, int debug) {
+    const int* __restrict__ row_offsets, int debug, Epilogue epi) {
   __shared__ float tile[2][kTileFloats];
   const bool dbg_no_compute = debug & 1, dbg_no_stage = debug & 2;
 
@@ -92,7 +92,8 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled64_kernel(
         const int row = row_indices[slot];
         const float4 acc4 = gather_row_strip(values, column_indices, row_offsets[row],
                                              row_offsets[row + 1], dense + n0 + i * 4, n);
-        *reinterpret_cast<float4*>(out + static_cast<int64_t>(row) * n + n0 + i * 4) = acc4;
+        *reinterpret_cast<float4*>(out + static_cast<int64_t>(row) * n + n0 + i * 4) =
+            apply_epilogue(acc4, epi, row);
       }
     }
     return;
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled64_kernel(
     if (slot < m) {
       const int row = row_indices[slot];
       *reinterpret_cast<float4*>(out + static_cast<int64_t>(row) * n + n0 + i * 4) =
-          make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+          apply_epilogue(make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]), epi, row);
     }
   }
 }
@@ -231,7 +232,7 @@ int spmm_tiled64_exec(int m, int k, int n, int nonzeros, int replicas, const int
                       const float* values, int64_t values_stride, const int* row_offsets,
                       const int* column_indices, const float* dense, int64_t dense_stride,
                       float* out, int64_t out_stride, const void* workspace,
-                      hipStream_t stream) {
+                      hipStream_t stream, Epilogue epi) {
   const int slots = slots_of(m);
   const int* row_ok = static_cast<const int*>(workspace);
   const int* table =
@@ -244,7 +245,7 @@ int spmm_tiled64_exec(int m, int k, int n, int nonzeros, int replicas, const int
   hipLaunchKernelGGL(spmm_tiled64_kernel, dim3((slots / kBM) * n_tiles, replicas), dim3(kThreads),
                      0, stream, m, k, n, nonzeros, slots, chunks_of(k), n_tiles, row_indices,
                      values, values_stride, column_indices, table, dense, dense_stride, out,
-                     out_stride, row_ok, row_offsets, debug);
+                     out_stride, row_ok, row_offsets, debug, epi);
   return launch_status();
 }
 

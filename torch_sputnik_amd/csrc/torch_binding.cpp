@@ -25,6 +25,7 @@
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "../../include/sputnik_hip.h"
@@ -94,7 +95,8 @@ int to_int(int64_t v, const char* name) {
 // Shared by spmm (values [nnz] / [R,nnz]) and left_spmm (values [nnz], shared).
 Tensor spmm_impl(int64_t m64, int64_t k64, const Tensor& values_in, const Tensor& row_indices,
                  const Tensor& row_offsets, const Tensor& column_indices, const Tensor& dense_in,
-                 bool left, const char* what) {
+                 bool left, const char* what, const c10::optional<Tensor>& bias_in = c10::nullopt,
+                 bool relu = false) {
   const int m = to_int(m64, "m"), k = to_int(k64, "k");
   const Tensor values = as_float(values_in, "values");
   const Tensor dense = as_float(dense_in, "dense");
@@ -135,13 +137,20 @@ Tensor spmm_impl(int64_t m64, int64_t k64, const Tensor& values_in, const Tensor
   if (ws_bytes > 0)
     workspace = at::empty({static_cast<int64_t>(ws_bytes)}, options.dtype(at::kByte));
 
-  check_status(sputnik_hip_spmm_batched(
+  Tensor bias;
+  if (bias_in.has_value()) {
+    bias = as_float(*bias_in, "bias");
+    TORCH_CHECK(bias.device() == values.device(), "bias must be on ", values.device());
+    TORCH_CHECK(bias.dim() == 1 && bias.size(0) == m, "bias should have m = ", m,
+                " elements (one per output row), got ", bias.sizes());
+  }
+  check_status(sputnik_hip_spmm_bias_batched(
                    m, k, n, topo.nonzeros, replicas, topo.row_indices.data_ptr<int>(),
                    values.data_ptr<float>(), values_stride, topo.row_offsets.data_ptr<int>(),
                    topo.column_indices.data_ptr<int>(), dense.data_ptr<float>(),
-                   static_cast<int64_t>(k) * n, out.data_ptr<float>(),
-                   static_cast<int64_t>(m) * n, ws_bytes ? workspace.data_ptr() : nullptr,
-                   ws_bytes, current_stream(values)),
+                   static_cast<int64_t>(k) * n, bias.defined() ? bias.data_ptr<float>() : nullptr,
+                   relu ? 1 : 0, out.data_ptr<float>(), static_cast<int64_t>(m) * n,
+                   ws_bytes ? workspace.data_ptr() : nullptr, ws_bytes, current_stream(values)),
                what);
   return out;
 }
@@ -198,8 +207,9 @@ Tensor sddmm(int64_t m64, int64_t n64, const Tensor& row_indices, const Tensor& 
   return out;
 }
 
-Tensor sparse_softmax(const Tensor& values_in, const Tensor& row_indices,
-                      const Tensor& row_offsets, const Tensor& column_indices) {
+Tensor sparse_softmax_scaled(const Tensor& values_in, const Tensor& row_indices,
+                             const Tensor& row_offsets, const Tensor& column_indices,
+                             double scale) {
   const Tensor values = as_float(values_in, "values");
   TORCH_CHECK(values.dim() == 1 || values.dim() == 2,
               "values should have 1 or 2 dimensions, got ", values.dim());
@@ -211,12 +221,42 @@ Tensor sparse_softmax(const Tensor& values_in, const Tensor& row_indices,
   const int replicas = values.dim() == 2 ? to_int(values.size(0), "replicas") : 1;
 
   Tensor out = at::empty_like(values);
-  check_status(sputnik_hip_sparse_softmax_batched(
+  check_status(sputnik_hip_sparse_softmax_scaled_batched(
                    m, /*n=*/-1, topo.nonzeros, replicas, values.data_ptr<float>(), topo.nonzeros,
                    topo.row_indices.data_ptr<int>(), topo.row_offsets.data_ptr<int>(),
-                   topo.column_indices.data_ptr<int>(), out.data_ptr<float>(), topo.nonzeros,
-                   current_stream(values)),
+                   topo.column_indices.data_ptr<int>(), static_cast<float>(scale),
+                   out.data_ptr<float>(), topo.nonzeros, current_stream(values)),
                "sparse_softmax");
+  return out;
+}
+
+Tensor sparse_softmax(const Tensor& values, const Tensor& row_indices, const Tensor& row_offsets,
+                      const Tensor& column_indices) {
+  return sparse_softmax_scaled(values, row_indices, row_offsets, column_indices, 1.0);
+}
+
+// grad of softmax(scale * x) w.r.t. x; softmax_out / grad_out [nnz] or [R,nnz].
+Tensor sparse_softmax_backward(const Tensor& softmax_out_in, const Tensor& grad_out_in,
+                               const Tensor& row_offsets_in, double scale) {
+  const Tensor y = as_float(softmax_out_in, "softmax_out");
+  const Tensor g = as_float(grad_out_in, "grad_out");
+  TORCH_CHECK(y.sizes() == g.sizes(), "softmax_out and grad_out must have one shape, got ",
+              y.sizes(), " and ", g.sizes());
+  TORCH_CHECK(y.dim() == 1 || y.dim() == 2, "softmax_out should have 1 or 2 dimensions, got ",
+              y.dim());
+  TORCH_CHECK(y.device() == g.device(), "softmax_out and grad_out must be on one device");
+  const c10::DeviceGuard guard(y.device());
+  const Tensor row_offsets = as_index(row_offsets_in, "row_offsets", y);
+  TORCH_CHECK(row_offsets.size(0) >= 1, "row_offsets must not be empty");
+  const int m = to_int(row_offsets.size(0) - 1, "m");
+  const int nonzeros = to_int(y.size(-1), "nonzeros");
+  const int replicas = y.dim() == 2 ? to_int(y.size(0), "replicas") : 1;
+  Tensor out = at::empty_like(y);
+  check_status(sputnik_hip_sparse_softmax_backward_batched(
+                   m, nonzeros, replicas, y.data_ptr<float>(), nonzeros, g.data_ptr<float>(),
+                   nonzeros, row_offsets.data_ptr<int>(), static_cast<float>(scale),
+                   out.data_ptr<float>(), nonzeros, current_stream(y)),
+               "sparse_softmax_backward");
   return out;
 }
 
@@ -275,6 +315,247 @@ std::vector<Tensor> csr_transpose_with_permutation(int64_t m, int64_t n, const T
   return csr_transpose_impl(m, n, values, row_offsets, column_indices, true);
 }
 
+Tensor spmm_bias(int64_t m, int64_t k, const Tensor& values, const Tensor& row_indices,
+                 const Tensor& row_offsets, const Tensor& column_indices, const Tensor& bias,
+                 const Tensor& dense) {
+  return spmm_impl(m, k, values, row_indices, row_offsets, column_indices, dense, false,
+                   "spmm_bias", bias, false);
+}
+
+Tensor spmm_bias_relu(int64_t m, int64_t k, const Tensor& values, const Tensor& row_indices,
+                      const Tensor& row_offsets, const Tensor& column_indices,
+                      const Tensor& bias, const Tensor& dense) {
+  return spmm_impl(m, k, values, row_indices, row_offsets, column_indices, dense, false,
+                   "spmm_bias_relu", bias, true);
+}
+
+// ---------------------------------------------------------------------------
+// many-mask family (tests/transformer/functions.py, tests/transformer/utils.py:17-38):
+// b topologies, concatenated; replica r uses mask r / (R / b).
+// ---------------------------------------------------------------------------
+struct ManyMask {
+  int masks, m, replicas, width;  // width = max nonzeros
+  std::vector<int> nonzeros;
+  Tensor row_indices, row_offsets, column_indices;  // flat int32
+  bool uniform;                                     // every mask has `width` nonzeros
+};
+
+Tensor as_flat_index(const Tensor& t, const char* name, const Tensor& like) {
+  TORCH_CHECK(t.scalar_type() == at::kInt || t.scalar_type() == at::kLong, name,
+              " must be an int32 (or int64) tensor, got ", t.scalar_type());
+  TORCH_CHECK(t.device() == like.device(), name, " must be on ", like.device(), ", got ",
+              t.device());
+  return t.to(at::kInt).contiguous().view({-1});
+}
+
+// `nonzeros` is the tensor tests/transformer/utils.py:36 builds with
+// torch.tensor(nnzs): it lives on the host.  A device tensor is accepted but
+// costs a synchronising copy.
+ManyMask check_many_mask(int64_t b, int64_t m, const Tensor& nonzeros,
+                         const c10::optional<Tensor>& row_indices, const Tensor& row_offsets,
+                         const Tensor& column_indices, const Tensor& like, int64_t replicas) {
+  ManyMask mm;
+  mm.masks = to_int(b, "b");
+  mm.m = to_int(m, "m");
+  mm.replicas = to_int(replicas, "replicas");
+  TORCH_CHECK(mm.masks > 0, "b must be positive");
+  TORCH_CHECK(mm.replicas % mm.masks == 0, "the number of replicas (", replicas,
+              ") must be a multiple of the number of masks (", b, ")");
+  TORCH_CHECK(nonzeros.numel() == mm.masks, "nonzeros should have b = ", b, " entries, got ",
+              nonzeros.numel());
+  TORCH_CHECK(at::isIntegralType(nonzeros.scalar_type(), false), "nonzeros must be integral");
+  const Tensor host = nonzeros.to(at::kCPU, at::kLong).contiguous();
+  int64_t total = 0;
+  mm.width = 0;
+  mm.uniform = true;
+  for (int i = 0; i < mm.masks; ++i) {
+    const int64_t v = host.data_ptr<int64_t>()[i];
+    mm.nonzeros.push_back(to_int(v, "nonzeros[i]"));
+    total += v;
+    mm.width = std::max(mm.width, mm.nonzeros.back());
+  }
+  for (int v : mm.nonzeros) mm.uniform = mm.uniform && v == mm.width;
+  mm.row_offsets = as_flat_index(row_offsets, "row_offsets", like);
+  mm.column_indices = as_flat_index(column_indices, "column_indices", like);
+  TORCH_CHECK(mm.row_offsets.numel() == static_cast<int64_t>(mm.masks) * (mm.m + 1),
+              "row_offsets should have b * (m + 1) = ", static_cast<int64_t>(mm.masks) * (mm.m + 1),
+              " entries, got ", mm.row_offsets.numel());
+  TORCH_CHECK(mm.column_indices.numel() == total, "column_indices should have sum(nonzeros) = ",
+              total, " entries, got ", mm.column_indices.numel());
+  if (row_indices.has_value()) {
+    mm.row_indices = as_flat_index(*row_indices, "row_indices", like);
+    TORCH_CHECK(mm.row_indices.numel() == static_cast<int64_t>(mm.masks) * mm.m,
+                "row_indices should have b * m = ", static_cast<int64_t>(mm.masks) * mm.m,
+                " entries, got ", mm.row_indices.numel());
+  }
+  return mm;
+}
+
+Tensor many_mask_values(const Tensor& t, const ManyMask& mm, const char* name) {
+  TORCH_CHECK(t.dim() == 2, name, " should be [replicas, max(nonzeros)], got ", t.sizes());
+  TORCH_CHECK(t.size(0) == mm.replicas, name, ": expected ", mm.replicas, " replicas, got ",
+              t.size(0));
+  TORCH_CHECK(t.size(1) >= mm.width, name, ": rows must hold max(nonzeros) = ", mm.width,
+              " entries, got ", t.size(1));
+  return t;
+}
+
+Tensor spmm_many_mask(int64_t b, int64_t m64, int64_t k64, const Tensor& nonzeros,
+                      const Tensor& values_in, const Tensor& row_indices,
+                      const Tensor& row_offsets, const Tensor& column_indices,
+                      const Tensor& dense_in) {
+  const Tensor values = as_float(values_in, "values");
+  const Tensor dense = as_float(dense_in, "dense");
+  TORCH_CHECK(dense.dim() == 3, "dense should be [replicas, k, n], got ", dense.sizes());
+  TORCH_CHECK(dense.device() == values.device(), "values and dense must be on one device");
+  const c10::DeviceGuard guard(values.device());
+  const ManyMask mm = check_many_mask(b, m64, nonzeros, row_indices, row_offsets, column_indices,
+                                      values, dense.size(0));
+  many_mask_values(values, mm, "values");
+  const int k = to_int(k64, "k"), n = to_int(dense.size(2), "n");
+  TORCH_CHECK(dense.size(1) == k, "inner matrix dimensions must match: dense has ",
+              dense.size(1), " rows, k = ", k);
+  Tensor out = at::empty({mm.replicas, mm.m, n}, values.options());
+  const size_t ws_bytes = sputnik_hip_spmm_workspace_bytes(mm.m, k, n, mm.width);
+  Tensor workspace;
+  if (ws_bytes > 0)
+    workspace = at::empty({static_cast<int64_t>(ws_bytes)}, values.options().dtype(at::kByte));
+  check_status(sputnik_hip_spmm_many_mask(
+                   mm.masks, mm.m, k, n, mm.nonzeros.data(), mm.replicas,
+                   mm.row_indices.data_ptr<int>(), values.data_ptr<float>(), values.size(1),
+                   mm.row_offsets.data_ptr<int>(), mm.column_indices.data_ptr<int>(),
+                   dense.data_ptr<float>(), static_cast<int64_t>(k) * n, out.data_ptr<float>(),
+                   static_cast<int64_t>(mm.m) * n, ws_bytes ? workspace.data_ptr() : nullptr,
+                   ws_bytes, current_stream(values)),
+               "spmm_many_mask");
+  return out;
+}
+
+Tensor sddmm_many_mask(int64_t b, int64_t m64, int64_t n64, const Tensor& nonzeros,
+                       const Tensor& row_indices, const Tensor& row_offsets,
+                       const Tensor& column_indices, const Tensor& lhs_in, const Tensor& rhs_in) {
+  const Tensor lhs = as_float(lhs_in, "lhs_matrix");
+  const Tensor rhs = as_float(rhs_in, "rhs_matrix");
+  TORCH_CHECK(lhs.dim() == 3 && rhs.dim() == 3, "expected 3-dim lhs_matrix and rhs_matrix");
+  TORCH_CHECK(lhs.device() == rhs.device(), "lhs_matrix and rhs_matrix must be on one device");
+  TORCH_CHECK(lhs.size(0) == rhs.size(0), "first dim of lhs_matrix and rhs_matrix must match");
+  TORCH_CHECK(lhs.size(2) == rhs.size(2), "last dim of input matrices must match");
+  const c10::DeviceGuard guard(lhs.device());
+  const ManyMask mm = check_many_mask(b, m64, nonzeros, row_indices, row_offsets, column_indices,
+                                      lhs, lhs.size(0));
+  const int n = to_int(n64, "n"), k = to_int(lhs.size(2), "k");
+  TORCH_CHECK(lhs.size(1) == mm.m, "lhs_matrix should have m = ", mm.m, " rows");
+  TORCH_CHECK(rhs.size(1) == n, "rhs_matrix should have n = ", n, " rows");
+  // Entries past a replica's own count stay zero.
+  Tensor out = mm.uniform ? at::empty({mm.replicas, mm.width}, lhs.options())
+                          : at::zeros({mm.replicas, mm.width}, lhs.options());
+  const size_t ws_bytes = sputnik_hip_sddmm_workspace_bytes(mm.m, k, n, mm.width);
+  Tensor workspace;
+  if (ws_bytes > 0)
+    workspace = at::empty({static_cast<int64_t>(ws_bytes)}, lhs.options().dtype(at::kByte));
+  check_status(sputnik_hip_sddmm_many_mask(
+                   mm.masks, mm.m, k, n, mm.nonzeros.data(), mm.replicas,
+                   mm.row_indices.data_ptr<int>(), mm.row_offsets.data_ptr<int>(),
+                   mm.column_indices.data_ptr<int>(), lhs.data_ptr<float>(),
+                   static_cast<int64_t>(mm.m) * k, rhs.data_ptr<float>(),
+                   static_cast<int64_t>(n) * k, out.data_ptr<float>(), mm.width,
+                   ws_bytes ? workspace.data_ptr() : nullptr, ws_bytes, current_stream(lhs)),
+               "sddmm_many_mask");
+  return out;
+}
+
+Tensor sparse_softmax_many_mask_scaled(int64_t b, int64_t m64, const Tensor& nonzeros,
+                                       const Tensor& values_in, const Tensor& row_indices,
+                                       const Tensor& row_offsets, const Tensor& column_indices,
+                                       double scale) {
+  const Tensor values = as_float(values_in, "values");
+  const c10::DeviceGuard guard(values.device());
+  TORCH_CHECK(values.dim() == 2, "values should be [replicas, max(nonzeros)]");
+  const ManyMask mm = check_many_mask(b, m64, nonzeros, row_indices, row_offsets, column_indices,
+                                      values, values.size(0));
+  many_mask_values(values, mm, "values");
+  Tensor out = mm.uniform && values.size(1) == mm.width ? at::empty_like(values)
+                                                        : at::zeros_like(values);
+  check_status(sputnik_hip_sparse_softmax_many_mask(
+                   mm.masks, mm.m, mm.nonzeros.data(), mm.replicas, values.data_ptr<float>(),
+                   values.size(1), mm.row_indices.data_ptr<int>(),
+                   mm.row_offsets.data_ptr<int>(), mm.column_indices.data_ptr<int>(),
+                   static_cast<float>(scale), out.data_ptr<float>(), out.size(1),
+                   current_stream(values)),
+               "sparse_softmax_many_mask");
+  return out;
+}
+
+Tensor sparse_softmax_many_mask(int64_t b, int64_t m, const Tensor& nonzeros,
+                                const Tensor& values, const Tensor& row_indices,
+                                const Tensor& row_offsets, const Tensor& column_indices) {
+  return sparse_softmax_many_mask_scaled(b, m, nonzeros, values, row_indices, row_offsets,
+                                         column_indices, 1.0);
+}
+
+Tensor sparse_softmax_backward_many_mask(int64_t b, int64_t m64, const Tensor& nonzeros,
+                                         const Tensor& softmax_out_in, const Tensor& grad_out_in,
+                                         const Tensor& row_offsets, double scale) {
+  const Tensor y = as_float(softmax_out_in, "softmax_out");
+  const Tensor g = as_float(grad_out_in, "grad_out");
+  TORCH_CHECK(y.dim() == 2 && y.sizes() == g.sizes(),
+              "softmax_out and grad_out should be [replicas, max(nonzeros)] and match");
+  const c10::DeviceGuard guard(y.device());
+  const int masks = to_int(b, "b"), m = to_int(m64, "m");
+  TORCH_CHECK(masks > 0 && y.size(0) % masks == 0, "replicas must be a multiple of b");
+  TORCH_CHECK(nonzeros.numel() == masks, "nonzeros should have b entries");
+  const Tensor host = nonzeros.to(at::kCPU, at::kLong).contiguous();
+  std::vector<int> counts;
+  bool full = true;
+  for (int i = 0; i < masks; ++i) {
+    counts.push_back(to_int(host.data_ptr<int64_t>()[i], "nonzeros[i]"));
+    TORCH_CHECK(counts.back() <= y.size(1), "nonzeros[i] exceeds the row length of softmax_out");
+    full = full && counts.back() == y.size(1);
+  }
+  const Tensor offsets = as_flat_index(row_offsets, "row_offsets", y);
+  TORCH_CHECK(offsets.numel() == static_cast<int64_t>(masks) * (m + 1),
+              "row_offsets should have b * (m + 1) entries");
+  Tensor out = full ? at::empty_like(y) : at::zeros_like(y);
+  check_status(sputnik_hip_sparse_softmax_backward_many_mask(
+                   masks, m, counts.data(), to_int(y.size(0), "replicas"), y.data_ptr<float>(),
+                   y.size(1), g.data_ptr<float>(), g.size(1), offsets.data_ptr<int>(),
+                   static_cast<float>(scale), out.data_ptr<float>(), out.size(1),
+                   current_stream(y)),
+               "sparse_softmax_backward_many_mask");
+  return out;
+}
+
+std::vector<Tensor> csr_transpose_many_mask(int64_t b, int64_t m64, int64_t n64,
+                                            const Tensor& nonzeros, const Tensor& values_in,
+                                            const Tensor& row_offsets,
+                                            const Tensor& column_indices) {
+  const Tensor values = as_float(values_in, "values");
+  const c10::DeviceGuard guard(values.device());
+  TORCH_CHECK(values.dim() == 2, "values should be [replicas, max(nonzeros)]");
+  const ManyMask mm = check_many_mask(b, m64, nonzeros, c10::nullopt, row_offsets,
+                                      column_indices, values, values.size(0));
+  many_mask_values(values, mm, "values");
+  const int n = to_int(n64, "n");
+  const auto index_options = values.options().dtype(at::kInt);
+  Tensor out_values = mm.uniform && values.size(1) == mm.width ? at::empty_like(values)
+                                                               : at::zeros_like(values);
+  // [b, n + 1]: tests/transformer/utils.py:51-62 (diffsort_many_mask) indexes it per mask
+  Tensor out_row_offsets = at::empty({mm.masks, n + 1}, index_options);
+  Tensor out_column_indices = at::empty({mm.column_indices.numel()}, index_options);
+  const size_t ws_bytes = sputnik_hip_csr_transpose_workspace_bytes(mm.m, n, mm.width);
+  Tensor workspace =
+      at::empty({static_cast<int64_t>(ws_bytes)}, values.options().dtype(at::kByte));
+  check_status(sputnik_hip_csr_transpose_many_mask(
+                   mm.masks, mm.m, n, mm.nonzeros.data(), mm.replicas, values.data_ptr<float>(),
+                   values.size(1), mm.row_offsets.data_ptr<int>(),
+                   mm.column_indices.data_ptr<int>(), out_values.data_ptr<float>(),
+                   out_values.size(1), out_row_offsets.data_ptr<int>(),
+                   out_column_indices.data_ptr<int>(), nullptr, workspace.data_ptr(), ws_bytes,
+                   current_stream(values)),
+               "csr_transpose_many_mask");
+  return {out_values, out_row_offsets, out_column_indices};
+}
+
 }  // namespace
 
 TORCH_LIBRARY(torch_sputnik, m) {
@@ -296,6 +577,37 @@ TORCH_LIBRARY(torch_sputnik, m) {
   m.def(
       "csr_transpose_with_permutation(int m, int n, Tensor values, Tensor row_offsets, "
       "Tensor column_indices) -> Tensor[]");
+  // extensions
+  m.def(
+      "spmm_bias(int m, int k, Tensor values, Tensor row_indices, Tensor row_offsets, "
+      "Tensor column_indices, Tensor bias, Tensor dense_matrix) -> Tensor");
+  m.def(
+      "spmm_bias_relu(int m, int k, Tensor values, Tensor row_indices, Tensor row_offsets, "
+      "Tensor column_indices, Tensor bias, Tensor dense_matrix) -> Tensor");
+  m.def(
+      "sparse_softmax_scaled(Tensor values, Tensor row_indices, Tensor row_offsets, "
+      "Tensor column_indices, float scale) -> Tensor");
+  m.def(
+      "sparse_softmax_backward(Tensor softmax_out, Tensor grad_out, Tensor row_offsets, "
+      "float scale) -> Tensor");
+  m.def(
+      "spmm_many_mask(int b, int m, int k, Tensor nonzeros, Tensor values, Tensor row_indices, "
+      "Tensor row_offsets, Tensor column_indices, Tensor dense_matrix) -> Tensor");
+  m.def(
+      "sddmm_many_mask(int b, int m, int n, Tensor nonzeros, Tensor row_indices, "
+      "Tensor row_offsets, Tensor column_indices, Tensor lhs_matrix, Tensor rhs_matrix) -> Tensor");
+  m.def(
+      "sparse_softmax_many_mask(int b, int m, Tensor nonzeros, Tensor values, "
+      "Tensor row_indices, Tensor row_offsets, Tensor column_indices) -> Tensor");
+  m.def(
+      "sparse_softmax_many_mask_scaled(int b, int m, Tensor nonzeros, Tensor values, "
+      "Tensor row_indices, Tensor row_offsets, Tensor column_indices, float scale) -> Tensor");
+  m.def(
+      "sparse_softmax_backward_many_mask(int b, int m, Tensor nonzeros, Tensor softmax_out, "
+      "Tensor grad_out, Tensor row_offsets, float scale) -> Tensor");
+  m.def(
+      "csr_transpose_many_mask(int b, int m, int n, Tensor nonzeros, Tensor values, "
+      "Tensor row_offsets, Tensor column_indices) -> Tensor[]");
 }
 
 // "CUDA" is the dispatch key of HIP tensors in a ROCm build of PyTorch.
@@ -306,4 +618,14 @@ TORCH_LIBRARY_IMPL(torch_sputnik, CUDA, m) {
   m.impl("sparse_softmax", &sparse_softmax);
   m.impl("csr_transpose", &csr_transpose);
   m.impl("csr_transpose_with_permutation", &csr_transpose_with_permutation);
+  m.impl("spmm_bias", &spmm_bias);
+  m.impl("spmm_bias_relu", &spmm_bias_relu);
+  m.impl("sparse_softmax_scaled", &sparse_softmax_scaled);
+  m.impl("sparse_softmax_backward", &sparse_softmax_backward);
+  m.impl("spmm_many_mask", &spmm_many_mask);
+  m.impl("sddmm_many_mask", &sddmm_many_mask);
+  m.impl("sparse_softmax_many_mask", &sparse_softmax_many_mask);
+  m.impl("sparse_softmax_many_mask_scaled", &sparse_softmax_many_mask_scaled);
+  m.impl("sparse_softmax_backward_many_mask", &sparse_softmax_backward_many_mask);
+  m.impl("csr_transpose_many_mask", &csr_transpose_many_mask);
 }

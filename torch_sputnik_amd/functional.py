@@ -165,24 +165,125 @@ class SparseLinearFunction(torch.autograd.Function):
 
 
 class SparseSoftmax(torch.autograd.Function):
-    """sparse_softmax with a gradient: dX = Y * (dY - rowsum(dY * Y)), the row
-    sums taken over the stored entries (extension)."""
+    """sparse_softmax with a gradient: dX = scale * Y * (dY - rowsum(dY * Y)), the
+    row sums taken over the stored entries (extension).
+    ``apply(values, row_indices, row_offsets, column_indices[, scale])`` computes
+    softmax(scale * values)."""
 
     @staticmethod
-    def forward(ctx, values, row_indices, row_offsets, column_indices):
-        out = ops.sparse_softmax(values, row_indices, row_offsets, column_indices)
+    def forward(ctx, values, row_indices, row_offsets, column_indices, scale=1.0):
+        if scale == 1.0:
+            out = ops.sparse_softmax(values, row_indices, row_offsets, column_indices)
+        else:
+            out = ops.sparse_softmax_scaled(values, row_indices, row_offsets, column_indices,
+                                            scale)
+        ctx.scale = float(scale)
         ctx.save_for_backward(out, row_offsets)
         return out
 
     @staticmethod
     def backward(ctx, grad_output):
         out, row_offsets = ctx.saved_tensors
-        lengths = (row_offsets[1:] - row_offsets[:-1]).to(torch.int64)
-        rows = torch.repeat_interleave(
-            torch.arange(lengths.numel(), device=out.device), lengths)
-        prod = grad_output * out
-        row_sum = torch.zeros(out.shape[:-1] + (lengths.numel(),), dtype=out.dtype,
-                              device=out.device)
-        row_sum.index_add_(-1, rows, prod)
-        grad_values = out * (grad_output - row_sum.index_select(-1, rows))
-        return grad_values, None, None, None
+        grad_values = ops.sparse_softmax_backward(out, grad_output.contiguous(), row_offsets,
+                                                  ctx.scale)
+        return grad_values, None, None, None, None
+
+
+# ---------------------------------------------------------------------------
+# many-mask family: one mask per batch element, shared by its heads.  Same
+# ``apply`` signatures and gradient positions as the reference's sketches in
+# tests/transformer/functions.py (Spmm :5-69, CsrSoftmax :70-120, Sddmm :122-188).
+# ---------------------------------------------------------------------------
+def diffsort_many_mask(row_offsets, masks):
+    """Per-mask ``diffsort`` of stacked / concatenated offsets
+    (tests/transformer/utils.py:51-62) -> flat [masks * rows]."""
+    per_mask = row_offsets.reshape(masks, -1)
+    return torch.cat([diffsort(per_mask[i]) for i in range(masks)])
+
+
+class SpmmManyMask(torch.autograd.Function):
+    """tests/transformer/functions.py:5-69."""
+
+    @staticmethod
+    def forward(ctx, b, m, k, nonzeros, values, row_indices, row_offsets, column_indices, dense):
+        ctx.dims = (b, m, k)
+        ctx.nonzeros = nonzeros
+        ctx.save_for_backward(values, row_indices, row_offsets, column_indices, dense)
+        return ops.spmm_many_mask(b, m, k, nonzeros, values, row_indices, row_offsets,
+                                  column_indices, dense)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        b, m, k = ctx.dims
+        nonzeros = ctx.nonzeros
+        values, row_indices, row_offsets, column_indices, dense = ctx.saved_tensors
+        grad_output = grad_output.contiguous()
+        grad_values = grad_dense = None
+        if ctx.needs_input_grad[4]:
+            grad_values = ops.sddmm_many_mask(b, m, k, nonzeros, row_indices, row_offsets,
+                                              column_indices, grad_output, dense)
+            if grad_values.shape[-1] != values.shape[-1]:  # values rows were padded
+                grad_values = torch.nn.functional.pad(
+                    grad_values, (0, values.shape[-1] - grad_values.shape[-1]))
+        if ctx.needs_input_grad[8]:
+            values_t, row_offsets_t, column_indices_t = ops.csr_transpose_many_mask(
+                b, m, k, nonzeros, values.detach(), row_offsets, column_indices)
+            row_indices_t = diffsort_many_mask(row_offsets_t, b)
+            grad_dense = ops.spmm_many_mask(b, k, m, nonzeros, values_t, row_indices_t,
+                                            row_offsets_t, column_indices_t, grad_output)
+        return None, None, None, None, grad_values, None, None, None, grad_dense
+
+
+class SddmmManyMask(torch.autograd.Function):
+    """tests/transformer/functions.py:122-188."""
+
+    @staticmethod
+    def forward(ctx, b, m, n, nonzeros, row_indices, row_offsets, column_indices, lhs_matrix,
+                rhs_matrix):
+        ctx.dims = (b, m, n)
+        ctx.nonzeros = nonzeros
+        ctx.save_for_backward(row_indices, row_offsets, column_indices, lhs_matrix, rhs_matrix)
+        return ops.sddmm_many_mask(b, m, n, nonzeros, row_indices, row_offsets, column_indices,
+                                   lhs_matrix, rhs_matrix)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        b, m, n = ctx.dims
+        nonzeros = ctx.nonzeros
+        row_indices, row_offsets, column_indices, lhs_matrix, rhs_matrix = ctx.saved_tensors
+        grad_output = grad_output.contiguous()
+        grad_lhs = grad_rhs = None
+        if ctx.needs_input_grad[7]:
+            grad_lhs = ops.spmm_many_mask(b, m, n, nonzeros, grad_output, row_indices,
+                                          row_offsets, column_indices, rhs_matrix)
+        if ctx.needs_input_grad[8]:
+            grad_t, row_offsets_t, column_indices_t = ops.csr_transpose_many_mask(
+                b, m, n, nonzeros, grad_output, row_offsets, column_indices)
+            row_indices_t = diffsort_many_mask(row_offsets_t, b)
+            grad_rhs = ops.spmm_many_mask(b, n, m, nonzeros, grad_t, row_indices_t,
+                                          row_offsets_t, column_indices_t, lhs_matrix)
+        return None, None, None, None, None, None, None, grad_lhs, grad_rhs
+
+
+class CsrSoftmaxManyMask(torch.autograd.Function):
+    """tests/transformer/functions.py:70-120 with the softmax Jacobian in the
+    backward (the sketch there returns ``s * (1 - s)`` of a dense softmax of the
+    incoming gradient).  Optional trailing ``scale``."""
+
+    @staticmethod
+    def forward(ctx, b, m, nonzeros, scores, row_indices, row_offsets, column_indices,
+                scale=1.0):
+        out = ops.sparse_softmax_many_mask(b, m, nonzeros, scores, row_indices, row_offsets,
+                                           column_indices, None if scale == 1.0 else scale)
+        ctx.dims = (b, m, float(scale))
+        ctx.nonzeros = nonzeros
+        ctx.save_for_backward(out, row_offsets)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        b, m, scale = ctx.dims
+        out, row_offsets = ctx.saved_tensors
+        grad_scores = ops.sparse_softmax_backward_many_mask(
+            b, m, ctx.nonzeros, out, grad_output.contiguous(), row_offsets, scale)
+        return None, None, None, grad_scores, None, None, None, None

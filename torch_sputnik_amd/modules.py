@@ -82,10 +82,14 @@ class SparseAttention(nn.Module):
 
         # [B*H, nnz]: scores only at the mask's nonzeros
         scores = self.sddmm(self.m, self.n, self.row_indices, self.row_offsets,
-                            self.column_indices, q3d, k3d) / math.sqrt(self.head_dim)
-        softmax = SparseSoftmax.apply if self.differentiable_softmax else ops.sparse_softmax
+                            self.column_indices, q3d, k3d)
+        # the reference divides the scores in a pass of its own
+        # (modules/sparse_attention.py:72); here the softmax kernel applies it
+        scale = 1.0 / math.sqrt(self.head_dim)
+        softmax = (SparseSoftmax.apply if self.differentiable_softmax
+                   else ops.sparse_softmax_scaled)
         attention_weights = softmax(scores, self.row_indices, self.row_offsets,
-                                    self.column_indices)
+                                    self.column_indices, scale)
         # [B*H, S, D]
         return self.spmm(self.m, self.n, attention_weights, self.row_indices, self.row_offsets,
                          self.column_indices, v3d)

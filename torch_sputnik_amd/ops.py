@@ -1,6 +1,8 @@
 """The five operators of the reference's ``torch_sputnik`` module
 (src/sputnik.cpp:36-42), same names, positional signatures and return types,
-backed by ``torch.ops.torch_sputnik.*`` (HIP kernels for gfx950).
+backed by ``torch.ops.torch_sputnik.*`` (HIP kernels for gfx950), followed by
+the extensions whose call sites exist only in the reference's tests
+(``spmm_bias``, the ``*_many_mask`` family) or not at all (softmax gradient).
 
 GPU only: a CPU tensor raises from the dispatcher; there is no fallback.
 """
@@ -54,3 +56,77 @@ def csr_transpose_with_permutation(m, n, values, row_offsets, column_indices):
     topology's transpose can be cached by the caller."""
     return _ops.csr_transpose_with_permutation(int(m), int(n), values, row_offsets,
                                                column_indices)
+
+
+# ---------------------------------------------------------------------------
+# extensions (SURVEY.md 8f)
+# ---------------------------------------------------------------------------
+def spmm_bias(m, k, values, row_indices, row_offsets, column_indices, bias, dense_matrix):
+    """spmm with ``bias[i]`` added to output row i in the kernel's epilogue.
+    Call site tests/test_spmm_bias_relu.py:35-37."""
+    return _ops.spmm_bias(int(m), int(k), values, row_indices, row_offsets, column_indices, bias,
+                          dense_matrix)
+
+
+def spmm_bias_relu(m, k, values, row_indices, row_offsets, column_indices, bias, dense_matrix):
+    """``relu(spmm + bias)`` in one pass."""
+    return _ops.spmm_bias_relu(int(m), int(k), values, row_indices, row_offsets, column_indices,
+                               bias, dense_matrix)
+
+
+def sparse_softmax_scaled(values, row_indices, row_offsets, column_indices, scale):
+    """softmax(scale * values): the 1/sqrt(d) of modules/sparse_attention.py:72 folded in."""
+    return _ops.sparse_softmax_scaled(values, row_indices, row_offsets, column_indices,
+                                      float(scale))
+
+
+def sparse_softmax_backward(softmax_out, grad_out, row_offsets, scale=1.0):
+    """Gradient of softmax(scale * x) w.r.t. x given the forward output."""
+    return _ops.sparse_softmax_backward(softmax_out, grad_out, row_offsets, float(scale))
+
+
+def _counts(nonzeros):
+    import torch
+    return nonzeros if torch.is_tensor(nonzeros) else torch.tensor(list(nonzeros),
+                                                                    dtype=torch.int64)
+
+
+def spmm_many_mask(b, m, k, nonzeros, values, row_indices, row_offsets, column_indices,
+                   dense_matrix):
+    """One mask per batch element, shared by its heads: replica r of
+    values [R, max nnz] / dense [R,k,n] uses mask r // (R // b).
+    tests/transformer/functions.py:20; layout tests/transformer/utils.py:17-38."""
+    return _ops.spmm_many_mask(int(b), int(m), int(k), _counts(nonzeros), values, row_indices,
+                               row_offsets, column_indices, dense_matrix)
+
+
+def sddmm_many_mask(b, m, n, nonzeros, row_indices, row_offsets, column_indices, lhs_matrix,
+                    rhs_matrix):
+    """-> [R, max(nonzeros)], zero past a replica's own count.
+    tests/transformer/functions.py:135; tests/test_attention_many_masks.py:120-127."""
+    return _ops.sddmm_many_mask(int(b), int(m), int(n), _counts(nonzeros), row_indices,
+                                row_offsets, column_indices, lhs_matrix, rhs_matrix)
+
+
+def sparse_softmax_many_mask(b, m, nonzeros, values, row_indices, row_offsets, column_indices,
+                             scale=None):
+    """tests/transformer/functions.py:81; tests/test_attention_many_masks.py:132-138."""
+    if scale is None:
+        return _ops.sparse_softmax_many_mask(int(b), int(m), _counts(nonzeros), values,
+                                             row_indices, row_offsets, column_indices)
+    return _ops.sparse_softmax_many_mask_scaled(int(b), int(m), _counts(nonzeros), values,
+                                                row_indices, row_offsets, column_indices,
+                                                float(scale))
+
+
+def sparse_softmax_backward_many_mask(b, m, nonzeros, softmax_out, grad_out, row_offsets,
+                                      scale=1.0):
+    return _ops.sparse_softmax_backward_many_mask(int(b), int(m), _counts(nonzeros), softmax_out,
+                                                  grad_out, row_offsets, float(scale))
+
+
+def csr_transpose_many_mask(b, m, n, nonzeros, values, row_offsets, column_indices):
+    """-> [values_t [R, max nnz], row_offsets_t [b, n+1], column_indices_t [sum nnz]].
+    tests/transformer/functions.py:50,165."""
+    return _ops.csr_transpose_many_mask(int(b), int(m), int(n), _counts(nonzeros), values,
+                                        row_offsets, column_indices)
