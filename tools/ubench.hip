@@ -229,6 +229,46 @@ DEF_KERNEL(k_spmm_step_scalar,
            "v_pk_fma_f32 v[26:27], s[30:31], v[22:23], v[26:27] op_sel:[1,0,0]\nv_pk_fma_f32 v[28:29], s[30:31], v[24:25], v[28:29] op_sel:[1,0,0]\n",
            V32, "v44", "v45", "v46", "v47")
 
+// m) v_mov_b32 with a DPP row_newbcast source
+DEF_KERNEL(k_mov_dpp32,
+           "v_mov_b32_dpp v10, v3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+           "v_mov_b32_dpp v11, v3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+           "v_mov_b32_dpp v12, v3 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+           "v_mov_b32_dpp v13, v3 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+           "v_mov_b32_dpp v14, v3 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+           "v_mov_b32_dpp v15, v3 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+           "v_mov_b32_dpp v16, v3 row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+           "v_mov_b32_dpp v17, v3 row_newbcast:7 row_mask:0xf bank_mask:0xf\n"
+           "v_mov_b32_dpp v18, v3 row_newbcast:8 row_mask:0xf bank_mask:0xf\n"
+           "v_mov_b32_dpp v19, v3 row_newbcast:9 row_mask:0xf bank_mask:0xf\n"
+           "v_mov_b32_dpp v20, v3 row_newbcast:10 row_mask:0xf bank_mask:0xf\n"
+           "v_mov_b32_dpp v21, v3 row_newbcast:11 row_mask:0xf bank_mask:0xf\n"
+           "v_mov_b32_dpp v22, v3 row_newbcast:12 row_mask:0xf bank_mask:0xf\n"
+           "v_mov_b32_dpp v23, v3 row_newbcast:13 row_mask:0xf bank_mask:0xf\n"
+           "v_mov_b32_dpp v24, v3 row_newbcast:14 row_mask:0xf bank_mask:0xf\n"
+           "v_mov_b32_dpp v25, v3 row_newbcast:15 row_mask:0xf bank_mask:0xf\n",
+           V16)
+
+// n) 64-bit DPP move (DP-rate DPP only supports row_newbcast): broadcasts a register PAIR
+DEF_KERNEL(k_mov_dpp64,
+           "v_mov_b64_dpp v[10:11], v[2:3] row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+           "v_mov_b64_dpp v[12:13], v[2:3] row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+           "v_mov_b64_dpp v[14:15], v[2:3] row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+           "v_mov_b64_dpp v[16:17], v[2:3] row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+           "v_mov_b64_dpp v[18:19], v[2:3] row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+           "v_mov_b64_dpp v[20:21], v[2:3] row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+           "v_mov_b64_dpp v[22:23], v[2:3] row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+           "v_mov_b64_dpp v[24:25], v[2:3] row_newbcast:7 row_mask:0xf bank_mask:0xf\n"
+           "v_mov_b64_dpp v[26:27], v[2:3] row_newbcast:8 row_mask:0xf bank_mask:0xf\n"
+           "v_mov_b64_dpp v[28:29], v[2:3] row_newbcast:9 row_mask:0xf bank_mask:0xf\n"
+           "v_mov_b64_dpp v[30:31], v[2:3] row_newbcast:10 row_mask:0xf bank_mask:0xf\n"
+           "v_mov_b64_dpp v[32:33], v[2:3] row_newbcast:11 row_mask:0xf bank_mask:0xf\n"
+           "v_mov_b64_dpp v[34:35], v[2:3] row_newbcast:12 row_mask:0xf bank_mask:0xf\n"
+           "v_mov_b64_dpp v[36:37], v[2:3] row_newbcast:13 row_mask:0xf bank_mask:0xf\n"
+           "v_mov_b64_dpp v[38:39], v[2:3] row_newbcast:14 row_mask:0xf bank_mask:0xf\n"
+           "v_mov_b64_dpp v[42:43], v[2:3] row_newbcast:15 row_mask:0xf bank_mask:0xf\n",
+           V32, "v41")
+
 typedef void (*kern_t)(unsigned long long*, int);
 
 static void run(const char* name, kern_t k, int per_block_insts) {
@@ -277,5 +317,7 @@ int main() {
   run("salu", k_salu, 16);
   run("salu+valu(16)", k_salu_valu, 16);
   run("spmm_step_scalar(4nz)", k_spmm_step_scalar, 4);
+  run("mov_dpp32", k_mov_dpp32, 16);
+  run("mov_dpp64", k_mov_dpp64, 16);
   return 0;
 }

@@ -208,36 +208,60 @@ template <int N>
 __device__ __forceinline__ float row_rotate_f(float v) {
   return __builtin_bit_cast(float, row_rotate_i<N>(__builtin_bit_cast(int, v)));
 }
-__device__ __forceinline__ void dpp_group2_at0(float (&acc)[4], int roff, float rval,
-                                               const char* __restrict__ lane_base) {
-  const int o0 = row_bcast_i<0>(roff), o1 = row_bcast_i<1>(roff);
-  const float4 b0 = *reinterpret_cast<const float4*>(lane_base + o0);
-  const float4 b1 = *reinterpret_cast<const float4*>(lane_base + o1);
-  const float a0 = row_bcast_f<0>(rval), a1 = row_bcast_f<1>(rval);
-  SPUTNIK_HIP_FMA4(acc, a0, b0);
-  SPUTNIK_HIP_FMA4(acc, a1, b1);
+// (offset, value) of an entry travel as ONE 64-bit register pair: a 64-bit DPP
+// move broadcasts both halves for the price of a 32-bit one (measured:
+// tools/ubench.hip, mov_dpp64 vs mov_dpp32), which saves one DPP operation per
+// nonzero against broadcasting the two words separately.  (64-bit DPP only
+// knows row_newbcast, so the rotation stays two 32-bit moves.)
+using entry_pair = unsigned long long;
+__device__ __forceinline__ entry_pair make_entry(int roff, float rval) {
+  return static_cast<unsigned int>(roff) |
+         (static_cast<entry_pair>(__builtin_bit_cast(unsigned int, rval)) << 32);
 }
-__device__ __forceinline__ void dpp_group1_at0(float (&acc)[4], int roff, float rval,
-                                               const char* __restrict__ lane_base) {
-  const int o0 = row_bcast_i<0>(roff);
-  const float4 b0 = *reinterpret_cast<const float4*>(lane_base + o0);
-  const float a0 = row_bcast_f<0>(rval);
-  SPUTNIK_HIP_FMA4(acc, a0, b0);
+template <int U>
+__device__ __forceinline__ entry_pair row_bcast_entry(entry_pair e) {
+  return __builtin_amdgcn_update_dpp(entry_pair{0}, e, 0x150 + U, 0xF, 0xF, true);
+}
+__device__ __forceinline__ int entry_off(entry_pair e) { return static_cast<int>(e & 0xffffffffu); }
+__device__ __forceinline__ float entry_val(entry_pair e) {
+  return __builtin_bit_cast(float, static_cast<unsigned int>(e >> 32));
+}
+template <int N>
+__device__ __forceinline__ entry_pair row_rotate_entry(entry_pair e) {
+  return make_entry(row_rotate_i<N>(entry_off(e)), row_rotate_f<N>(entry_val(e)));
+}
+
+template <int COUNT>
+__device__ __forceinline__ void dpp_group_at0(float (&acc)[4], entry_pair e,
+                                              const char* __restrict__ lane_base) {
+  static_assert(COUNT == 1 || COUNT == 2 || COUNT == 4, "");
+  const entry_pair e0 = row_bcast_entry<0>(e);
+  const entry_pair e1 = COUNT > 1 ? row_bcast_entry<1>(e) : 0;
+  const entry_pair e2 = COUNT > 2 ? row_bcast_entry<2>(e) : 0;
+  const entry_pair e3 = COUNT > 2 ? row_bcast_entry<3>(e) : 0;
+  float4 b0, b1, b2, b3;
+  b0 = *reinterpret_cast<const float4*>(lane_base + entry_off(e0));
+  if (COUNT > 1) b1 = *reinterpret_cast<const float4*>(lane_base + entry_off(e1));
+  if (COUNT > 2) b2 = *reinterpret_cast<const float4*>(lane_base + entry_off(e2));
+  if (COUNT > 2) b3 = *reinterpret_cast<const float4*>(lane_base + entry_off(e3));
+  SPUTNIK_HIP_FMA4(acc, entry_val(e0), b0);
+  if (COUNT > 1) SPUTNIK_HIP_FMA4(acc, entry_val(e1), b1);
+  if (COUNT > 2) SPUTNIK_HIP_FMA4(acc, entry_val(e2), b2);
+  if (COUNT > 2) SPUTNIK_HIP_FMA4(acc, entry_val(e3), b3);
 }
 __device__ __forceinline__ void dpp_entries_exact(float (&acc)[4], int n16, int roff, float rval,
                                                   const char* __restrict__ lane_base) {
+  entry_pair e = make_entry(roff, rval);
   int left = n16;
   for (; left >= 4; left -= 4) {
-    dpp_group4<0>(acc, roff, rval, lane_base);
-    roff = row_rotate_i<4>(roff);
-    rval = row_rotate_f<4>(rval);
+    dpp_group_at0<4>(acc, e, lane_base);
+    e = row_rotate_entry<4>(e);
   }
   if (left & 2) {
-    dpp_group2_at0(acc, roff, rval, lane_base);
-    roff = row_rotate_i<2>(roff);
-    rval = row_rotate_f<2>(rval);
+    dpp_group_at0<2>(acc, e, lane_base);
+    e = row_rotate_entry<2>(e);
   }
-  if (left & 1) dpp_group1_at0(acc, roff, rval, lane_base);
+  if (left & 1) dpp_group_at0<1>(acc, e, lane_base);
 }
 
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v / 2); }
