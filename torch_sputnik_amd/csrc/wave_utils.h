@@ -64,6 +64,37 @@ __device__ __forceinline__ float group_max(float v) {
   return group_allreduce<WIDTH>(v, MaxOp{});
 }
 
+// Transposing reduction inside each 16-lane row: every lane brings 16 partial
+// values p[0..15]; lane i (its index in the row) returns the row-wide sum of
+// p[i].  Halving exchange: at each of the four steps a lane keeps one half of
+// its values, hands the other half to a partner and adds what the partner
+// hands over: 8 + 4 + 2 + 1 = 15 DPP adds (plus two selects each) for 16
+// sums, against 16 x 4 for sixteen separate all-reduces.  The partners
+// (i^8, i^7, i^2, i^1) are the four single-instruction DPP permutations that
+// pair lanes differing in bit 3, 2, 1, 0 and together span the row.
+constexpr int kDppRowRor8 = 0x128;  // lane i <- lane i ^ 8
+__device__ __forceinline__ float row_transpose_sum16(const float (&p)[16], int i) {
+  const bool b3 = (i & 8) != 0, b2 = (i & 4) != 0, b1 = (i & 2) != 0, b0 = (i & 1) != 0;
+  float q[8], r[4], s[2];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const float keep = b3 ? p[u + 8] : p[u], send = b3 ? p[u] : p[u + 8];
+    q[u] = keep + dpp_f32<kDppRowRor8>(send);
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const float keep = b2 ? q[u + 4] : q[u], send = b2 ? q[u] : q[u + 4];
+    r[u] = keep + dpp_f32<kDppRowHalfMirror>(send);
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const float keep = b1 ? r[u + 2] : r[u], send = b1 ? r[u] : r[u + 2];
+    s[u] = keep + dpp_f32<kDppQuadXor2>(send);
+  }
+  const float keep = b0 ? s[1] : s[0], send = b0 ? s[0] : s[1];
+  return keep + dpp_f32<kDppQuadXor1>(send);
+}
+
 // Broadcast from lane `src` of the caller's aligned WIDTH-lane group.
 template <int WIDTH, typename T>
 __device__ __forceinline__ T group_broadcast(T v, int src) {
