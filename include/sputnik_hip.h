@@ -44,6 +44,8 @@ extern "C" {
 typedef struct ihipStream_t* sputnik_hip_stream_t;
 
 #define SPUTNIK_HIP_INVALID_ARGUMENT (-1)
+/* a fused entry point does not serve this shape / alignment: use the separate operators */
+#define SPUTNIK_HIP_UNSUPPORTED (-2)
 
 /* Exported-symbol marker (the library is built with -fvisibility=hidden). */
 #define SPUTNIK_HIP_API __attribute__((visibility("default")))
@@ -214,6 +216,31 @@ SPUTNIK_HIP_API int sputnik_hip_sparse_softmax_backward_batched(int m, int nonze
                              const float* grad_out, int64_t grad_out_stride,
                              const int* row_offsets, float scale, float* grad_values,
                              int64_t grad_values_stride, sputnik_hip_stream_t stream);
+
+/*
+ * Fused sparse attention forward, one launch for
+ *   out = spmm(softmax(scale * sddmm(q, k)), v)
+ * i.e. the chain of modules/sparse_attention.py:66-82 (sddmm :68-71, the
+ * division by sqrt(d) :72, sparse_softmax :76, spmm :79-82) without the
+ * [replicas, nonzeros] intermediates.  q [m,d], k and v [n,d] per replica,
+ * out [m,d]; `lse` (may be NULL) receives log(sum(exp(scale*score))) per row
+ * for a later backward.  Served shapes: d = 64 with 16-byte aligned operands
+ * (sputnik_hip_sparse_attention_supported); anything else returns
+ * SPUTNIK_HIP_UNSUPPORTED and the caller composes the three operators.
+ * Rows without entries produce zeros (and lse = -inf).
+ */
+SPUTNIK_HIP_API int sputnik_hip_sparse_attention_supported(int m, int n, int d, int nonzeros);
+
+SPUTNIK_HIP_API size_t sputnik_hip_sparse_attention_workspace_bytes(int m, int n, int d,
+                                                                    int nonzeros);
+
+SPUTNIK_HIP_API int sputnik_hip_sparse_attention_forward(int m, int n, int d, int nonzeros,
+                             int replicas, const int* row_indices, const int* row_offsets,
+                             const int* column_indices, const float* q, int64_t q_stride,
+                             const float* k, int64_t k_stride, const float* v,
+                             int64_t v_stride, float scale, float* out, int64_t out_stride,
+                             float* lse, int64_t lse_stride, void* workspace,
+                             size_t workspace_bytes, sputnik_hip_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * "many mask" family: `masks` topologies of the same m x n shape, laid out

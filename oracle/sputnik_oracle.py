@@ -270,6 +270,23 @@ def sparse_softmax_backward(softmax_out, grad_out, row_offsets, scale=1.0):
     return np.stack([one(y[r], g[r]) for r in range(y.shape[0])])
 
 
+def sparse_attention(q, k, v, row_indices, row_offsets, column_indices, scale):
+    """spmm(softmax(scale * sddmm(q, k)), v): the chain of
+    modules/sparse_attention.py:66-82 (sddmm :68-71, ``/ math.sqrt(d)`` :72,
+    sparse_softmax :76, spmm :79-82).  q [R,m,d], k and v [R,n,d] -> [R,m,d];
+    rows without entries give zeros."""
+    q = np.asarray(q, np.float64)
+    k = np.asarray(k, np.float64)
+    v = np.asarray(v, np.float64)
+    m, n = q.shape[-2], k.shape[-2]
+    scores = sddmm(m, n, row_indices, row_offsets, column_indices, q, k)
+    weights = sparse_softmax_scaled(scores, row_indices, row_offsets, column_indices, scale)
+    if q.ndim == 2:
+        return spmm(m, n, weights, row_indices, row_offsets, column_indices, v)
+    return spmm(m, n, weights, row_indices, row_offsets, column_indices, v).reshape(
+        q.shape[0], m, v.shape[-1])
+
+
 def dense_to_csr_many_mask(masks):
     """[b, m, n] 0/1 array -> (row_indices [b*m], row_offsets [b*(m+1)],
     column_indices [sum nnz], nnzs [b]).

@@ -85,6 +85,11 @@ def _sparse_softmax_backward(softmax_out, grad_out, row_offsets, scale):
                                           scale))
 
 
+def _sparse_attention(q, k, v, row_indices, row_offsets, column_indices, scale):
+    return _f32(O.sparse_attention(_np(q), _np(k), _np(v), _np(row_indices), _np(row_offsets),
+                                   _np(column_indices), scale))
+
+
 def _spmm_many_mask(b, m, k, nonzeros, values, row_indices, row_offsets, column_indices, dense):
     return _f32(O.spmm_many_mask(b, m, k, _np(nonzeros), _np(values), _np(row_indices),
                                  _np(row_offsets), _np(column_indices), _np(dense)))
@@ -135,6 +140,7 @@ def install():
     _lib.impl("spmm_bias_relu", _spmm_bias_relu, "CPU")
     _lib.impl("sparse_softmax_scaled", _sparse_softmax_scaled, "CPU")
     _lib.impl("sparse_softmax_backward", _sparse_softmax_backward, "CPU")
+    _lib.impl("sparse_attention", _sparse_attention, "CPU")
     _lib.impl("spmm_many_mask", _spmm_many_mask, "CPU")
     _lib.impl("sddmm_many_mask", _sddmm_many_mask, "CPU")
     _lib.impl("sparse_softmax_many_mask", _sparse_softmax_many_mask, "CPU")

@@ -151,3 +151,41 @@ def test_many_mask_argument_checks(cpu_ops):
                                      torch.zeros(8, dtype=torch.int32),
                                      torch.zeros(10, dtype=torch.int32),
                                      torch.zeros(1, dtype=torch.int32), torch.zeros(2, 4, 3))
+
+
+def test_sparse_attention_oracle_matches_dense_masked_attention():
+    rng = np.random.default_rng(11)
+    r, s, d = 3, 40, 16
+    mask = O.random_mask(s, s, 0.7, rng=rng) != 0
+    mask[7] = False  # a query without keys
+    _, ri, ro, ci = O.dense_to_csr(mask.astype(np.float32))
+    q, k, v = (rng.uniform(-1, 1, (r, s, d)) for _ in range(3))
+    scale = 1.0 / np.sqrt(d)
+    got = O.sparse_attention(q, k, v, ri, ro, ci, scale)
+    logits = np.where(mask[None], np.matmul(q, np.swapaxes(k, 1, 2)) * scale, -np.inf)
+    with np.errstate(invalid="ignore"):
+        w = np.exp(logits - logits.max(axis=-1, keepdims=True))
+        w = np.nan_to_num(w / w.sum(axis=-1, keepdims=True))
+    want = np.matmul(w, v)
+    assert rel_err(got, want) < 1e-12
+    assert not got[:, 7].any()
+
+
+def test_attention_module_fused_and_composed_paths_agree(cpu_ops):
+    from torch_sputnik_amd.modules import SparseAttention
+    torch.manual_seed(0)
+    layer = SparseAttention(num_heads=2, embedding_size=16, max_sequence_length=24,
+                            device=torch.device("cpu"), sparsity=0.6,
+                            mask_generator=np.random.default_rng(5))
+    for lin in layer.linears:
+        with torch.no_grad():
+            lin.weight.copy_(torch.from_numpy(
+                O.random_mask(16, 16, 0.5, rng=np.random.default_rng(1)) *
+                np.random.default_rng(2).uniform(-1, 1, (16, 16)).astype(np.float32)))
+        lin.setup_sparse_tensors()
+    x = torch.rand(2, 24, 16)
+    with torch.no_grad():
+        fused = layer(x, x, x)
+        layer.fused_inference = False
+        composed = layer(x, x, x)
+    assert rel_err(fused.numpy(), composed.numpy()) < 1e-5

@@ -288,3 +288,104 @@ def test_many_mask_errors(ts, dev, golden):
         ts.sddmm_many_mask(b, s, s, nn[:2], *topo, T(g["q"], dev), T(g["k"], dev))
     with pytest.raises(RuntimeError):  # value rows shorter than the longest mask
         ts.spmm_many_mask(b, s, s, nn, T(g["weights"][:, :10], dev), *topo, T(g["v"], dev))
+
+
+# ----------------------------------------------------------------------------
+# fused sparse attention forward
+# ----------------------------------------------------------------------------
+ATTENTION_SHAPES = [
+    # m, n, sparsity, replicas, empty rows, row order
+    (256, 256, 0.9, 4, (0, 255), "ascending"),
+    (1024, 1024, 0.9, 8, (), "ascending"),        # BASELINE config 3 mask shape
+    (200, 300, 0.8, 3, (17,), "random"),          # ragged: partial row block, partial last chunk
+    (128, 512, 0.5, 2, (), "descending"),         # > 32 entries of a row inside one chunk
+    (64, 128, 0.0, 2, (), "identity"),            # dense mask
+    (130, 70, 0.97, 5, (1, 2, 3), "ascending"),   # mostly empty windows
+]
+
+
+@pytest.mark.parametrize("m,n,sparsity,replicas,empty,order", ATTENTION_SHAPES)
+def test_sparse_attention_capi_vs_oracle(capi, dev, m, n, sparsity, replicas, empty, order):
+    d = 64
+    _, _, ri, ro, ci = make_csr(m, n, sparsity, seed=m + 3 * n, empty_rows=empty, order=order)
+    rng = np.random.default_rng(m)
+    q = rng.uniform(-2, 2, (replicas, m, d)).astype(np.float32)
+    k = rng.uniform(-2, 2, (replicas, n, d)).astype(np.float32)
+    v = rng.uniform(-1, 1, (replicas, n, d)).astype(np.float32)
+    scale = 1.0 / np.sqrt(d)
+    assert capi.sparse_attention_supported(m, n, d, len(ci))
+    ws = torch.empty(capi.sparse_attention_workspace_bytes(m, n, d, len(ci)), dtype=torch.uint8,
+                     device=dev)
+    out = torch.full((replicas, m, d), float("nan"), device=dev)
+    lse = torch.full((replicas, m), float("nan"), device=dev)
+    capi.sparse_attention_forward(m, n, d, replicas, T(ri, dev), T(ro, dev), T(ci, dev), T(q, dev),
+                                  T(k, dev), T(v, dev), scale, out, lse, ws)
+    got = out.cpu().numpy()
+    assert not np.isnan(got).any(), "some output elements were never written"
+    want = O.sparse_attention(q, k, v, ri, ro, ci, scale)
+    assert rel_err(got, want) < TOL
+    for r in empty:
+        assert not got[:, r].any()
+    # log-sum-exp of the scaled scores, per row
+    scores = O.sddmm(m, n, ri, ro, ci, q, k) * scale
+    want_lse = np.full((replicas, m), -np.inf)
+    for r in range(m):
+        if ro[r + 1] > ro[r]:
+            seg = scores[:, ro[r]:ro[r + 1]]
+            mx = seg.max(axis=1)
+            want_lse[:, r] = mx + np.log(np.exp(seg - mx[:, None]).sum(axis=1))
+    got_lse = lse.cpu().numpy()
+    finite = np.isfinite(want_lse)
+    assert np.array_equal(np.isneginf(got_lse), ~finite)
+    assert np.max(np.abs(got_lse[finite] - want_lse[finite])) < 1e-4 * (1 + np.abs(want_lse[finite]).max())
+
+
+def test_sparse_attention_unsorted_columns(capi, dev):
+    m, n, d, replicas = 256, 256, 64, 2
+    _, _, ri, ro, ci = make_csr(m, n, 0.85, seed=77)
+    rng = np.random.default_rng(5)
+    ci = ci.copy()
+    for r in range(0, m, 5):
+        ci[ro[r]:ro[r + 1]] = ci[ro[r]:ro[r + 1]][rng.permutation(ro[r + 1] - ro[r])]
+    q = rng.uniform(-1, 1, (replicas, m, d)).astype(np.float32)
+    k = rng.uniform(-1, 1, (replicas, n, d)).astype(np.float32)
+    v = rng.uniform(-1, 1, (replicas, n, d)).astype(np.float32)
+    ws = torch.empty(capi.sparse_attention_workspace_bytes(m, n, d, len(ci)), dtype=torch.uint8,
+                     device=dev)
+    out = torch.empty(replicas, m, d, device=dev)
+    capi.sparse_attention_forward(m, n, d, replicas, T(ri, dev), T(ro, dev), T(ci, dev), T(q, dev),
+                                  T(k, dev), T(v, dev), 0.125, out, None, ws)
+    assert rel_err(out.cpu().numpy(), O.sparse_attention(q, k, v, ri, ro, ci, 0.125)) < TOL
+
+
+def test_sparse_attention_op_matches_three_op_chain(ts, dev):
+    rng = np.random.default_rng(9)
+    for d in (64, 32):  # 32: not served by the fused kernel, composed by the op
+        m = n = 192
+        _, _, ri, ro, ci = make_csr(m, n, 0.8, seed=d)
+        topo = [T(x, dev) for x in (ri, ro, ci)]
+        q, k, v = (T(rng.uniform(-1, 1, (6, m, d)).astype(np.float32), dev) for _ in range(3))
+        scale = 1.0 / np.sqrt(d)
+        fused = ts.sparse_attention(q, k, v, *topo, scale)
+        chain = ts.spmm(m, n, ts.sparse_softmax(ts.sddmm(m, n, *topo, q, k) * scale, *topo),
+                        *topo, v)
+        assert fused.shape == chain.shape == (6, m, d)
+        assert rel_err(fused.cpu().numpy(), chain.cpu().numpy()) < TOL
+        want = O.sparse_attention(q.cpu().numpy(), k.cpu().numpy(), v.cpu().numpy(), ri, ro, ci,
+                                  scale)
+        assert rel_err(fused.cpu().numpy(), want) < TOL
+
+
+def test_sparse_attention_large_scores_stay_finite(ts, dev):
+    """Scores around +-90: exp of the raw values would overflow fp32."""
+    m = n = 128
+    _, _, ri, ro, ci = make_csr(m, n, 0.7, seed=3)
+    rng = np.random.default_rng(4)
+    q = (rng.uniform(-1, 1, (2, m, 64)) * 12).astype(np.float32)
+    k = (rng.uniform(-1, 1, (2, n, 64)) * 12).astype(np.float32)
+    v = rng.uniform(-1, 1, (2, n, 64)).astype(np.float32)
+    out = ts.sparse_attention(T(q, dev), T(k, dev), T(v, dev), T(ri, dev), T(ro, dev), T(ci, dev),
+                              0.125)
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert rel_err(got, O.sparse_attention(q, k, v, ri, ro, ci, 0.125)) < TOL

@@ -87,6 +87,17 @@ def bench_attention_ops(dev, iters, s=1024, d=64, replicas=64, density=0.1):
                      gflops=2.0 * nnz * d * replicas / med / 1e9, alg_gbs=by / med / 1e9,
                      hbm_frac=by / med / 8e12))
     print(json.dumps(rows[-1]), flush=True)
+    if capi.sparse_attention_supported(s, s, d, nnz):
+        aws = torch.empty(capi.sparse_attention_workspace_bytes(s, s, d, nnz), dtype=torch.uint8,
+                          device=dev)
+        scale = 1.0 / d ** 0.5
+        med, best = timeit(lambda: capi.sparse_attention_forward(s, s, d, replicas, ri, ro, ci, q, kk,
+                                                                 v, scale, ctx, None, aws), iters)
+        by = replicas * 4.0 * 4 * s * d + 4 * nnz + 4 * (2 * s + 1)  # Q, K, V in; O out
+        rows.append(dict(op="attention_fused", s=s, d=d, replicas=replicas, nnz=nnz, ms=med * 1e3,
+                         ms_min=best * 1e3, gflops=4.0 * nnz * d * replicas / med / 1e9,
+                         alg_gbs=by / med / 1e9, hbm_frac=by / med / 8e12))
+        print(json.dumps(rows[-1]), flush=True)
     return rows
 
 

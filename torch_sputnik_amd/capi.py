@@ -51,6 +51,11 @@ SIGNATURES = {
         _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_float, _c_ptr, _c_i64, _c_ptr]),
     "sputnik_hip_sparse_softmax_backward_batched": (_c_int, [_c_int] * 3 + [
         _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_float, _c_ptr, _c_i64, _c_ptr]),
+    "sputnik_hip_sparse_attention_supported": (_c_int, [_c_int] * 4),
+    "sputnik_hip_sparse_attention_workspace_bytes": (_c_size, [_c_int] * 4),
+    "sputnik_hip_sparse_attention_forward": (_c_int, [_c_int] * 5 + [
+        _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_float, _c_ptr,
+        _c_i64, _c_ptr, _c_i64, _c_ptr, _c_size, _c_ptr]),
     "sputnik_hip_spmm_many_mask": (_c_int, [_c_int] * 4 + [_c_ptr, _c_int, _c_ptr, _c_ptr, _c_i64,
                                                           _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr,
                                                           _c_i64, _c_ptr, _c_size, _c_ptr]),
@@ -326,3 +331,29 @@ def csr_transpose_many_mask(masks, m, n, nonzeros, replicas, values, row_offsets
         _ptr(out_column_indices), _ptr(out_permutation), _ptr(workspace), _ws_bytes(workspace),
         _stream(out_row_offsets)), "sputnik_hip_csr_transpose_many_mask")
     return out_values, out_row_offsets, out_column_indices
+
+
+def sparse_attention_supported(m, n, d, nonzeros):
+    return bool(lib().sputnik_hip_sparse_attention_supported(m, n, d, nonzeros))
+
+
+def sparse_attention_workspace_bytes(m, n, d, nonzeros):
+    return lib().sputnik_hip_sparse_attention_workspace_bytes(m, n, d, nonzeros)
+
+
+def sparse_attention_forward(m, n, d, replicas, row_indices, row_offsets, column_indices, q, k, v,
+                             scale, out, lse=None, workspace=None):
+    """Fused softmax(scale * q k^T at the mask) v.  q [R,m,d], k and v [R,n,d]."""
+    nonzeros = column_indices.numel()
+    for t, dt, nm in ((row_indices, torch.int32, "row_indices"),
+                      (row_offsets, torch.int32, "row_offsets"),
+                      (column_indices, torch.int32, "column_indices"), (q, torch.float32, "q"),
+                      (k, torch.float32, "k"), (v, torch.float32, "v"),
+                      (out, torch.float32, "out")):
+        _require(t, dt, nm)
+    _check(lib().sputnik_hip_sparse_attention_forward(
+        m, n, d, nonzeros, replicas, _ptr(row_indices), _ptr(row_offsets), _ptr(column_indices),
+        _ptr(q), m * d, _ptr(k), n * d, _ptr(v), n * d, float(scale), _ptr(out), m * d, _ptr(lse),
+        m, _ptr(workspace), _ws_bytes(workspace), _stream(out)),
+        "sputnik_hip_sparse_attention_forward")
+    return out

@@ -1,0 +1,350 @@
+// Fused sparse attention forward for gfx950:
+//
+//   out[i, :] = sum_j softmax_j(scale * <q_i, k_j>) * v_j      j over the stored
+//                                                               columns of mask row i
+//
+// One kernel for the chain the reference runs as three library calls and an
+// elementwise pass -- sddmm, "/ sqrt(d)", sparse_softmax, spmm
+// (modules/sparse_attention.py:66-82) -- so the [replicas, nnz] score and
+// weight arrays never exist: HBM traffic is Q, K, V and the output only.
+//
+// Decomposition (the 64-column SpMM kernel's, spmm_tiled64.hip): a workgroup
+// owns 128 query rows and walks the key/value rows in chunks of 128; each
+// chunk's K rows and V rows are staged into LDS by direct global->LDS copies
+// (double buffered).  A 16-lane row group owns one query row: its q fragment
+// (pre-multiplied by the scale), running maximum, running sum and 4 output
+// columns per lane stay in registers for the whole walk (online softmax).
+// Per 16-entry window of a row's columns inside the chunk:
+//   1. 16 partial dot products per lane against the K rows (ds_read_b128 of a
+//      DPP-broadcast address), then ONE transposing DPP reduction that leaves
+//      score u in lane u;
+//   2. window maximum and sum with two 16-lane DPP all-reduces, one exp per
+//      lane, rescale of the accumulators;
+//   3. the weights go back out to all lanes entry by entry, paired with the
+//      tile offset in one 64-bit DPP broadcast, against the V rows (same
+//      offsets: the V tile sits at a fixed distance from the K tile).
+// Needs ascending columns inside rows (checked by the shared pre-pass); row
+// blocks that fail take an order-independent path (K, V gathered from L2).
+#include "spmm_tiled_common.h"
+
+namespace sputnik_hip {
+namespace {
+
+using namespace tiled;
+
+constexpr int kD = 64;      // head dimension served by this kernel
+constexpr int kWaves = 16;  // waves per workgroup
+constexpr int kRQ = 2;      // row quads per wave (4 query rows each)
+constexpr int kBK = 128;    // key/value rows per LDS stage
+constexpr int kBM = kWaves * kRQ * 4;
+constexpr int kThreads = kWaves * kWave;
+constexpr int kTileFloats = kBK * kD;  // one of K / V: 32 KiB
+constexpr int kWin = 2;                // 16-entry windows prefetched per row and chunk
+constexpr int kCopiesPerWave = (kBK / 4) / kWaves;  // 1 KiB copies of 4 rows each
+static_assert((kBK / 4) % kWaves == 0, "stage copies split evenly over the waves");
+
+__device__ __forceinline__ void stage_kv(float* __restrict__ tile, const float* __restrict__ k,
+                                         const float* __restrict__ v, int n, int jc, int wave,
+                                         int lane) {
+  const int g = lane >> 4, i = lane & 15;
+#pragma unroll
+  for (int j = 0; j < kCopiesPerWave; ++j) {
+    const int r0 = (wave + j * kWaves) * 4;
+    const int src_row = min(jc + r0 + g, n - 1);  // past the last key: re-read the last row
+    const unsigned off = (static_cast<unsigned>(src_row) * kD + i * 4u) * 4u;
+    lds_dma_row(k, off, tile + r0 * kD);
+    lds_dma_row(v, off, tile + kTileFloats + r0 * kD);
+  }
+}
+
+struct RowAcc {
+  float4 q;    // scale * q fragment (elements 4i .. 4i+3)
+  float4 acc;  // unnormalised output columns 4i .. 4i+3
+  float mx, l;
+};
+
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) {
+  float s = a.x * b.x;
+  s = fmaf(a.y, b.y, s);
+  s = fmaf(a.z, b.z, s);
+  return fmaf(a.w, b.w, s);
+}
+
+// Online-softmax update of one row with `e`-weighted V contributions still to
+// be added by the caller: returns the factor the old accumulators were scaled by.
+__device__ __forceinline__ void rescale(RowAcc& r, float m_new) {
+  const float alpha = __expf(r.mx - m_new);  // mx = -inf gives 0
+  r.l *= alpha;
+  r.acc.x *= alpha;
+  r.acc.y *= alpha;
+  r.acc.z *= alpha;
+  r.acc.w *= alpha;
+  r.mx = m_new;
+}
+
+__global__ __launch_bounds__(kThreads) void sparse_attention_kernel(
+    int m, int n, int nonzeros, int slots, int nchunks, const int* __restrict__ row_indices,
+    const int* __restrict__ row_offsets, const int* __restrict__ column_indices,
+    const int* __restrict__ table, const int* __restrict__ row_ok, const float* __restrict__ q,
+    int64_t q_stride, const float* __restrict__ k, int64_t k_stride, const float* __restrict__ v,
+    int64_t v_stride, float scale, float* __restrict__ out, int64_t out_stride,
+    float* __restrict__ lse, int64_t lse_stride) {
+  __shared__ float tile[2][2 * kTileFloats];  // [buffer][K rows | V rows]
+
+  const int lane = threadIdx.x % kWave;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int g = lane >> 4, i = lane & 15;
+  const int mblock = blockIdx.x;
+  const int replica = blockIdx.y;
+  q += replica * q_stride;
+  k += replica * k_stride;
+  v += replica * v_stride;
+  out += replica * out_stride;
+  if (lse != nullptr) lse += replica * lse_stride;
+  const int slot0 = mblock * kBM + wave * (kRQ * 4);
+  const int last = nonzeros - 1;
+
+  RowAcc st[kRQ];
+  int my_row[kRQ];
+#pragma unroll
+  for (int t = 0; t < kRQ; ++t) {
+    const int slot = slot0 + 4 * t + g;
+    my_row[t] = slot < m ? row_indices[slot] : -1;
+    float4 qf = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (my_row[t] >= 0)
+      qf = *reinterpret_cast<const float4*>(q + static_cast<int64_t>(my_row[t]) * kD + 4 * i);
+    st[t].q = make_float4(qf.x * scale, qf.y * scale, qf.z * scale, qf.w * scale);
+    st[t].acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    st[t].mx = -INFINITY;
+    st[t].l = 0.f;
+  }
+
+  auto finish = [&]() {
+#pragma unroll
+    for (int t = 0; t < kRQ; ++t) {
+      if (my_row[t] < 0) continue;
+      const float inv = st[t].l > 0.f ? 1.f / st[t].l : 0.f;  // rows without entries give zeros
+      *reinterpret_cast<float4*>(out + static_cast<int64_t>(my_row[t]) * kD + 4 * i) =
+          make_float4(st[t].acc.x * inv, st[t].acc.y * inv, st[t].acc.z * inv,
+                      st[t].acc.w * inv);
+      if (lse != nullptr && i == 0)
+        lse[my_row[t]] = st[t].l > 0.f ? st[t].mx + __logf(st[t].l) : -INFINITY;
+    }
+  };
+
+  // Row blocks whose columns do not ascend inside rows: order-independent path,
+  // one entry at a time, K and V rows gathered from global memory.
+  if (!block_rows_ok(row_ok, mblock * kBM, kBM)) {
+    for (int t = 0; t < kRQ; ++t) {
+      const int p0 = my_row[t] >= 0 ? row_offsets[my_row[t]] : 0;
+      const int p1 = my_row[t] >= 0 ? row_offsets[my_row[t] + 1] : 0;
+      for (int p = p0; p < p1; ++p) {
+        const int64_t base = static_cast<int64_t>(column_indices[p]) * kD + 4 * i;
+        const float4 kf = *reinterpret_cast<const float4*>(k + base);
+        const float4 vf = *reinterpret_cast<const float4*>(v + base);
+        const float s = group_sum<16>(dot4(st[t].q, kf));
+        if (s > st[t].mx) rescale(st[t], s);
+        const float e = __expf(s - st[t].mx);
+        st[t].l += e;
+        st[t].acc.x = fmaf(e, vf.x, st[t].acc.x);
+        st[t].acc.y = fmaf(e, vf.y, st[t].acc.y);
+        st[t].acc.z = fmaf(e, vf.z, st[t].acc.z);
+        st[t].acc.w = fmaf(e, vf.w, st[t].acc.w);
+      }
+    }
+    finish();
+    return;
+  }
+
+  const int* __restrict__ my_table = table + slot0 + g;
+  int ps[kRQ], pe[kRQ], wcol[kRQ][kWin];
+#pragma unroll
+  for (int t = 0; t < kRQ; ++t) {
+    ps[t] = my_table[4 * t];
+    pe[t] = my_table[slots + 4 * t];
+#pragma unroll
+    for (int w = 0; w < kWin; ++w) wcol[t][w] = column_indices[min(ps[t] + 16 * w + i, last)];
+  }
+
+  stage_kv(tile[0], k, v, n, 0, wave, lane);
+  wait_vm<0>();
+  __syncthreads();
+
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    const bool more = c + 1 < nchunks;
+    if (more) stage_kv(tile[buf ^ 1], k, v, n, (c + 1) * kBK, wave, lane);
+
+    int pe_next[kRQ], ncol[kRQ][kWin];
+#pragma unroll
+    for (int t = 0; t < kRQ; ++t) {
+      pe_next[t] = more ? my_table[static_cast<int64_t>(c + 2) * slots + 4 * t] : pe[t];
+#pragma unroll
+      for (int w = 0; w < kWin; ++w)
+        ncol[t][w] = more ? column_indices[min(pe[t] + 16 * w + i, last)] : 0;
+    }
+
+    const char* __restrict__ k_base = reinterpret_cast<const char*>(&tile[buf][0] + i * 4);
+    const char* __restrict__ v_base = k_base + kTileFloats * sizeof(float);
+    const int jc = c * kBK;
+
+#pragma unroll
+    for (int t = 0; t < kRQ; ++t) {
+      const int cnt = pe[t] - ps[t];  // this group's row; the same in its 16 lanes
+
+      auto window = [&](int ecol, int w0) {
+        const int left = cnt - w0;
+        if (left <= 0) return;
+        const bool valid = i < left;
+        const int roff = valid ? ((ecol - jc) * (kD * 4)) : 0;
+
+        // 1. scores: partial dot products of entries G..G+3, then the transposing sum
+        float p[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) p[u] = 0.f;
+        auto scores4 = [&](auto G) {
+          constexpr int kG = decltype(G)::value;
+          const int o0 = row_bcast_i<kG + 0>(roff), o1 = row_bcast_i<kG + 1>(roff);
+          const int o2 = row_bcast_i<kG + 2>(roff), o3 = row_bcast_i<kG + 3>(roff);
+          const float4 b0 = *reinterpret_cast<const float4*>(k_base + o0);
+          const float4 b1 = *reinterpret_cast<const float4*>(k_base + o1);
+          const float4 b2 = *reinterpret_cast<const float4*>(k_base + o2);
+          const float4 b3 = *reinterpret_cast<const float4*>(k_base + o3);
+          p[kG + 0] = dot4(st[t].q, b0);
+          p[kG + 1] = dot4(st[t].q, b1);
+          p[kG + 2] = dot4(st[t].q, b2);
+          p[kG + 3] = dot4(st[t].q, b3);
+        };
+        scores4(std::integral_constant<int, 0>{});
+        if (left > 4) scores4(std::integral_constant<int, 4>{});
+        if (left > 8) scores4(std::integral_constant<int, 8>{});
+        if (left > 12) scores4(std::integral_constant<int, 12>{});
+        float s = row_transpose_sum16(p, i);
+        s = valid ? s : -INFINITY;
+
+        // 2. online softmax over the window (at least one entry is valid)
+        const float m_new = fmaxf(st[t].mx, group_max<16>(s));
+        rescale(st[t], m_new);
+        const float e = valid ? __expf(s - m_new) : 0.f;
+        st[t].l += group_sum<16>(e);
+
+        // 3. weighted V rows; padded entries carry weight 0 and offset 0
+        const entry_pair ent = make_entry(roff, e);
+        float a4[4] = {st[t].acc.x, st[t].acc.y, st[t].acc.z, st[t].acc.w};
+        auto values4 = [&](auto G) {
+          constexpr int kG = decltype(G)::value;
+          const entry_pair e0 = row_bcast_entry<kG + 0>(ent), e1 = row_bcast_entry<kG + 1>(ent);
+          const entry_pair e2 = row_bcast_entry<kG + 2>(ent), e3 = row_bcast_entry<kG + 3>(ent);
+          const float4 b0 = *reinterpret_cast<const float4*>(v_base + entry_off(e0));
+          const float4 b1 = *reinterpret_cast<const float4*>(v_base + entry_off(e1));
+          const float4 b2 = *reinterpret_cast<const float4*>(v_base + entry_off(e2));
+          const float4 b3 = *reinterpret_cast<const float4*>(v_base + entry_off(e3));
+          SPUTNIK_HIP_FMA4(a4, entry_val(e0), b0);
+          SPUTNIK_HIP_FMA4(a4, entry_val(e1), b1);
+          SPUTNIK_HIP_FMA4(a4, entry_val(e2), b2);
+          SPUTNIK_HIP_FMA4(a4, entry_val(e3), b3);
+        };
+        values4(std::integral_constant<int, 0>{});
+        if (left > 4) values4(std::integral_constant<int, 4>{});
+        if (left > 8) values4(std::integral_constant<int, 8>{});
+        if (left > 12) values4(std::integral_constant<int, 12>{});
+        st[t].acc = make_float4(a4[0], a4[1], a4[2], a4[3]);
+      };
+#pragma unroll
+      for (int w = 0; w < kWin; ++w) window(wcol[t][w], 16 * w);
+      // more than 32 entries of one row inside one chunk: fetch on demand
+      const int longest = max(max(__builtin_amdgcn_readlane(cnt, 0), __builtin_amdgcn_readlane(cnt, 16)),
+                              max(__builtin_amdgcn_readlane(cnt, 32), __builtin_amdgcn_readlane(cnt, 48)));
+      for (int w0 = 16 * kWin; w0 < longest; w0 += 16)
+        window(column_indices[min(ps[t] + w0 + i, last)], w0);
+    }
+
+#pragma unroll
+    for (int t = 0; t < kRQ; ++t) {
+      ps[t] = pe[t];
+      pe[t] = pe_next[t];
+#pragma unroll
+      for (int w = 0; w < kWin; ++w) wcol[t][w] = ncol[t][w];
+    }
+    wait_vm<0>();     // the next K/V tiles have landed
+    __syncthreads();  // ... for every wave, and the current buffer is free
+  }
+  finish();
+}
+
+inline int slots_of(int m) { return ceil_div(m, kBM) * kBM; }
+inline int chunks_of(int n) { return ceil_div(n, kBK); }
+
+bool supported(int m, int n, int d, int nonzeros) {
+  return d == kD && m > 0 && n > 0 && nonzeros > 0 &&
+         static_cast<int64_t>(n) * kD * 4 < (int64_t{1} << 32);
+}
+
+}  // namespace
+}  // namespace sputnik_hip
+
+using namespace sputnik_hip;
+
+extern "C" {
+
+int sputnik_hip_sparse_attention_supported(int m, int n, int d, int nonzeros) {
+  return supported(m, n, d, nonzeros) ? 1 : 0;
+}
+
+size_t sputnik_hip_sparse_attention_workspace_bytes(int m, int n, int d, int nonzeros) {
+  if (!supported(m, n, d, nonzeros)) return 0;
+  return row_ok_bytes(slots_of(m)) +
+         sizeof(int) * static_cast<size_t>(chunks_of(n) + 1) * slots_of(m);
+}
+
+int sputnik_hip_sparse_attention_forward(int m, int n, int d, int nonzeros, int replicas,
+                                         const int* row_indices, const int* row_offsets,
+                                         const int* column_indices, const float* q,
+                                         int64_t q_stride, const float* k, int64_t k_stride,
+                                         const float* v, int64_t v_stride, float scale,
+                                         float* out, int64_t out_stride, float* lse,
+                                         int64_t lse_stride, void* workspace,
+                                         size_t workspace_bytes, sputnik_hip_stream_t stream) {
+  if (m < 0 || n < 0 || d < 0 || nonzeros < 0 || replicas < 0) return SPUTNIK_HIP_INVALID_ARGUMENT;
+  if (m == 0 || replicas == 0) return 0;
+  if (nonzeros == 0 || n == 0) {  // every row is empty: zeros (and -inf log-sum-exp)
+    for (int r = 0; r < replicas; ++r) {
+      hipError_t e = hipMemsetAsync(out + r * out_stride, 0, sizeof(float) * m * d, stream);
+      if (e != hipSuccess) return static_cast<int>(e);
+      if (lse != nullptr) {
+        e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(lse + r * lse_stride),
+                              static_cast<int>(0xff800000u), m, stream);
+        if (e != hipSuccess) return static_cast<int>(e);
+      }
+    }
+    return 0;
+  }
+  if (!supported(m, n, d, nonzeros) || !aligned_to(q, 16) || !aligned_to(k, 16) ||
+      !aligned_to(v, 16) || !aligned_to(out, 16) || q_stride % 4 != 0 || k_stride % 4 != 0 ||
+      v_stride % 4 != 0 || out_stride % 4 != 0)
+    return SPUTNIK_HIP_UNSUPPORTED;
+  if (workspace == nullptr || !aligned_to(workspace, 16) ||
+      workspace_bytes < sputnik_hip_sparse_attention_workspace_bytes(m, n, d, nonzeros))
+    return SPUTNIK_HIP_INVALID_ARGUMENT;
+  const int slots = slots_of(m), nchunks = chunks_of(n);
+  int* row_ok = static_cast<int*>(workspace);
+  int* table = reinterpret_cast<int*>(static_cast<char*>(workspace) + row_ok_bytes(slots));
+  hipLaunchKernelGGL((spmm_chunk_table_kernel<ilog2(kBK)>), dim3(ceil_div(slots, 4)), dim3(256),
+                     0, stream, m, n, slots, nchunks, row_indices, row_offsets, column_indices,
+                     table, row_ok);
+  int st = launch_status();
+  if (st != 0) return st;
+  for (int r0 = 0; r0 < replicas; r0 += kMaxGridYZ) {
+    const int ry = min(replicas - r0, kMaxGridYZ);
+    hipLaunchKernelGGL(sparse_attention_kernel, dim3(slots / kBM, ry), dim3(kThreads), 0, stream,
+                       m, n, nonzeros, slots, nchunks, row_indices, row_offsets, column_indices,
+                       table, row_ok, q + r0 * q_stride, q_stride, k + r0 * k_stride, k_stride,
+                       v + r0 * v_stride, v_stride, scale, out + r0 * out_stride, out_stride,
+                       lse != nullptr ? lse + r0 * lse_stride : nullptr, lse_stride);
+    st = launch_status();
+    if (st != 0) return st;
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -315,6 +315,49 @@ std::vector<Tensor> csr_transpose_with_permutation(int64_t m, int64_t n, const T
   return csr_transpose_impl(m, n, values, row_offsets, column_indices, true);
 }
 
+// Fused softmax(scale * sddmm(q, k)) @ v over a fixed mask
+// (modules/sparse_attention.py:66-82).  q [R,m,d] / [m,d]; k, v [R,n,d] / [n,d].
+// Shapes the fused kernel does not serve are composed from the three operators.
+Tensor sparse_attention(const Tensor& q_in, const Tensor& k_in, const Tensor& v_in,
+                        const Tensor& row_indices, const Tensor& row_offsets,
+                        const Tensor& column_indices, double scale) {
+  const Tensor q = as_float(q_in, "query");
+  const Tensor k = as_float(k_in, "key");
+  const Tensor v = as_float(v_in, "value");
+  TORCH_CHECK(q.dim() == 2 || q.dim() == 3, "expected 2-dim or 3-dim query, got ", q.dim());
+  TORCH_CHECK(k.dim() == q.dim() && v.dim() == q.dim(), "query, key, value must match in dims");
+  TORCH_CHECK(k.sizes() == v.sizes(), "key and value must have one shape");
+  TORCH_CHECK(q.size(-1) == k.size(-1), "query and key must have one head dimension");
+  TORCH_CHECK(q.device() == k.device() && q.device() == v.device(),
+              "query, key, value must be on one device");
+  const c10::DeviceGuard guard(q.device());
+  const int m = to_int(q.size(-2), "m"), n = to_int(k.size(-2), "n");
+  const int d = to_int(q.size(-1), "d");
+  const int replicas = q.dim() == 3 ? to_int(q.size(0), "replicas") : 1;
+  TORCH_CHECK(q.dim() == 2 || k.size(0) == replicas, "first dim of query and key must match");
+  const Topology topo = check_topology(m, row_indices, row_offsets, column_indices, q);
+
+  if (!sputnik_hip_sparse_attention_supported(m, n, d, topo.nonzeros)) {
+    Tensor weights = sparse_softmax_scaled(
+        sddmm(m, n, topo.row_indices, topo.row_offsets, topo.column_indices, q, k),
+        topo.row_indices, topo.row_offsets, topo.column_indices, scale);
+    return spmm(m, n, weights, topo.row_indices, topo.row_offsets, topo.column_indices, v);
+  }
+  Tensor out = at::empty_like(q);
+  const size_t ws_bytes = sputnik_hip_sparse_attention_workspace_bytes(m, n, d, topo.nonzeros);
+  Tensor workspace = at::empty({static_cast<int64_t>(ws_bytes)}, q.options().dtype(at::kByte));
+  check_status(sputnik_hip_sparse_attention_forward(
+                   m, n, d, topo.nonzeros, replicas, topo.row_indices.data_ptr<int>(),
+                   topo.row_offsets.data_ptr<int>(), topo.column_indices.data_ptr<int>(),
+                   q.data_ptr<float>(), static_cast<int64_t>(m) * d, k.data_ptr<float>(),
+                   static_cast<int64_t>(n) * d, v.data_ptr<float>(), static_cast<int64_t>(n) * d,
+                   static_cast<float>(scale), out.data_ptr<float>(),
+                   static_cast<int64_t>(m) * d, nullptr, 0, workspace.data_ptr(), ws_bytes,
+                   current_stream(q)),
+               "sparse_attention");
+  return out;
+}
+
 Tensor spmm_bias(int64_t m, int64_t k, const Tensor& values, const Tensor& row_indices,
                  const Tensor& row_offsets, const Tensor& column_indices, const Tensor& bias,
                  const Tensor& dense) {
@@ -591,6 +634,9 @@ TORCH_LIBRARY(torch_sputnik, m) {
       "sparse_softmax_backward(Tensor softmax_out, Tensor grad_out, Tensor row_offsets, "
       "float scale) -> Tensor");
   m.def(
+      "sparse_attention(Tensor query, Tensor key, Tensor value, Tensor row_indices, "
+      "Tensor row_offsets, Tensor column_indices, float scale) -> Tensor");
+  m.def(
       "spmm_many_mask(int b, int m, int k, Tensor nonzeros, Tensor values, Tensor row_indices, "
       "Tensor row_offsets, Tensor column_indices, Tensor dense_matrix) -> Tensor");
   m.def(
@@ -622,6 +668,7 @@ TORCH_LIBRARY_IMPL(torch_sputnik, CUDA, m) {
   m.impl("spmm_bias_relu", &spmm_bias_relu);
   m.impl("sparse_softmax_scaled", &sparse_softmax_scaled);
   m.impl("sparse_softmax_backward", &sparse_softmax_backward);
+  m.impl("sparse_attention", &sparse_attention);
   m.impl("spmm_many_mask", &spmm_many_mask);
   m.impl("sddmm_many_mask", &sddmm_many_mask);
   m.impl("sparse_softmax_many_mask", &sparse_softmax_many_mask);

@@ -56,7 +56,8 @@ class SparseAttention(nn.Module):
     projections."""
 
     def __init__(self, num_heads, embedding_size, max_sequence_length=512, device=None,
-                 sparsity=0.9, mask_generator=None, differentiable_softmax=False):
+                 sparsity=0.9, mask_generator=None, differentiable_softmax=False,
+                 fused_inference=True):
         super().__init__()
         assert embedding_size % num_heads == 0, \
             "Model dimension must be divisible by the number of heads."
@@ -74,18 +75,26 @@ class SparseAttention(nn.Module):
         self.sddmm = Sddmm.apply
         self.spmm = Spmm.apply
         self.differentiable_softmax = differentiable_softmax
+        # forward-only calls (no gradient wanted) take the one-kernel attention
+        self.fused_inference = fused_inference
 
     def attention(self, query, key, value, mask):
         q3d = self.four_d_to_three_d(query)
         k3d = self.four_d_to_three_d(key)
         v3d = self.four_d_to_three_d(value)
 
+        scale = 1.0 / math.sqrt(self.head_dim)
+        needs_grad = torch.is_grad_enabled() and (
+            q3d.requires_grad or k3d.requires_grad or v3d.requires_grad)
+        if self.fused_inference and not needs_grad:
+            return ops.sparse_attention(q3d, k3d, v3d, self.row_indices, self.row_offsets,
+                                        self.column_indices, scale)
+
         # [B*H, nnz]: scores only at the mask's nonzeros
         scores = self.sddmm(self.m, self.n, self.row_indices, self.row_offsets,
                             self.column_indices, q3d, k3d)
         # the reference divides the scores in a pass of its own
         # (modules/sparse_attention.py:72); here the softmax kernel applies it
-        scale = 1.0 / math.sqrt(self.head_dim)
         softmax = (SparseSoftmax.apply if self.differentiable_softmax
                    else ops.sparse_softmax_scaled)
         attention_weights = softmax(scores, self.row_indices, self.row_offsets,

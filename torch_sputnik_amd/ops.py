@@ -85,6 +85,14 @@ def sparse_softmax_backward(softmax_out, grad_out, row_offsets, scale=1.0):
     return _ops.sparse_softmax_backward(softmax_out, grad_out, row_offsets, float(scale))
 
 
+def sparse_attention(query, key, value, row_indices, row_offsets, column_indices, scale):
+    """softmax(scale * sddmm(query, key)) @ value over a fixed mask in ONE kernel
+    (forward only): the chain of modules/sparse_attention.py:66-82 without the
+    [replicas, nnz] intermediates.  query [R,S,D], key/value [R,S',D] -> [R,S,D]."""
+    return _ops.sparse_attention(query, key, value, row_indices, row_offsets, column_indices,
+                                 float(scale))
+
+
 def _counts(nonzeros):
     import torch
     return nonzeros if torch.is_tensor(nonzeros) else torch.tensor(list(nonzeros),
