@@ -347,6 +347,9 @@ using CfgLarge = TileConfig<256, 16, 16, 64>;  // 256 x 256 tile of C per workgr
 // problems whose 256-row blocks would leave most of the 256 CUs idle (e.g. one
 // 2048^3 product is only 64 large tiles).  Same workspace layout.
 using CfgMedium = TileConfig<256, 16, 8, 64>;
+// 8 waves x 8 rows (64 x 256 tiles): four times the workgroups of the large
+// tile for problems that would otherwise cover a fraction of the chip.
+using CfgSmall = TileConfig<256, 8, 8, 64>;
 
 inline bool tiled_applicable(int m, int k, int n, int nonzeros) {
   // Needs full column tiles, and enough work per row block to amortise staging
@@ -438,23 +441,28 @@ int spmm_tiled_exec(int m, int k, int n, int nonzeros, int replicas, const int* 
   const bool sparse = forced >= 0
                           ? forced != 0
                           : static_cast<int64_t>(nonzeros) < int64_t{12} * m * plan.nchunks;
-  static const int force_medium = [] {
-    const char* e = getenv("SPUTNIK_HIP_SPMM_MEDIUM");  // developer knob
+  static const int force_tile = [] {
+    const char* e = getenv("SPUTNIK_HIP_SPMM_MEDIUM");  // developer knob: 1 = medium, 2 = small tile
     return e ? atoi(e) : 0;
   }();
-  const bool large = !force_medium && static_cast<int64_t>(blocks) * replicas >= 192;
+  // Largest tile that still gives about one workgroup per CU (256 CUs).
+  const int64_t large_blocks = static_cast<int64_t>(blocks) * replicas;
+  const int tile = force_tile ? force_tile : large_blocks >= 192 ? 0 : 2 * large_blocks >= 192 ? 1 : 2;
 #define SPUTNIK_HIP_LAUNCH_TILED(CFG, SPARSE_)                                                    \
   hipLaunchKernelGGL((spmm_tiled_kernel<CFG, SPARSE_>),                                           \
                      dim3((plan.slots / CFG::kBM) * plan.n_tiles, replicas), dim3(CFG::kThreads), \
                      0, stream, m, k, n, nonzeros, plan.slots, plan.nchunks, plan.n_tiles,        \
                      row_indices, values, values_stride, column_indices, table, dense,            \
                      dense_stride, out, out_stride, row_ok, row_offsets, debug, epi)
-  if (large) {
+  if (tile == 0) {
     if (sparse) SPUTNIK_HIP_LAUNCH_TILED(CfgLarge, true);
     else SPUTNIK_HIP_LAUNCH_TILED(CfgLarge, false);
-  } else {
+  } else if (tile == 1) {
     if (sparse) SPUTNIK_HIP_LAUNCH_TILED(CfgMedium, true);
     else SPUTNIK_HIP_LAUNCH_TILED(CfgMedium, false);
+  } else {
+    if (sparse) SPUTNIK_HIP_LAUNCH_TILED(CfgSmall, true);
+    else SPUTNIK_HIP_LAUNCH_TILED(CfgSmall, false);
   }
 #undef SPUTNIK_HIP_LAUNCH_TILED
   *handled = true;
