@@ -165,6 +165,14 @@ def other_ops(dev):
     t = event_time_ms(lambda: capi.spmm_batched(s, s, d, reps, ri, probs, nnz, ro, ci, v, ctx, ws3), 20)
     by = reps * (4.0 * nnz + 8.0 * s * d) + 4.0 * nnz + 4.0 * (2 * s + 1)
     res["spmm_c3"] = {"ms": t, "gflops": 2.0 * nnz * d * reps / t / 1e6, "alg_gbs": by / t / 1e6}
+    # the same chain as ONE kernel (online softmax; scores / weights never reach HBM)
+    aws = torch.empty(capi.sparse_attention_workspace_bytes(s, s, d, nnz), dtype=torch.uint8,
+                      device=dev)
+    t = event_time_ms(lambda: capi.sparse_attention_forward(s, s, d, reps, ri, ro, ci, q, kk, v,
+                                                            d ** -0.5, ctx, None, aws), 20)
+    by = reps * 16.0 * s * d + 4.0 * nnz + 4.0 * (2 * s + 1)
+    res["attention_fused_c3"] = {"ms": t, "gflops": 4.0 * nnz * d * reps / t / 1e6,
+                                 "alg_gbs": by / t / 1e6}
     # Whole SparseAttention.forward (modules/sparse_attention.py:105-128) through the
     # torch ops: 4 SparseLinear (left_spmm) + SDDMM + scale + softmax + SpMM, B=8, H=8, D=64.
     try:
@@ -195,6 +203,20 @@ def other_ops(dev):
     t = event_time_ms(lambda: capi.csr_transpose(m, n, 1, vals, ro, ci, ov, oro, oci, None, ws), 20)
     by = 16.0 * nnz + 4.0 * (m + n + 2)
     res["csr_transpose_c5"] = {"ms": t, "alg_gbs": by / t / 1e6, "hbm_frac": by / t / 1e6 / HBM_PEAK_GBS}
+    # config 5, SparseLinear forward / backward operators (modules/sparse_linear.py:18-67):
+    # 2048 x 2048 weight at density 0.2; batch 8 x seq 512 (BASELINE.json gives neither)
+    batch, seq = 8, 512
+    x = uniform((batch, n, seq), dev, 21)
+    gy = uniform((batch, m, seq), dev, 22)
+    y = torch.empty(batch, m, seq, device=dev)
+    ws5 = torch.empty(capi.spmm_workspace_bytes(m, n, seq, nnz) + 16, dtype=torch.uint8, device=dev)
+    t = event_time_ms(lambda: capi.spmm_batched(m, n, seq, batch, ri, vals, 0, ro, ci, x, y, ws5), 10)
+    res["left_spmm_c5"] = {"ms": t, "gflops": 2.0 * nnz * seq * batch / t / 1e6, "batch": batch,
+                           "seq": seq}
+    gw = torch.empty(batch, nnz, device=dev)
+    sws = torch.empty(capi.sddmm_workspace_bytes(m, seq, n, nnz) + 16, dtype=torch.uint8, device=dev)
+    t = event_time_ms(lambda: capi.sddmm_batched(m, seq, n, batch, ri, ro, ci, gy, x, gw, sws), 10)
+    res["sddmm_grad_values_c5"] = {"ms": t, "gflops": 2.0 * nnz * seq * batch / t / 1e6}
     return res
 
 
