@@ -1,0 +1,132 @@
+"""GPU: seeded random shapes for every operator against the oracle -- ragged
+sizes around the tile boundaries of the kernels (64 / 128 / 256 rows and
+columns), empty rows, every row order, 1..5 replicas.  One process, a few
+hundred small launches; sizes are kept where the numpy oracle takes
+milliseconds."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sputnik_oracle as O
+from helpers import make_csr, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+ORDERS = ("descending", "ascending", "random", "identity")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from torch_sputnik_amd import capi
+    return capi
+
+
+def T(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def _dims(rng, choices):
+    return int(rng.choice(choices)) + int(rng.integers(-3, 4)) * int(rng.random() < 0.5)
+
+
+def _case(rng, rows, cols):
+    m = max(1, _dims(rng, rows))
+    n = max(1, _dims(rng, cols))
+    sparsity = float(rng.choice([0.0, 0.5, 0.8, 0.9, 0.97]))
+    empty = tuple(int(x) for x in rng.integers(0, m, size=int(rng.integers(0, 3))))
+    order = ORDERS[int(rng.integers(0, len(ORDERS)))]
+    replicas = int(rng.integers(1, 6))
+    return m, n, sparsity, empty, order, replicas
+
+
+def test_fuzz_spmm(capi, dev):
+    rng = np.random.default_rng(20261003)
+    for it in range(40):
+        m, k, sparsity, empty, order, replicas = _case(rng, [16, 64, 128, 256, 300], [32, 64, 128, 256, 520])
+        n = int(rng.choice([1, 7, 18, 64, 128, 192, 256, 512]))
+        _, vals, ri, ro, ci = make_csr(m, k, sparsity, seed=it, round_to=1, empty_rows=empty,
+                                       order=order)
+        shared = bool(rng.random() < 0.5)
+        values = vals if shared else rng.uniform(-1, 1, (replicas, len(ci))).astype(np.float32)
+        b = rng.uniform(-1, 1, (replicas, k, n)).astype(np.float32)
+        bias = rng.uniform(-1, 1, m).astype(np.float32) if rng.random() < 0.5 else None
+        relu = bool(rng.random() < 0.5)
+        want = np.stack([O.spmm_bias(m, k, values if shared else values[r], ri, ro, ci, bias, b[r],
+                                     relu=relu) for r in range(replicas)])
+        out = torch.full((replicas, m, n), float("nan"), device=dev)
+        ws = torch.empty(capi.spmm_workspace_bytes(m, k, n, len(ci)) + 16, dtype=torch.uint8,
+                         device=dev)
+        dummy = torch.zeros(1, dtype=torch.int32, device=dev)
+        capi.spmm_bias_batched(m, k, n, replicas, T(ri, dev), T(values, dev) if len(ci) else
+                               torch.zeros(1, device=dev), 0 if shared else len(ci), T(ro, dev),
+                               T(ci, dev) if len(ci) else dummy, T(b, dev),
+                               None if bias is None else T(bias, dev), relu, out, ws)
+        got = out.cpu().numpy()
+        assert not np.isnan(got).any(), (it, m, k, n)
+        assert rel_err(got, want) < TOL, (it, m, k, n, sparsity, order, replicas)
+
+
+def test_fuzz_sddmm_softmax_transpose(capi, dev):
+    rng = np.random.default_rng(77)
+    for it in range(40):
+        m, n, sparsity, empty, order, replicas = _case(rng, [16, 64, 128, 256, 300], [16, 64, 128, 256, 300])
+        k = int(rng.choice([1, 5, 32, 64, 64, 128, 128, 200]))
+        _, _, ri, ro, ci = make_csr(m, n, sparsity, seed=100 + it, round_to=1, empty_rows=empty,
+                                    order=order)
+        nnz = len(ci)
+        if nnz == 0:
+            continue
+        lhs = rng.uniform(-1, 1, (replicas, m, k)).astype(np.float32)
+        rhs = rng.uniform(-1, 1, (replicas, n, k)).astype(np.float32)
+        d_ri, d_ro, d_ci = T(ri, dev), T(ro, dev), T(ci, dev)
+        ws = torch.empty(capi.sddmm_workspace_bytes(m, k, n, nnz) + 16, dtype=torch.uint8, device=dev)
+        scores = torch.full((replicas, nnz), float("nan"), device=dev)
+        capi.sddmm_batched(m, k, n, replicas, d_ri, d_ro, d_ci, T(lhs, dev), T(rhs, dev), scores, ws)
+        got = scores.cpu().numpy()
+        assert not np.isnan(got).any(), (it, m, k, n)
+        assert rel_err(got, O.sddmm(m, n, ri, ro, ci, lhs, rhs)) < TOL, (it, m, k, n, sparsity)
+
+        scale = float(rng.choice([1.0, 0.125, 2.0]))
+        probs = capi.sparse_softmax_scaled_batched(m, replicas, scores, d_ri, d_ro, d_ci, scale,
+                                                   torch.empty_like(scores))
+        want_p = O.sparse_softmax_scaled(got, ri, ro, ci, scale)
+        assert rel_err(probs.cpu().numpy(), want_p) < TOL, (it, m, n)
+
+        tws = torch.empty(capi.csr_transpose_workspace_bytes(m, n, nnz), dtype=torch.uint8, device=dev)
+        vt = torch.empty_like(probs)
+        rot = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        cit = torch.empty(nnz, dtype=torch.int32, device=dev)
+        perm = torch.empty(nnz, dtype=torch.int32, device=dev)
+        capi.csr_transpose(m, n, replicas, probs, d_ro, d_ci, vt, rot, cit, perm, tws)
+        w_vt, w_rot, w_cit = O.csr_transpose(m, n, probs.cpu().numpy(), ro, ci)
+        assert np.array_equal(rot.cpu().numpy(), w_rot) and np.array_equal(cit.cpu().numpy(), w_cit)
+        assert np.array_equal(vt.cpu().numpy(), w_vt)
+        assert np.array_equal(probs.cpu().numpy()[:, perm.cpu().numpy()], w_vt)
+
+
+def test_fuzz_sparse_attention(capi, dev):
+    rng = np.random.default_rng(5150)
+    for it in range(25):
+        m, n, sparsity, empty, order, replicas = _case(rng, [16, 64, 128, 256, 300], [16, 64, 128, 256, 300])
+        _, _, ri, ro, ci = make_csr(m, n, sparsity, seed=200 + it, round_to=1, empty_rows=empty,
+                                    order=order)
+        if len(ci) == 0:
+            continue
+        q = rng.uniform(-2, 2, (replicas, m, 64)).astype(np.float32)
+        k = rng.uniform(-2, 2, (replicas, n, 64)).astype(np.float32)
+        v = rng.uniform(-1, 1, (replicas, n, 64)).astype(np.float32)
+        ws = torch.empty(capi.sparse_attention_workspace_bytes(m, n, 64, len(ci)), dtype=torch.uint8,
+                         device=dev)
+        out = torch.full((replicas, m, 64), float("nan"), device=dev)
+        capi.sparse_attention_forward(m, n, 64, replicas, T(ri, dev), T(ro, dev), T(ci, dev),
+                                      T(q, dev), T(k, dev), T(v, dev), 0.125, out, None, ws)
+        got = out.cpu().numpy()
+        assert not np.isnan(got).any(), (it, m, n)
+        assert rel_err(got, O.sparse_attention(q, k, v, ri, ro, ci, 0.125)) < TOL, (it, m, n, sparsity)
