@@ -92,14 +92,15 @@ __device__ __forceinline__ void stage_chunk(float* __restrict__ tile, const floa
 // Every vector-memory operation inside the loop is issued from inline asm, in
 // a fixed order and number per chunk, so the waits can be counted by hand:
 //   A  kStageRowsPerWave (S) LDS-DMA copies of B rows for chunk c+1
-//   B  1 load of the rows' stream positions two chunks ahead
+//   B  the rows' stream positions one chunk ahead: a SCALAR load into SGPRs
+//      (not counted by vmcnt)
 //   C  after each row r: 2 loads = the entry window of the row that is D rows
 //      further down the walk (row r+D of this chunk, or row r+D-RPW of the
 //      next one); D windows (2*D VGPRs) are live at any time.
 // A window is consumed D rows after it was requested.  In between exactly
-// D-1 other windows were requested (2*(D-1) operations), plus A and B if the
+// D-1 other windows were requested (2*(D-1) operations), plus A if the
 // chunk boundary was crossed (rows r < D): `vmcnt` with that count retires it
-// and nothing newer.  At the end of a chunk `vmcnt(2*RPW+1)` retires A (the B
+// and nothing newer.  At the end of a chunk `vmcnt(2*RPW)` retires A (the B
 // tile of the next chunk) and leaves B and C in flight across the barrier.
 // The last chunk issues the same (clamped, unused) operations so that the
 // counts hold for every iteration; the first one starts from a full drain.
@@ -114,8 +115,8 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
   constexpr int D = 8;  // windows in flight
   static_assert(RPW % D == 0 && D <= RPW, "window ring");
   constexpr int kWaitSameChunk = 2 * (D - 1);
-  constexpr int kWaitCrossChunk = 2 * (D - 1) + S + 1;
-  constexpr int kWaitStage = 2 * RPW + 1;
+  constexpr int kWaitCrossChunk = 2 * (D - 1) + S;
+  constexpr int kWaitStage = 2 * RPW;
   static_assert(kWaitStage <= 63, "vmcnt is a 6-bit counter");
 
   // SPARSE: the window holds 16 entries, already replicated in every 16-lane
@@ -124,7 +125,6 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
   // (rotating groups).  For short segments only: the rare segment with more
   // than 16 entries fetches the rest on demand, draining the wave's loads.
   constexpr int kWindow = SPARSE ? 16 : kWave;
-  const unsigned ptr_off = static_cast<unsigned>(min(lane, RPW - 1)) * 4u;
   const int* __restrict__ my_table = table + slot0;  // wave-uniform
   const int e16x4 = (lane & 15) * 4;
   const unsigned lane4 = static_cast<unsigned>(SPARSE ? (lane & 15) : lane) * 4u;
@@ -132,11 +132,14 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
   const float* lane_tile = tile0 + lane * VEC;
   const unsigned b_lane_off = static_cast<unsigned>(n0 + lane * 4) * 4u;
 
-  // lane r: stream position of row r at the start of chunk c / at its end
-  int v_ps = untracked_load_i32(my_table, ptr_off);
-  int v_pe = untracked_load_i32(my_table + slots, ptr_off);
-  wait_vm<0>();
-  asm volatile("" : "+v"(v_ps), "+v"(v_pe));
+  // Stream positions of this wave's rows at the start of the current chunk and
+  // at its end: SGPRs (scalar loads of RPW table entries; B in the comment above
+  // is therefore not a vector-memory operation).
+  using Pos = Positions<RPW>;
+  typename Pos::type s_ps = Pos::load(my_table);
+  typename Pos::type s_pe = Pos::load(my_table + slots);
+  wait_positions(s_ps);
+  wait_positions(s_pe);
 
   // Entry window of a row: 64 consecutive stream entries (lane = entry)
   // starting at `start`, loaded with a wave-uniform base and a constant lane
@@ -153,9 +156,8 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
     vval[slot] = untracked_load_f32(values + base, lane4);
   };
 #pragma unroll
-  for (int r = 0; r < D; ++r) request(r, __builtin_amdgcn_readlane(v_ps, r));
+  for (int r = 0; r < D; ++r) request(r, s_ps[r]);
   stage_chunk<Cfg>(tile0, dense, n, k, 0, wave, b_lane_off);
-  int v_pe_next = untracked_load_i32(my_table + static_cast<int64_t>(min(2, nchunks)) * slots, ptr_off);
   wait_vm<0>();
   __syncthreads();
 
@@ -165,14 +167,14 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
     // chunk 0, so that the operation count the waits assume is unchanged)
     stage_chunk<Cfg>(tile0 + (buf ^ 1) * (BK * BN), dense, n, k,
                      dbg_no_stage ? 0 : min(c + 1, nchunks - 1) * BK, wave, b_lane_off);
-    // B
-    int v_pe_after =
-        untracked_load_i32(my_table + static_cast<int64_t>(min(c + 3, nchunks)) * slots, ptr_off);
+    // B: positions at the end of chunk c+1, needed when that chunk begins (a
+    // scalar load has the whole chunk to land)
+    typename Pos::type s_pe_next =
+        Pos::load(my_table + static_cast<int64_t>(min(c + 2, nchunks)) * slots);
     // Tile row of column j starts at (j - c*BK) * BN floats: fold the chunk's
     // first column into the lane's base address once per chunk.
     const char* __restrict__ lane_base = reinterpret_cast<const char*>(
         lane_tile + buf * (BK * BN) - static_cast<int64_t>(c) * (BK * BN));
-    int v_cnt = v_pe - v_ps;
     const int kc_off = c * (BK * BN * 4);  // byte offset that lane_base turns into tile row 0
 
 #pragma unroll
@@ -180,11 +182,11 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
       int& wcol = vcol[r % D];
       float& wval = vval[r % D];
       if (r < D) {
-        wait_vm<kWaitCrossChunk>(wcol, wval, v_cnt);
+        wait_vm<kWaitCrossChunk>(wcol, wval);
       } else {
-        wait_vm<kWaitSameChunk>(wcol, wval, v_cnt);
+        wait_vm<kWaitSameChunk>(wcol, wval);
       }
-      const int cnt = dbg_no_compute ? 0 : __builtin_amdgcn_readlane(v_cnt, r);
+      const int cnt = dbg_no_compute ? 0 : s_pe[r] - s_ps[r];
       if constexpr (SPARSE) {
         if (cnt > 0) {
           int rcol = wcol;
@@ -197,7 +199,7 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
           }
           dpp_entries_exact(acc[r], min(16, cnt), rcol * (BN * 4), rval, lane_base);
           if (cnt > 16) {  // rare: the rest of a long segment, 16 entries at a time
-            const int start = __builtin_amdgcn_readlane(v_ps, r);
+            const int start = s_ps[r];
             for (int q0 = 16; q0 < cnt; q0 += 16) {
               const int base = min(start + q0, last_window);
               const int sh = start + q0 - base;
@@ -230,12 +232,11 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
       }
       }
       // C: request the window that will be consumed D rows from now.
-      request(r % D, (r + D < RPW) ? __builtin_amdgcn_readlane(v_ps, (r + D) % RPW)
-                                   : __builtin_amdgcn_readlane(v_pe, (r + D) % RPW));
+      request(r % D, (r + D < RPW) ? s_ps[(r + D) % RPW] : s_pe[(r + D) % RPW]);
     }
-    v_ps = v_pe;
-    v_pe = v_pe_next;
-    v_pe_next = v_pe_after;
+    wait_positions(s_pe_next);
+    s_ps = s_pe;
+    s_pe = s_pe_next;
     wait_vm<kWaitStage>();  // next B tile landed; windows and positions stay in flight
     __syncthreads();
   }

@@ -107,8 +107,47 @@ __device__ __forceinline__ void wait_vm(int& a, float& b, int& c) {
   asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N) : "memory");
 }
 template <int N>
+__device__ __forceinline__ void wait_vm(int& a, float& b) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+template <int N>
 __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+}
+
+// ROWS consecutive table entries (stream positions of a wave's rows at one
+// chunk boundary) straight into SGPRs: one scalar load instead of a per-lane
+// vector load plus a v_readlane per use.  Untracked like the vector loads
+// above: `wait_positions` must come before the first use.  (The scalar cache
+// shares `lgkmcnt` with LDS; one extra operation in flight only makes the
+// compiler's own counted LDS waits stricter, never looser.)
+template <int ROWS>
+struct Positions;
+template <>
+struct Positions<16> {
+  using type = int __attribute__((ext_vector_type(16)));
+  static __device__ __forceinline__ type load(const int* p /* wave-uniform */) {
+    type v;
+    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(v) : "s"(p) : "memory");
+    return v;
+  }
+};
+template <>
+struct Positions<8> {
+  using type = int __attribute__((ext_vector_type(8)));
+  static __device__ __forceinline__ type load(const int* p /* wave-uniform */) {
+    type v;
+    asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(v) : "s"(p) : "memory");
+    return v;
+  }
+};
+template <typename V>
+__device__ __forceinline__ void wait_positions(V& a) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a) : : "memory");
+}
+template <typename V>
+__device__ __forceinline__ void wait_positions(V& a, V& b, V& c) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c) : : "memory");
 }
 
 // One nonzero against the staged tile: acc[0..3] += a * (float4 read from the tile).
