@@ -103,10 +103,6 @@ __device__ __forceinline__ float untracked_load_f32(const float* base, unsigned 
 // Wait until at most N vector-memory operations of this wave are in flight;
 // the operands tie later uses of the loaded registers to the wait.
 template <int N>
-__device__ __forceinline__ void wait_vm(int& a, float& b, int& c) {
-  asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N) : "memory");
-}
-template <int N>
 __device__ __forceinline__ void wait_vm(int& a, float& b) {
   asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
 }
@@ -144,10 +140,6 @@ struct Positions<8> {
 template <typename V>
 __device__ __forceinline__ void wait_positions(V& a) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a) : : "memory");
-}
-template <typename V>
-__device__ __forceinline__ void wait_positions(V& a, V& b, V& c) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c) : : "memory");
 }
 
 // One nonzero against the staged tile: acc[0..3] += a * (float4 read from the tile).
