@@ -88,6 +88,14 @@ class SpmmProblem:
                                self.nnz if self.replicas > 1 else 0, self.ro, self.ci,
                                self.dense, self.out, self.ws)
 
+    def step_range(self, a, b):
+        """The hot path for replicas a..b-1 only (pipelined exchange)."""
+        vals = self.values[a:b] if self.replicas > 1 else self.values
+        self.capi.spmm_batched(M, K, N, b - a, self.ri, vals,
+                               self.nnz if self.replicas > 1 else 0, self.ro, self.ci,
+                               self.dense.reshape(self.replicas, K, N)[a:b],
+                               self.out.reshape(self.replicas, M, N)[a:b], self.ws)
+
     def kernel_only(self):
         """Dominant kernel alone, on an already planned workspace."""
         self.capi.spmm_batched_planned(M, K, N, self.replicas, self.ri, self.values,
@@ -116,8 +124,15 @@ def cpu_baseline(problem):
         c_oracle.spmm(M, K, vals, ro, ci, dense, f32_accumulate=True)
         times.append(time.perf_counter() - t0)
     med = sorted(times)[len(times) // 2]
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")),
+                             cpu_model)
+    except OSError:
+        pass
     base = {"value": 2.0 * problem.nnz * N / med / 1e9, "unit": "GFLOP/s", "cores": threads,
-            "kind": "port",
+            "kind": "port", "cpu_model": cpu_model,
             "sample": f"{len(times)} runs of the full C2 d={HEADLINE_DENSITY} SpMM "
                       f"(oracle/csrc/sputnik_oracle.c oracle_spmm_f32, OpenMP over rows), median",
             "ms": med * 1e3}
@@ -239,6 +254,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--allgather", action="store_true",
                     help="N>1: all-gather C over RCCL inside the timed step")
+    ap.add_argument("--overlap-chunks", type=int, default=1,
+                    help="with --allgather: split the replicas into this many chunks and "
+                         "exchange chunk i (side stream) while chunk i+1 is computed")
     ap.add_argument("--replicas-per-gpu", type=int, default=0,
                     help="override (default 1 at --gpus 1, 16 otherwise)")
     ap.add_argument("--no-extras", action="store_true", help="skip sweep / cpu baseline / other ops")
@@ -265,13 +283,33 @@ def main():
     problem = SpmmProblem(dev, HEADLINE_DENSITY, replicas, seed=1234 + 1000 * DENSITIES.index(HEADLINE_DENSITY) + rank)
 
     gathered = None
+    chunks = max(1, min(args.overlap_chunks, replicas))
     if distributed and args.allgather:
-        gathered = torch.empty((world,) + tuple(problem.out.reshape(replicas, M, N).shape), device=dev)
+        # [chunk][rank][replicas in chunk, M, N]: chunk-major so that every exchange
+        # is one contiguous all_gather_into_tensor
+        per = (replicas + chunks - 1) // chunks
+        bounds = [(a, min(a + per, replicas)) for a in range(0, replicas, per)]
+        gathered = [torch.empty((world, b - a, M, N), device=dev) for a, b in bounds]
+        side = torch.cuda.Stream(device=dev)
 
     def step():
-        problem.step()
-        if gathered is not None:
-            dist.all_gather_into_tensor(gathered, problem.out.reshape(replicas, M, N))
+        if gathered is None:
+            problem.step()
+            return
+        if len(gathered) == 1:
+            problem.step()
+            dist.all_gather_into_tensor(gathered[0], problem.out.reshape(replicas, M, N))
+            return
+        # pipelined: compute chunk i on the main stream, gather it on the side stream
+        main = torch.cuda.current_stream(dev)
+        for g, (a, b) in zip(gathered, bounds):
+            problem.step_range(a, b)
+            done = torch.cuda.Event()
+            done.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(done)
+                dist.all_gather_into_tensor(g, problem.out.reshape(replicas, M, N)[a:b])
+        main.wait_stream(side)
 
     for _ in range(args.warmup):
         step()
@@ -314,13 +352,17 @@ def main():
                  % (replicas, replicas * n_gpus)),
                 "replicas_per_gpu": replicas, "nnz": problem.nnz,
                 "step": "sputnik_hip_spmm_batched (pre-pass + kernel) via the C ABI",
-                "collective": "all_gather(C) over RCCL" if gathered is not None else "none (independent shards)",
+                "collective": ("none (independent shards)" if gathered is None else
+                               "all_gather(C) over RCCL" if len(gathered) == 1 else
+                               "all_gather(C) over RCCL, %d chunks overlapped with compute" % len(gathered)),
                 "inputs": "uniform-random sparsity (tests/connectors.py distribution), U[0,1) values, resident in HBM",
             },
             "algorithmic_gbs": problem.bytes * n_gpus / (ms_per_step * 1e-3) / 1e9,
             "roofline": {
                 "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": load_pmc_traffic(),
+                "frac": achieved_gbs / HBM_PEAK_GBS,
+                # the PMC passes were taken at one replica per launch
+                "traffic": load_pmc_traffic() if replicas == 1 else None,
                 "kernel": "spmm_tiled_kernel", "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_launch": problem.bytes,
                 "note": "fp32 SpMM at this size is above the HBM ridge (93 flop/B vs 19.7): see roofline_valu",
