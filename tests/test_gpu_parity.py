@@ -222,6 +222,11 @@ SDDMM_SHAPES = [
     (300, 64, 500, 0.8, 3),    # tiled kernel, ragged row / column blocks
     (256, 128, 256, 0.5, 2),   # tiled kernel, k = 128, > 32 entries per row and chunk
     (64, 64, 64, 0.0, 1),      # tiled kernel, dense mask
+    (300, 256, 200, 0.8, 2),   # stationary kernel, k = 256 (128-row slabs), ragged
+    (512, 512, 512, 0.8, 2),   # k = 512 (64-row slabs): SparseLinear weight gradient shape
+    (130, 512, 70, 0.3, 1),    # k = 512, > 16 entries per row and slab, partial last slab
+    (256, 1024, 96, 0.7, 2),   # k = 1024 (32-row slabs)
+    (64, 1024, 64, 0.0, 1),    # k = 1024, dense mask: two full windows per row and slab
 ]
 
 

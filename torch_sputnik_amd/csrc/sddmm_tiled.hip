@@ -46,7 +46,8 @@ struct Slab {
   static constexpr int kdim = 64 * KV;
   static constexpr int kBytes = KV <= 2 ? 64 * 1024 : 128 * 1024;
   static constexpr int kRows = kBytes / (kdim * 4);
-  static constexpr int kRing = KV <= 2 ? 3 : 2;  // lhs fragments in flight (KV float4 each)
+  // lhs fragments in flight (KV float4 each): fetched 2 / 1 / 0 rows ahead
+  static constexpr int kRing = KV <= 2 ? 3 : KV <= 8 ? 2 : 1;
   static_assert(kRows >= 16, "a slab holds at least one full column window");
 };
 
@@ -151,12 +152,12 @@ __global__ __launch_bounds__(kSThreads) void sddmm_stationary_kernel(
       }
       return acc;
     };
-    // Four entries.  Short rows (k <= 128): all reads in flight at once.  Longer
+    // Four entries.  k = 64: all reads in flight at once.  Longer
     // ones: two register sets, the reads of entry e+1 issued before the FMAs of
     // entry e.
     auto partial4 = [&](const char* a0, const char* a1, const char* a2, const char* a3, float& d0,
                         float& d1, float& d2, float& d3) {
-      if constexpr (KV <= 2) {
+      if constexpr (KV <= 1) {
         float4 b0[KV], b1[KV], b2[KV], b3[KV];
         load_row(b0, a0);
         load_row(b1, a1);
@@ -167,15 +168,24 @@ __global__ __launch_bounds__(kSThreads) void sddmm_stationary_kernel(
         d2 = dot(b2);
         d3 = dot(b3);
       } else {
+        // Pinned order: left alone, the compiler sinks the FMAs down to the
+        // reduction and hoists the reads of many entries at once (70
+        // ds_read_b128 in a row at k = 512), which spills.  The empty asm
+        // statements tie each partial sum (and, through the memory clobber,
+        // the following reads) to its place.
         float4 ba[KV], bb[KV];
         load_row(ba, a0);
         load_row(bb, a1);
         d0 = dot(ba);
+        asm volatile("" : "+v"(d0) : : "memory");
         load_row(ba, a2);
         d1 = dot(bb);
+        asm volatile("" : "+v"(d1) : : "memory");
         load_row(bb, a3);
         d2 = dot(ba);
+        asm volatile("" : "+v"(d2) : : "memory");
         d3 = dot(bb);
+        asm volatile("" : "+v"(d3) : : "memory");
       }
     };
 
