@@ -77,7 +77,7 @@ def test_fuzz_sddmm_softmax_transpose(capi, dev):
     rng = np.random.default_rng(77)
     for it in range(40):
         m, n, sparsity, empty, order, replicas = _case(rng, [16, 64, 128, 256, 300], [16, 64, 128, 256, 300])
-        k = int(rng.choice([1, 5, 32, 64, 64, 128, 128, 200, 256, 512, 1024]))
+        k = int(rng.choice([1, 5, 32, 64, 64, 128, 128, 200, 256, 320, 512, 768, 1024]))
         _, _, ri, ro, ci = make_csr(m, n, sparsity, seed=100 + it, round_to=1, empty_rows=empty,
                                     order=order)
         nnz = len(ci)

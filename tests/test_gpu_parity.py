@@ -225,8 +225,12 @@ SDDMM_SHAPES = [
     (300, 256, 200, 0.8, 2),   # stationary kernel, k = 256 (128-row slabs), ragged
     (512, 512, 512, 0.8, 2),   # k = 512 (64-row slabs): SparseLinear weight gradient shape
     (130, 512, 70, 0.3, 1),    # k = 512, > 16 entries per row and slab, partial last slab
-    (256, 1024, 96, 0.7, 2),   # k = 1024 (32-row slabs)
-    (64, 1024, 64, 0.0, 1),    # k = 1024, dense mask: two full windows per row and slab
+    (256, 1024, 96, 0.7, 2),   # k = 1024: two panels of 512, the second accumulates
+    (64, 1024, 64, 0.0, 1),    # k = 1024, dense mask: full windows in every slab
+    (200, 768, 130, 0.8, 2),   # three panels of 256
+    (96, 320, 200, 0.6, 1),    # five panels of 64
+    (128, 2048, 128, 0.9, 1),  # four panels of 512 (Spmm backward shapes)
+    (64, 4160, 64, 0.5, 1),    # 65 x 64: too many panels, row-wave kernel
 ]
 
 

@@ -1,6 +1,7 @@
-// LDS-tiled SDDMM for inner dimensions k in {64, 128, 256, 512, 1024}
-// (attention heads; the weight gradient of SparseLinear, where k is the
-// sequence length):
+// LDS-tiled SDDMM for inner dimensions k that are a multiple of 64 (attention
+// heads; the weight gradient of SparseLinear / Spmm, where k is the sequence
+// length or the dense operand's width), walked in at most 8 panels of 64, 128,
+// 256 or 512 columns (one launch per panel, later panels add into the output):
 //
 //   out[p] = < lhs[i_p, 0:k], rhs[j_p, 0:k] >   for every stored (i_p, j_p)
 //
@@ -8,7 +9,7 @@
 // (nnz*k*4 bytes of cache traffic: 1.7 GB for config 3, 13.7 GB for config 5,
 // and it runs at the L2 gather rate).  Here the rhs operand is STATIONARY: a
 // workgroup keeps one slab of rhs rows, full k wide, in LDS for its whole
-// life (64 KiB up to k = 128, 128 KiB above: 256 / 128 / 128 / 64 / 32 rows),
+// life (64 KiB up to panel width 128, 128 KiB above: 256 / 128 / 128 / 64 rows),
 // staged once by direct global->LDS copies behind a single barrier, and walks
 // mask rows instead.  For every mask row only the entries whose column falls
 // in the slab are computed (found with the chunk table of the shared
@@ -46,20 +47,25 @@ struct Slab {
   static constexpr int kdim = 64 * KV;
   static constexpr int kBytes = KV <= 2 ? 64 * 1024 : 128 * 1024;
   static constexpr int kRows = kBytes / (kdim * 4);
-  // lhs fragments in flight (KV float4 each): fetched 2 / 1 / 0 rows ahead
-  static constexpr int kRing = KV <= 2 ? 3 : KV <= 8 ? 2 : 1;
+  // lhs fragments in flight (KV float4 each): fetched 2 rows / 1 row ahead
+  static constexpr int kRing = KV <= 2 ? 3 : 2;
   static_assert(kRows >= 16, "a slab holds at least one full column window");
 };
 
+// Occupancy is set by LDS: two 64 KiB workgroups (4 waves per SIMD) or one of
+// 128 KiB (2 waves per SIMD); telling the compiler stops it from spilling to
+// keep a wave count the LDS footprint rules out anyway.
 template <int KV>
-__global__ __launch_bounds__(kSThreads) void sddmm_stationary_kernel(
+__global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(2, (KV <= 2 ? 4 : 2))))
+void sddmm_stationary_kernel(
     int m, int n, int nonzeros, int slots, const int* __restrict__ row_indices,
     const int* __restrict__ row_offsets, const int* __restrict__ column_indices,
     const int* __restrict__ table, const int* __restrict__ row_ok,
     const float* __restrict__ lhs, int64_t lhs_stride, const float* __restrict__ rhs,
-    int64_t rhs_stride, float* __restrict__ out, int64_t out_stride, int debug) {
+    int64_t rhs_stride, int ld /* floats between rows of lhs / rhs */, int accumulate,
+    float* __restrict__ out, int64_t out_stride, int debug) {
   using S = Slab<KV>;
-  constexpr int kdim = S::kdim;
+  constexpr int kdim = S::kdim;  // panel width; lhs / rhs point at the panel's first column
   constexpr int kRowBytes = kdim * 4;
   __shared__ float tile[S::kBytes / 4];
 
@@ -81,7 +87,8 @@ __global__ __launch_bounds__(kSThreads) void sddmm_stationary_kernel(
       const int piece = wave + j * kSWaves;
       const unsigned b = static_cast<unsigned>(piece) * 1024u + lane * 16u;  // byte in the slab
       const int src_row = min(jc + static_cast<int>(b / kRowBytes), n - 1);  // past the end: last row
-      const unsigned off = static_cast<unsigned>(src_row) * kRowBytes + b % kRowBytes;
+      const unsigned off =
+          static_cast<unsigned>(src_row) * (static_cast<unsigned>(ld) * 4u) + b % kRowBytes;
       lds_dma_row(rhs, off, tile + piece * 256);
     }
   }
@@ -122,7 +129,7 @@ __global__ __launch_bounds__(kSThreads) void sddmm_stationary_kernel(
 #pragma unroll
     for (int v = 0; v < KV; ++v)
       lf[slot_in_ring][v] = *reinterpret_cast<const float4*>(
-          lhs + static_cast<int64_t>(row[r]) * kdim + 64 * v + 4 * i);
+          lhs + static_cast<int64_t>(row[r]) * ld + 64 * v + 4 * i);
   };
 #pragma unroll
   for (int r = 0; r < kRing - 1; ++r) fetch(r, r);
@@ -130,9 +137,9 @@ __global__ __launch_bounds__(kSThreads) void sddmm_stationary_kernel(
   __syncthreads();
 
   const char* __restrict__ lane_base = reinterpret_cast<const char*>(&tile[0] + i * 4);
-#pragma unroll
-  for (int r = 0; r < kSRows; ++r) {
-    if (r + kRing - 1 < kSRows) fetch(r + kRing - 1, (r + kRing - 1) % kRing);
+  static_for<kSRows>([&](auto R) {
+    constexpr int r = decltype(R)::value;
+    if constexpr (r + kRing - 1 < kSRows) fetch(r + kRing - 1, (r + kRing - 1) % kRing);
     const float4 (&cur_lf)[KV] = lf[r % kRing];
     const int cur_ps = ps[r];
 
@@ -195,9 +202,9 @@ __global__ __launch_bounds__(kSThreads) void sddmm_stationary_kernel(
       for (int p = cur_ps; p < p1; ++p) {
         float4 b[KV];
         load_row(b, reinterpret_cast<const char*>(
-                        rhs + static_cast<int64_t>(column_indices[p]) * kdim + 4 * i));
+                        rhs + static_cast<int64_t>(column_indices[p]) * ld + 4 * i));
         const float total = group_sum<16>(dot(b));
-        if (i == 0) out[p] = total;
+        if (i == 0) out[p] = accumulate ? out[p] + total : total;
       }
     }
     const int n_here = (debug & 1) ? 0 : max(cnt[r], 0);
@@ -232,7 +239,10 @@ __global__ __launch_bounds__(kSThreads) void sddmm_stationary_kernel(
         const float t2 = group_sum<16>(d2), t3 = group_sum<16>(d3);
         result = (i == 0) ? t0 : (i == 1) ? t1 : (i == 2) ? t2 : t3;
       }
-      if (valid) out[cur_ps + w0 + i] = result;
+      if (valid) {
+        float* dst = out + cur_ps + w0 + i;
+        *dst = accumulate ? *dst + result : result;
+      }
     };
 #pragma unroll
     for (int w = 0; w < kWin; ++w) window(wcol[r % kRing][w], 16 * w);
@@ -242,15 +252,23 @@ __global__ __launch_bounds__(kSThreads) void sddmm_stationary_kernel(
             max(__builtin_amdgcn_readlane(n_here, 32), __builtin_amdgcn_readlane(n_here, 48)));
     for (int w0 = 16 * kWin; w0 < longest; w0 += 16)
       window(column_indices[min(cur_ps + w0 + i, last)], w0);
-  }
+  });
 }
 
 inline int slots_of(int m) { return ceil_div(m, kSGroups * kSRows) * (kSGroups * kSRows); }
-inline bool served(int k) { return k == 64 || k == 128 || k == 256 || k == 512 || k == 1024; }
-inline int slab_rows(int k) { return (k <= 128 ? 64 * 1024 : 128 * 1024) / (k * 4); }
+constexpr int kMaxPanels = 8;
+// Widest panel that divides k (0 if k is not a multiple of 64).
+inline int panel_width(int k) {
+  return k <= 0 ? 0 : k % 512 == 0 ? 512 : k % 256 == 0 ? 256 : k % 128 == 0 ? 128 : k % 64 == 0 ? 64 : 0;
+}
+inline bool served(int k) { return panel_width(k) != 0 && k / panel_width(k) <= kMaxPanels; }
+inline int slab_rows(int k) {
+  const int w = panel_width(k);
+  return (w <= 128 ? 64 * 1024 : 128 * 1024) / (w * 4);
+}
 
 template <int KV>
-int launch(int m, int n, int nonzeros, int replicas, int slots, const int* row_indices,
+int launch(int m, int k, int n, int nonzeros, int replicas, int slots, const int* row_indices,
            const int* row_offsets, const int* column_indices, int* table, int* row_ok,
            const float* lhs, int64_t lhs_stride, const float* rhs, int64_t rhs_stride, float* out,
            int64_t out_stride, int debug, hipStream_t stream) {
@@ -265,15 +283,17 @@ int launch(int m, int n, int nonzeros, int replicas, int slots, const int* row_i
   if (st != 0) return st;
   const int row_blocks = slots / (kSGroups * kSRows);
   if (row_blocks > kMaxGridYZ) return SPUTNIK_HIP_INVALID_ARGUMENT;
-  for (int r0 = 0; r0 < replicas; r0 += kMaxGridYZ) {
-    const int rz = min(replicas - r0, kMaxGridYZ);
-    hipLaunchKernelGGL(sddmm_stationary_kernel<KV>, dim3(slabs, row_blocks, rz), dim3(kSThreads),
-                       0, stream, m, n, nonzeros, slots, row_indices, row_offsets,
-                       column_indices, table, row_ok, lhs + r0 * lhs_stride, lhs_stride,
-                       rhs + r0 * rhs_stride, rhs_stride, out + r0 * out_stride, out_stride,
-                       debug);
-    st = launch_status();
-    if (st != 0) return st;
+  for (int k0 = 0; k0 < k; k0 += S::kdim) {  // one launch per panel; later panels accumulate
+    for (int r0 = 0; r0 < replicas; r0 += kMaxGridYZ) {
+      const int rz = min(replicas - r0, kMaxGridYZ);
+      hipLaunchKernelGGL(sddmm_stationary_kernel<KV>, dim3(slabs, row_blocks, rz),
+                         dim3(kSThreads), 0, stream, m, n, nonzeros, slots, row_indices,
+                         row_offsets, column_indices, table, row_ok, lhs + r0 * lhs_stride + k0,
+                         lhs_stride, rhs + r0 * rhs_stride + k0, rhs_stride, k, k0 != 0,
+                         out + r0 * out_stride, out_stride, debug);
+      st = launch_status();
+      if (st != 0) return st;
+    }
   }
   return 0;
 }
@@ -304,15 +324,15 @@ int sddmm_tiled_launch(int m, int k, int n, int nonzeros, int replicas, const in
   const int slots = slots_of(m);
   int* row_ok = static_cast<int*>(workspace);
   int* table = reinterpret_cast<int*>(static_cast<char*>(workspace) + row_ok_bytes(slots));
-#define SPUTNIK_HIP_SD(KV)                                                                     \
-  return launch<KV>(m, n, nonzeros, replicas, slots, row_indices, row_offsets, column_indices, \
-                    table, row_ok, lhs, lhs_stride, rhs, rhs_stride, out, out_stride, debug, stream)
-  switch (k) {
+#define SPUTNIK_HIP_SD(KV)                                                               \
+  return launch<KV>(m, k, n, nonzeros, replicas, slots, row_indices, row_offsets,        \
+                    column_indices, table, row_ok, lhs, lhs_stride, rhs, rhs_stride, out, \
+                    out_stride, debug, stream)
+  switch (panel_width(k)) {
     case 64: SPUTNIK_HIP_SD(1);
     case 128: SPUTNIK_HIP_SD(2);
     case 256: SPUTNIK_HIP_SD(4);
     case 512: SPUTNIK_HIP_SD(8);
-    case 1024: SPUTNIK_HIP_SD(16);
     default: return SPUTNIK_HIP_INVALID_ARGUMENT;
   }
 #undef SPUTNIK_HIP_SD

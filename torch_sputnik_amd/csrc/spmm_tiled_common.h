@@ -3,6 +3,9 @@
 // direct global->LDS copy, hand-counted waits and the DPP broadcast helpers.
 #pragma once
 
+#include <type_traits>
+#include <utility>
+
 #include "common.h"
 #include "wave_utils.h"
 
@@ -293,6 +296,18 @@ __device__ __forceinline__ void dpp_entries_exact(float (&acc)[4], int n16, int 
     e = row_rotate_entry<2>(e);
   }
   if (left & 1) dpp_group_at0<1>(acc, e, lane_base);
+}
+
+// Compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(<N-1>): a loop
+// whose body indexes register arrays by the counter must not be left to
+// `#pragma unroll` (a refused unroll turns the arrays into scratch memory).
+template <typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
 }
 
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v / 2); }
