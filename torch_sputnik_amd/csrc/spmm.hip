@@ -17,7 +17,7 @@
 
 namespace sputnik_hip {
 
-int spmm_tiled_plan(int m, int k, int n, int nonzeros, const int* row_indices,
+int spmm_tiled_plan(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
                     const int* row_offsets, const int* column_indices, void* workspace,
                     size_t workspace_bytes, hipStream_t stream, bool* planned);
 int spmm_tiled_exec(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
@@ -166,9 +166,9 @@ int sputnik_hip_spmm_plan(int m, int k, int n, int nonzeros, const int* row_indi
                           size_t workspace_bytes, sputnik_hip_stream_t stream) {
   if (m < 0 || k < 0 || n < 0 || nonzeros < 0) return SPUTNIK_HIP_INVALID_ARGUMENT;
   if (m == 0 || n == 0) return 0;
-  bool planned = false;
-  return spmm_tiled_plan(m, k, n, nonzeros, row_indices, row_offsets, column_indices, workspace,
-                         workspace_bytes, stream, &planned);
+  bool planned = false;  // replica count not known yet: plan for either tiled kernel
+  return spmm_tiled_plan(m, k, n, nonzeros, -1, row_indices, row_offsets, column_indices,
+                         workspace, workspace_bytes, stream, &planned);
 }
 
 namespace {
@@ -223,8 +223,11 @@ int sputnik_hip_spmm_bias_batched(int m, int k, int n, int nonzeros, int replica
                                   int64_t dense_stride, const float* bias, int relu, float* out,
                                   int64_t out_stride, void* workspace, size_t workspace_bytes,
                                   sputnik_hip_stream_t stream) {
-  const int st = sputnik_hip_spmm_plan(m, k, n, nonzeros, row_indices, row_offsets,
-                                       column_indices, workspace, workspace_bytes, stream);
+  if (m < 0 || k < 0 || n < 0 || nonzeros < 0 || replicas < 0) return SPUTNIK_HIP_INVALID_ARGUMENT;
+  if (m == 0 || n == 0 || replicas == 0) return 0;
+  bool planned = false;
+  const int st = spmm_tiled_plan(m, k, n, nonzeros, replicas, row_indices, row_offsets,
+                                 column_indices, workspace, workspace_bytes, stream, &planned);
   if (st != 0) return st;
   Epilogue epi;
   epi.bias = bias;

@@ -352,50 +352,96 @@ using CfgMedium = TileConfig<256, 16, 8, 64>;
 // tile for problems that would otherwise cover a fraction of the chip.
 using CfgSmall = TileConfig<256, 8, 8, 64>;
 
+// developer knob SPUTNIK_HIP_SPMM_FORCE64: 1 = 64-column kernel only, -1 = 256-column
+// kernel whenever it applies
+inline int force_narrow() {
+  static const int v = [] {
+    const char* e = getenv("SPUTNIK_HIP_SPMM_FORCE64");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
+
 inline bool tiled_applicable(int m, int k, int n, int nonzeros) {
+  if (force_narrow() > 0) return false;
   // Needs full column tiles, and enough work per row block to amortise staging
   // B (each workgroup stages k x 256 floats): mean row length >= 16.
   return n % CfgLarge::kBN == 0 && k >= CfgLarge::kBK && m >= 64 &&
          nonzeros >= 16 * static_cast<int64_t>(m);
 }
 
+// Which tiled kernel serves a call.  Both may be applicable (n a multiple of
+// 256): the 256-column kernel wins when even its 64-row tiles give about one
+// workgroup per CU, the 64-column kernel when they would cover a fraction of the
+// chip (measured at 2048 x 2048, density 0.2: n = 256 with 4 replicas 10.6 vs
+// 15.2 TFLOP/s, with 16 replicas 28.5 vs 23.2).  The choice needs the replica
+// count, which a plan made ahead of time does not know: then both tables are
+// built (side by side in the workspace) and the call decides.
+enum class Kernel { kNone, kWide, kNarrow, kEither };
+
+inline size_t wide_workspace_bytes(int m, int k, int n) {
+  const Plan plan = make_plan<CfgLarge>(m, k, n);
+  return (row_ok_bytes(plan.slots) + plan.table_bytes + 15) / 16 * 16;
+}
+
+inline Kernel choose_kernel(int m, int k, int n, int nonzeros, int replicas /* < 0: unknown */) {
+  const bool wide = tiled_applicable(m, k, n, nonzeros);
+  const bool narrow = spmm_tiled64_applicable(m, k, n, nonzeros);
+  if (!wide) return narrow ? Kernel::kNarrow : Kernel::kNone;
+  if (!narrow || force_narrow() < 0) return Kernel::kWide;
+  const int64_t small_tiles = static_cast<int64_t>(ceil_div(m, CfgSmall::kBM)) * (n / CfgSmall::kBN);
+  // cross-over measured between 256 (narrow 8-10 % ahead) and 512 (wide 20 % ahead) tiles
+  constexpr int64_t kWideFrom = 384;
+  if (small_tiles >= kWideFrom) return Kernel::kWide;  // whatever the replica count
+  if (replicas < 0) return Kernel::kEither;
+  return small_tiles * replicas >= kWideFrom ? Kernel::kWide : Kernel::kNarrow;
+}
+
 }  // namespace
 
 size_t spmm_tiled_workspace_bytes(int m, int k, int n, int nonzeros) {
-  if (tiled_applicable(m, k, n, nonzeros)) {
-    const Plan plan = make_plan<CfgLarge>(m, k, n);
-    return row_ok_bytes(plan.slots) + plan.table_bytes;
+  switch (choose_kernel(m, k, n, nonzeros, -1)) {
+    case Kernel::kWide: return wide_workspace_bytes(m, k, n);
+    case Kernel::kNarrow: return spmm_tiled64_workspace_bytes(m, k);
+    case Kernel::kEither: return wide_workspace_bytes(m, k, n) + spmm_tiled64_workspace_bytes(m, k);
+    default: return 0;
   }
-  if (spmm_tiled64_applicable(m, k, n, nonzeros)) return spmm_tiled64_workspace_bytes(m, k);
-  return 0;
 }
 
 // Pre-pass only: topology -> per-row order status + chunk table in `workspace`.  Depends
 // on the topology alone, so a caller with a static pattern can run it once and
-// reuse the workspace for any number of spmm_tiled_exec calls.
-int spmm_tiled_plan(int m, int k, int n, int nonzeros, const int* row_indices,
+// reuse the workspace for any number of spmm_tiled_exec calls (`replicas` < 0:
+// not known yet).
+int spmm_tiled_plan(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
                     const int* row_offsets, const int* column_indices, void* workspace,
                     size_t workspace_bytes, hipStream_t stream, bool* planned) {
   *planned = false;
-  if (!tiled_applicable(m, k, n, nonzeros)) {
-    if (!spmm_tiled64_applicable(m, k, n, nonzeros) || workspace == nullptr ||
-        workspace_bytes < spmm_tiled64_workspace_bytes(m, k) || !aligned_to(workspace, 16))
-      return 0;
-    *planned = true;
-    return spmm_tiled64_plan(m, k, row_indices, row_offsets, column_indices, workspace, stream);
-  }
-  using Cfg = CfgLarge;
-  const Plan plan = make_plan<Cfg>(m, k, n);
-  if (workspace == nullptr || workspace_bytes < row_ok_bytes(plan.slots) + plan.table_bytes ||
-      !aligned_to(workspace, 16))
+  const Kernel which = choose_kernel(m, k, n, nonzeros, replicas);
+  if (which == Kernel::kNone || workspace == nullptr || !aligned_to(workspace, 16) ||
+      workspace_bytes < spmm_tiled_workspace_bytes(m, k, n, nonzeros))
     return 0;
-  int* row_ok = static_cast<int*>(workspace);
-  int* table = reinterpret_cast<int*>(static_cast<char*>(workspace) + row_ok_bytes(plan.slots));
-  hipLaunchKernelGGL((spmm_chunk_table_kernel<ilog2(Cfg::kBK)>), dim3(ceil_div(plan.slots, 4)),
-                     dim3(256), 0, stream, m, k, plan.slots, plan.nchunks, row_indices,
-                     row_offsets, column_indices, table, row_ok);
+  // the narrow kernel's tables follow the wide kernel's whenever both could be needed
+  const bool both_possible = choose_kernel(m, k, n, nonzeros, -1) == Kernel::kEither;
+  if (which == Kernel::kNarrow || which == Kernel::kEither) {
+    void* ws64 = both_possible ? static_cast<char*>(workspace) + wide_workspace_bytes(m, k, n)
+                               : workspace;
+    const int st =
+        spmm_tiled64_plan(m, k, row_indices, row_offsets, column_indices, ws64, stream);
+    if (st != 0) return st;
+  }
+  if (which == Kernel::kWide || which == Kernel::kEither) {
+    using Cfg = CfgLarge;
+    const Plan plan = make_plan<Cfg>(m, k, n);
+    int* row_ok = static_cast<int*>(workspace);
+    int* table = reinterpret_cast<int*>(static_cast<char*>(workspace) + row_ok_bytes(plan.slots));
+    hipLaunchKernelGGL((spmm_chunk_table_kernel<ilog2(Cfg::kBK)>), dim3(ceil_div(plan.slots, 4)),
+                       dim3(256), 0, stream, m, k, plan.slots, plan.nchunks, row_indices,
+                       row_offsets, column_indices, table, row_ok);
+    const int st = launch_status();
+    if (st != 0) return st;
+  }
   *planned = true;
-  return launch_status();
+  return 0;
 }
 
 // Main kernel on a planned workspace.
@@ -405,25 +451,24 @@ int spmm_tiled_exec(int m, int k, int n, int nonzeros, int replicas, const int* 
                     float* out, int64_t out_stride, const void* workspace,
                     size_t workspace_bytes, hipStream_t stream, Epilogue epi, bool* handled) {
   *handled = false;
-  if (!tiled_applicable(m, k, n, nonzeros)) {
-    if (!spmm_tiled64_applicable(m, k, n, nonzeros) || workspace == nullptr ||
-        workspace_bytes < spmm_tiled64_workspace_bytes(m, k) || !aligned_to(workspace, 16) ||
-        !aligned_to(dense, 16) || !aligned_to(out, 16) || dense_stride % 4 != 0 ||
-        out_stride % 4 != 0 || replicas > kMaxGridYZ)
-      return 0;
+  const Kernel which = choose_kernel(m, k, n, nonzeros, replicas);
+  if (which == Kernel::kNone || workspace == nullptr || !aligned_to(workspace, 16) ||
+      workspace_bytes < spmm_tiled_workspace_bytes(m, k, n, nonzeros) || !aligned_to(dense, 16) ||
+      !aligned_to(out, 16) || dense_stride % 4 != 0 || out_stride % 4 != 0 ||
+      replicas > kMaxGridYZ)
+    return 0;
+  if (which == Kernel::kNarrow) {
+    const bool both_possible = choose_kernel(m, k, n, nonzeros, -1) == Kernel::kEither;
+    const void* ws64 = both_possible
+                           ? static_cast<const char*>(workspace) + wide_workspace_bytes(m, k, n)
+                           : workspace;
     *handled = true;
     return spmm_tiled64_exec(m, k, n, nonzeros, replicas, row_indices, values, values_stride,
                              row_offsets, column_indices, dense, dense_stride, out, out_stride,
-                             workspace, stream, epi);
+                             ws64, stream, epi);
   }
   using Cfg = CfgLarge;
   const Plan plan = make_plan<Cfg>(m, k, n);
-  if (workspace == nullptr || workspace_bytes < row_ok_bytes(plan.slots) + plan.table_bytes ||
-      !aligned_to(workspace, 16))
-    return 0;
-  if (!aligned_to(dense, 16) || !aligned_to(out, 16) || dense_stride % 4 != 0 ||
-      out_stride % 4 != 0 || replicas > kMaxGridYZ)
-    return 0;
   const int* row_ok = static_cast<const int*>(workspace);
   const int* table = reinterpret_cast<const int*>(static_cast<const char*>(workspace) +
                                                   row_ok_bytes(plan.slots));
