@@ -161,28 +161,41 @@ template <int U>
 __device__ __forceinline__ int row_bcast_i(int v) {
   return __builtin_amdgcn_update_dpp(0, v, 0x150 + U, 0xF, 0xF, true);
 }
-template <int U>
-__device__ __forceinline__ float row_bcast_f(float v) {
-  return __builtin_bit_cast(float, row_bcast_i<U>(__builtin_bit_cast(int, v)));
-}
 
+// (offset, value) of an entry travel as ONE 64-bit register pair: a 64-bit DPP
+// move broadcasts both halves for the price of a 32-bit one (measured:
+// tools/ubench.hip, mov_dpp64 vs mov_dpp32), which saves one DPP operation per
+// nonzero against broadcasting the two words separately.  (64-bit DPP only
+// knows row_newbcast, so the rotation stays two 32-bit moves.)
+using entry_pair = unsigned long long;
+__device__ __forceinline__ entry_pair make_entry(int roff, float rval) {
+  return static_cast<unsigned int>(roff) |
+         (static_cast<entry_pair>(__builtin_bit_cast(unsigned int, rval)) << 32);
+}
+template <int U>
+__device__ __forceinline__ entry_pair row_bcast_entry(entry_pair e) {
+  return __builtin_amdgcn_update_dpp(entry_pair{0}, e, 0x150 + U, 0xF, 0xF, true);
+}
+__device__ __forceinline__ int entry_off(entry_pair e) { return static_cast<int>(e & 0xffffffffu); }
+__device__ __forceinline__ float entry_val(entry_pair e) {
+  return __builtin_bit_cast(float, static_cast<unsigned int>(e >> 32));
+}
 // Four nonzeros G..G+3 of the replicated 16-entry set (roff = byte offset of
 // the B row inside the staged tile, rval = value; both per entry lane).
 template <int G>
 __device__ __forceinline__ void dpp_group4(float (&acc)[4], int roff, float rval,
                                            const char* __restrict__ lane_base) {
-  const int o0 = row_bcast_i<G + 0>(roff), o1 = row_bcast_i<G + 1>(roff);
-  const int o2 = row_bcast_i<G + 2>(roff), o3 = row_bcast_i<G + 3>(roff);
-  const float4 b0 = *reinterpret_cast<const float4*>(lane_base + o0);
-  const float4 b1 = *reinterpret_cast<const float4*>(lane_base + o1);
-  const float4 b2 = *reinterpret_cast<const float4*>(lane_base + o2);
-  const float4 b3 = *reinterpret_cast<const float4*>(lane_base + o3);
-  const float a0 = row_bcast_f<G + 0>(rval), a1 = row_bcast_f<G + 1>(rval);
-  const float a2 = row_bcast_f<G + 2>(rval), a3 = row_bcast_f<G + 3>(rval);
-  SPUTNIK_HIP_FMA4(acc, a0, b0);
-  SPUTNIK_HIP_FMA4(acc, a1, b1);
-  SPUTNIK_HIP_FMA4(acc, a2, b2);
-  SPUTNIK_HIP_FMA4(acc, a3, b3);
+  const entry_pair e = make_entry(roff, rval);
+  const entry_pair e0 = row_bcast_entry<G + 0>(e), e1 = row_bcast_entry<G + 1>(e);
+  const entry_pair e2 = row_bcast_entry<G + 2>(e), e3 = row_bcast_entry<G + 3>(e);
+  const float4 b0 = *reinterpret_cast<const float4*>(lane_base + entry_off(e0));
+  const float4 b1 = *reinterpret_cast<const float4*>(lane_base + entry_off(e1));
+  const float4 b2 = *reinterpret_cast<const float4*>(lane_base + entry_off(e2));
+  const float4 b3 = *reinterpret_cast<const float4*>(lane_base + entry_off(e3));
+  SPUTNIK_HIP_FMA4(acc, entry_val(e0), b0);
+  SPUTNIK_HIP_FMA4(acc, entry_val(e1), b1);
+  SPUTNIK_HIP_FMA4(acc, entry_val(e2), b2);
+  SPUTNIK_HIP_FMA4(acc, entry_val(e3), b3);
 }
 
 // True iff every one of the workgroup's `rows` row slots (starting at
@@ -241,24 +254,6 @@ __device__ __forceinline__ int row_rotate_i(int v) {
 template <int N>
 __device__ __forceinline__ float row_rotate_f(float v) {
   return __builtin_bit_cast(float, row_rotate_i<N>(__builtin_bit_cast(int, v)));
-}
-// (offset, value) of an entry travel as ONE 64-bit register pair: a 64-bit DPP
-// move broadcasts both halves for the price of a 32-bit one (measured:
-// tools/ubench.hip, mov_dpp64 vs mov_dpp32), which saves one DPP operation per
-// nonzero against broadcasting the two words separately.  (64-bit DPP only
-// knows row_newbcast, so the rotation stays two 32-bit moves.)
-using entry_pair = unsigned long long;
-__device__ __forceinline__ entry_pair make_entry(int roff, float rval) {
-  return static_cast<unsigned int>(roff) |
-         (static_cast<entry_pair>(__builtin_bit_cast(unsigned int, rval)) << 32);
-}
-template <int U>
-__device__ __forceinline__ entry_pair row_bcast_entry(entry_pair e) {
-  return __builtin_amdgcn_update_dpp(entry_pair{0}, e, 0x150 + U, 0xF, 0xF, true);
-}
-__device__ __forceinline__ int entry_off(entry_pair e) { return static_cast<int>(e & 0xffffffffu); }
-__device__ __forceinline__ float entry_val(entry_pair e) {
-  return __builtin_bit_cast(float, static_cast<unsigned int>(e >> 32));
 }
 template <int N>
 __device__ __forceinline__ entry_pair row_rotate_entry(entry_pair e) {
