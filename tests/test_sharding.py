@@ -64,6 +64,10 @@ def _worker(rank, world, port, replicas, results):
         ok = ok and torch.equal(sd, ops.sddmm(m, k, *topo, lhs, rhs).reshape(replicas, -1))
         sm = sharding.sparse_softmax(sd, *topo)
         ok = ok and torch.equal(sm, ops.sparse_softmax(sd, *topo))
+        q = torch.from_numpy(rng.uniform(-1, 1, (replicas, m, 8)).astype(np.float32))
+        kv = torch.from_numpy(rng.uniform(-1, 1, (replicas, k, 8)).astype(np.float32))
+        att = sharding.sparse_attention(q, kv, kv, *topo, 0.35)
+        ok = ok and torch.equal(att, ops.sparse_attention(q, kv, kv, *topo, 0.35))
         results[rank] = bool(ok)
     finally:
         dist.destroy_process_group()

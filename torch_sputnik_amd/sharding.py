@@ -192,3 +192,16 @@ def sparse_softmax(values, row_indices, row_offsets, column_indices, group=None,
         return ops.sparse_softmax(v, row_indices, row_offsets, column_indices)
 
     return replica_parallel(op, [(values, True)], replicas, group, gather_output, gather_mode)
+
+
+def sparse_attention(query, key, value, row_indices, row_offsets, column_indices, scale,
+                     group=None, gather_output=True, gather_mode="collective"):
+    """Replica-parallel fused attention: query [R,S,D], key / value [R,S',D] sharded
+    along R (batch x heads), the mask replicated."""
+    replicas = query.size(0)
+
+    def op(q, k, v):
+        return ops.sparse_attention(q, k, v, row_indices, row_offsets, column_indices, scale)
+
+    return replica_parallel(op, [(query, True), (key, True), (value, True)], replicas, group,
+                            gather_output, gather_mode)
