@@ -8,7 +8,7 @@ Layers, bottom up:
   sharding              replica-dimension sharding over the GPUs of a node (RCCL)
 
 Importing this package loads the native libraries and fails loudly when they
-have not been built (``python -m torch_sputnik_amd.build``).
+have not been built (``python torch_sputnik_amd/build.py``).
 """
 from . import ops  # noqa: F401  (loads libsputnik_hip.so + libtorch_sputnik_ops.so)
 from .ops import (  # noqa: F401

@@ -10,7 +10,7 @@ LIB_DIR = os.path.join(_HERE, "lib")
 KERNEL_LIB = os.path.join(LIB_DIR, "libsputnik_hip.so")
 OPS_LIB = os.path.join(LIB_DIR, "libtorch_sputnik_ops.so")
 
-_BUILD_HINT = ("build it with `python -m torch_sputnik_amd.build` "
+_BUILD_HINT = ("build it with `python torch_sputnik_amd/build.py` "
                "(hipcc --offload-arch=gfx950; needs no GPU)")
 
 _kernel_lib = None

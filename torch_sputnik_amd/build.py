@@ -3,8 +3,9 @@
   lib/libsputnik_hip.so        HIP kernels behind the C ABI (include/sputnik_hip.h)
   lib/libtorch_sputnik_ops.so  TORCH_LIBRARY registration on top of it (g++, no device code)
 
-Run as ``python -m torch_sputnik_amd.build``; ``__graft_entry__.build()`` calls
-``build_all()``.  hipcc cross-compiles without a GPU.
+Run as a script, ``python torch_sputnik_amd/build.py`` (NOT ``-m``: importing
+the package loads the libraries this script is about to build);
+``__graft_entry__.build()`` loads this file by path and calls ``build_all()``.  hipcc cross-compiles without a GPU.
 """
 import os
 import subprocess
