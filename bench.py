@@ -261,6 +261,8 @@ def main():
                     help="override (default 1 at --gpus 1, 16 otherwise)")
     ap.add_argument("--no-extras", action="store_true", help="skip sweep / cpu baseline / other ops")
     args = ap.parse_args()
+    import __graft_entry__
+    __graft_entry__.ensure_built()  # fresh checkout: compile the native libraries first
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

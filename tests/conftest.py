@@ -15,17 +15,12 @@ def _ensure_built():
     """A fresh checkout has no native libraries (they are git-ignored): build
     them once, exactly as __graft_entry__.build() does.  On the GPU box the
     snapshot carries the built files, so this is a no-op there."""
-    wanted = [os.path.join(REPO, "torch_sputnik_amd", "lib", "libsputnik_hip.so"),
-              os.path.join(REPO, "torch_sputnik_amd", "lib", "libtorch_sputnik_ops.so"),
-              os.path.join(REPO, "oracle", "libsputnik_oracle.so")]
-    if all(os.path.exists(p) for p in wanted):
-        return
     import importlib.util
     spec = importlib.util.spec_from_file_location("_graft_entry_for_tests",
                                                   os.path.join(REPO, "__graft_entry__.py"))
     entry = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(entry)
-    entry.build()
+    entry.ensure_built()
 
 
 def pytest_configure(config):
