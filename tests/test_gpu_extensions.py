@@ -389,3 +389,32 @@ def test_sparse_attention_large_scores_stay_finite(ts, dev):
     got = out.cpu().numpy()
     assert np.isfinite(got).all()
     assert rel_err(got, O.sparse_attention(q, k, v, ri, ro, ci, 0.125)) < TOL
+
+
+def test_many_mask_with_an_empty_mask(ts, dev):
+    """One batch element masks everything out: its heads get zeros / nothing."""
+    rng = np.random.default_rng(12)
+    b, heads, s, hn = 3, 2, 32, 16
+    masks = np.stack([O.random_mask(s, s, 0.5, rng=rng), np.zeros((s, s), np.float32),
+                      O.random_mask(s, s, 0.8, rng=rng)])
+    ri, ro, ci, nn = O.dense_to_csr_many_mask(masks)
+    assert nn[1] == 0
+    r = b * heads
+    q = rng.uniform(-1, 1, (r, s, hn)).astype(np.float32)
+    k = rng.uniform(-1, 1, (r, s, hn)).astype(np.float32)
+    v = rng.uniform(-1, 1, (r, s, hn)).astype(np.float32)
+    topo = [T(ri, dev), T(ro, dev), T(ci, dev)]
+    nnt = torch.from_numpy(nn)
+    scores = ts.sddmm_many_mask(b, s, s, nnt, *topo, T(q, dev), T(k, dev))
+    assert rel_err(scores.cpu().numpy(), O.sddmm_many_mask(b, s, s, nn, ri, ro, ci, q, k)) < TOL
+    weights = ts.sparse_softmax_many_mask(b, s, nnt, scores, *topo)
+    out = ts.spmm_many_mask(b, s, s, nnt, weights, *topo, T(v, dev))
+    want = O.spmm_many_mask(b, s, s, nn, O.sparse_softmax_many_mask(
+        b, s, nn, scores.cpu().numpy(), ri, ro, ci), ri, ro, ci, v)
+    got = out.cpu().numpy()
+    assert rel_err(got, want) < TOL
+    assert not got[heads:2 * heads].any()
+    vt, rot, cit = ts.csr_transpose_many_mask(b, s, s, nnt, weights, topo[1], topo[2])
+    w_vt, w_rot, w_cit = O.csr_transpose_many_mask(b, s, s, nn, weights.cpu().numpy(), ro, ci)
+    assert np.array_equal(rot.cpu().numpy(), w_rot) and np.array_equal(cit.cpu().numpy(), w_cit)
+    assert np.array_equal(vt.cpu().numpy(), w_vt)
