@@ -57,3 +57,15 @@ def cpu_ops():
     torch_cpu_backend.install()
     import torch_sputnik_amd
     return torch_sputnik_amd
+
+
+@pytest.fixture(params=["auto", "wide", "narrow", "gather"])
+def spmm_kernel(request, monkeypatch):
+    """Small inputs take the single-launch row-gather kernel on their own; the
+    library's test knob steers them onto each tiled kernel in turn (a kernel
+    that does not apply to a shape falls through to the next one)."""
+    if request.param == "auto":
+        monkeypatch.delenv("SPUTNIK_HIP_SPMM_KERNEL", raising=False)
+    else:
+        monkeypatch.setenv("SPUTNIK_HIP_SPMM_KERNEL", request.param)
+    return request.param

@@ -51,7 +51,7 @@ BIAS_SHAPES = [
 
 @pytest.mark.parametrize("m,k,n,sparsity,replicas", BIAS_SHAPES)
 @pytest.mark.parametrize("relu", [0, 1])
-def test_spmm_bias_capi_vs_oracle(capi, dev, m, k, n, sparsity, replicas, relu):
+def test_spmm_bias_capi_vs_oracle(capi, dev, spmm_kernel, m, k, n, sparsity, replicas, relu):
     _, vals, ri, ro, ci = make_csr(m, k, sparsity, seed=m + n + relu, order="ascending")
     rng = np.random.default_rng(k)
     vals = (vals * rng.choice([-1.0, 1.0], size=vals.shape)).astype(np.float32)
@@ -84,7 +84,7 @@ def test_spmm_null_bias_is_plain_spmm(capi, dev):
     assert torch.equal(a, c)
 
 
-def test_spmm_bias_unsorted_columns_take_the_fallback_epilogue(capi, dev):
+def test_spmm_bias_unsorted_columns_take_the_fallback_epilogue(capi, dev, spmm_kernel):
     m, k, n = 256, 512, 256
     _, vals, ri, ro, ci = make_csr(m, k, 0.7, seed=21)
     rng = np.random.default_rng(3)

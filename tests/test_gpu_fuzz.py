@@ -46,7 +46,7 @@ def _case(rng, rows, cols):
     return m, n, sparsity, empty, order, replicas
 
 
-def test_fuzz_spmm(capi, dev):
+def test_fuzz_spmm(capi, dev, spmm_kernel):
     rng = np.random.default_rng(20261003)
     for it in range(40):
         m, k, sparsity, empty, order, replicas = _case(rng, [16, 64, 128, 256, 300], [32, 64, 128, 256, 520])

@@ -68,7 +68,7 @@ SPMM_SHAPES = [
 
 
 @pytest.mark.parametrize("m,k,n,sparsity,order,empty", SPMM_SHAPES)
-def test_spmm_capi_vs_oracle(capi, dev, m, k, n, sparsity, order, empty):
+def test_spmm_capi_vs_oracle(capi, dev, spmm_kernel, m, k, n, sparsity, order, empty):
     _, vals, ri, ro, ci = make_csr(m, k, sparsity, seed=m * 7 + n, empty_rows=empty, order=order)
     b = np.random.default_rng(n).uniform(-1, 1, size=(k, n)).astype(np.float32)
     want = c_oracle.spmm(m, k, vals, ro, ci, b)
@@ -98,7 +98,7 @@ STRESS = [
 
 @pytest.mark.parametrize("m,k,n,sparsity", STRESS)
 @pytest.mark.parametrize("order", ["descending", "random"])
-def test_spmm_tiled_stress(capi, dev, m, k, n, sparsity, order):
+def test_spmm_tiled_stress(capi, dev, spmm_kernel, m, k, n, sparsity, order):
     _, vals, ri, ro, ci = make_csr(m, k, sparsity, seed=3 * m + k + n, round_to=1, order=order,
                                    empty_rows=(m - 1,) if sparsity > 0.5 else ())
     b = np.random.default_rng(m + n).uniform(-1, 1, size=(k, n)).astype(np.float32)
@@ -147,7 +147,7 @@ def test_spmm_full_size_linearity(capi, dev):
     (3, False, 130, 96, 136), (5, True, 130, 96, 136), (1, False, 130, 96, 136),
     (4, False, 512, 512, 64), (3, True, 300, 256, 128),       # 64-column tiled kernel
     (2, False, 512, 512, 256), (3, True, 256, 1024, 512)])    # 256-column tiled kernel
-def test_spmm_batched_capi(capi, dev, replicas, shared, m, k, n):
+def test_spmm_batched_capi(capi, dev, spmm_kernel, replicas, shared, m, k, n):
     _, vals, ri, ro, ci = make_csr(m, k, 0.85, seed=21)
     rng = np.random.default_rng(22)
     b = rng.uniform(-1, 1, size=(replicas, k, n)).astype(np.float32)
@@ -163,7 +163,7 @@ def test_spmm_batched_capi(capi, dev, replicas, shared, m, k, n):
 
 
 @pytest.mark.parametrize("m,k,n", [(96, 200, 128), (256, 512, 256), (300, 1000, 512), (200, 300, 64)])
-def test_spmm_unsorted_columns(capi, dev, m, k, n):
+def test_spmm_unsorted_columns(capi, dev, spmm_kernel, m, k, n):
     """Column indices need not ascend inside a row (the CUDA library does not
     require it either).  The larger shapes qualify for the LDS-tiled kernel,
     whose pre-pass must notice the order and hand over to the row-gather kernel."""

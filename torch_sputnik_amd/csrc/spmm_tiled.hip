@@ -352,18 +352,18 @@ using CfgMedium = TileConfig<256, 16, 8, 64>;
 // tile for problems that would otherwise cover a fraction of the chip.
 using CfgSmall = TileConfig<256, 8, 8, 64>;
 
-// developer knob SPUTNIK_HIP_SPMM_FORCE64: 1 = 64-column kernel only, -1 = 256-column
-// kernel whenever it applies
-inline int force_narrow() {
-  static const int v = [] {
-    const char* e = getenv("SPUTNIK_HIP_SPMM_FORCE64");
-    return e ? atoi(e) : 0;
-  }();
-  return v;
+// Developer / test knob SPUTNIK_HIP_SPMM_KERNEL, read at every call: "wide" =
+// 256-column kernel whenever it applies, "narrow" = 64-column kernel whenever
+// it applies, "gather" = row-gather kernel; anything else = the automatic choice.
+// (The parity tests use it to reach every kernel with small inputs.)
+inline int forced_kernel() {
+  const char* e = getenv("SPUTNIK_HIP_SPMM_KERNEL");
+  if (e == nullptr) return 0;
+  return e[0] == 'w' ? -1 : e[0] == 'n' ? 1 : e[0] == 'g' ? 2 : 0;
 }
 
 inline bool tiled_applicable(int m, int k, int n, int nonzeros) {
-  if (force_narrow() > 0) return false;
+  if (forced_kernel() > 0) return false;
   // Needs full column tiles, and enough work per row block to amortise staging
   // B (each workgroup stages k x 256 floats): mean row length >= 16.
   return n % CfgLarge::kBN == 0 && k >= CfgLarge::kBK && m >= 64 &&
@@ -385,10 +385,20 @@ inline size_t wide_workspace_bytes(int m, int k, int n) {
 }
 
 inline Kernel choose_kernel(int m, int k, int n, int nonzeros, int replicas /* < 0: unknown */) {
+  // Small calls are launch-latency bound: the workspace-free row-gather kernel is
+  // one launch, the tiled kernels are a pre-pass plus a kernel with a staging
+  // pipeline to fill (measured cross-over around 2.5e8 multiply-adds: 1024^3 at
+  // density 0.1 31 vs 42 us, 64^3 12 vs 17 us; config 3's 4.3e8 already favours
+  // the tiled kernel, 62 vs 91 us).
+  const int forced = forced_kernel();
+  if (forced == 2) return Kernel::kNone;
+  if (replicas >= 0 && forced == 0 &&
+      static_cast<int64_t>(nonzeros) * n * replicas < (int64_t{1} << 28))
+    return Kernel::kNone;
   const bool wide = tiled_applicable(m, k, n, nonzeros);
   const bool narrow = spmm_tiled64_applicable(m, k, n, nonzeros);
   if (!wide) return narrow ? Kernel::kNarrow : Kernel::kNone;
-  if (!narrow || force_narrow() < 0) return Kernel::kWide;
+  if (!narrow || forced < 0) return Kernel::kWide;
   const int64_t small_tiles = static_cast<int64_t>(ceil_div(m, CfgSmall::kBM)) * (n / CfgSmall::kBN);
   // cross-over measured between 256 (narrow 8-10 % ahead) and 512 (wide 20 % ahead) tiles
   constexpr int64_t kWideFrom = 384;
