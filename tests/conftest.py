@@ -69,3 +69,13 @@ def spmm_kernel(request, monkeypatch):
     else:
         monkeypatch.setenv("SPUTNIK_HIP_SPMM_KERNEL", request.param)
     return request.param
+
+
+@pytest.fixture(params=["auto", "tiled", "wave"])
+def sddmm_kernel(request, monkeypatch):
+    """As spmm_kernel, for the SDDMM dispatch (LDS-tiled / row-wave)."""
+    if request.param == "auto":
+        monkeypatch.delenv("SPUTNIK_HIP_SDDMM_KERNEL", raising=False)
+    else:
+        monkeypatch.setenv("SPUTNIK_HIP_SDDMM_KERNEL", request.param)
+    return request.param

@@ -73,7 +73,7 @@ def test_fuzz_spmm(capi, dev, spmm_kernel):
         assert rel_err(got, want) < TOL, (it, m, k, n, sparsity, order, replicas)
 
 
-def test_fuzz_sddmm_softmax_transpose(capi, dev):
+def test_fuzz_sddmm_softmax_transpose(capi, dev, sddmm_kernel):
     rng = np.random.default_rng(77)
     for it in range(40):
         m, n, sparsity, empty, order, replicas = _case(rng, [16, 64, 128, 256, 300], [16, 64, 128, 256, 300])

@@ -235,7 +235,7 @@ SDDMM_SHAPES = [
 
 
 @pytest.mark.parametrize("m,k,n,sparsity,replicas", SDDMM_SHAPES)
-def test_sddmm_capi_vs_oracle(capi, dev, m, k, n, sparsity, replicas):
+def test_sddmm_capi_vs_oracle(capi, dev, sddmm_kernel, m, k, n, sparsity, replicas):
     _, _, ri, ro, ci = make_csr(m, n, sparsity, seed=m + k + n, round_to=1, empty_rows=(m // 2,))
     rng = np.random.default_rng(k)
     lhs = rng.uniform(-1, 1, size=(replicas, m, k)).astype(np.float32)

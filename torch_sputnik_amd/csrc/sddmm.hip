@@ -11,6 +11,8 @@
 // (no LDS crossbar up to 16 lanes).  Lane t keeps result t, so the LPN
 // results leave as one coalesced store.  Long inner dimensions are walked in
 // panels of LPN*VEC*KSL elements; later panels add into the output.
+#include <stdlib.h>
+
 #include "common.h"
 #include "wave_utils.h"
 
@@ -166,7 +168,17 @@ int sputnik_hip_sddmm_batched(int m, int k, int n, int nonzeros, int replicas,
     }
     return 0;
   }
-  if (workspace != nullptr && aligned_to(workspace, 16) &&
+  // Small calls are launch-latency bound: the row-wave kernel is one launch,
+  // the tiled path a pre-pass plus a kernel that first stages its slab.
+  // Measured cross-over (tools/small_sddmm.py): about 2.7e8 multiply-adds at
+  // k = 64, 1.3e8 at k = 128, 3e7 at k = 512, i.e. nnz * k^2 * replicas ~ 2^34.
+  // Test knob SPUTNIK_HIP_SDDMM_KERNEL (read per call): "tiled" / "wave".
+  const char* forced = getenv("SPUTNIK_HIP_SDDMM_KERNEL");
+  const bool force_tiled = forced != nullptr && forced[0] == 't';
+  const bool force_wave = forced != nullptr && forced[0] == 'w';
+  const bool small = static_cast<double>(nonzeros) * k * k * replicas < 17179869184.0;  // 2^34
+  if (!force_wave && (force_tiled || !small) && workspace != nullptr &&
+      aligned_to(workspace, 16) &&
       sddmm_tiled_applicable(m, k, n, nonzeros, lhs, lhs_stride, rhs, rhs_stride) &&
       workspace_bytes >= sddmm_tiled_workspace_bytes(m, k, n, nonzeros))
     return sddmm_tiled_launch(m, k, n, nonzeros, replicas, row_indices, row_offsets,
