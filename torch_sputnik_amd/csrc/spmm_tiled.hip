@@ -387,14 +387,20 @@ inline size_t wide_workspace_bytes(int m, int k, int n) {
 inline Kernel choose_kernel(int m, int k, int n, int nonzeros, int replicas /* < 0: unknown */) {
   // Small calls are launch-latency bound: the workspace-free row-gather kernel is
   // one launch, the tiled kernels are a pre-pass plus a kernel with a staging
-  // pipeline to fill (measured cross-over around 2.5e8 multiply-adds: 1024^3 at
-  // density 0.1 31 vs 42 us, 64^3 12 vs 17 us; config 3's 4.3e8 already favours
-  // the tiled kernel, 62 vs 91 us).
+  // pipeline to fill, and a lone product gives them few workgroups.  Measured
+  // (tools/n_sweep.py, tools/small_sweep.py), W = multiply-adds of the call:
+  // below 1.3e8 the row-gather kernel always wins (64^3 12 vs 17 us, 1024^3 at
+  // density 0.1 31 vs 42 us); with 8 or more replicas the tiled kernels win from
+  // there on (512^2 x 1024, 8 replicas: 39 vs 51 us; config 3: 62 vs 91 us); with
+  // fewer they need about 5e8 (4096^2 x 256, one replica, 4.3e8: 94 us row gather
+  // vs 132 us tiled; 2048^3 at density 0.1, 8.6e8: tiled).
   const int forced = forced_kernel();
   if (forced == 2) return Kernel::kNone;
-  if (replicas >= 0 && forced == 0 &&
-      static_cast<int64_t>(nonzeros) * n * replicas < (int64_t{1} << 28))
-    return Kernel::kNone;
+  if (replicas >= 0 && forced == 0) {
+    const int64_t work = static_cast<int64_t>(nonzeros) * n * replicas;
+    if (work < (int64_t{1} << 27) || (replicas < 8 && work < (int64_t{1} << 29)))
+      return Kernel::kNone;
+  }
   const bool wide = tiled_applicable(m, k, n, nonzeros);
   const bool narrow = spmm_tiled64_applicable(m, k, n, nonzeros);
   if (!wide) return narrow ? Kernel::kNarrow : Kernel::kNone;
