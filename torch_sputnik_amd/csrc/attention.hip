@@ -108,8 +108,8 @@ __global__ __launch_bounds__(kThreads) void sparse_attention_kernel(
   int my_row[kRQ];
 #pragma unroll
   for (int t = 0; t < kRQ; ++t) {
-    const int slot = slot0 + 4 * t + g;
-    my_row[t] = slot < m ? row_indices[slot] : -1;
+    const int entry = dealt_index(slot0 + 4 * t + g, slots, kBM);
+    my_row[t] = entry < m ? row_indices[entry] : -1;
     float4 qf = make_float4(0.f, 0.f, 0.f, 0.f);
     if (my_row[t] >= 0)
       qf = *reinterpret_cast<const float4*>(q + static_cast<int64_t>(my_row[t]) * kD + 4 * i);
@@ -330,7 +330,7 @@ int sputnik_hip_sparse_attention_forward(int m, int n, int d, int nonzeros, int 
   int* row_ok = static_cast<int*>(workspace);
   int* table = reinterpret_cast<int*>(static_cast<char*>(workspace) + row_ok_bytes(slots));
   hipLaunchKernelGGL((spmm_chunk_table_kernel<ilog2(kBK)>), dim3(ceil_div(slots, 4)), dim3(256),
-                     0, stream, m, n, slots, nchunks, row_indices, row_offsets, column_indices,
+                     0, stream, m, n, slots, kBM, nchunks, row_indices, row_offsets, column_indices,
                      table, row_ok);
   int st = launch_status();
   if (st != 0) return st;

@@ -106,10 +106,10 @@ void sddmm_stationary_kernel(
   int row[kSRows], ps[kSRows], cnt[kSRows];
 #pragma unroll
   for (int r = 0; r < kSRows; ++r) {
-    const int slot = slot_begin + r * kSGroups + gid;
-    const bool live = slot < m;
-    const int sl = live ? slot : 0;
-    row[r] = row_indices[sl];
+    const int sl = slot_begin + r * kSGroups + gid;  // < slots: table and status are padded
+    const int entry = dealt_index(sl, slots, kSGroups * kSRows);
+    const bool live = entry < m;
+    row[r] = row_indices[live ? entry : 0];
     const int a0 = tab0[sl], a1 = tab1[sl];
     // rows whose columns do not ascend have no valid table entries: slab 0 does
     // the whole row in storage order (negative count), the other slabs skip it
@@ -277,7 +277,8 @@ int launch(int m, int k, int n, int nonzeros, int replicas, int slots, const int
   // The chunk table is the SpMM one with the mask's columns (n) in the role of
   // k, cut at slab boundaries.
   hipLaunchKernelGGL((spmm_chunk_table_kernel<ilog2(S::kRows)>), dim3(ceil_div(slots, 4)),
-                     dim3(256), 0, stream, m, n, slots, slabs, row_indices, row_offsets,
+                     dim3(256), 0, stream, m, n, slots, kSGroups * kSRows, slabs, row_indices,
+                     row_offsets,
                      column_indices, table, row_ok);
   int st = launch_status();
   if (st != 0) return st;

@@ -54,6 +54,11 @@ using namespace tiled;
 // ---------------------------------------------------------------------------
 // Main kernel.
 // ---------------------------------------------------------------------------
+// Row slots are dealt to workgroups in runs of this many (dealt_index): the
+// largest tile's row count, so that the 128- and 64-row tiles, which share the
+// table, get balanced halves / quarters of such a run.
+constexpr int kDealPer = 256;
+
 template <int BN, int WAVES, int RPW, int BK>
 struct TileConfig {
   static constexpr int kBN = BN;        // columns of C per workgroup
@@ -290,9 +295,9 @@ __global__ __launch_bounds__(Cfg::kThreads) void spmm_tiled_kernel(
   // K chunk: they take the order-independent path (B gathered from L2).
   if (!block_rows_ok(row_ok, mblock * Cfg::kBM, Cfg::kBM)) {
     for (int r = 0; r < RPW; ++r) {
-      const int slot = slot0 + r;
-      if (slot >= m) break;
-      const int row = row_indices[slot];
+      const int entry = dealt_index(slot0 + r, slots, kDealPer);
+      if (entry >= m) continue;
+      const int row = row_indices[entry];
       const float4 acc4 = gather_row_strip(values, column_indices, row_offsets[row],
                                            row_offsets[row + 1], dense + n0 + lane * VEC, n);
       *reinterpret_cast<float4*>(out + static_cast<int64_t>(row) * n + n0 + lane * VEC) =
@@ -315,9 +320,9 @@ __global__ __launch_bounds__(Cfg::kThreads) void spmm_tiled_kernel(
 
 #pragma unroll
   for (int r = 0; r < RPW; ++r) {
-    const int slot = slot0 + r;
-    if (slot < m) {
-      const int row = row_indices[slot];
+    const int entry = dealt_index(slot0 + r, slots, kDealPer);
+    if (entry < m) {
+      const int row = row_indices[entry];
       *reinterpret_cast<float4*>(out + static_cast<int64_t>(row) * n + n0 + lane * VEC) =
           apply_epilogue(make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]), epi, row);
     }
@@ -451,7 +456,7 @@ int spmm_tiled_plan(int m, int k, int n, int nonzeros, int replicas, const int* 
     int* row_ok = static_cast<int*>(workspace);
     int* table = reinterpret_cast<int*>(static_cast<char*>(workspace) + row_ok_bytes(plan.slots));
     hipLaunchKernelGGL((spmm_chunk_table_kernel<ilog2(Cfg::kBK)>), dim3(ceil_div(plan.slots, 4)),
-                       dim3(256), 0, stream, m, k, plan.slots, plan.nchunks, row_indices,
+                       dim3(256), 0, stream, m, k, plan.slots, kDealPer, plan.nchunks, row_indices,
                        row_offsets, column_indices, table, row_ok);
     const int st = launch_status();
     if (st != 0) return st;

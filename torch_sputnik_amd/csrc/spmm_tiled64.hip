@@ -87,9 +87,9 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled64_kernel(
   // order-independent path (B gathered from L2), one row per 16-lane group.
   if (!block_rows_ok(row_ok, mblock * kBM, kBM)) {
     for (int t = 0; t < kRQ; ++t) {
-      const int slot = slot0 + 4 * t + g;
-      if (slot < m) {
-        const int row = row_indices[slot];
+      const int entry = dealt_index(slot0 + 4 * t + g, slots, kBM);
+      if (entry < m) {
+        const int row = row_indices[entry];
         const float4 acc4 = gather_row_strip(values, column_indices, row_offsets[row],
                                              row_offsets[row + 1], dense + n0 + i * 4, n);
         *reinterpret_cast<float4*>(out + static_cast<int64_t>(row) * n + n0 + i * 4) =
@@ -192,9 +192,9 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled64_kernel(
 
 #pragma unroll
   for (int t = 0; t < kRQ; ++t) {
-    const int slot = slot0 + 4 * t + g;
-    if (slot < m) {
-      const int row = row_indices[slot];
+    const int entry = dealt_index(slot0 + 4 * t + g, slots, kBM);
+    if (entry < m) {
+      const int row = row_indices[entry];
       *reinterpret_cast<float4*>(out + static_cast<int64_t>(row) * n + n0 + i * 4) =
           apply_epilogue(make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]), epi, row);
     }
@@ -223,7 +223,7 @@ int spmm_tiled64_plan(int m, int k, const int* row_indices, const int* row_offse
   int* row_ok = static_cast<int*>(workspace);
   int* table = reinterpret_cast<int*>(static_cast<char*>(workspace) + row_ok_bytes(slots));
   hipLaunchKernelGGL((spmm_chunk_table_kernel<ilog2(kBK)>), dim3(ceil_div(slots, 4)), dim3(256),
-                     0, stream, m, k, slots, chunks_of(k), row_indices, row_offsets,
+                     0, stream, m, k, slots, kBM, chunks_of(k), row_indices, row_offsets,
                      column_indices, table, row_ok);
   return launch_status();
 }

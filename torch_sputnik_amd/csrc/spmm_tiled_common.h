@@ -21,23 +21,36 @@ inline size_t row_ok_bytes(int slots) { return (sizeof(int) * static_cast<size_t
 // ---------------------------------------------------------------------------
 // Pre-pass: chunk table + per-row order check.  One wave per row slot.
 // table[c * slots + slot], c in [0, nchunks]: index of the first nonzero of
-// row row_indices[slot] whose column is >= c*BK (row end if none).  Padding
-// slots (slot >= m) get 0 everywhere, i.e. empty rows.
+// the row in slot `slot` (see dealt_index) whose column is >= c*BK (row end if
+// none).  Padding slots get 0 everywhere, i.e. empty rows.
 // ---------------------------------------------------------------------------
+// Row slots are DEALT to workgroups: slot s holds entry
+// (s % per) * (slots / per) + s / per of `row_indices`, so that every run of
+// `per` consecutive slots (a workgroup's rows) takes every (slots/per)-th entry.
+// Callers pass row_indices sorted by row length (modules/spmm.py:4-6,
+// tests/sparse_matrix.py:22); contiguous blocks of that order would give the
+// first workgroup the longest rows and the last one the shortest (+-10 % of
+// work at 4096^2, density 0.1), and with about one workgroup per CU the launch
+// lasts as long as the slowest (measured 427 -> 408 us).  Entries >= m are padding.
+__device__ __forceinline__ int dealt_index(int slot, int slots, int per) {
+  return (slot % per) * (slots / per) + slot / per;
+}
+
 template <int BK_LOG2>
 __global__ __launch_bounds__(256) void spmm_chunk_table_kernel(
-    int m, int k, int slots, int nchunks, const int* __restrict__ row_indices,
+    int m, int k, int slots, int per, int nchunks, const int* __restrict__ row_indices,
     const int* __restrict__ row_offsets, const int* __restrict__ column_indices,
     int* __restrict__ table, int* __restrict__ row_ok) {
   const int lane = threadIdx.x % kWave;
   const int slot = blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
   if (slot >= slots) return;
-  if (slot >= m) {
+  const int entry = dealt_index(slot, slots, per);
+  if (entry >= m) {
     for (int c = lane; c <= nchunks; c += kWave) table[static_cast<int64_t>(c) * slots + slot] = 0;
     if (lane == 0) row_ok[slot] = 1;
     return;
   }
-  const int row = row_indices[slot];
+  const int row = row_indices[entry];
   const int p0 = row_offsets[row];
   const int p1 = row_offsets[row + 1];
   bool ok = true;
