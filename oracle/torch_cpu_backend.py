@@ -90,6 +90,23 @@ def _sparse_attention(q, k, v, row_indices, row_offsets, column_indices, scale):
                                    _np(column_indices), scale))
 
 
+def _sparse_attention_with_lse(q, k, v, row_indices, row_offsets, column_indices, scale):
+    out = _sparse_attention(q, k, v, row_indices, row_offsets, column_indices, scale)
+    qn, kn = _np(q).astype(np.float64), _np(k).astype(np.float64)
+    ro = _np(row_offsets).astype(np.int64)
+    scores = O.sddmm(qn.shape[-2], kn.shape[-2], _np(row_indices), ro, _np(column_indices), qn,
+                     kn) * scale
+    scores = scores.reshape(-1, scores.shape[-1])
+    lse = np.full((scores.shape[0], ro.shape[0] - 1), -np.inf)
+    for i in range(ro.shape[0] - 1):
+        if ro[i + 1] > ro[i]:
+            seg = scores[:, ro[i]:ro[i + 1]]
+            mx = seg.max(axis=1)
+            lse[:, i] = mx + np.log(np.exp(seg - mx[:, None]).sum(axis=1))
+    lse = lse if q.dim() == 3 else lse[0]
+    return [out, _f32(lse)]
+
+
 def _spmm_many_mask(b, m, k, nonzeros, values, row_indices, row_offsets, column_indices, dense):
     return _f32(O.spmm_many_mask(b, m, k, _np(nonzeros), _np(values), _np(row_indices),
                                  _np(row_offsets), _np(column_indices), _np(dense)))
@@ -141,6 +158,7 @@ def install():
     _lib.impl("sparse_softmax_scaled", _sparse_softmax_scaled, "CPU")
     _lib.impl("sparse_softmax_backward", _sparse_softmax_backward, "CPU")
     _lib.impl("sparse_attention", _sparse_attention, "CPU")
+    _lib.impl("sparse_attention_with_lse", _sparse_attention_with_lse, "CPU")
     _lib.impl("spmm_many_mask", _spmm_many_mask, "CPU")
     _lib.impl("sddmm_many_mask", _sddmm_many_mask, "CPU")
     _lib.impl("sparse_softmax_many_mask", _sparse_softmax_many_mask, "CPU")

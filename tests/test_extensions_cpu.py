@@ -189,3 +189,25 @@ def test_attention_module_fused_and_composed_paths_agree(cpu_ops):
         layer.fused_inference = False
         composed = layer(x, x, x)
     assert rel_err(fused.numpy(), composed.numpy()) < 1e-5
+
+
+def test_sparse_attention_function_matches_dense_autograd(cpu_ops):
+    from torch_sputnik_amd.functional import SparseAttentionFunction
+    rng = np.random.default_rng(21)
+    r, s, d = 2, 28, 8
+    mask = O.random_mask(s, s, 0.6, rng=rng) != 0
+    mask[3] = False
+    _, ri, ro, ci = O.dense_to_csr(mask.astype(np.float32))
+    topo = [torch.from_numpy(x) for x in (ri, ro, ci)]
+    q, k, v, go = (rng.uniform(-1, 1, (r, s, d)).astype(np.float32) for _ in range(4))
+    qt, kt, vt = (torch.from_numpy(x).requires_grad_(True) for x in (q, k, v))
+    out = SparseAttentionFunction.apply(qt, kt, vt, *topo, 0.3)
+    out.backward(torch.from_numpy(go))
+    qd, kd, vd = (torch.from_numpy(x).double().requires_grad_(True) for x in (q, k, v))
+    logits = (qd @ kd.transpose(1, 2) * 0.3).masked_fill(~torch.from_numpy(mask), float("-inf"))
+    w = torch.nan_to_num(torch.softmax(logits, -1))
+    dense = w @ vd
+    dense.backward(torch.from_numpy(go).double())
+    assert rel_err(out.detach().numpy(), dense.detach().numpy()) < 1e-5
+    for got, want in ((qt.grad, qd.grad), (kt.grad, kd.grad), (vt.grad, vd.grad)):
+        assert rel_err(got.numpy(), torch.nan_to_num(want).numpy()) < 2e-5

@@ -418,3 +418,30 @@ def test_many_mask_with_an_empty_mask(ts, dev):
     w_vt, w_rot, w_cit = O.csr_transpose_many_mask(b, s, s, nn, weights.cpu().numpy(), ro, ci)
     assert np.array_equal(rot.cpu().numpy(), w_rot) and np.array_equal(cit.cpu().numpy(), w_cit)
     assert np.array_equal(vt.cpu().numpy(), w_vt)
+
+
+def test_sparse_attention_function_gradients(ts, dev):
+    """Fused forward + recomputing backward against dense float64 autograd."""
+    from torch_sputnik_amd.functional import SparseAttentionFunction
+    rng = np.random.default_rng(31)
+    r, s, d = 4, 256, 64
+    mask = O.random_mask(s, s, 0.9, rng=rng) != 0
+    mask[9] = False
+    _, ri, ro, ci = O.dense_to_csr(mask.astype(np.float32))
+    topo = [T(x, dev) for x in (ri, ro, ci)]
+    q, k, v, go = (rng.uniform(-1, 1, (r, s, d)).astype(np.float32) for _ in range(4))
+    qt, kt, vt = (T(x, dev).requires_grad_(True) for x in (q, k, v))
+    scale = 0.125
+    out = SparseAttentionFunction.apply(qt, kt, vt, *topo, scale)
+    out.backward(T(go, dev))
+    qd, kd, vd = (torch.from_numpy(x).double().requires_grad_(True) for x in (q, k, v))
+    logits = (qd @ kd.transpose(1, 2) * scale).masked_fill(~torch.from_numpy(mask), float("-inf"))
+    dense = torch.nan_to_num(torch.softmax(logits, -1)) @ vd
+    dense.backward(torch.from_numpy(go).double())
+    assert rel_err(out.detach().cpu().numpy(), dense.detach().numpy()) < TOL
+    for got, want in ((qt.grad, qd.grad), (kt.grad, kd.grad), (vt.grad, vd.grad)):
+        assert rel_err(got.cpu().numpy(), torch.nan_to_num(want).numpy()) < TOL
+    # the op that also returns the log-sum-exp agrees with the plain one
+    o2, lse = ts.sparse_attention_with_lse(T(q, dev), T(k, dev), T(v, dev), *topo, scale)
+    assert torch.equal(o2, out.detach()) and lse.shape == (r, s)
+    assert torch.isneginf(lse[:, 9]).all() and torch.isfinite(lse[:, 10]).all()

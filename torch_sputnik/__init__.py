@@ -18,6 +18,7 @@ from torch_sputnik_amd.ops import (  # noqa: F401
     sddmm,
     sddmm_many_mask,
     sparse_attention,
+    sparse_attention_with_lse,
     sparse_softmax,
     sparse_softmax_backward,
     sparse_softmax_backward_many_mask,
@@ -33,4 +34,4 @@ __all__ = ["spmm", "left_spmm", "left_replicated_spmm", "sddmm", "sparse_softmax
            "csr_transpose", "csr_transpose_with_permutation", "spmm_bias", "spmm_bias_relu",
            "sparse_softmax_scaled", "sparse_softmax_backward", "spmm_many_mask",
            "sddmm_many_mask", "sparse_softmax_many_mask", "sparse_softmax_backward_many_mask",
-           "csr_transpose_many_mask", "sparse_attention"]
+           "csr_transpose_many_mask", "sparse_attention", "sparse_attention_with_lse"]

@@ -318,9 +318,11 @@ std::vector<Tensor> csr_transpose_with_permutation(int64_t m, int64_t n, const T
 // Fused softmax(scale * sddmm(q, k)) @ v over a fixed mask
 // (modules/sparse_attention.py:66-82).  q [R,m,d] / [m,d]; k, v [R,n,d] / [n,d].
 // Shapes the fused kernel does not serve are composed from the three operators.
-Tensor sparse_attention(const Tensor& q_in, const Tensor& k_in, const Tensor& v_in,
-                        const Tensor& row_indices, const Tensor& row_offsets,
-                        const Tensor& column_indices, double scale) {
+std::vector<Tensor> sparse_attention_impl(const Tensor& q_in, const Tensor& k_in,
+                                          const Tensor& v_in, const Tensor& row_indices,
+                                          const Tensor& row_offsets,
+                                          const Tensor& column_indices, double scale,
+                                          bool want_lse) {
   const Tensor q = as_float(q_in, "query");
   const Tensor k = as_float(k_in, "key");
   const Tensor v = as_float(v_in, "value");
@@ -338,12 +340,17 @@ Tensor sparse_attention(const Tensor& q_in, const Tensor& k_in, const Tensor& v_
   const Topology topo = check_topology(m, row_indices, row_offsets, column_indices, q);
 
   if (!sputnik_hip_sparse_attention_supported(m, n, d, topo.nonzeros)) {
+    TORCH_CHECK(!want_lse, "sparse_attention_with_lse: head dimension ", d,
+                " is not served by the fused kernel (64 is)");
     Tensor weights = sparse_softmax_scaled(
         sddmm(m, n, topo.row_indices, topo.row_offsets, topo.column_indices, q, k),
         topo.row_indices, topo.row_offsets, topo.column_indices, scale);
-    return spmm(m, n, weights, topo.row_indices, topo.row_offsets, topo.column_indices, v);
+    return {spmm(m, n, weights, topo.row_indices, topo.row_offsets, topo.column_indices, v)};
   }
   Tensor out = at::empty_like(q);
+  Tensor lse;
+  if (want_lse)
+    lse = q.dim() == 3 ? at::empty({replicas, m}, q.options()) : at::empty({m}, q.options());
   const size_t ws_bytes = sputnik_hip_sparse_attention_workspace_bytes(m, n, d, topo.nonzeros);
   Tensor workspace = at::empty({static_cast<int64_t>(ws_bytes)}, q.options().dtype(at::kByte));
   check_status(sputnik_hip_sparse_attention_forward(
@@ -352,10 +359,26 @@ Tensor sparse_attention(const Tensor& q_in, const Tensor& k_in, const Tensor& v_
                    q.data_ptr<float>(), static_cast<int64_t>(m) * d, k.data_ptr<float>(),
                    static_cast<int64_t>(n) * d, v.data_ptr<float>(), static_cast<int64_t>(n) * d,
                    static_cast<float>(scale), out.data_ptr<float>(),
-                   static_cast<int64_t>(m) * d, nullptr, 0, workspace.data_ptr(), ws_bytes,
-                   current_stream(q)),
+                   static_cast<int64_t>(m) * d, want_lse ? lse.data_ptr<float>() : nullptr, m,
+                   workspace.data_ptr(), ws_bytes, current_stream(q)),
                "sparse_attention");
-  return out;
+  if (want_lse) return {out, lse};
+  return {out};
+}
+
+Tensor sparse_attention(const Tensor& q, const Tensor& k, const Tensor& v,
+                        const Tensor& row_indices, const Tensor& row_offsets,
+                        const Tensor& column_indices, double scale) {
+  return sparse_attention_impl(q, k, v, row_indices, row_offsets, column_indices, scale, false)[0];
+}
+
+// {out, lse}: lse[r, i] = log sum_j exp(scale * <q_i, k_j>) over the stored j
+// (-inf for rows without entries), what a backward needs to rebuild the weights.
+std::vector<Tensor> sparse_attention_with_lse(const Tensor& q, const Tensor& k, const Tensor& v,
+                                              const Tensor& row_indices,
+                                              const Tensor& row_offsets,
+                                              const Tensor& column_indices, double scale) {
+  return sparse_attention_impl(q, k, v, row_indices, row_offsets, column_indices, scale, true);
 }
 
 Tensor spmm_bias(int64_t m, int64_t k, const Tensor& values, const Tensor& row_indices,
@@ -637,6 +660,9 @@ TORCH_LIBRARY(torch_sputnik, m) {
       "sparse_attention(Tensor query, Tensor key, Tensor value, Tensor row_indices, "
       "Tensor row_offsets, Tensor column_indices, float scale) -> Tensor");
   m.def(
+      "sparse_attention_with_lse(Tensor query, Tensor key, Tensor value, Tensor row_indices, "
+      "Tensor row_offsets, Tensor column_indices, float scale) -> Tensor[]");
+  m.def(
       "spmm_many_mask(int b, int m, int k, Tensor nonzeros, Tensor values, Tensor row_indices, "
       "Tensor row_offsets, Tensor column_indices, Tensor dense_matrix) -> Tensor");
   m.def(
@@ -669,6 +695,7 @@ TORCH_LIBRARY_IMPL(torch_sputnik, CUDA, m) {
   m.impl("sparse_softmax_scaled", &sparse_softmax_scaled);
   m.impl("sparse_softmax_backward", &sparse_softmax_backward);
   m.impl("sparse_attention", &sparse_attention);
+  m.impl("sparse_attention_with_lse", &sparse_attention_with_lse);
   m.impl("spmm_many_mask", &spmm_many_mask);
   m.impl("sddmm_many_mask", &sddmm_many_mask);
   m.impl("sparse_softmax_many_mask", &sparse_softmax_many_mask);

@@ -189,6 +189,54 @@ class SparseSoftmax(torch.autograd.Function):
         return grad_values, None, None, None, None
 
 
+class SparseAttentionFunction(torch.autograd.Function):
+    """softmax(scale * sddmm(q, k)) @ v with the ONE-kernel forward
+    (ops.sparse_attention) and a backward built from the separate operators.
+    Nothing of size [R, nnz] is kept between the passes: the backward recomputes
+    the weights (sddmm + scaled softmax) and then runs the standard chain
+
+        dV = P^T dO          dP = sddmm(dO, v)
+        dS = softmax'(P, dP) (sparse_softmax_backward, carries the scale)
+        dQ = dS k            dK = dS^T q
+
+    on the mask and its transpose (one csr_transpose with permutation per call,
+    or the cached transposed topology)."""
+
+    @staticmethod
+    def forward(ctx, query, key, value, row_indices, row_offsets, column_indices, scale):
+        out = ops.sparse_attention(query, key, value, row_indices, row_offsets, column_indices,
+                                   scale)
+        ctx.scale = float(scale)
+        ctx.save_for_backward(query, key, value, row_indices, row_offsets, column_indices)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        query, key, value, row_indices, row_offsets, column_indices = ctx.saved_tensors
+        topo = (row_indices, row_offsets, column_indices)
+        m, n = query.size(-2), key.size(-2)
+        grad_output = grad_output.contiguous()
+        scores = ops.sddmm(m, n, *topo, query, key)
+        weights = ops.sparse_softmax_scaled(scores, *topo, ctx.scale)
+        grad_weights = ops.sddmm(m, n, *topo, grad_output, value)
+        grad_scores = ops.sparse_softmax_backward(weights, grad_weights, row_offsets, ctx.scale)
+        grad_query = grad_key = grad_value = None
+        if ctx.needs_input_grad[0]:
+            grad_query = ops.spmm(m, n, grad_scores, *topo, key)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            grad_scores_t, row_offsets_t, column_indices_t, perm = \
+                ops.csr_transpose_with_permutation(m, n, grad_scores, row_offsets, column_indices)
+            row_indices_t = diffsort(row_offsets_t)
+            if ctx.needs_input_grad[1]:
+                grad_key = ops.spmm(n, m, grad_scores_t, row_indices_t, row_offsets_t,
+                                    column_indices_t, query)
+            if ctx.needs_input_grad[2]:
+                weights_t = weights.index_select(-1, perm.to(torch.int64))
+                grad_value = ops.spmm(n, m, weights_t, row_indices_t, row_offsets_t,
+                                      column_indices_t, grad_output)
+        return grad_query, grad_key, grad_value, None, None, None, None
+
+
 # ---------------------------------------------------------------------------
 # many-mask family: one mask per batch element, shared by its heads.  Same
 # ``apply`` signatures and gradient positions as the reference's sketches in

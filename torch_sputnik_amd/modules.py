@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .functional import Sddmm, SparseLinearFunction, SparseSoftmax, Spmm
+from .functional import SparseAttentionFunction, Sddmm, SparseLinearFunction, SparseSoftmax, Spmm
 from .topology import dense_to_sparse, generate_mask
 
 
@@ -57,7 +57,7 @@ class SparseAttention(nn.Module):
 
     def __init__(self, num_heads, embedding_size, max_sequence_length=512, device=None,
                  sparsity=0.9, mask_generator=None, differentiable_softmax=False,
-                 fused_inference=True):
+                 fused_inference=True, fused_training=False):
         super().__init__()
         assert embedding_size % num_heads == 0, \
             "Model dimension must be divisible by the number of heads."
@@ -77,6 +77,10 @@ class SparseAttention(nn.Module):
         self.differentiable_softmax = differentiable_softmax
         # forward-only calls (no gradient wanted) take the one-kernel attention
         self.fused_inference = fused_inference
+        # training through the fused forward: the weights are recomputed in the
+        # backward instead of being kept (and, unlike the reference's raw softmax
+        # call, the gradient reaches Q and K)
+        self.fused_training = fused_training
 
     def attention(self, query, key, value, mask):
         q3d = self.four_d_to_three_d(query)
@@ -89,6 +93,9 @@ class SparseAttention(nn.Module):
         if self.fused_inference and not needs_grad:
             return ops.sparse_attention(q3d, k3d, v3d, self.row_indices, self.row_offsets,
                                         self.column_indices, scale)
+        if self.fused_training:
+            return SparseAttentionFunction.apply(q3d, k3d, v3d, self.row_indices,
+                                                 self.row_offsets, self.column_indices, scale)
 
         # [B*H, nnz]: scores only at the mask's nonzeros
         scores = self.sddmm(self.m, self.n, self.row_indices, self.row_offsets,

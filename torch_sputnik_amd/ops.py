@@ -93,6 +93,13 @@ def sparse_attention(query, key, value, row_indices, row_offsets, column_indices
                                  float(scale))
 
 
+def sparse_attention_with_lse(query, key, value, row_indices, row_offsets, column_indices, scale):
+    """As sparse_attention, returning [out, lse]: lse[r, i] = log-sum-exp of row i's
+    scaled scores (-inf for rows without entries).  Head dimension 64 only."""
+    return _ops.sparse_attention_with_lse(query, key, value, row_indices, row_offsets,
+                                          column_indices, float(scale))
+
+
 def _counts(nonzeros):
     import torch
     return nonzeros if torch.is_tensor(nonzeros) else torch.tensor(list(nonzeros),
