@@ -114,7 +114,8 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
     float (&acc)[Cfg::kRPW][Cfg::kVec], float* __restrict__ tile0, int lane, int wave, int slot0,
     int slots, int nchunks, int nonzeros, int n, int k, int n0, const float* __restrict__ values,
     const int* __restrict__ column_indices, const int* __restrict__ table,
-    const float* __restrict__ dense, bool dbg_no_compute, bool dbg_no_stage) {
+    const float* __restrict__ dense, bool dbg_no_compute, bool dbg_no_stage,
+    bool dbg_no_barrier = false) {
   constexpr int BN = Cfg::kBN, BK = Cfg::kBK, RPW = Cfg::kRPW, VEC = Cfg::kVec;
   constexpr int S = Cfg::kStageRowsPerWave;
   constexpr int D = 8;  // windows in flight
@@ -243,7 +244,7 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
     s_ps = s_pe;
     s_pe = s_pe_next;
     wait_vm<kWaitStage>();  // next B tile landed; windows and positions stay in flight
-    __syncthreads();
+    if (!dbg_no_barrier) __syncthreads();
   }
   wait_vm<0>();  // nothing may be in flight (LDS-DMA!) when the wave ends
 }
@@ -261,6 +262,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void spmm_tiled_kernel(
     const int* __restrict__ row_offsets, int debug, Epilogue epi) {
   // Timing experiments only (SPUTNIK_HIP_SPMM_DEBUG): 1 = no compute, 2 = no staging.
   const bool dbg_no_compute = debug & 1, dbg_no_stage = debug & 2;
+  const bool dbg_no_barrier = debug & 4;  // wrong results: how much the per-chunk rendezvous costs
 
   constexpr int BN = Cfg::kBN, BK = Cfg::kBK, RPW = Cfg::kRPW, VEC = Cfg::kVec;
   static_assert(BK <= kWave, "a row has at most BK <= 64 entries per chunk (one window)");
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void spmm_tiled_kernel(
   {
     spmm_tiled_body_dpp<Cfg, SPARSE>(acc, &tile[0][0], lane, wave, slot0, slots, nchunks, nonzeros, n, k,
                              n0, values, column_indices, table, dense, dbg_no_compute,
-                             dbg_no_stage);
+                             dbg_no_stage, dbg_no_barrier);
   }
 
 #pragma unroll
