@@ -392,6 +392,14 @@ def main():
                     del p
             result["sweep"] = sweep
             result["other_ops"] = other_ops(dev)
+            # the same headline call WITH output / workspace allocation, i.e.
+            # through the reference-compatible torch op (src/spmm_cuda.cu:9-60 semantics)
+            import torch_sputnik
+            ms_op = event_time_ms(lambda: torch_sputnik.spmm(M, K, problem.values, problem.ri,
+                                                             problem.ro, problem.ci, problem.dense), 20)
+            result["other_ops"]["spmm_c2_d010_via_torch_op"] = {
+                "ms": ms_op, "gflops": problem.flops / ms_op / 1e6,
+                "note": "allocates C and the workspace per call (caching allocator)"}
             result["cpu_baseline"] = cpu_baseline(problem)
         elif n_gpus == 1:
             result["cpu_baseline"] = None
