@@ -129,6 +129,21 @@ SPUTNIK_HIP_API int sputnik_hip_sddmm_batched(int m, int k, int n, int nonzeros,
                               int64_t out_stride, void* workspace,
                               size_t workspace_bytes, sputnik_hip_stream_t stream);
 
+/* Two-step form for static masks (as sputnik_hip_spmm_plan): `plan` runs the
+ * topology-only pre-pass into the workspace once, `batched_planned` reuses it.
+ * No counterpart in the reference (src/sddmm_cuda.cu:45-54 re-derives per call). */
+SPUTNIK_HIP_API int sputnik_hip_sddmm_plan(int m, int k, int n, int nonzeros,
+                              const int* row_indices, const int* row_offsets,
+                              const int* column_indices, void* workspace,
+                              size_t workspace_bytes, sputnik_hip_stream_t stream);
+
+SPUTNIK_HIP_API int sputnik_hip_sddmm_batched_planned(int m, int k, int n, int nonzeros,
+                              int replicas, const int* row_indices, const int* row_offsets,
+                              const int* column_indices, const float* lhs,
+                              int64_t lhs_stride, const float* rhs, int64_t rhs_stride,
+                              float* out, int64_t out_stride, const void* workspace,
+                              size_t workspace_bytes, sputnik_hip_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Sparse softmax: per CSR row, exp(x - max) / sum(exp(x - max)) over the
  * stored entries.  `n` is unused (the reference passes -1,
@@ -240,6 +255,20 @@ SPUTNIK_HIP_API int sputnik_hip_sparse_attention_forward(int m, int n, int d, in
                              const float* k, int64_t k_stride, const float* v,
                              int64_t v_stride, float scale, float* out, int64_t out_stride,
                              float* lse, int64_t lse_stride, void* workspace,
+                             size_t workspace_bytes, sputnik_hip_stream_t stream);
+
+/* The same in two steps for a static mask: plan once, run any number of times. */
+SPUTNIK_HIP_API int sputnik_hip_sparse_attention_plan(int m, int n, int d, int nonzeros,
+                             const int* row_indices, const int* row_offsets,
+                             const int* column_indices, void* workspace,
+                             size_t workspace_bytes, sputnik_hip_stream_t stream);
+
+SPUTNIK_HIP_API int sputnik_hip_sparse_attention_forward_planned(int m, int n, int d,
+                             int nonzeros, int replicas, const int* row_indices,
+                             const int* row_offsets, const int* column_indices, const float* q,
+                             int64_t q_stride, const float* k, int64_t k_stride, const float* v,
+                             int64_t v_stride, float scale, float* out, int64_t out_stride,
+                             float* lse, int64_t lse_stride, const void* workspace,
                              size_t workspace_bytes, sputnik_hip_stream_t stream);
 
 /* ------------------------------------------------------------------------

@@ -139,6 +139,26 @@ def _csr_transpose_many_mask(b, m, n, nonzeros, values, row_offsets, column_indi
     return [_f32(v), torch.from_numpy(ro), torch.from_numpy(ci)]
 
 
+def _plan(*_args):
+    return torch.zeros(16, dtype=torch.uint8)  # the CPU checker has nothing to pre-compute
+
+
+def _spmm_planned(m, k, values, row_indices, row_offsets, column_indices, dense, plan):
+    return _spmm(m, k, values, row_indices, row_offsets, column_indices, dense)
+
+
+def _left_spmm_planned(m, k, values, row_indices, row_offsets, column_indices, dense, plan):
+    return _left_spmm(m, k, values, row_indices, row_offsets, column_indices, dense)
+
+
+def _sddmm_planned(m, n, row_indices, row_offsets, column_indices, lhs, rhs, plan):
+    return _sddmm(m, n, row_indices, row_offsets, column_indices, lhs, rhs)
+
+
+def _sparse_attention_planned(q, k, v, row_indices, row_offsets, column_indices, scale, plan):
+    return _sparse_attention(q, k, v, row_indices, row_offsets, column_indices, scale)
+
+
 def install():
     """Idempotent.  Needs the product's op schemas, so it imports the package
     (which loads the native libraries; no GPU is touched)."""
@@ -159,6 +179,13 @@ def install():
     _lib.impl("sparse_softmax_backward", _sparse_softmax_backward, "CPU")
     _lib.impl("sparse_attention", _sparse_attention, "CPU")
     _lib.impl("sparse_attention_with_lse", _sparse_attention_with_lse, "CPU")
+    _lib.impl("spmm_plan", _plan, "CPU")
+    _lib.impl("sddmm_plan", _plan, "CPU")
+    _lib.impl("sparse_attention_plan", _plan, "CPU")
+    _lib.impl("spmm_planned", _spmm_planned, "CPU")
+    _lib.impl("left_spmm_planned", _left_spmm_planned, "CPU")
+    _lib.impl("sddmm_planned", _sddmm_planned, "CPU")
+    _lib.impl("sparse_attention_planned", _sparse_attention_planned, "CPU")
     _lib.impl("spmm_many_mask", _spmm_many_mask, "CPU")
     _lib.impl("sddmm_many_mask", _sddmm_many_mask, "CPU")
     _lib.impl("sparse_softmax_many_mask", _sparse_softmax_many_mask, "CPU")

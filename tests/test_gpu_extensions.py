@@ -445,3 +445,61 @@ def test_sparse_attention_function_gradients(ts, dev):
     o2, lse = ts.sparse_attention_with_lse(T(q, dev), T(k, dev), T(v, dev), *topo, scale)
     assert torch.equal(o2, out.detach()) and lse.shape == (r, s)
     assert torch.isneginf(lse[:, 9]).all() and torch.isfinite(lse[:, 10]).all()
+
+
+# ----------------------------------------------------------------------------
+# static topologies: plan once, run many times
+# ----------------------------------------------------------------------------
+@pytest.mark.parametrize("m,k,n,replicas", [(512, 512, 256, 8), (256, 300, 64, 4), (100, 64, 18, 2),
+                                            (2048, 2048, 256, 4)])
+def test_planned_ops_equal_the_per_call_ops(ts, dev, spmm_kernel, sddmm_kernel, m, k, n, replicas):
+    rng = np.random.default_rng(m + n)
+    _, vals, ri, ro, ci = make_csr(m, k, 0.8, seed=m, order="ascending")
+    topo = [T(x, dev) for x in (ri, ro, ci)]
+    b = T(rng.uniform(-1, 1, (replicas, k, n)).astype(np.float32), dev)
+    v = T(rng.uniform(-1, 1, (replicas, len(ci))).astype(np.float32), dev)
+    plan = ts.spmm_plan(m, k, n, *topo)
+    for _ in range(2):  # a plan is reusable
+        assert torch.equal(ts.spmm_planned(m, k, v, *topo, b, plan), ts.spmm(m, k, v, *topo, b))
+    assert torch.equal(ts.left_spmm_planned(m, k, v[0].contiguous(), *topo, b, plan),
+                       ts.left_spmm(m, k, v[0].contiguous(), *topo, b))
+    for kk in (64, 40):
+        lhs = T(rng.uniform(-1, 1, (replicas, m, kk)).astype(np.float32), dev)
+        rhs = T(rng.uniform(-1, 1, (replicas, k, kk)).astype(np.float32), dev)
+        splan = ts.sddmm_plan(m, k, kk, *topo)
+        assert torch.equal(ts.sddmm_planned(m, k, *topo, lhs, rhs, splan),
+                           ts.sddmm(m, k, *topo, lhs, rhs))
+    from torch_sputnik_amd import capi
+    if capi.spmm_workspace_bytes(m, k, n, len(ci)) > 4:
+        with pytest.raises(RuntimeError):  # a plan made for other sizes is refused
+            ts.spmm_planned(m, k, v, *topo, b, torch.zeros(4, dtype=torch.uint8, device=dev))
+
+
+def test_planned_attention_and_modules(ts, dev):
+    from torch_sputnik_amd.modules import SparseAttention
+    rng = np.random.default_rng(8)
+    m = n = 256
+    _, _, ri, ro, ci = make_csr(m, n, 0.9, seed=2, order="ascending")
+    topo = [T(x, dev) for x in (ri, ro, ci)]
+    for d in (64, 32):
+        q, k, v = (T(rng.uniform(-1, 1, (6, m, d)).astype(np.float32), dev) for _ in range(3))
+        plan = ts.sparse_attention_plan(m, n, d, *topo)
+        for _ in range(2):
+            assert torch.equal(ts.sparse_attention_planned(q, k, v, *topo, 0.2, plan),
+                               ts.sparse_attention(q, k, v, *topo, 0.2))
+    torch.manual_seed(0)
+    layer = SparseAttention(num_heads=2, embedding_size=128, max_sequence_length=256, device=dev,
+                            sparsity=0.9, mask_generator=np.random.default_rng(5))
+    for lin in layer.linears:
+        lin.weight = torch.nn.Parameter(torch.randn(128, 128, device=dev) *
+                                        (torch.rand(128, 128, device=dev) < 0.3))
+        lin.setup_sparse_tensors()
+    x = torch.randn(3, 256, 128, device=dev)
+    with torch.no_grad():
+        first = layer(x, x, x)     # builds the plans
+        second = layer(x, x, x)    # reuses them
+        assert len(layer.linears[0]._plans) == 1 and layer._attention_plan is not None
+    assert torch.equal(first, second)
+    # the differentiable path (per-call pre-passes, separate operators) agrees
+    y = layer(x.requires_grad_(True), x, x)
+    assert rel_err(y.detach().cpu().numpy(), first.cpu().numpy()) < TOL

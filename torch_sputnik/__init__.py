@@ -17,7 +17,11 @@ from torch_sputnik_amd.ops import (  # noqa: F401
     left_spmm,
     sddmm,
     sddmm_many_mask,
+    sddmm_plan,
+    sddmm_planned,
     sparse_attention,
+    sparse_attention_plan,
+    sparse_attention_planned,
     sparse_attention_with_lse,
     sparse_softmax,
     sparse_softmax_backward,
@@ -28,10 +32,15 @@ from torch_sputnik_amd.ops import (  # noqa: F401
     spmm_bias,
     spmm_bias_relu,
     spmm_many_mask,
+    spmm_plan,
+    spmm_planned,
+    left_spmm_planned,
 )
 
 __all__ = ["spmm", "left_spmm", "left_replicated_spmm", "sddmm", "sparse_softmax",
            "csr_transpose", "csr_transpose_with_permutation", "spmm_bias", "spmm_bias_relu",
            "sparse_softmax_scaled", "sparse_softmax_backward", "spmm_many_mask",
            "sddmm_many_mask", "sparse_softmax_many_mask", "sparse_softmax_backward_many_mask",
-           "csr_transpose_many_mask", "sparse_attention", "sparse_attention_with_lse"]
+           "csr_transpose_many_mask", "sparse_attention", "sparse_attention_with_lse", "spmm_plan", "spmm_planned",
+           "left_spmm_planned", "sddmm_plan", "sddmm_planned", "sparse_attention_plan",
+           "sparse_attention_planned"]

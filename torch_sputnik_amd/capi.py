@@ -36,6 +36,10 @@ SIGNATURES = {
     "sputnik_hip_sddmm_batched": (_c_int, [_c_int] * 5 + [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64,
                                                          _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr,
                                                          _c_size, _c_ptr]),
+    "sputnik_hip_sddmm_plan": (_c_int, [_c_int] * 4 + [_c_ptr] * 4 + [_c_size, _c_ptr]),
+    "sputnik_hip_sddmm_batched_planned": (_c_int, [_c_int] * 5 + [_c_ptr, _c_ptr, _c_ptr, _c_ptr,
+                                                                 _c_i64, _c_ptr, _c_i64, _c_ptr,
+                                                                 _c_i64, _c_ptr, _c_size, _c_ptr]),
     "sputnik_hip_sparse_softmax": (_c_int, [_c_int] * 3 + [_c_ptr] * 6),
     "sputnik_hip_sparse_softmax_batched": (_c_int, [_c_int] * 4 + [_c_ptr, _c_i64, _c_ptr, _c_ptr,
                                                                   _c_ptr, _c_ptr, _c_i64, _c_ptr]),
@@ -54,6 +58,10 @@ SIGNATURES = {
     "sputnik_hip_sparse_attention_supported": (_c_int, [_c_int] * 4),
     "sputnik_hip_sparse_attention_workspace_bytes": (_c_size, [_c_int] * 4),
     "sputnik_hip_sparse_attention_forward": (_c_int, [_c_int] * 5 + [
+        _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_float, _c_ptr,
+        _c_i64, _c_ptr, _c_i64, _c_ptr, _c_size, _c_ptr]),
+    "sputnik_hip_sparse_attention_plan": (_c_int, [_c_int] * 4 + [_c_ptr] * 4 + [_c_size, _c_ptr]),
+    "sputnik_hip_sparse_attention_forward_planned": (_c_int, [_c_int] * 5 + [
         _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_float, _c_ptr,
         _c_i64, _c_ptr, _c_i64, _c_ptr, _c_size, _c_ptr]),
     "sputnik_hip_spmm_many_mask": (_c_int, [_c_int] * 4 + [_c_ptr, _c_int, _c_ptr, _c_ptr, _c_i64,
@@ -356,4 +364,42 @@ def sparse_attention_forward(m, n, d, replicas, row_indices, row_offsets, column
         _ptr(q), m * d, _ptr(k), n * d, _ptr(v), n * d, float(scale), _ptr(out), m * d, _ptr(lse),
         m, _ptr(workspace), _ws_bytes(workspace), _stream(out)),
         "sputnik_hip_sparse_attention_forward")
+    return out
+
+
+def sddmm_plan(m, k, n, row_indices, row_offsets, column_indices, workspace):
+    """Topology-only pre-pass of the tiled SDDMM kernels into `workspace`."""
+    _check(lib().sputnik_hip_sddmm_plan(m, k, n, column_indices.numel(), _ptr(row_indices),
+                                        _ptr(row_offsets), _ptr(column_indices), _ptr(workspace),
+                                        _ws_bytes(workspace), _stream(row_offsets)),
+           "sputnik_hip_sddmm_plan")
+    return workspace
+
+
+def sddmm_batched_planned(m, k, n, replicas, row_indices, row_offsets, column_indices, lhs, rhs,
+                          out, workspace):
+    nonzeros = column_indices.numel()
+    _check(lib().sputnik_hip_sddmm_batched_planned(
+        m, k, n, nonzeros, replicas, _ptr(row_indices), _ptr(row_offsets), _ptr(column_indices),
+        _ptr(lhs), m * k, _ptr(rhs), n * k, _ptr(out), nonzeros, _ptr(workspace),
+        _ws_bytes(workspace), _stream(out)), "sputnik_hip_sddmm_batched_planned")
+    return out
+
+
+def sparse_attention_plan(m, n, d, row_indices, row_offsets, column_indices, workspace):
+    _check(lib().sputnik_hip_sparse_attention_plan(
+        m, n, d, column_indices.numel(), _ptr(row_indices), _ptr(row_offsets),
+        _ptr(column_indices), _ptr(workspace), _ws_bytes(workspace), _stream(row_offsets)),
+        "sputnik_hip_sparse_attention_plan")
+    return workspace
+
+
+def sparse_attention_forward_planned(m, n, d, replicas, row_indices, row_offsets, column_indices,
+                                     q, k, v, scale, out, lse, workspace):
+    nonzeros = column_indices.numel()
+    _check(lib().sputnik_hip_sparse_attention_forward_planned(
+        m, n, d, nonzeros, replicas, _ptr(row_indices), _ptr(row_offsets), _ptr(column_indices),
+        _ptr(q), m * d, _ptr(k), n * d, _ptr(v), n * d, float(scale), _ptr(out), m * d, _ptr(lse),
+        m, _ptr(workspace), _ws_bytes(workspace), _stream(out)),
+        "sputnik_hip_sparse_attention_forward_planned")
     return out

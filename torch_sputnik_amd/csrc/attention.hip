@@ -297,14 +297,14 @@ size_t sputnik_hip_sparse_attention_workspace_bytes(int m, int n, int d, int non
          sizeof(int) * static_cast<size_t>(chunks_of(n) + 1) * slots_of(m);
 }
 
-int sputnik_hip_sparse_attention_forward(int m, int n, int d, int nonzeros, int replicas,
-                                         const int* row_indices, const int* row_offsets,
-                                         const int* column_indices, const float* q,
-                                         int64_t q_stride, const float* k, int64_t k_stride,
-                                         const float* v, int64_t v_stride, float scale,
-                                         float* out, int64_t out_stride, float* lse,
-                                         int64_t lse_stride, void* workspace,
-                                         size_t workspace_bytes, sputnik_hip_stream_t stream) {
+namespace {
+
+int attention_exec(int m, int n, int d, int nonzeros, int replicas, const int* row_indices,
+                   const int* row_offsets, const int* column_indices, const float* q,
+                   int64_t q_stride, const float* k, int64_t k_stride, const float* v,
+                   int64_t v_stride, float scale, float* out, int64_t out_stride, float* lse,
+                   int64_t lse_stride, void* workspace, size_t workspace_bytes, bool planned,
+                   hipStream_t stream) {
   if (m < 0 || n < 0 || d < 0 || nonzeros < 0 || replicas < 0) return SPUTNIK_HIP_INVALID_ARGUMENT;
   if (m == 0 || replicas == 0) return 0;
   if (nonzeros == 0 || n == 0) {  // every row is empty: zeros (and -inf log-sum-exp)
@@ -329,11 +329,14 @@ int sputnik_hip_sparse_attention_forward(int m, int n, int d, int nonzeros, int 
   const int slots = slots_of(m), nchunks = chunks_of(n);
   int* row_ok = static_cast<int*>(workspace);
   int* table = reinterpret_cast<int*>(static_cast<char*>(workspace) + row_ok_bytes(slots));
-  hipLaunchKernelGGL((spmm_chunk_table_kernel<ilog2(kBK)>), dim3(ceil_div(slots, 4)), dim3(256),
-                     0, stream, m, n, slots, kBM, nchunks, row_indices, row_offsets, column_indices,
-                     table, row_ok);
-  int st = launch_status();
-  if (st != 0) return st;
+  int st = 0;
+  if (!planned) {
+    hipLaunchKernelGGL((spmm_chunk_table_kernel<ilog2(kBK)>), dim3(ceil_div(slots, 4)),
+                       dim3(256), 0, stream, m, n, slots, kBM, nchunks, row_indices, row_offsets,
+                       column_indices, table, row_ok);
+    st = launch_status();
+    if (st != 0) return st;
+  }
   for (int r0 = 0; r0 < replicas; r0 += kMaxGridYZ) {
     const int ry = min(replicas - r0, kMaxGridYZ);
     hipLaunchKernelGGL(sparse_attention_kernel, dim3(slots / kBM, ry), dim3(kThreads), 0, stream,
@@ -345,6 +348,51 @@ int sputnik_hip_sparse_attention_forward(int m, int n, int d, int nonzeros, int 
     if (st != 0) return st;
   }
   return 0;
+}
+
+}  // namespace
+
+int sputnik_hip_sparse_attention_forward(int m, int n, int d, int nonzeros, int replicas,
+                                         const int* row_indices, const int* row_offsets,
+                                         const int* column_indices, const float* q,
+                                         int64_t q_stride, const float* k, int64_t k_stride,
+                                         const float* v, int64_t v_stride, float scale,
+                                         float* out, int64_t out_stride, float* lse,
+                                         int64_t lse_stride, void* workspace,
+                                         size_t workspace_bytes, sputnik_hip_stream_t stream) {
+  return attention_exec(m, n, d, nonzeros, replicas, row_indices, row_offsets, column_indices, q,
+                        q_stride, k, k_stride, v, v_stride, scale, out, out_stride, lse,
+                        lse_stride, workspace, workspace_bytes, /*planned=*/false, stream);
+}
+
+int sputnik_hip_sparse_attention_plan(int m, int n, int d, int nonzeros, const int* row_indices,
+                                      const int* row_offsets, const int* column_indices,
+                                      void* workspace, size_t workspace_bytes,
+                                      sputnik_hip_stream_t stream) {
+  if (m < 0 || n < 0 || d < 0 || nonzeros < 0) return SPUTNIK_HIP_INVALID_ARGUMENT;
+  if (!supported(m, n, d, nonzeros)) return SPUTNIK_HIP_UNSUPPORTED;
+  if (workspace == nullptr || !aligned_to(workspace, 16) ||
+      workspace_bytes < sputnik_hip_sparse_attention_workspace_bytes(m, n, d, nonzeros))
+    return SPUTNIK_HIP_INVALID_ARGUMENT;
+  const int slots = slots_of(m);
+  int* row_ok = static_cast<int*>(workspace);
+  int* table = reinterpret_cast<int*>(static_cast<char*>(workspace) + row_ok_bytes(slots));
+  hipLaunchKernelGGL((spmm_chunk_table_kernel<ilog2(kBK)>), dim3(ceil_div(slots, 4)), dim3(256),
+                     0, stream, m, n, slots, kBM, chunks_of(n), row_indices, row_offsets,
+                     column_indices, table, row_ok);
+  return launch_status();
+}
+
+int sputnik_hip_sparse_attention_forward_planned(
+    int m, int n, int d, int nonzeros, int replicas, const int* row_indices,
+    const int* row_offsets, const int* column_indices, const float* q, int64_t q_stride,
+    const float* k, int64_t k_stride, const float* v, int64_t v_stride, float scale, float* out,
+    int64_t out_stride, float* lse, int64_t lse_stride, const void* workspace,
+    size_t workspace_bytes, sputnik_hip_stream_t stream) {
+  return attention_exec(m, n, d, nonzeros, replicas, row_indices, row_offsets, column_indices, q,
+                        q_stride, k, k_stride, v, v_stride, scale, out, out_stride, lse,
+                        lse_stride, const_cast<void*>(workspace), workspace_bytes,
+                        /*planned=*/true, stream);
 }
 
 }  // extern "C"

@@ -21,10 +21,12 @@ namespace sputnik_hip {
 bool sddmm_tiled_applicable(int m, int k, int n, int nonzeros, const float* lhs,
                             int64_t lhs_stride, const float* rhs, int64_t rhs_stride);
 size_t sddmm_tiled_workspace_bytes(int m, int k, int n, int nonzeros);
+int sddmm_tiled_plan(int m, int k, int n, const int* row_indices, const int* row_offsets,
+                     const int* column_indices, void* workspace, hipStream_t stream);
 int sddmm_tiled_launch(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
                        const int* row_offsets, const int* column_indices, const float* lhs,
                        int64_t lhs_stride, const float* rhs, int64_t rhs_stride, float* out,
-                       int64_t out_stride, void* workspace, hipStream_t stream);
+                       int64_t out_stride, const void* workspace, hipStream_t stream);
 
 namespace {
 
@@ -152,12 +154,33 @@ size_t sputnik_hip_sddmm_workspace_bytes(int m, int k, int n, int nonzeros) {
   return sddmm_tiled_workspace_bytes(m, k, n, nonzeros);
 }
 
-int sputnik_hip_sddmm_batched(int m, int k, int n, int nonzeros, int replicas,
-                              const int* row_indices, const int* row_offsets,
-                              const int* column_indices, const float* lhs, int64_t lhs_stride,
-                              const float* rhs, int64_t rhs_stride, float* out,
-                              int64_t out_stride, void* workspace, size_t workspace_bytes,
-                              sputnik_hip_stream_t stream) {
+namespace {
+
+// Does this call take the LDS-tiled kernels?  Small calls are launch-latency
+// bound: the row-wave kernel is one launch, the tiled path a pre-pass plus a
+// kernel that first stages its slab.  Measured cross-over
+// (tools/small_sddmm.py): about 2.7e8 multiply-adds at k = 64, 1.3e8 at k =
+// 128, 3e7 at k = 512, i.e. nnz * k^2 * replicas ~ 2^34.
+// Test knob SPUTNIK_HIP_SDDMM_KERNEL (read per call): "tiled" / "wave".
+bool takes_tiled(int m, int k, int n, int nonzeros, int replicas /* < 0: unknown */,
+                 const float* lhs, int64_t lhs_stride, const float* rhs, int64_t rhs_stride,
+                 const void* workspace, size_t workspace_bytes) {
+  const char* forced = getenv("SPUTNIK_HIP_SDDMM_KERNEL");
+  const bool force_tiled = forced != nullptr && forced[0] == 't';
+  const bool force_wave = forced != nullptr && forced[0] == 'w';
+  const bool small = replicas >= 0 &&
+                     static_cast<double>(nonzeros) * k * k * replicas < 17179869184.0;  // 2^34
+  return !force_wave && (force_tiled || !small) && workspace != nullptr &&
+         aligned_to(workspace, 16) &&
+         sddmm_tiled_applicable(m, k, n, nonzeros, lhs, lhs_stride, rhs, rhs_stride) &&
+         workspace_bytes >= sddmm_tiled_workspace_bytes(m, k, n, nonzeros);
+}
+
+int sddmm_exec(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
+               const int* row_offsets, const int* column_indices, const float* lhs,
+               int64_t lhs_stride, const float* rhs, int64_t rhs_stride, float* out,
+               int64_t out_stride, void* workspace, size_t workspace_bytes, bool planned,
+               hipStream_t stream) {
   if (m < 0 || k < 0 || n < 0 || nonzeros < 0 || replicas < 0) return SPUTNIK_HIP_INVALID_ARGUMENT;
   if (m == 0 || nonzeros == 0 || replicas == 0) return 0;
   if (k == 0) {
@@ -168,22 +191,17 @@ int sputnik_hip_sddmm_batched(int m, int k, int n, int nonzeros, int replicas,
     }
     return 0;
   }
-  // Small calls are launch-latency bound: the row-wave kernel is one launch,
-  // the tiled path a pre-pass plus a kernel that first stages its slab.
-  // Measured cross-over (tools/small_sddmm.py): about 2.7e8 multiply-adds at
-  // k = 64, 1.3e8 at k = 128, 3e7 at k = 512, i.e. nnz * k^2 * replicas ~ 2^34.
-  // Test knob SPUTNIK_HIP_SDDMM_KERNEL (read per call): "tiled" / "wave".
-  const char* forced = getenv("SPUTNIK_HIP_SDDMM_KERNEL");
-  const bool force_tiled = forced != nullptr && forced[0] == 't';
-  const bool force_wave = forced != nullptr && forced[0] == 'w';
-  const bool small = static_cast<double>(nonzeros) * k * k * replicas < 17179869184.0;  // 2^34
-  if (!force_wave && (force_tiled || !small) && workspace != nullptr &&
-      aligned_to(workspace, 16) &&
-      sddmm_tiled_applicable(m, k, n, nonzeros, lhs, lhs_stride, rhs, rhs_stride) &&
-      workspace_bytes >= sddmm_tiled_workspace_bytes(m, k, n, nonzeros))
+  if (takes_tiled(m, k, n, nonzeros, replicas, lhs, lhs_stride, rhs, rhs_stride, workspace,
+                  workspace_bytes)) {
+    if (!planned) {
+      const int st = sddmm_tiled_plan(m, k, n, row_indices, row_offsets, column_indices,
+                                      workspace, stream);
+      if (st != 0) return st;
+    }
     return sddmm_tiled_launch(m, k, n, nonzeros, replicas, row_indices, row_offsets,
                               column_indices, lhs, lhs_stride, rhs, rhs_stride, out, out_stride,
                               workspace, stream);
+  }
   int vec = vector_width(lhs, k, lhs_stride);
   vec = min(vec, vector_width(rhs, k, rhs_stride));
   switch (vec) {
@@ -197,6 +215,43 @@ int sputnik_hip_sddmm_batched(int m, int k, int n, int nonzeros, int replicas,
       return launch_vec<1>(m, k, replicas, row_indices, row_offsets, column_indices, lhs,
                            lhs_stride, rhs, rhs_stride, out, out_stride, stream);
   }
+}
+
+}  // namespace
+
+int sputnik_hip_sddmm_batched(int m, int k, int n, int nonzeros, int replicas,
+                              const int* row_indices, const int* row_offsets,
+                              const int* column_indices, const float* lhs, int64_t lhs_stride,
+                              const float* rhs, int64_t rhs_stride, float* out,
+                              int64_t out_stride, void* workspace, size_t workspace_bytes,
+                              sputnik_hip_stream_t stream) {
+  return sddmm_exec(m, k, n, nonzeros, replicas, row_indices, row_offsets, column_indices, lhs,
+                    lhs_stride, rhs, rhs_stride, out, out_stride, workspace, workspace_bytes,
+                    /*planned=*/false, stream);
+}
+
+int sputnik_hip_sddmm_plan(int m, int k, int n, int nonzeros, const int* row_indices,
+                           const int* row_offsets, const int* column_indices, void* workspace,
+                           size_t workspace_bytes, sputnik_hip_stream_t stream) {
+  if (m < 0 || k < 0 || n < 0 || nonzeros < 0) return SPUTNIK_HIP_INVALID_ARGUMENT;
+  if (m == 0 || nonzeros == 0 || k == 0) return 0;
+  // operand alignment is checked again by the planned call; here only the shape matters
+  if (workspace == nullptr || !aligned_to(workspace, 16) ||
+      sddmm_tiled_workspace_bytes(m, k, n, nonzeros) == 0 ||
+      workspace_bytes < sddmm_tiled_workspace_bytes(m, k, n, nonzeros))
+    return 0;  // nothing to plan: the row-wave kernel needs no workspace
+  return sddmm_tiled_plan(m, k, n, row_indices, row_offsets, column_indices, workspace, stream);
+}
+
+int sputnik_hip_sddmm_batched_planned(int m, int k, int n, int nonzeros, int replicas,
+                                      const int* row_indices, const int* row_offsets,
+                                      const int* column_indices, const float* lhs,
+                                      int64_t lhs_stride, const float* rhs, int64_t rhs_stride,
+                                      float* out, int64_t out_stride, const void* workspace,
+                                      size_t workspace_bytes, sputnik_hip_stream_t stream) {
+  return sddmm_exec(m, k, n, nonzeros, replicas, row_indices, row_offsets, column_indices, lhs,
+                    lhs_stride, rhs, rhs_stride, out, out_stride, const_cast<void*>(workspace),
+                    workspace_bytes, /*planned=*/true, stream);
 }
 
 int sputnik_hip_sddmm(int m, int k, int n, int nonzeros, const int* row_indices,

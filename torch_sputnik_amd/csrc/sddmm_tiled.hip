@@ -267,21 +267,26 @@ inline int slab_rows(int k) {
   return (w <= 128 ? 64 * 1024 : 128 * 1024) / (w * 4);
 }
 
+// The chunk table is the SpMM one with the mask's columns (n) in the role of k,
+// cut at slab boundaries.  Topology only: a caller with a static mask runs it once.
+template <int KV>
+int plan(int m, int n, int slots, const int* row_indices, const int* row_offsets,
+         const int* column_indices, int* table, int* row_ok, hipStream_t stream) {
+  using S = Slab<KV>;
+  hipLaunchKernelGGL((spmm_chunk_table_kernel<ilog2(S::kRows)>), dim3(ceil_div(slots, 4)),
+                     dim3(256), 0, stream, m, n, slots, kSGroups * kSRows, ceil_div(n, S::kRows),
+                     row_indices, row_offsets, column_indices, table, row_ok);
+  return launch_status();
+}
+
 template <int KV>
 int launch(int m, int k, int n, int nonzeros, int replicas, int slots, const int* row_indices,
-           const int* row_offsets, const int* column_indices, int* table, int* row_ok,
-           const float* lhs, int64_t lhs_stride, const float* rhs, int64_t rhs_stride, float* out,
-           int64_t out_stride, int debug, hipStream_t stream) {
+           const int* row_offsets, const int* column_indices, const int* table,
+           const int* row_ok, const float* lhs, int64_t lhs_stride, const float* rhs,
+           int64_t rhs_stride, float* out, int64_t out_stride, int debug, hipStream_t stream) {
   using S = Slab<KV>;
   const int slabs = ceil_div(n, S::kRows);
-  // The chunk table is the SpMM one with the mask's columns (n) in the role of
-  // k, cut at slab boundaries.
-  hipLaunchKernelGGL((spmm_chunk_table_kernel<ilog2(S::kRows)>), dim3(ceil_div(slots, 4)),
-                     dim3(256), 0, stream, m, n, slots, kSGroups * kSRows, slabs, row_indices,
-                     row_offsets,
-                     column_indices, table, row_ok);
-  int st = launch_status();
-  if (st != 0) return st;
+  int st = 0;
   const int row_blocks = slots / (kSGroups * kSRows);
   if (row_blocks > kMaxGridYZ) return SPUTNIK_HIP_INVALID_ARGUMENT;
   for (int k0 = 0; k0 < k; k0 += S::kdim) {  // one launch per panel; later panels accumulate
@@ -314,17 +319,33 @@ size_t sddmm_tiled_workspace_bytes(int m, int k, int n, int nonzeros) {
          sizeof(int) * static_cast<size_t>(ceil_div(n, slab_rows(k)) + 1) * slots_of(m);
 }
 
+int sddmm_tiled_plan(int m, int k, int n, const int* row_indices, const int* row_offsets,
+                     const int* column_indices, void* workspace, hipStream_t stream) {
+  const int slots = slots_of(m);
+  int* row_ok = static_cast<int*>(workspace);
+  int* table = reinterpret_cast<int*>(static_cast<char*>(workspace) + row_ok_bytes(slots));
+  switch (panel_width(k)) {
+    case 64: return plan<1>(m, n, slots, row_indices, row_offsets, column_indices, table, row_ok, stream);
+    case 128: return plan<2>(m, n, slots, row_indices, row_offsets, column_indices, table, row_ok, stream);
+    case 256: return plan<4>(m, n, slots, row_indices, row_offsets, column_indices, table, row_ok, stream);
+    case 512: return plan<8>(m, n, slots, row_indices, row_offsets, column_indices, table, row_ok, stream);
+    default: return SPUTNIK_HIP_INVALID_ARGUMENT;
+  }
+}
+
+// Kernels only, on a planned workspace.
 int sddmm_tiled_launch(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
                        const int* row_offsets, const int* column_indices, const float* lhs,
                        int64_t lhs_stride, const float* rhs, int64_t rhs_stride, float* out,
-                       int64_t out_stride, void* workspace, hipStream_t stream) {
+                       int64_t out_stride, const void* workspace, hipStream_t stream) {
   static const int debug = [] {
     const char* e = getenv("SPUTNIK_HIP_SDDMM_DEBUG");  // timing experiments only
     return e ? atoi(e) : 0;
   }();
   const int slots = slots_of(m);
-  int* row_ok = static_cast<int*>(workspace);
-  int* table = reinterpret_cast<int*>(static_cast<char*>(workspace) + row_ok_bytes(slots));
+  const int* row_ok = static_cast<const int*>(workspace);
+  const int* table =
+      reinterpret_cast<const int*>(static_cast<const char*>(workspace) + row_ok_bytes(slots));
 #define SPUTNIK_HIP_SD(KV)                                                               \
   return launch<KV>(m, k, n, nonzeros, replicas, slots, row_indices, row_offsets,        \
                     column_indices, table, row_ok, lhs, lhs_stride, rhs, rhs_stride, out, \

@@ -92,11 +92,22 @@ int to_int(int64_t v, const char* name) {
   return static_cast<int>(v);
 }
 
+// A plan is the workspace of the matching *_workspace_bytes query after the
+// topology-only pre-pass ran in it (spmm_plan / sddmm_plan / sparse_attention_plan).
+void check_plan(const Tensor& plan, size_t bytes, const Tensor& like) {
+  TORCH_CHECK(plan.scalar_type() == at::kByte && plan.is_contiguous() && plan.dim() == 1,
+              "plan must be the uint8 tensor a *_plan op returned");
+  TORCH_CHECK(plan.device() == like.device(), "plan must be on ", like.device());
+  TORCH_CHECK(static_cast<size_t>(plan.numel()) >= bytes,
+              "plan is too small for this call (", plan.numel(), " < ", bytes,
+              " bytes): it was made for other sizes");
+}
+
 // Shared by spmm (values [nnz] / [R,nnz]) and left_spmm (values [nnz], shared).
 Tensor spmm_impl(int64_t m64, int64_t k64, const Tensor& values_in, const Tensor& row_indices,
                  const Tensor& row_offsets, const Tensor& column_indices, const Tensor& dense_in,
                  bool left, const char* what, const c10::optional<Tensor>& bias_in = c10::nullopt,
-                 bool relu = false) {
+                 bool relu = false, const c10::optional<Tensor>& plan = c10::nullopt) {
   const int m = to_int(m64, "m"), k = to_int(k64, "k");
   const Tensor values = as_float(values_in, "values");
   const Tensor dense = as_float(dense_in, "dense");
@@ -133,6 +144,19 @@ Tensor spmm_impl(int64_t m64, int64_t k64, const Tensor& values_in, const Tensor
                                         : at::empty({replicas, m, n}, options);
   const int64_t values_stride = (left || values.dim() == 1) ? 0 : topo.nonzeros;
   const size_t ws_bytes = sputnik_hip_spmm_workspace_bytes(m, k, n, topo.nonzeros);
+  if (plan.has_value()) {
+    // static topology: the pre-pass ran once (spmm_plan); kernels only
+    check_plan(*plan, ws_bytes, values);
+    check_status(sputnik_hip_spmm_batched_planned(
+                     m, k, n, topo.nonzeros, replicas, topo.row_indices.data_ptr<int>(),
+                     values.data_ptr<float>(), values_stride, topo.row_offsets.data_ptr<int>(),
+                     topo.column_indices.data_ptr<int>(), dense.data_ptr<float>(),
+                     static_cast<int64_t>(k) * n, out.data_ptr<float>(),
+                     static_cast<int64_t>(m) * n, ws_bytes ? plan->data_ptr() : nullptr, ws_bytes,
+                     current_stream(values)),
+                 what);
+    return out;
+  }
   Tensor workspace;
   if (ws_bytes > 0)
     workspace = at::empty({static_cast<int64_t>(ws_bytes)}, options.dtype(at::kByte));
@@ -166,8 +190,9 @@ Tensor left_spmm(int64_t m, int64_t k, const Tensor& values, const Tensor& row_i
                    "left_spmm");
 }
 
-Tensor sddmm(int64_t m64, int64_t n64, const Tensor& row_indices, const Tensor& row_offsets,
-             const Tensor& column_indices, const Tensor& lhs_in, const Tensor& rhs_in) {
+Tensor sddmm_impl(int64_t m64, int64_t n64, const Tensor& row_indices, const Tensor& row_offsets,
+                  const Tensor& column_indices, const Tensor& lhs_in, const Tensor& rhs_in,
+                  const c10::optional<Tensor>& plan) {
   const int m = to_int(m64, "m"), n = to_int(n64, "n");
   const Tensor lhs = as_float(lhs_in, "lhs_matrix");
   const Tensor rhs = as_float(rhs_in, "rhs_matrix");
@@ -194,6 +219,17 @@ Tensor sddmm(int64_t m64, int64_t n64, const Tensor& row_indices, const Tensor& 
   Tensor out = replicas == 1 ? at::empty({topo.nonzeros}, lhs.options())
                              : at::empty({replicas, topo.nonzeros}, lhs.options());
   const size_t ws_bytes = sputnik_hip_sddmm_workspace_bytes(m, k, n, topo.nonzeros);
+  if (plan.has_value()) {
+    check_plan(*plan, ws_bytes, lhs);
+    check_status(sputnik_hip_sddmm_batched_planned(
+                     m, k, n, topo.nonzeros, replicas, topo.row_indices.data_ptr<int>(),
+                     topo.row_offsets.data_ptr<int>(), topo.column_indices.data_ptr<int>(),
+                     lhs.data_ptr<float>(), static_cast<int64_t>(m) * k, rhs.data_ptr<float>(),
+                     static_cast<int64_t>(n) * k, out.data_ptr<float>(), topo.nonzeros,
+                     ws_bytes ? plan->data_ptr() : nullptr, ws_bytes, current_stream(lhs)),
+                 "sddmm_planned");
+    return out;
+  }
   Tensor workspace;
   if (ws_bytes > 0)
     workspace = at::empty({static_cast<int64_t>(ws_bytes)}, lhs.options().dtype(at::kByte));
@@ -205,6 +241,75 @@ Tensor sddmm(int64_t m64, int64_t n64, const Tensor& row_indices, const Tensor& 
                    ws_bytes ? workspace.data_ptr() : nullptr, ws_bytes, current_stream(lhs)),
                "sddmm");
   return out;
+}
+
+Tensor sddmm(int64_t m, int64_t n, const Tensor& row_indices, const Tensor& row_offsets,
+             const Tensor& column_indices, const Tensor& lhs, const Tensor& rhs) {
+  return sddmm_impl(m, n, row_indices, row_offsets, column_indices, lhs, rhs, c10::nullopt);
+}
+
+// ---------------------------------------------------------------------------
+// Static topologies: run the topology-only pre-pass once, keep the result (a
+// uint8 "plan" tensor) and hand it to the *_planned ops.  The reference
+// re-derives everything per call (src/spmm_cuda.cu:48-57).
+// ---------------------------------------------------------------------------
+Tensor make_plan_tensor(size_t bytes, const Tensor& like) {
+  return at::empty({static_cast<int64_t>(std::max<size_t>(bytes, 16))},
+                   like.options().dtype(at::kByte));
+}
+
+Tensor spmm_plan(int64_t m64, int64_t k64, int64_t n64, const Tensor& row_indices,
+                 const Tensor& row_offsets, const Tensor& column_indices) {
+  const int m = to_int(m64, "m"), k = to_int(k64, "k"), n = to_int(n64, "n");
+  TORCH_CHECK(row_offsets.is_cuda(), "row_offsets must be a GPU (HIP) tensor");
+  const c10::DeviceGuard guard(row_offsets.device());
+  const Topology topo = check_topology(m, row_indices, row_offsets, column_indices, row_offsets);
+  const size_t bytes = sputnik_hip_spmm_workspace_bytes(m, k, n, topo.nonzeros);
+  Tensor plan = make_plan_tensor(bytes, row_offsets);
+  check_status(sputnik_hip_spmm_plan(m, k, n, topo.nonzeros, topo.row_indices.data_ptr<int>(),
+                                     topo.row_offsets.data_ptr<int>(),
+                                     topo.column_indices.data_ptr<int>(),
+                                     bytes ? plan.data_ptr() : nullptr, bytes,
+                                     current_stream(row_offsets)),
+               "spmm_plan");
+  return plan;
+}
+
+Tensor spmm_planned(int64_t m, int64_t k, const Tensor& values, const Tensor& row_indices,
+                    const Tensor& row_offsets, const Tensor& column_indices, const Tensor& dense,
+                    const Tensor& plan) {
+  return spmm_impl(m, k, values, row_indices, row_offsets, column_indices, dense, false,
+                   "spmm_planned", c10::nullopt, false, plan);
+}
+
+Tensor left_spmm_planned(int64_t m, int64_t k, const Tensor& values, const Tensor& row_indices,
+                         const Tensor& row_offsets, const Tensor& column_indices,
+                         const Tensor& dense, const Tensor& plan) {
+  return spmm_impl(m, k, values, row_indices, row_offsets, column_indices, dense, true,
+                   "left_spmm_planned", c10::nullopt, false, plan);
+}
+
+Tensor sddmm_plan(int64_t m64, int64_t n64, int64_t k64, const Tensor& row_indices,
+                  const Tensor& row_offsets, const Tensor& column_indices) {
+  const int m = to_int(m64, "m"), n = to_int(n64, "n"), k = to_int(k64, "k");
+  TORCH_CHECK(row_offsets.is_cuda(), "row_offsets must be a GPU (HIP) tensor");
+  const c10::DeviceGuard guard(row_offsets.device());
+  const Topology topo = check_topology(m, row_indices, row_offsets, column_indices, row_offsets);
+  const size_t bytes = sputnik_hip_sddmm_workspace_bytes(m, k, n, topo.nonzeros);
+  Tensor plan = make_plan_tensor(bytes, row_offsets);
+  check_status(sputnik_hip_sddmm_plan(m, k, n, topo.nonzeros, topo.row_indices.data_ptr<int>(),
+                                      topo.row_offsets.data_ptr<int>(),
+                                      topo.column_indices.data_ptr<int>(),
+                                      bytes ? plan.data_ptr() : nullptr, bytes,
+                                      current_stream(row_offsets)),
+               "sddmm_plan");
+  return plan;
+}
+
+Tensor sddmm_planned(int64_t m, int64_t n, const Tensor& row_indices, const Tensor& row_offsets,
+                     const Tensor& column_indices, const Tensor& lhs, const Tensor& rhs,
+                     const Tensor& plan) {
+  return sddmm_impl(m, n, row_indices, row_offsets, column_indices, lhs, rhs, plan);
 }
 
 Tensor sparse_softmax_scaled(const Tensor& values_in, const Tensor& row_indices,
@@ -322,7 +427,8 @@ std::vector<Tensor> sparse_attention_impl(const Tensor& q_in, const Tensor& k_in
                                           const Tensor& v_in, const Tensor& row_indices,
                                           const Tensor& row_offsets,
                                           const Tensor& column_indices, double scale,
-                                          bool want_lse) {
+                                          bool want_lse,
+                                          const c10::optional<Tensor>& plan = c10::nullopt) {
   const Tensor q = as_float(q_in, "query");
   const Tensor k = as_float(k_in, "key");
   const Tensor v = as_float(v_in, "value");
@@ -352,6 +458,21 @@ std::vector<Tensor> sparse_attention_impl(const Tensor& q_in, const Tensor& k_in
   if (want_lse)
     lse = q.dim() == 3 ? at::empty({replicas, m}, q.options()) : at::empty({m}, q.options());
   const size_t ws_bytes = sputnik_hip_sparse_attention_workspace_bytes(m, n, d, topo.nonzeros);
+  if (plan.has_value()) {
+    check_plan(*plan, ws_bytes, q);
+    check_status(sputnik_hip_sparse_attention_forward_planned(
+                     m, n, d, topo.nonzeros, replicas, topo.row_indices.data_ptr<int>(),
+                     topo.row_offsets.data_ptr<int>(), topo.column_indices.data_ptr<int>(),
+                     q.data_ptr<float>(), static_cast<int64_t>(m) * d, k.data_ptr<float>(),
+                     static_cast<int64_t>(n) * d, v.data_ptr<float>(),
+                     static_cast<int64_t>(n) * d, static_cast<float>(scale),
+                     out.data_ptr<float>(), static_cast<int64_t>(m) * d,
+                     want_lse ? lse.data_ptr<float>() : nullptr, m, plan->data_ptr(), ws_bytes,
+                     current_stream(q)),
+                 "sparse_attention_planned");
+    if (want_lse) return {out, lse};
+    return {out};
+  }
   Tensor workspace = at::empty({static_cast<int64_t>(ws_bytes)}, q.options().dtype(at::kByte));
   check_status(sputnik_hip_sparse_attention_forward(
                    m, n, d, topo.nonzeros, replicas, topo.row_indices.data_ptr<int>(),
@@ -379,6 +500,32 @@ std::vector<Tensor> sparse_attention_with_lse(const Tensor& q, const Tensor& k, 
                                               const Tensor& row_offsets,
                                               const Tensor& column_indices, double scale) {
   return sparse_attention_impl(q, k, v, row_indices, row_offsets, column_indices, scale, true);
+}
+
+// Empty plan (numel 0 is never returned; 16 bytes) when the fused kernel does not
+// serve the shape: sparse_attention_planned then composes the three operators.
+Tensor sparse_attention_plan(int64_t m64, int64_t n64, int64_t d64, const Tensor& row_indices,
+                             const Tensor& row_offsets, const Tensor& column_indices) {
+  const int m = to_int(m64, "m"), n = to_int(n64, "n"), d = to_int(d64, "d");
+  TORCH_CHECK(row_offsets.is_cuda(), "row_offsets must be a GPU (HIP) tensor");
+  const c10::DeviceGuard guard(row_offsets.device());
+  const Topology topo = check_topology(m, row_indices, row_offsets, column_indices, row_offsets);
+  const size_t bytes = sputnik_hip_sparse_attention_workspace_bytes(m, n, d, topo.nonzeros);
+  Tensor plan = make_plan_tensor(bytes, row_offsets);
+  if (sputnik_hip_sparse_attention_supported(m, n, d, topo.nonzeros))
+    check_status(sputnik_hip_sparse_attention_plan(
+                     m, n, d, topo.nonzeros, topo.row_indices.data_ptr<int>(),
+                     topo.row_offsets.data_ptr<int>(), topo.column_indices.data_ptr<int>(),
+                     plan.data_ptr(), bytes, current_stream(row_offsets)),
+                 "sparse_attention_plan");
+  return plan;
+}
+
+Tensor sparse_attention_planned(const Tensor& q, const Tensor& k, const Tensor& v,
+                                const Tensor& row_indices, const Tensor& row_offsets,
+                                const Tensor& column_indices, double scale, const Tensor& plan) {
+  return sparse_attention_impl(q, k, v, row_indices, row_offsets, column_indices, scale, false,
+                               plan)[0];
 }
 
 Tensor spmm_bias(int64_t m, int64_t k, const Tensor& values, const Tensor& row_indices,
@@ -663,6 +810,27 @@ TORCH_LIBRARY(torch_sputnik, m) {
       "sparse_attention_with_lse(Tensor query, Tensor key, Tensor value, Tensor row_indices, "
       "Tensor row_offsets, Tensor column_indices, float scale) -> Tensor[]");
   m.def(
+      "spmm_plan(int m, int k, int n, Tensor row_indices, Tensor row_offsets, "
+      "Tensor column_indices) -> Tensor");
+  m.def(
+      "spmm_planned(int m, int k, Tensor values, Tensor row_indices, Tensor row_offsets, "
+      "Tensor column_indices, Tensor dense_matrix, Tensor plan) -> Tensor");
+  m.def(
+      "left_spmm_planned(int m, int k, Tensor values, Tensor row_indices, Tensor row_offsets, "
+      "Tensor column_indices, Tensor dense_matrix, Tensor plan) -> Tensor");
+  m.def(
+      "sddmm_plan(int m, int n, int k, Tensor row_indices, Tensor row_offsets, "
+      "Tensor column_indices) -> Tensor");
+  m.def(
+      "sddmm_planned(int m, int n, Tensor row_indices, Tensor row_offsets, Tensor column_indices, "
+      "Tensor lhs_matrix, Tensor rhs_matrix, Tensor plan) -> Tensor");
+  m.def(
+      "sparse_attention_plan(int m, int n, int d, Tensor row_indices, Tensor row_offsets, "
+      "Tensor column_indices) -> Tensor");
+  m.def(
+      "sparse_attention_planned(Tensor query, Tensor key, Tensor value, Tensor row_indices, "
+      "Tensor row_offsets, Tensor column_indices, float scale, Tensor plan) -> Tensor");
+  m.def(
       "spmm_many_mask(int b, int m, int k, Tensor nonzeros, Tensor values, Tensor row_indices, "
       "Tensor row_offsets, Tensor column_indices, Tensor dense_matrix) -> Tensor");
   m.def(
@@ -696,6 +864,13 @@ TORCH_LIBRARY_IMPL(torch_sputnik, CUDA, m) {
   m.impl("sparse_softmax_backward", &sparse_softmax_backward);
   m.impl("sparse_attention", &sparse_attention);
   m.impl("sparse_attention_with_lse", &sparse_attention_with_lse);
+  m.impl("spmm_plan", &spmm_plan);
+  m.impl("spmm_planned", &spmm_planned);
+  m.impl("left_spmm_planned", &left_spmm_planned);
+  m.impl("sddmm_plan", &sddmm_plan);
+  m.impl("sddmm_planned", &sddmm_planned);
+  m.impl("sparse_attention_plan", &sparse_attention_plan);
+  m.impl("sparse_attention_planned", &sparse_attention_planned);
   m.impl("spmm_many_mask", &spmm_many_mask);
   m.impl("sddmm_many_mask", &sddmm_many_mask);
   m.impl("sparse_softmax_many_mask", &sparse_softmax_many_mask);

@@ -145,3 +145,46 @@ def csr_transpose_many_mask(b, m, n, nonzeros, values, row_offsets, column_indic
     tests/transformer/functions.py:50,165."""
     return _ops.csr_transpose_many_mask(int(b), int(m), int(n), _counts(nonzeros), values,
                                         row_offsets, column_indices)
+
+
+# ---------------------------------------------------------------------------
+# static topologies: plan once, run many times (no counterpart in the reference,
+# which re-derives everything per call, src/spmm_cuda.cu:48-57)
+# ---------------------------------------------------------------------------
+def spmm_plan(m, k, n, row_indices, row_offsets, column_indices):
+    """Topology-only pre-pass for spmm / left_spmm with a dense operand of width
+    `n`; returns the plan (a uint8 tensor) for spmm_planned / left_spmm_planned.
+    Valid as long as the three index tensors, m, k and n do not change."""
+    return _ops.spmm_plan(int(m), int(k), int(n), row_indices, row_offsets, column_indices)
+
+
+def spmm_planned(m, k, values, row_indices, row_offsets, column_indices, dense_matrix, plan):
+    return _ops.spmm_planned(int(m), int(k), values, row_indices, row_offsets, column_indices,
+                             dense_matrix, plan)
+
+
+def left_spmm_planned(m, k, values, row_indices, row_offsets, column_indices, dense_matrix, plan):
+    return _ops.left_spmm_planned(int(m), int(k), values, row_indices, row_offsets,
+                                  column_indices, dense_matrix, plan)
+
+
+def sddmm_plan(m, n, k, row_indices, row_offsets, column_indices):
+    """Pre-pass for sddmm over an m x n mask with inner dimension k."""
+    return _ops.sddmm_plan(int(m), int(n), int(k), row_indices, row_offsets, column_indices)
+
+
+def sddmm_planned(m, n, row_indices, row_offsets, column_indices, lhs_matrix, rhs_matrix, plan):
+    return _ops.sddmm_planned(int(m), int(n), row_indices, row_offsets, column_indices,
+                              lhs_matrix, rhs_matrix, plan)
+
+
+def sparse_attention_plan(m, n, d, row_indices, row_offsets, column_indices):
+    """Pre-pass for the fused attention over an m x n mask with head dimension d."""
+    return _ops.sparse_attention_plan(int(m), int(n), int(d), row_indices, row_offsets,
+                                      column_indices)
+
+
+def sparse_attention_planned(query, key, value, row_indices, row_offsets, column_indices, scale,
+                             plan):
+    return _ops.sparse_attention_planned(query, key, value, row_indices, row_offsets,
+                                         column_indices, float(scale), plan)
