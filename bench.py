@@ -204,6 +204,12 @@ def other_ops(dev):
         x = torch.randn(batch, s, emb, device=dev)
         with torch.no_grad():
             t = event_time_ms(lambda: attn(x, x, x, None), 10)
+        try:  # the same forward replayed from one hipGraph (torch_sputnik_amd/graphs.py)
+            from torch_sputnik_amd.graphs import capture_forward
+            fast = capture_forward(attn, x, x, x)
+            res["sparse_attention_forward_c3_hip_graph"] = {"ms": event_time_ms(lambda: fast(x, x, x), 10)}
+        except Exception as e:  # noqa: BLE001
+            res["sparse_attention_forward_c3_hip_graph"] = {"error": str(e)[:200]}
         res["sparse_attention_forward_c3"] = {"ms": t, "batch": batch, "heads": heads, "seq": s,
                                               "head_dim": emb // heads, "mask_density": 0.1,
                                               "projection_density": 0.1}

@@ -503,3 +503,26 @@ def test_planned_attention_and_modules(ts, dev):
     # the differentiable path (per-call pre-passes, separate operators) agrees
     y = layer(x.requires_grad_(True), x, x)
     assert rel_err(y.detach().cpu().numpy(), first.cpu().numpy()) < TOL
+
+
+def test_hip_graph_replay_of_a_module_forward(dev):
+    from torch_sputnik_amd.graphs import capture_forward
+    from torch_sputnik_amd.modules import SparseAttention
+    torch.manual_seed(1)
+    layer = SparseAttention(num_heads=2, embedding_size=128, max_sequence_length=256, device=dev,
+                            sparsity=0.9, mask_generator=np.random.default_rng(6))
+    for lin in layer.linears:
+        lin.weight = torch.nn.Parameter(torch.randn(128, 128, device=dev) *
+                                        (torch.rand(128, 128, device=dev) < 0.3))
+        lin.setup_sparse_tensors()
+    x = torch.randn(2, 256, 128, device=dev)
+    fast = capture_forward(layer, x, x, x)
+    with torch.no_grad():
+        want = layer(x, x, x)
+    assert torch.equal(fast(x, x, x), want)
+    x2 = torch.randn(2, 256, 128, device=dev)
+    with torch.no_grad():
+        want2 = layer(x2, x2, x2)
+    assert torch.equal(fast(x2, x2, x2), want2)
+    with pytest.raises(ValueError):
+        fast(x2[:1], x2[:1], x2[:1])
