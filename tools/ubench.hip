@@ -33,11 +33,11 @@
     unsigned int base = (threadIdx.x % 64) * 16;                                      \
     asm volatile("v_mov_b32 v40, %0\n"                                                \
                  "s_mov_b32 s30, 0x3f800000\ns_mov_b32 s31, 0x3f800000\n"             \
-                 "s_mov_b32 s38, 5\nv_mov_b32 v5, 0\nv_mov_b32 v6, 0\n"                                                 \
+                 "s_mov_b32 s38, 5\nv_mov_b32 v5, 0\nv_mov_b32 v6, 0\nv_mov_b32 v7, 0\n"                                                 \
                  LOOP_BEGIN BODY BODY BODY BODY LOOP_END                                             \
                  "s_waitcnt lgkmcnt(0)\n"                                             \
                  : : "v"(base), "s"(iters)                                            \
-                 : "memory", "s20", "s30", "s31", "s38", "s33", "s34", "s35", "s36", "v40", "v5", "v6", CLOBBERS); \
+                 : "memory", "s20", "s30", "s31", "s38", "s33", "s34", "s35", "s36", "v40", "v5", "v6", "v7", CLOBBERS); \
     unsigned long long t1 = __builtin_amdgcn_s_memtime();                             \
     if (threadIdx.x % 64 == 0) out[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0; \
     if (lds[threadIdx.x] < -1.f) out[0] = 0;                                          \
@@ -269,6 +269,37 @@ DEF_KERNEL(k_mov_dpp64,
            "v_mov_b64_dpp v[42:43], v[2:3] row_newbcast:15 row_mask:0xf bank_mask:0xf\n",
            V32, "v41")
 
+// o) SpMM step as shipped: per nonzero v_mov_b64_dpp (offset, value) + v_add_u32 + ds_read_b128 + 4 v_fmac_f32
+#define NZP4(U, PAIR_LO, PAIR_HI, ADDR, B0, B3) \
+  "v_mov_b64_dpp v[" PAIR_LO ":" PAIR_HI "], v[6:7] row_newbcast:" U " row_mask:0xf bank_mask:0xf\n" \
+  "v_add_u32 " ADDR ", v" PAIR_LO ", v40\n" \
+  "ds_read_b128 v[" B0 ":" B3 "], " ADDR "\n"
+#define FM4(A, B0, B1, B2, B3) \
+  "v_fmac_f32 v26, " A ", " B0 "\nv_fmac_f32 v27, " A ", " B1 "\nv_fmac_f32 v28, " A ", " B2 "\nv_fmac_f32 v29, " A ", " B3 "\n"
+DEF_KERNEL(k_step_pair_v4,
+           NZP4("0", "30", "31", "v44", "10", "13") NZP4("1", "32", "33", "v45", "14", "17")
+           NZP4("2", "34", "35", "v46", "18", "21") NZP4("3", "36", "37", "v47", "22", "25")
+           "s_waitcnt lgkmcnt(3)\n" FM4("v31", "v10", "v11", "v12", "v13")
+           "s_waitcnt lgkmcnt(2)\n" FM4("v33", "v14", "v15", "v16", "v17")
+           "s_waitcnt lgkmcnt(1)\n" FM4("v35", "v18", "v19", "v20", "v21")
+           "s_waitcnt lgkmcnt(0)\n" FM4("v37", "v22", "v23", "v24", "v25"),
+           V32, "v44", "v45", "v46", "v47")
+
+// p) the same with 2 columns per lane (128-column tiles): ds_read_b64 + 2 v_fmac_f32 per nonzero
+#define NZP2(U, PAIR_LO, PAIR_HI, ADDR, B0, B1) \
+  "v_mov_b64_dpp v[" PAIR_LO ":" PAIR_HI "], v[6:7] row_newbcast:" U " row_mask:0xf bank_mask:0xf\n" \
+  "v_add_u32 " ADDR ", v" PAIR_LO ", v40\n" \
+  "ds_read_b64 v[" B0 ":" B1 "], " ADDR "\n"
+#define FM2(A, B0, B1) "v_fmac_f32 v26, " A ", " B0 "\nv_fmac_f32 v27, " A ", " B1 "\n"
+DEF_KERNEL(k_step_pair_v2,
+           NZP2("0", "30", "31", "v44", "10", "11") NZP2("1", "32", "33", "v45", "14", "15")
+           NZP2("2", "34", "35", "v46", "18", "19") NZP2("3", "36", "37", "v47", "22", "23")
+           "s_waitcnt lgkmcnt(3)\n" FM2("v31", "v10", "v11")
+           "s_waitcnt lgkmcnt(2)\n" FM2("v33", "v14", "v15")
+           "s_waitcnt lgkmcnt(1)\n" FM2("v35", "v18", "v19")
+           "s_waitcnt lgkmcnt(0)\n" FM2("v37", "v22", "v23"),
+           V32, "v44", "v45", "v46", "v47")
+
 typedef void (*kern_t)(unsigned long long*, int);
 
 static void run(const char* name, kern_t k, int per_block_insts) {
@@ -297,6 +328,25 @@ static void run(const char* name, kern_t k, int per_block_insts) {
     printf("%-18s waves/SIMD=%d  wall=%.3f ms  ns/inst/SIMD=%.3f  memtime_ticks/wave=%.0f\n", name,
            waves / 4, ms, ms * 1e6 / insts_per_simd, avg);
   }
+  {  // 8 waves per SIMD: two 16-wave workgroups per CU (64 KiB of LDS each)
+    const int waves = 16, blocks = 512;
+    unsigned long long* d2;
+    CHECK(hipMalloc(&d2, sizeof(unsigned long long) * blocks * 16));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(waves * 64), 0, 0, d2, 1000);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(waves * 64), 0, 0, d2, iters);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipDeviceSynchronize());
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double insts_per_simd = double(iters) * 4 * per_block_insts * 8;
+    printf("%-18s waves/SIMD=8  wall=%.3f ms  ns/inst/SIMD=%.3f\n", name, ms, ms * 1e6 / insts_per_simd);
+    CHECK(hipFree(d2));
+  }
   CHECK(hipFree(d));
 }
 
@@ -317,6 +367,8 @@ int main() {
   run("salu", k_salu, 16);
   run("salu+valu(16)", k_salu_valu, 16);
   run("spmm_step_scalar(4nz)", k_spmm_step_scalar, 4);
+  run("step_pair_v4(4nz)", k_step_pair_v4, 4);
+  run("step_pair_v2(4nz)", k_step_pair_v2, 4);
   run("mov_dpp32", k_mov_dpp32, 16);
   run("mov_dpp64", k_mov_dpp64, 16);
   return 0;
