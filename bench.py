@@ -258,6 +258,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--device-warmup-s", type=float, default=0.25,
+                    help="seconds of untimed steps before the W warm-up steps (clock ramp)")
     ap.add_argument("--allgather", action="store_true",
                     help="N>1: all-gather C over RCCL inside the timed step")
     ap.add_argument("--overlap-chunks", type=int, default=1,
@@ -319,6 +321,15 @@ def main():
                 dist.all_gather_into_tensor(g, problem.out.reshape(replicas, M, N)[a:b])
         main.wait_stream(side)
 
+    # The GPU needs a few tens of milliseconds of load before its clocks settle
+    # (tools/sustain_test.py: the first 50 back-to-back steps average 0.433 ms,
+    # every later batch 0.397-0.405 ms): bring it to its sustained state first,
+    # untimed, so that K timed steps measure the steady rate whatever W is.
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < args.device_warmup_s:
+        for _ in range(10):
+            problem.step()  # compute only: a time-based loop must not contain collectives
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -359,6 +370,7 @@ def main():
                 ("C4: batched SpMM M=N=K=4096 density 0.1, %d replicas per GPU, %d total, replica-sharded"
                  % (replicas, replicas * n_gpus)),
                 "replicas_per_gpu": replicas, "nnz": problem.nnz,
+                "device_warmup_s": args.device_warmup_s,
                 "step": "sputnik_hip_spmm_batched (pre-pass + kernel) via the C ABI",
                 "collective": ("none (independent shards)" if gathered is None else
                                "all_gather(C) over RCCL" if len(gathered) == 1 else
