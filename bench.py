@@ -269,6 +269,12 @@ def main():
                     help="override (default 1 at --gpus 1, 16 otherwise)")
     ap.add_argument("--no-extras", action="store_true", help="skip sweep / cpu baseline / other ops")
     args = ap.parse_args()
+    # Contract: stdout carries ONE JSON line.  Libraries print there too (RCCL's
+    # version banner at communicator creation, for one), so stdout is pointed at
+    # stderr for the whole run and the result goes to the saved descriptor.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     import __graft_entry__
     __graft_entry__.ensure_built()  # fresh checkout: compile the native libraries first
 
@@ -425,7 +431,9 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result))
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(result) + "\n").encode())
+    os.close(result_fd)
 
 
 if __name__ == "__main__":
