@@ -276,7 +276,14 @@ def main():
     result_fd = os.dup(1)
     os.dup2(2, 1)
     import __graft_entry__
-    __graft_entry__.ensure_built()  # fresh checkout: compile the native libraries first
+    # fresh checkout: compile the native libraries first (one rank per node builds,
+    # the others wait for the files)
+    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        __graft_entry__.ensure_built()
+    else:
+        deadline = time.time() + 900
+        while not __graft_entry__.is_built() and time.time() < deadline:
+            time.sleep(2)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
