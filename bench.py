@@ -282,8 +282,12 @@ def main():
         __graft_entry__.ensure_built()
     else:
         deadline = time.time() + 900
+        waited = False
         while not __graft_entry__.is_built() and time.time() < deadline:
             time.sleep(2)
+            waited = True
+        if waited:
+            time.sleep(10)  # the last link step may still be writing
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
