@@ -29,7 +29,11 @@ import os
 import sys
 import time
 
-import torch
+# dmabuf IPC is the only mode the host driver supports: without this RCCL's
+# cross-process buffer sharing fails (hipIpcGetMemHandle: invalid argument).
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
