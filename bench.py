@@ -439,6 +439,18 @@ def main():
             result["other_ops"]["spmm_c2_d010_via_torch_op"] = {
                 "ms": ms_op, "gflops": problem.flops / ms_op / 1e6,
                 "note": "allocates C and the workspace per call (caching allocator)"}
+            # What one GPU does in the N > 1 runs (config 4's share: 16 replicas in one
+            # launch), so that weak-scaling efficiency can be taken against the SAME
+            # per-GPU workload rather than against the single product above.
+            try:
+                p16 = SpmmProblem(dev, HEADLINE_DENSITY, REPLICAS_PER_GPU_MULTI, seed=4234)
+                p16.step()
+                ms16 = event_time_ms(p16.step, 10)
+                result["per_gpu_share_of_multi_gpu_runs"] = {
+                    "replicas": REPLICAS_PER_GPU_MULTI, "ms": ms16, "gflops": p16.flops / ms16 / 1e6}
+                del p16
+            except Exception as e:  # noqa: BLE001 - extra metric, best effort
+                result["per_gpu_share_of_multi_gpu_runs"] = {"error": str(e)[:200]}
             result["cpu_baseline"] = cpu_baseline(problem)
         elif n_gpus == 1:
             result["cpu_baseline"] = None
