@@ -24,6 +24,8 @@
 // (EXEC-masked), so no LDS traffic is spent on the shorter rows' padding.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "spmm_tiled_common.h"
 
 namespace sputnik_hip {
@@ -105,54 +107,92 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled64_kernel(
 #pragma unroll
     for (int v = 0; v < 4; ++v) acc[t][v] = 0.f;
 
-  // Per quad t, this lane's row is slot0 + 4t + g: stream position at the start
-  // / end of the current chunk, and its first 32 entries (window w, lane i =
-  // entry 16w + i).
+  // Per quad t, this lane's row is slot0 + 4t + g.  Its stream positions at the
+  // chunk boundaries c .. c+2 sit in p0 .. p2 (p3 = boundary c+3 is in flight),
+  // and its first 32 entries of a chunk (window w, lane i = entry 16w + i) in
+  // one of THREE register sets: the windows of chunk c+2 are requested while
+  // chunk c is computed, so their (HBM) latency has two chunks to pass.  Every
+  // vector-memory operation of the loop is issued from inline asm in a fixed
+  // order and number per chunk,
+  //   D  kCopiesPerWave LDS-DMA copies of the B tile of chunk c+1
+  //   T  kRQ loads of the positions at boundary c+3
+  //   W  2*kRQ*kWin loads of the windows of chunk c+2
+  // so the waits are counted by hand (vmcnt retires in order): the windows of
+  // chunk c were issued two groups ago (two whole groups may stay in flight);
+  // at the end of the chunk D and T of this group must have landed and W may
+  // stay in flight.  The last chunks issue the same (clamped, unused)
+  // operations so that the counts hold for every iteration.
   constexpr int kWin = 2;
-  const int* __restrict__ my_table = table + slot0 + g;
-  int ps[kRQ], pe[kRQ], wcol[kRQ][kWin];
-  float wval[kRQ][kWin];
+  constexpr int kWindowOps = 2 * kRQ * kWin;
+  constexpr int kGroupOps = kCopiesPerWave + kRQ + kWindowOps;
+  static_assert(2 * kGroupOps <= 63, "vmcnt is a 6-bit counter");
+  const unsigned tab_lane = static_cast<unsigned>(slot0 + g) * 4u;
+  auto load_positions = [&](int (&p)[kRQ], int boundary) {
+    const unsigned row_off =
+        static_cast<unsigned>(min(boundary, nchunks)) * static_cast<unsigned>(slots) * 4u + tab_lane;
 #pragma unroll
-  for (int t = 0; t < kRQ; ++t) {
-    ps[t] = my_table[4 * t];
-    pe[t] = my_table[slots + 4 * t];
+    for (int t = 0; t < kRQ; ++t) p[t] = untracked_load_i32(table, row_off + 16u * t);
+  };
+  int wc[3][kRQ][kWin];
+  float wv[3][kRQ][kWin];
+  auto request = [&](auto SET, const int (&start)[kRQ]) {
+    constexpr int set = decltype(SET)::value;
 #pragma unroll
-    for (int w = 0; w < kWin; ++w) {
-      const int idx = min(ps[t] + 16 * w + i, last);
-      wcol[t][w] = column_indices[idx];
-      wval[t][w] = values[idx];
-    }
-  }
-
-  stage_chunk64(tile[0], dense, n, k, n0, 0, wave, lane);
-  wait_vm<0>();
-  __syncthreads();
-
-  for (int c = 0; c < nchunks; ++c) {
-    const int buf = c & 1;
-    const bool more = c + 1 < nchunks;
-    if (more && !dbg_no_stage) stage_chunk64(tile[buf ^ 1], dense, n, k, n0, (c + 1) * kBK, wave, lane);
-
-    // Next chunk's positions and entry windows: requested now, used after the barrier.
-    int pe_next[kRQ], ncol[kRQ][kWin];
-    float nval[kRQ][kWin];
-#pragma unroll
-    for (int t = 0; t < kRQ; ++t) {
-      pe_next[t] = more ? my_table[static_cast<int64_t>(c + 2) * slots + 4 * t] : pe[t];
+    for (int t = 0; t < kRQ; ++t)
 #pragma unroll
       for (int w = 0; w < kWin; ++w) {
-        const int idx = min(pe[t] + 16 * w + i, last);
-        ncol[t][w] = more ? column_indices[idx] : 0;
-        nval[t][w] = more ? values[idx] : 0.f;
+        const unsigned off = static_cast<unsigned>(min(start[t] + 16 * w + i, last)) * 4u;
+        wc[set][t][w] = untracked_load_i32(column_indices, off);
+        wv[set][t][w] = untracked_load_f32(values, off);
       }
-    }
+  };
+  auto arrived = [&](auto SET) {  // ties the set's registers to the wait before them
+    constexpr int set = decltype(SET)::value;
+#pragma unroll
+    for (int t = 0; t < kRQ; ++t)
+#pragma unroll
+      for (int w = 0; w < kWin; ++w) {
+        tie_reg(wc[set][t][w]);
+        tie_reg(wv[set][t][w]);
+      }
+  };
+
+  int p0[kRQ], p1[kRQ], p2[kRQ], p3[kRQ];
+  load_positions(p0, 0);
+  load_positions(p1, 1);
+  load_positions(p2, 2);
+  wait_vm<0>();
+#pragma unroll
+  for (int t = 0; t < kRQ; ++t) {
+    tie_reg(p0[t]);
+    tie_reg(p1[t]);
+    tie_reg(p2[t]);
+  }
+  stage_chunk64(tile[0], dense, n, k, n0, 0, wave, lane);
+  request(std::integral_constant<int, 0>{}, p0);
+  request(std::integral_constant<int, 1>{}, p1);
+  wait_vm<0>();
+  arrived(std::integral_constant<int, 0>{});
+  arrived(std::integral_constant<int, 1>{});
+  __syncthreads();
+
+  auto chunk = [&](auto R, int c) {
+    constexpr int r = decltype(R)::value;  // = c % 3: the register set of this chunk's windows
+    const int buf = c & 1;
+    // D, T, W (the timing experiment without staging still issues the copies,
+    // from chunk 0, so that the operation count the waits assume is unchanged)
+    stage_chunk64(tile[buf ^ 1], dense, n, k, n0,
+                  dbg_no_stage ? 0 : min(c + 1, nchunks - 1) * kBK, wave, lane);
+    load_positions(p3, c + 3);
+    request(std::integral_constant<int, (r + 2) % 3>{}, p2);
+    wait_vm<2 * kGroupOps>();
+    arrived(R);
 
     const char* __restrict__ lane_base = reinterpret_cast<const char*>(&tile[buf][0] + i * 4);
     const int kc = c * kBK;
-
 #pragma unroll
     for (int t = 0; t < kRQ; ++t) {
-      const int cnt = dbg_no_compute ? 0 : pe[t] - ps[t];  // this group's row; the same in its 16 lanes
+      const int cnt = dbg_no_compute ? 0 : p1[t] - p0[t];  // this group's row; the same in its 16 lanes
       // One 16-entry window of this group's row: groups of four entries, each
       // group of lanes stopping at its own row's count (EXEC-masked).
       auto window = [&](int ecol, float eval, int w0) {
@@ -166,29 +206,33 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled64_kernel(
         if (left > 12) dpp_group4<12>(acc[t], roff, rval, lane_base);
       };
 #pragma unroll
-      for (int w = 0; w < kWin; ++w) window(wcol[t][w], wval[t][w], 16 * w);
+      for (int w = 0; w < kWin; ++w) window(wc[r][t][w], wv[r][t][w], 16 * w);
       // longer rows (more than 32 entries inside one chunk): fetch on demand
+      // (ordinary loads: the compiler's own wait drains everything in flight)
       const int longest = max(max(__builtin_amdgcn_readlane(cnt, 0), __builtin_amdgcn_readlane(cnt, 16)),
                               max(__builtin_amdgcn_readlane(cnt, 32), __builtin_amdgcn_readlane(cnt, 48)));
       for (int w0 = 16 * kWin; w0 < longest; w0 += 16) {
-        const int idx = min(ps[t] + w0 + i, last);
+        const int idx = min(p0[t] + w0 + i, last);
         window(column_indices[idx], values[idx], w0);
       }
     }
 
+    wait_vm<kWindowOps>();  // D and T of this group have landed; W stays in flight
 #pragma unroll
     for (int t = 0; t < kRQ; ++t) {
-      ps[t] = pe[t];
-      pe[t] = pe_next[t];
-#pragma unroll
-      for (int w = 0; w < kWin; ++w) {
-        wcol[t][w] = ncol[t][w];
-        wval[t][w] = nval[t][w];
-      }
+      tie_reg(p3[t]);
+      p0[t] = p1[t];
+      p1[t] = p2[t];
+      p2[t] = p3[t];
     }
-    wait_vm<0>();     // the next B tile has landed (the windows landed long ago)
-    __syncthreads();  // ... for every wave, and the current buffer is free
+    __syncthreads();  // the next tile is there for every wave, and the current buffer is free
+  };
+  for (int c0 = 0; c0 < nchunks; c0 += 3) {
+    chunk(std::integral_constant<int, 0>{}, c0);
+    if (c0 + 1 < nchunks) chunk(std::integral_constant<int, 1>{}, c0 + 1);
+    if (c0 + 2 < nchunks) chunk(std::integral_constant<int, 2>{}, c0 + 2);
   }
+  wait_vm<0>();  // nothing may be in flight (LDS-DMA!) when the wave ends
 
 #pragma unroll
   for (int t = 0; t < kRQ; ++t) {

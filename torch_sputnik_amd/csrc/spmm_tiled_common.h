@@ -127,6 +127,11 @@ __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
 }
 
+// Marks a register as written "here": placed after a hand-counted wait it keeps
+// the compiler from using an asm-loaded register before that wait.
+__device__ __forceinline__ void tie_reg(int& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void tie_reg(float& v) { asm volatile("" : "+v"(v)); }
+
 // ROWS consecutive table entries (stream positions of a wave's rows at one
 // chunk boundary) straight into SGPRs: one scalar load instead of a per-lane
 // vector load plus a v_readlane per use.  Untracked like the vector loads
