@@ -285,6 +285,19 @@ DEF_KERNEL(k_step_pair_v4,
            "s_waitcnt lgkmcnt(0)\n" FM4("v37", "v22", "v23", "v24", "v25"),
            V32, "v44", "v45", "v46", "v47")
 
+// o2) as o) but every nonzero of a step accumulates into its OWN four registers
+//     (no FMA depends on the previous nonzero's FMA): does the dependent chain cost?
+#define FM4I(A, ACC0, ACC1, ACC2, ACC3, B0, B1, B2, B3) \
+  "v_fmac_f32 " ACC0 ", " A ", " B0 "\nv_fmac_f32 " ACC1 ", " A ", " B1 "\nv_fmac_f32 " ACC2 ", " A ", " B2 "\nv_fmac_f32 " ACC3 ", " A ", " B3 "\n"
+DEF_KERNEL(k_step_pair_v4_indep,
+           NZP4("0", "30", "31", "v44", "10", "13") NZP4("1", "32", "33", "v45", "14", "17")
+           NZP4("2", "34", "35", "v46", "18", "21") NZP4("3", "36", "37", "v47", "22", "25")
+           "s_waitcnt lgkmcnt(3)\n" FM4I("v31", "v26", "v27", "v28", "v29", "v10", "v11", "v12", "v13")
+           "s_waitcnt lgkmcnt(2)\n" FM4I("v33", "v48", "v49", "v50", "v51", "v14", "v15", "v16", "v17")
+           "s_waitcnt lgkmcnt(1)\n" FM4I("v35", "v52", "v53", "v54", "v55", "v18", "v19", "v20", "v21")
+           "s_waitcnt lgkmcnt(0)\n" FM4I("v37", "v56", "v57", "v58", "v59", "v22", "v23", "v24", "v25"),
+           V32, "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59")
+
 // p) the same with 2 columns per lane (128-column tiles): ds_read_b64 + 2 v_fmac_f32 per nonzero
 #define NZP2(U, PAIR_LO, PAIR_HI, ADDR, B0, B1) \
   "v_mov_b64_dpp v[" PAIR_LO ":" PAIR_HI "], v[6:7] row_newbcast:" U " row_mask:0xf bank_mask:0xf\n" \
@@ -368,6 +381,7 @@ int main() {
   run("salu+valu(16)", k_salu_valu, 16);
   run("spmm_step_scalar(4nz)", k_spmm_step_scalar, 4);
   run("step_pair_v4(4nz)", k_step_pair_v4, 4);
+  run("step_pair_v4_indep", k_step_pair_v4_indep, 4);
   run("step_pair_v2(4nz)", k_step_pair_v2, 4);
   run("mov_dpp32", k_mov_dpp32, 16);
   run("mov_dpp64", k_mov_dpp64, 16);
