@@ -24,7 +24,7 @@ def one(pattern):
     files = glob.glob(pattern, recursive=True)
     if not files:
         raise SystemExit(f"no file matches {pattern}")
-    return files[0]
+    return max(files, key=os.path.getmtime)  # a directory may hold several runs: the newest
 
 
 def short(name):
