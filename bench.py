@@ -242,6 +242,28 @@ def other_ops(dev):
     sws = torch.empty(capi.sddmm_workspace_bytes(m, seq, n, nnz) + 16, dtype=torch.uint8, device=dev)
     t = event_time_ms(lambda: capi.sddmm_batched(m, seq, n, batch, ri, ro, ci, gy, x, gw, sws), 10)
     res["sddmm_grad_values_c5"] = {"ms": t, "gflops": 2.0 * nnz * seq * batch / t / 1e6}
+    # config 5 end to end: SparseLinear forward + backward through the torch ops and the
+    # autograd Function (left_spmm; sddmm + csr_transpose + left_spmm), fp32 and with the
+    # input stored in fp16 (widened once at the op layer, fp32 arithmetic: DESIGN.md section 7)
+    try:
+        from torch_sputnik_amd import SparseLinear
+        layer = SparseLinear(n, m).to(dev)
+        w = torch.randn(m, n, device=dev) * (torch.rand(m, n, device=dev) < 0.2)
+        layer.weight = torch.nn.Parameter(w)
+        layer.setup_sparse_tensors()
+        for name, dt in (("fp32", torch.float32), ("fp16_storage", torch.float16)):
+            xin = torch.randn(batch, seq, n, device=dev).to(dt).requires_grad_(True)
+            gout = torch.randn(batch, m, seq, device=dev)
+
+            def fwd_bwd():
+                layer.values.grad = None
+                xin.grad = None
+                layer(xin).backward(gout)
+
+            res[f"sparse_linear_fwd_bwd_c5_{name}"] = {"ms": event_time_ms(fwd_bwd, 10), "batch": batch,
+                                                       "seq": seq}
+    except Exception as e:  # noqa: BLE001 - extra metric, best effort
+        res["sparse_linear_fwd_bwd_c5"] = {"error": str(e)[:200]}
     return res
 
 
