@@ -262,6 +262,15 @@ def other_ops(dev):
 
             res[f"sparse_linear_fwd_bwd_c5_{name}"] = {"ms": event_time_ms(fwd_bwd, 10), "batch": batch,
                                                        "seq": seq}
+            if name == "fp32":  # static weights: transposed topology computed once (opt-in cache)
+                from torch_sputnik_amd.functional import enable_transpose_cache
+                enable_transpose_cache(True)
+                try:
+                    fwd_bwd()
+                    res["sparse_linear_fwd_bwd_c5_fp32_cached_transpose"] = {
+                        "ms": event_time_ms(fwd_bwd, 10)}
+                finally:
+                    enable_transpose_cache(False)
     except Exception as e:  # noqa: BLE001 - extra metric, best effort
         res["sparse_linear_fwd_bwd_c5"] = {"error": str(e)[:200]}
     return res
