@@ -298,6 +298,26 @@ DEF_KERNEL(k_step_pair_v4_indep,
            "s_waitcnt lgkmcnt(0)\n" FM4I("v37", "v56", "v57", "v58", "v59", "v22", "v23", "v24", "v25"),
            V32, "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59")
 
+// o3) the VALU half of o) alone (no LDS reads) and o4) the LDS half alone (address
+//     forming + reads, no FMAs): how much of the 9.5 ns is imperfect overlap?
+#define NZP4_NOLDS(U, PAIR_LO, PAIR_HI, ADDR) \
+  "v_mov_b64_dpp v[" PAIR_LO ":" PAIR_HI "], v[6:7] row_newbcast:" U " row_mask:0xf bank_mask:0xf\n" \
+  "v_add_u32 " ADDR ", v" PAIR_LO ", v40\n"
+#define DPPQ(U, PAIR_LO, PAIR_HI) \
+  "v_mov_b64_dpp v[" PAIR_LO ":" PAIR_HI "], v[6:7] row_newbcast:" U " row_mask:0xf bank_mask:0xf\n"
+// (the four broadcasts first, then the four adds, as the compiler orders the shipped loop)
+DEF_KERNEL(k_step_valu_only,
+           DPPQ("0", "30", "31") DPPQ("1", "32", "33") DPPQ("2", "34", "35") DPPQ("3", "36", "37")
+           "v_add_u32 v44, v30, v40\nv_add_u32 v45, v32, v40\nv_add_u32 v46, v34, v40\nv_add_u32 v47, v36, v40\n"
+           FM4("v31", "v10", "v11", "v12", "v13") FM4("v33", "v14", "v15", "v16", "v17")
+           FM4("v35", "v18", "v19", "v20", "v21") FM4("v37", "v22", "v23", "v24", "v25"),
+           V32, "v44", "v45", "v46", "v47")
+DEF_KERNEL(k_step_lds_only,
+           NZP4("0", "30", "31", "v44", "10", "13") NZP4("1", "32", "33", "v45", "14", "17")
+           NZP4("2", "34", "35", "v46", "18", "21") NZP4("3", "36", "37", "v47", "22", "25")
+           "s_waitcnt lgkmcnt(0)\n",
+           V32, "v44", "v45", "v46", "v47")
+
 // p) the same with 2 columns per lane (128-column tiles): ds_read_b64 + 2 v_fmac_f32 per nonzero
 #define NZP2(U, PAIR_LO, PAIR_HI, ADDR, B0, B1) \
   "v_mov_b64_dpp v[" PAIR_LO ":" PAIR_HI "], v[6:7] row_newbcast:" U " row_mask:0xf bank_mask:0xf\n" \
@@ -312,6 +332,68 @@ DEF_KERNEL(k_step_pair_v2,
            "s_waitcnt lgkmcnt(1)\n" FM2("v35", "v18", "v19")
            "s_waitcnt lgkmcnt(0)\n" FM2("v37", "v22", "v23"),
            V32, "v44", "v45", "v46", "v47")
+
+// o5) o3 with the 64-bit DPP broadcasts replaced by 32-bit ones (two per nonzero),
+//     o6) by plain 64-bit moves: what do the DPP operations cost INSIDE the mix?
+#define DPP2(U, PAIR_LO, PAIR_HI) \
+  "v_mov_b32_dpp v" PAIR_LO ", v6 row_newbcast:" U " row_mask:0xf bank_mask:0xf\n" \
+  "v_mov_b32_dpp v" PAIR_HI ", v7 row_newbcast:" U " row_mask:0xf bank_mask:0xf\n"
+DEF_KERNEL(k_step_valu_dpp32,
+           DPP2("0", "30", "31") DPP2("1", "32", "33") DPP2("2", "34", "35") DPP2("3", "36", "37")
+           "v_add_u32 v44, v30, v40\nv_add_u32 v45, v32, v40\nv_add_u32 v46, v34, v40\nv_add_u32 v47, v36, v40\n"
+           FM4("v31", "v10", "v11", "v12", "v13") FM4("v33", "v14", "v15", "v16", "v17")
+           FM4("v35", "v18", "v19", "v20", "v21") FM4("v37", "v22", "v23", "v24", "v25"),
+           V32, "v44", "v45", "v46", "v47")
+#define MOVQ(PAIR_LO, PAIR_HI) "v_mov_b64 v[" PAIR_LO ":" PAIR_HI "], v[6:7]\n"
+DEF_KERNEL(k_step_valu_nodpp,
+           MOVQ("30", "31") MOVQ("32", "33") MOVQ("34", "35") MOVQ("36", "37")
+           "v_add_u32 v44, v30, v40\nv_add_u32 v45, v32, v40\nv_add_u32 v46, v34, v40\nv_add_u32 v47, v36, v40\n"
+           FM4("v31", "v10", "v11", "v12", "v13") FM4("v33", "v14", "v15", "v16", "v17")
+           FM4("v35", "v18", "v19", "v20", "v21") FM4("v37", "v22", "v23", "v24", "v25"),
+           V32, "v44", "v45", "v46", "v47")
+DEF_KERNEL(k_step_fma16_only,
+           FM4("v31", "v10", "v11", "v12", "v13") FM4("v33", "v14", "v15", "v16", "v17")
+           FM4("v35", "v18", "v19", "v20", "v21") FM4("v37", "v22", "v23", "v24", "v25"),
+           V32)
+
+// q) VGPR bank conflicts: the accumulator and the multiplicand in the SAME register bank
+//    (index mod 4) against all three operands in different banks
+DEF_KERNEL(k_fmac_bank_conflict,
+           "v_fmac_f32 v10, v48, v26\n"
+           "v_fmac_f32 v11, v49, v27\n"
+           "v_fmac_f32 v12, v50, v28\n"
+           "v_fmac_f32 v13, v51, v29\n"
+           "v_fmac_f32 v14, v48, v30\n"
+           "v_fmac_f32 v15, v49, v31\n"
+           "v_fmac_f32 v16, v50, v32\n"
+           "v_fmac_f32 v17, v51, v33\n"
+           "v_fmac_f32 v18, v48, v34\n"
+           "v_fmac_f32 v19, v49, v35\n"
+           "v_fmac_f32 v20, v50, v36\n"
+           "v_fmac_f32 v21, v51, v37\n"
+           "v_fmac_f32 v22, v48, v38\n"
+           "v_fmac_f32 v23, v49, v39\n"
+           "v_fmac_f32 v24, v50, v40\n"
+           "v_fmac_f32 v25, v51, v41\n",
+           V16)
+DEF_KERNEL(k_fmac_bank_free,
+           "v_fmac_f32 v10, v49, v27\n"
+           "v_fmac_f32 v11, v50, v28\n"
+           "v_fmac_f32 v12, v51, v29\n"
+           "v_fmac_f32 v13, v48, v30\n"
+           "v_fmac_f32 v14, v49, v31\n"
+           "v_fmac_f32 v15, v50, v32\n"
+           "v_fmac_f32 v16, v51, v33\n"
+           "v_fmac_f32 v17, v48, v34\n"
+           "v_fmac_f32 v18, v49, v35\n"
+           "v_fmac_f32 v19, v50, v36\n"
+           "v_fmac_f32 v20, v51, v37\n"
+           "v_fmac_f32 v21, v48, v38\n"
+           "v_fmac_f32 v22, v49, v39\n"
+           "v_fmac_f32 v23, v50, v40\n"
+           "v_fmac_f32 v24, v51, v41\n"
+           "v_fmac_f32 v25, v48, v42\n",
+           V16)
 
 typedef void (*kern_t)(unsigned long long*, int);
 
@@ -382,7 +464,14 @@ int main() {
   run("spmm_step_scalar(4nz)", k_spmm_step_scalar, 4);
   run("step_pair_v4(4nz)", k_step_pair_v4, 4);
   run("step_pair_v4_indep", k_step_pair_v4_indep, 4);
+  run("step_valu_only(4nz)", k_step_valu_only, 4);
+  run("step_lds_only(4nz)", k_step_lds_only, 4);
+  run("step_valu_dpp32(4nz)", k_step_valu_dpp32, 4);
+  run("step_valu_nodpp(4nz)", k_step_valu_nodpp, 4);
+  run("step_fma16_only(4nz)", k_step_fma16_only, 4);
   run("step_pair_v2(4nz)", k_step_pair_v2, 4);
+  run("fmac_bank_conflict", k_fmac_bank_conflict, 16);
+  run("fmac_bank_free", k_fmac_bank_free, 16);
   run("mov_dpp32", k_mov_dpp32, 16);
   run("mov_dpp64", k_mov_dpp64, 16);
   return 0;
