@@ -12,6 +12,11 @@ from helpers import make_csr, rel_err
 
 pytestmark = pytest.mark.gpu
 
+# SPUTNIK_FUZZ_SCALE=10 runs ten times the cases from a different seed (soak run)
+import os
+SCALE = int(os.environ.get("SPUTNIK_FUZZ_SCALE", "1"))
+SEED_SHIFT = 0 if SCALE == 1 else 1000003
+
 TOL = 1e-4
 ORDERS = ("descending", "ascending", "random", "identity")
 
@@ -47,8 +52,8 @@ def _case(rng, rows, cols):
 
 
 def test_fuzz_spmm(capi, dev, spmm_kernel):
-    rng = np.random.default_rng(20261003)
-    for it in range(40):
+    rng = np.random.default_rng(20261003 + SEED_SHIFT)
+    for it in range(40 * SCALE):
         m, k, sparsity, empty, order, replicas = _case(rng, [16, 64, 128, 256, 300], [32, 64, 128, 256, 520])
         n = int(rng.choice([1, 7, 18, 64, 128, 192, 256, 512]))
         _, vals, ri, ro, ci = make_csr(m, k, sparsity, seed=it, round_to=1, empty_rows=empty,
@@ -74,8 +79,8 @@ def test_fuzz_spmm(capi, dev, spmm_kernel):
 
 
 def test_fuzz_sddmm_softmax_transpose(capi, dev, sddmm_kernel):
-    rng = np.random.default_rng(77)
-    for it in range(40):
+    rng = np.random.default_rng(77 + SEED_SHIFT)
+    for it in range(40 * SCALE):
         m, n, sparsity, empty, order, replicas = _case(rng, [16, 64, 128, 256, 300], [16, 64, 128, 256, 300])
         k = int(rng.choice([1, 5, 32, 64, 64, 128, 128, 200, 256, 320, 512, 768, 1024]))
         _, _, ri, ro, ci = make_csr(m, n, sparsity, seed=100 + it, round_to=1, empty_rows=empty,
@@ -112,8 +117,8 @@ def test_fuzz_sddmm_softmax_transpose(capi, dev, sddmm_kernel):
 
 
 def test_fuzz_sparse_attention(capi, dev):
-    rng = np.random.default_rng(5150)
-    for it in range(25):
+    rng = np.random.default_rng(5150 + SEED_SHIFT)
+    for it in range(25 * SCALE):
         m, n, sparsity, empty, order, replicas = _case(rng, [16, 64, 128, 256, 300], [16, 64, 128, 256, 300])
         _, _, ri, ro, ci = make_csr(m, n, sparsity, seed=200 + it, round_to=1, empty_rows=empty,
                                     order=order)
