@@ -59,7 +59,7 @@ def cpu_ops():
     return torch_sputnik_amd
 
 
-@pytest.fixture(params=["auto", "wide", "narrow", "gather"])
+@pytest.fixture(params=["auto", "wide", "wide512", "narrow", "gather"])
 def spmm_kernel(request, monkeypatch):
     """Small inputs take the single-launch row-gather kernel on their own; the
     library's test knob steers them onto each tiled kernel in turn (a kernel

@@ -93,6 +93,10 @@ STRESS = [
     (2048, 2048, 256, 0.8),   # medium-tile configuration
     (512, 96, 64, 0.2),       # 64-column kernel, > 32 entries per row and chunk
     (90, 1000, 320, 0.9),     # 64-column kernel, five tiles, padded row slots
+    (300, 100, 1024, 0.1),    # 512-column kernel: dense rows (up to 32 entries per row and 32-row chunk)
+    (128, 32, 512, 0.0),      # 512-column kernel: one chunk, fully dense
+    (1000, 33, 1536, 0.5),    # 512-column kernel: three tiles, k % 32 = 1, row slots padded to 1024
+    (384, 4096, 512, 0.97),   # 512-column kernel: 128 chunks, most segments empty, slots padded to 512
 ]
 
 

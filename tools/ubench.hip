@@ -8,6 +8,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #define CHECK(x)                                                        \
@@ -395,9 +396,58 @@ DEF_KERNEL(k_fmac_bank_free,
            "v_fmac_f32 v25, v48, v42\n",
            V16)
 
+// r) 8 columns per lane (512-column tiles): per nonzero ONE broadcast + add, TWO ds_read_b128
+//    (second at +1 KiB) and 8 v_fmac_f32: does halving the broadcast work per FMA pay?
+#define NZP8(U, PAIR_LO, PAIR_HI, ADDR, B0, B3, B4, B7) \
+  "v_mov_b64_dpp v[" PAIR_LO ":" PAIR_HI "], v[6:7] row_newbcast:" U " row_mask:0xf bank_mask:0xf\n" \
+  "v_add_u32 " ADDR ", v" PAIR_LO ", v40\n" \
+  "ds_read_b128 v[" B0 ":" B3 "], " ADDR "\n" \
+  "ds_read_b128 v[" B4 ":" B7 "], " ADDR " offset:1024\n"
+#define FM8(A, B0, B1, B2, B3, B4, B5, B6, B7) \
+  "v_fmac_f32 v26, " A ", " B0 "\nv_fmac_f32 v27, " A ", " B1 "\nv_fmac_f32 v28, " A ", " B2 "\nv_fmac_f32 v29, " A ", " B3 "\n" \
+  "v_fmac_f32 v64, " A ", " B4 "\nv_fmac_f32 v65, " A ", " B5 "\nv_fmac_f32 v66, " A ", " B6 "\nv_fmac_f32 v67, " A ", " B7 "\n"
+#define V8X "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67"
+DEF_KERNEL(k_step_pair_v8,
+           NZP8("0", "30", "31", "v44", "10", "13", "14", "17") NZP8("1", "32", "33", "v45", "18", "21", "22", "25")
+           NZP8("2", "34", "35", "v46", "48", "51", "52", "55") NZP8("3", "36", "37", "v47", "56", "59", "60", "63")
+           "s_waitcnt lgkmcnt(6)\n" FM8("v31", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17")
+           "s_waitcnt lgkmcnt(4)\n" FM8("v33", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25")
+           "s_waitcnt lgkmcnt(2)\n" FM8("v35", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55")
+           "s_waitcnt lgkmcnt(0)\n" FM8("v37", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63"),
+           V32, V8X)
+// r2) the same with two nonzeros per wait group (half the B registers in flight)
+DEF_KERNEL(k_step_pair_v8x2,
+           NZP8("0", "30", "31", "v44", "10", "13", "14", "17") NZP8("1", "32", "33", "v45", "18", "21", "22", "25")
+           "s_waitcnt lgkmcnt(2)\n" FM8("v31", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17")
+           "s_waitcnt lgkmcnt(0)\n" FM8("v33", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25")
+           NZP8("2", "34", "35", "v46", "48", "51", "52", "55") NZP8("3", "36", "37", "v47", "56", "59", "60", "63")
+           "s_waitcnt lgkmcnt(2)\n" FM8("v35", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55")
+           "s_waitcnt lgkmcnt(0)\n" FM8("v37", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63"),
+           V32, V8X)
+// r3) software pipelined: the reads of group g+1 are issued before the FMAs of group g
+DEF_KERNEL(k_step_pair_v8_pipe,
+           NZP8("2", "34", "35", "v46", "48", "51", "52", "55") NZP8("3", "36", "37", "v47", "56", "59", "60", "63")
+           "s_waitcnt lgkmcnt(6)\n" FM8("v31", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17")
+           "s_waitcnt lgkmcnt(4)\n" FM8("v33", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25")
+           NZP8("0", "30", "31", "v44", "10", "13", "14", "17") NZP8("1", "32", "33", "v45", "18", "21", "22", "25")
+           "s_waitcnt lgkmcnt(6)\n" FM8("v35", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55")
+           "s_waitcnt lgkmcnt(4)\n" FM8("v37", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63"),
+           V32, V8X)
+// r4) 4-column step software pipelined the same way (for comparison with o))
+DEF_KERNEL(k_step_pair_v4_pipe,
+           NZP4("2", "34", "35", "v46", "18", "21") NZP4("3", "36", "37", "v47", "22", "25")
+           "s_waitcnt lgkmcnt(3)\n" FM4("v31", "v10", "v11", "v12", "v13")
+           "s_waitcnt lgkmcnt(2)\n" FM4("v33", "v14", "v15", "v16", "v17")
+           NZP4("0", "30", "31", "v44", "10", "13") NZP4("1", "32", "33", "v45", "14", "17")
+           "s_waitcnt lgkmcnt(3)\n" FM4("v35", "v18", "v19", "v20", "v21")
+           "s_waitcnt lgkmcnt(2)\n" FM4("v37", "v22", "v23", "v24", "v25"),
+           V32, "v44", "v45", "v46", "v47")
+
 typedef void (*kern_t)(unsigned long long*, int);
 
+static const char* g_filter = nullptr;
 static void run(const char* name, kern_t k, int per_block_insts) {
+  if (g_filter && !strstr(name, g_filter)) return;
   const int iters = 5000;
   unsigned long long* d;
   CHECK(hipMalloc(&d, sizeof(unsigned long long) * 256 * 16));
@@ -445,7 +495,8 @@ static void run(const char* name, kern_t k, int per_block_insts) {
   CHECK(hipFree(d));
 }
 
-int main() {
+int main(int argc, char** argv) {
+  if (argc > 1) g_filter = argv[1];  // run only the kernels whose name contains this
   run("fma_vgpr", k_fma_vgpr, 16);
   run("fma_sgpr", k_fma_sgpr, 16);
   run("pkfma_vgpr", k_pkfma_vgpr, 16);
@@ -474,5 +525,9 @@ int main() {
   run("fmac_bank_free", k_fmac_bank_free, 16);
   run("mov_dpp32", k_mov_dpp32, 16);
   run("mov_dpp64", k_mov_dpp64, 16);
+  run("step_pair_v8(4nz)", k_step_pair_v8, 4);
+  run("step_pair_v8x2(4nz)", k_step_pair_v8x2, 4);
+  run("step_pair_v8_pipe", k_step_pair_v8_pipe, 4);
+  run("step_pair_v4_pipe", k_step_pair_v4_pipe, 4);
   return 0;
 }

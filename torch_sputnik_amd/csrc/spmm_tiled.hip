@@ -66,10 +66,12 @@ struct TileConfig {
   static constexpr int kRPW = RPW;      // rows of C per wave
   static constexpr int kBK = BK;        // rows of B per LDS stage
   static constexpr int kBM = WAVES * RPW;
-  static constexpr int kVec = BN / kWave;  // floats per lane: 4 -> ds_read_b128
+  static constexpr int kVec = BN / kWave;  // floats per lane: 4 per 256-column piece
+  static constexpr int kPieces = BN / 256;  // 1 KiB LDS-DMA pieces (= ds_read_b128 per lane) per B row
   static constexpr int kThreads = WAVES * kWave;
   static constexpr int kStageRowsPerWave = BK / WAVES;
-  static_assert(BN == 256, "one 1 KiB LDS-DMA piece per B row");
+  static constexpr int kStageOps = kStageRowsPerWave * kPieces;  // LDS-DMA copies per wave and stage
+  static_assert(BN == 256 || BN == 512, "one or two 1 KiB LDS-DMA pieces per B row");
   static_assert(BK % WAVES == 0, "stage rows split evenly over the waves");
 };
 
@@ -78,17 +80,20 @@ __device__ __forceinline__ void stage_chunk(float* __restrict__ tile, const floa
                                             int n, int k, int kc, int wave,
                                             unsigned lane_byte_offset) {
   // Wave w copies B rows kc + w, kc + w + WAVES, ...; one wave instruction
-  // moves one row segment (lane_byte_offset = (n0 + lane*4) * 4 selects the
-  // workgroup's column tile and the lane's 16 bytes) straight into the
-  // row-major tile row.  Rows past the end of B (last, partial chunk) re-read
-  // row k-1: no nonzero refers to them, and every wave then issues exactly
-  // kStageRowsPerWave copies per stage, which the counted vmcnt waits of
+  // moves one 256-column piece of a row (lane_byte_offset = (n0 + lane*4) * 4
+  // selects the workgroup's column tile and the lane's 16 bytes) straight into
+  // the row-major tile row.  Rows past the end of B (last, partial chunk)
+  // re-read row k-1: no nonzero refers to them, and every wave then issues
+  // exactly kStageOps copies per stage, which the counted vmcnt waits of
   // main loop rely on.
 #pragma unroll
   for (int i = 0; i < Cfg::kStageRowsPerWave; ++i) {
     const int r = wave + i * Cfg::kWaves;
     const int src_row = min(kc + r, k - 1);
-    lds_dma_row(dense + static_cast<int64_t>(src_row) * n, lane_byte_offset, tile + r * Cfg::kBN);
+#pragma unroll
+    for (int h = 0; h < Cfg::kPieces; ++h)
+      lds_dma_row(dense + static_cast<int64_t>(src_row) * n + h * 256, lane_byte_offset,
+                  tile + r * Cfg::kBN + h * 256);
   }
 }
 
@@ -96,7 +101,7 @@ __device__ __forceinline__ void stage_chunk(float* __restrict__ tile, const floa
 //
 // Every vector-memory operation inside the loop is issued from inline asm, in
 // a fixed order and number per chunk, so the waits can be counted by hand:
-//   A  kStageRowsPerWave (S) LDS-DMA copies of B rows for chunk c+1
+//   A  kStageOps (S) LDS-DMA copies of B rows for chunk c+1
 //   B  the rows' stream positions one chunk ahead: a SCALAR load into SGPRs
 //      (not counted by vmcnt)
 //   C  after each row r: 2 loads = the entry window of the row that is D rows
@@ -116,9 +121,11 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
     const int* __restrict__ column_indices, const int* __restrict__ table,
     const float* __restrict__ dense, bool dbg_no_compute, bool dbg_no_stage,
     bool dbg_no_barrier = false) {
-  constexpr int BN = Cfg::kBN, BK = Cfg::kBK, RPW = Cfg::kRPW, VEC = Cfg::kVec;
-  constexpr int S = Cfg::kStageRowsPerWave;
-  constexpr int D = 8;  // windows in flight
+  constexpr int BN = Cfg::kBN, BK = Cfg::kBK, RPW = Cfg::kRPW;
+  constexpr int S = Cfg::kStageOps;
+  // windows in flight (the 512-column tile has no registers for more than four:
+  // 64 accumulators + 32 for the B strips of a four-entry batch)
+  constexpr int D = Cfg::kVec == 8 ? 4 : 8;
   static_assert(RPW % D == 0 && D <= RPW, "window ring");
   constexpr int kWaitSameChunk = 2 * (D - 1);
   constexpr int kWaitCrossChunk = 2 * (D - 1) + S;
@@ -135,7 +142,7 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
   const int e16x4 = (lane & 15) * 4;
   const unsigned lane4 = static_cast<unsigned>(SPARSE ? (lane & 15) : lane) * 4u;
   const int last_window = nonzeros - kWindow;  // >= 0: the dispatcher requires >= 1024 nonzeros
-  const float* lane_tile = tile0 + lane * VEC;
+  const float* lane_tile = tile0 + lane * 4;
   const unsigned b_lane_off = static_cast<unsigned>(n0 + lane * 4) * 4u;
 
   // Stream positions of this wave's rows at the start of the current chunk and
@@ -300,10 +307,14 @@ __global__ __launch_bounds__(Cfg::kThreads) void spmm_tiled_kernel(
       const int entry = dealt_index(slot0 + r, slots, kDealPer);
       if (entry >= m) continue;
       const int row = row_indices[entry];
-      const float4 acc4 = gather_row_strip(values, column_indices, row_offsets[row],
-                                           row_offsets[row + 1], dense + n0 + lane * VEC, n);
-      *reinterpret_cast<float4*>(out + static_cast<int64_t>(row) * n + n0 + lane * VEC) =
-          apply_epilogue(acc4, epi, row);
+#pragma unroll
+      for (int h = 0; h < Cfg::kPieces; ++h) {
+        const int col = n0 + h * 256 + lane * 4;
+        const float4 acc4 = gather_row_strip(values, column_indices, row_offsets[row],
+                                             row_offsets[row + 1], dense + col, n);
+        *reinterpret_cast<float4*>(out + static_cast<int64_t>(row) * n + col) =
+            apply_epilogue(acc4, epi, row);
+      }
     }
     return;
   }
@@ -325,8 +336,12 @@ __global__ __launch_bounds__(Cfg::kThreads) void spmm_tiled_kernel(
     const int entry = dealt_index(slot0 + r, slots, kDealPer);
     if (entry < m) {
       const int row = row_indices[entry];
-      *reinterpret_cast<float4*>(out + static_cast<int64_t>(row) * n + n0 + lane * VEC) =
-          apply_epilogue(make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]), epi, row);
+#pragma unroll
+      for (int h = 0; h < Cfg::kPieces; ++h)
+        *reinterpret_cast<float4*>(out + static_cast<int64_t>(row) * n + n0 + h * 256 + lane * 4) =
+            apply_epilogue(make_float4(acc[r][4 * h], acc[r][4 * h + 1], acc[r][4 * h + 2],
+                                       acc[r][4 * h + 3]),
+                           epi, row);
     }
   }
 }
@@ -342,7 +357,9 @@ Plan make_plan(int m, int k, int n) {
   Plan p;
   p.bm = Cfg::kBM;
   p.bk = Cfg::kBK;
-  p.slots = ceil_div(m, Cfg::kBM) * Cfg::kBM;
+  // whole runs of kDealPer slots (dealt_index), whatever the tile's row count
+  constexpr int kUnit = Cfg::kBM > kDealPer ? Cfg::kBM : kDealPer;
+  p.slots = ceil_div(m, kUnit) * kUnit;
   p.nchunks = ceil_div(k, Cfg::kBK);
   p.n_tiles = n / Cfg::kBN;
   p.table_bytes = sizeof(int) * static_cast<size_t>(p.nchunks + 1) * p.slots;
@@ -358,15 +375,24 @@ using CfgMedium = TileConfig<256, 16, 8, 64>;
 // 8 waves x 8 rows (64 x 256 tiles): four times the workgroups of the large
 // tile for problems that would otherwise cover a fraction of the chip.
 using CfgSmall = TileConfig<256, 8, 8, 64>;
+// 128 x 512 tile of C: eight columns per lane, i.e. ONE entry broadcast and
+// address per two ds_read_b128 and eight FMAs -- the inner step costs 2.0 ns per
+// FMA instruction against 2.6 with four columns (tools/ubench.hip, step_pair_v8
+// vs step_pair_v4).  The accumulators of 8 rows fill the registers that 16 rows
+// take above, and 32 rows of B are all that two LDS stages hold: a chunk table
+// of its own (BK = 32).  For problems large enough to give every CU a tile.
+using CfgWide512 = TileConfig<512, 16, 8, 32>;
 
 // Developer / test knob SPUTNIK_HIP_SPMM_KERNEL, read at every call: "wide" =
-// 256-column kernel whenever it applies, "narrow" = 64-column kernel whenever
-// it applies, "gather" = row-gather kernel; anything else = the automatic choice.
+// 256-column kernel whenever it applies, "wide512" = 512-column kernel whenever
+// it applies (else as "wide"), "narrow" = 64-column kernel whenever it applies,
+// "gather" = row-gather kernel; anything else = the automatic choice.
 // (The parity tests use it to reach every kernel with small inputs.)
 inline int forced_kernel() {
   const char* e = getenv("SPUTNIK_HIP_SPMM_KERNEL");
   if (e == nullptr) return 0;
-  return e[0] == 'w' ? -1 : e[0] == 'n' ? 1 : e[0] == 'g' ? 2 : 0;
+  if (e[0] == 'w') return (e[1] && e[2] && e[3] && e[4] == '5') ? -2 : -1;
+  return e[0] == 'n' ? 1 : e[0] == 'g' ? 2 : 0;
 }
 
 inline bool tiled_applicable(int m, int k, int n, int nonzeros) {
@@ -384,7 +410,17 @@ inline bool tiled_applicable(int m, int k, int n, int nonzeros) {
 // 15.2 TFLOP/s, with 16 replicas 28.5 vs 23.2).  The choice needs the replica
 // count, which a plan made ahead of time does not know: then both tables are
 // built (side by side in the workspace) and the call decides.
-enum class Kernel { kNone, kWide, kNarrow, kEither };
+enum class Kernel { kNone, kWide, kNarrow, kEither, kWide512 };
+
+inline bool tiled512_applicable(int m, int k, int n, int nonzeros) {
+  return forced_kernel() <= 0 && n % CfgWide512::kBN == 0 && k >= CfgWide512::kBK && m >= 64 &&
+         nonzeros >= 16 * static_cast<int64_t>(m);
+}
+
+inline size_t wide512_workspace_bytes(int m, int k, int n) {
+  const Plan plan = make_plan<CfgWide512>(m, k, n);
+  return (row_ok_bytes(plan.slots) + plan.table_bytes + 15) / 16 * 16;
+}
 
 inline size_t wide_workspace_bytes(int m, int k, int n) {
   const Plan plan = make_plan<CfgLarge>(m, k, n);
@@ -408,6 +444,14 @@ inline Kernel choose_kernel(int m, int k, int n, int nonzeros, int replicas /* <
     if (work < (int64_t{1} << 27) || (replicas < 8 && work < (int64_t{1} << 29)))
       return Kernel::kNone;
   }
+  // The 512-column kernel has one tile size: taken when the shape alone (whatever
+  // the replica count, so that a plan made ahead of the call knows) gives about
+  // one workgroup per CU.
+  if (tiled512_applicable(m, k, n, nonzeros)) {
+    const int64_t tiles512 =
+        static_cast<int64_t>(ceil_div(m, CfgWide512::kBM)) * (n / CfgWide512::kBN);
+    if (forced == -2 || (forced == 0 && tiles512 >= 192)) return Kernel::kWide512;
+  }
   const bool wide = tiled_applicable(m, k, n, nonzeros);
   const bool narrow = spmm_tiled64_applicable(m, k, n, nonzeros);
   if (!wide) return narrow ? Kernel::kNarrow : Kernel::kNone;
@@ -425,6 +469,7 @@ inline Kernel choose_kernel(int m, int k, int n, int nonzeros, int replicas /* <
 size_t spmm_tiled_workspace_bytes(int m, int k, int n, int nonzeros) {
   switch (choose_kernel(m, k, n, nonzeros, -1)) {
     case Kernel::kWide: return wide_workspace_bytes(m, k, n);
+    case Kernel::kWide512: return wide512_workspace_bytes(m, k, n);
     case Kernel::kNarrow: return spmm_tiled64_workspace_bytes(m, k);
     case Kernel::kEither: return wide_workspace_bytes(m, k, n) + spmm_tiled64_workspace_bytes(m, k);
     default: return 0;
@@ -452,14 +497,22 @@ int spmm_tiled_plan(int m, int k, int n, int nonzeros, int replicas, const int* 
         spmm_tiled64_plan(m, k, row_indices, row_offsets, column_indices, ws64, stream);
     if (st != 0) return st;
   }
-  if (which == Kernel::kWide || which == Kernel::kEither) {
-    using Cfg = CfgLarge;
-    const Plan plan = make_plan<Cfg>(m, k, n);
+  if (which == Kernel::kWide || which == Kernel::kEither || which == Kernel::kWide512) {
+    const bool w512 = which == Kernel::kWide512;
+    const Plan plan = w512 ? make_plan<CfgWide512>(m, k, n) : make_plan<CfgLarge>(m, k, n);
     int* row_ok = static_cast<int*>(workspace);
     int* table = reinterpret_cast<int*>(static_cast<char*>(workspace) + row_ok_bytes(plan.slots));
-    hipLaunchKernelGGL((spmm_chunk_table_kernel<ilog2(Cfg::kBK)>), dim3(ceil_div(plan.slots, 4)),
-                       dim3(256), 0, stream, m, k, plan.slots, kDealPer, plan.nchunks, row_indices,
-                       row_offsets, column_indices, table, row_ok);
+    if (w512) {
+      hipLaunchKernelGGL((spmm_chunk_table_kernel<ilog2(CfgWide512::kBK)>),
+                         dim3(ceil_div(plan.slots, 4)), dim3(256), 0, stream, m, k, plan.slots,
+                         kDealPer, plan.nchunks, row_indices, row_offsets, column_indices, table,
+                         row_ok);
+    } else {
+      hipLaunchKernelGGL((spmm_chunk_table_kernel<ilog2(CfgLarge::kBK)>),
+                         dim3(ceil_div(plan.slots, 4)), dim3(256), 0, stream, m, k, plan.slots,
+                         kDealPer, plan.nchunks, row_indices, row_offsets, column_indices, table,
+                         row_ok);
+    }
     const int st = launch_status();
     if (st != 0) return st;
   }
@@ -491,7 +544,8 @@ int spmm_tiled_exec(int m, int k, int n, int nonzeros, int replicas, const int* 
                              ws64, stream, epi);
   }
   using Cfg = CfgLarge;
-  const Plan plan = make_plan<Cfg>(m, k, n);
+  const bool w512 = which == Kernel::kWide512;
+  const Plan plan = w512 ? make_plan<CfgWide512>(m, k, n) : make_plan<Cfg>(m, k, n);
   const int* row_ok = static_cast<const int*>(workspace);
   const int* table = reinterpret_cast<const int*>(static_cast<const char*>(workspace) +
                                                   row_ok_bytes(plan.slots));
@@ -523,7 +577,10 @@ int spmm_tiled_exec(int m, int k, int n, int nonzeros, int replicas, const int* 
                      0, stream, m, k, n, nonzeros, plan.slots, plan.nchunks, plan.n_tiles,        \
                      row_indices, values, values_stride, column_indices, table, dense,            \
                      dense_stride, out, out_stride, row_ok, row_offsets, debug, epi)
-  if (tile == 0) {
+  if (w512) {
+    if (sparse) SPUTNIK_HIP_LAUNCH_TILED(CfgWide512, true);
+    else SPUTNIK_HIP_LAUNCH_TILED(CfgWide512, false);
+  } else if (tile == 0) {
     if (sparse) SPUTNIK_HIP_LAUNCH_TILED(CfgLarge, true);
     else SPUTNIK_HIP_LAUNCH_TILED(CfgLarge, false);
   } else if (tile == 1) {

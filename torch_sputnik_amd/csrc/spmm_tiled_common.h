@@ -163,7 +163,9 @@ __device__ __forceinline__ void wait_positions(V& a) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a) : : "memory");
 }
 
-// One nonzero against the staged tile: acc[0..3] += a * (float4 read from the tile).
+// One nonzero against the staged tile.  A lane owns 4 consecutive columns of
+// every 256-column piece of the tile row (VEC = 4: one piece, VEC = 8: two, the
+// second 1 KiB further on), so a B row strip is one or two ds_read_b128.
 #define SPUTNIK_HIP_FMA4(ACC, A, B)          \
   do {                                       \
     (ACC)[0] = fmaf((A), (B).x, (ACC)[0]);   \
@@ -171,6 +173,28 @@ __device__ __forceinline__ void wait_positions(V& a) {
     (ACC)[2] = fmaf((A), (B).z, (ACC)[2]);   \
     (ACC)[3] = fmaf((A), (B).w, (ACC)[3]);   \
   } while (0)
+template <int VEC>
+struct BStrip;
+template <>
+struct BStrip<4> {
+  float4 p0;
+  __device__ __forceinline__ void read(const char* __restrict__ at) {
+    p0 = *reinterpret_cast<const float4*>(at);
+  }
+  __device__ __forceinline__ void fma(float (&acc)[4], float a) const { SPUTNIK_HIP_FMA4(acc, a, p0); }
+};
+template <>
+struct BStrip<8> {
+  float4 p0, p1;
+  __device__ __forceinline__ void read(const char* __restrict__ at) {
+    p0 = *reinterpret_cast<const float4*>(at);
+    p1 = *reinterpret_cast<const float4*>(at + 1024);
+  }
+  __device__ __forceinline__ void fma(float (&acc)[8], float a) const {
+    SPUTNIK_HIP_FMA4(acc, a, p0);
+    SPUTNIK_HIP_FMA4(acc + 4, a, p1);
+  }
+};
 
 // DPP row_newbcast: every lane of a 16-lane row reads lane U of ITS row.  With
 // the same 16 entries replicated in all four rows this is a wave-wide
@@ -200,20 +224,27 @@ __device__ __forceinline__ float entry_val(entry_pair e) {
 }
 // Four nonzeros G..G+3 of the replicated 16-entry set (roff = byte offset of
 // the B row inside the staged tile, rval = value; both per entry lane).
-template <int G>
-__device__ __forceinline__ void dpp_group4(float (&acc)[4], int roff, float rval,
+template <int G, int VEC>
+__device__ __forceinline__ void dpp_group4(float (&acc)[VEC], int roff, float rval,
                                            const char* __restrict__ lane_base) {
   const entry_pair e = make_entry(roff, rval);
   const entry_pair e0 = row_bcast_entry<G + 0>(e), e1 = row_bcast_entry<G + 1>(e);
   const entry_pair e2 = row_bcast_entry<G + 2>(e), e3 = row_bcast_entry<G + 3>(e);
-  const float4 b0 = *reinterpret_cast<const float4*>(lane_base + entry_off(e0));
-  const float4 b1 = *reinterpret_cast<const float4*>(lane_base + entry_off(e1));
-  const float4 b2 = *reinterpret_cast<const float4*>(lane_base + entry_off(e2));
-  const float4 b3 = *reinterpret_cast<const float4*>(lane_base + entry_off(e3));
-  SPUTNIK_HIP_FMA4(acc, entry_val(e0), b0);
-  SPUTNIK_HIP_FMA4(acc, entry_val(e1), b1);
-  SPUTNIK_HIP_FMA4(acc, entry_val(e2), b2);
-  SPUTNIK_HIP_FMA4(acc, entry_val(e3), b3);
+  BStrip<VEC> b0, b1, b2, b3;
+  b0.read(lane_base + entry_off(e0));
+  b1.read(lane_base + entry_off(e1));
+  b2.read(lane_base + entry_off(e2));
+  b3.read(lane_base + entry_off(e3));
+  b0.fma(acc, entry_val(e0));
+  b1.fma(acc, entry_val(e1));
+  b2.fma(acc, entry_val(e2));
+  b3.fma(acc, entry_val(e3));
+  if constexpr (VEC == 8) {
+    // all eight reads of the batch in flight before the first FMA: left alone the
+    // scheduler trades the 32 strip registers for three dependent LDS round trips
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);  // DS reads
+    __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);  // VALU: the 16 v_pk_fma_f32
+  }
 }
 
 // True iff every one of the workgroup's `rows` row slots (starting at
@@ -250,7 +281,8 @@ __device__ __forceinline__ float4 gather_row_strip(const float* __restrict__ val
 // caller masks them).  Exact tails (pair/single groups at every position) were
 // tried: the extra branches and the 2-3x larger unrolled code of the 16 rows
 // cost more than the padded work they save (0.58 vs 0.50 ms at density 0.1).
-__device__ __forceinline__ void dpp_entries(float (&acc)[4], int n16, int roff, float rval,
+template <int VEC>
+__device__ __forceinline__ void dpp_entries(float (&acc)[VEC], int n16, int roff, float rval,
                                             const char* __restrict__ lane_base) {
   if (n16 > 0) dpp_group4<0>(acc, roff, rval, lane_base);
   if (n16 > 4) dpp_group4<4>(acc, roff, rval, lane_base);
@@ -278,25 +310,26 @@ __device__ __forceinline__ entry_pair row_rotate_entry(entry_pair e) {
   return make_entry(row_rotate_i<N>(entry_off(e)), row_rotate_f<N>(entry_val(e)));
 }
 
-template <int COUNT>
-__device__ __forceinline__ void dpp_group_at0(float (&acc)[4], entry_pair e,
+template <int COUNT, int VEC>
+__device__ __forceinline__ void dpp_group_at0(float (&acc)[VEC], entry_pair e,
                                               const char* __restrict__ lane_base) {
   static_assert(COUNT == 1 || COUNT == 2 || COUNT == 4, "");
   const entry_pair e0 = row_bcast_entry<0>(e);
   const entry_pair e1 = COUNT > 1 ? row_bcast_entry<1>(e) : 0;
   const entry_pair e2 = COUNT > 2 ? row_bcast_entry<2>(e) : 0;
   const entry_pair e3 = COUNT > 2 ? row_bcast_entry<3>(e) : 0;
-  float4 b0, b1, b2, b3;
-  b0 = *reinterpret_cast<const float4*>(lane_base + entry_off(e0));
-  if (COUNT > 1) b1 = *reinterpret_cast<const float4*>(lane_base + entry_off(e1));
-  if (COUNT > 2) b2 = *reinterpret_cast<const float4*>(lane_base + entry_off(e2));
-  if (COUNT > 2) b3 = *reinterpret_cast<const float4*>(lane_base + entry_off(e3));
-  SPUTNIK_HIP_FMA4(acc, entry_val(e0), b0);
-  if (COUNT > 1) SPUTNIK_HIP_FMA4(acc, entry_val(e1), b1);
-  if (COUNT > 2) SPUTNIK_HIP_FMA4(acc, entry_val(e2), b2);
-  if (COUNT > 2) SPUTNIK_HIP_FMA4(acc, entry_val(e3), b3);
+  BStrip<VEC> b0, b1, b2, b3;
+  b0.read(lane_base + entry_off(e0));
+  if (COUNT > 1) b1.read(lane_base + entry_off(e1));
+  if (COUNT > 2) b2.read(lane_base + entry_off(e2));
+  if (COUNT > 2) b3.read(lane_base + entry_off(e3));
+  b0.fma(acc, entry_val(e0));
+  if (COUNT > 1) b1.fma(acc, entry_val(e1));
+  if (COUNT > 2) b2.fma(acc, entry_val(e2));
+  if (COUNT > 2) b3.fma(acc, entry_val(e3));
 }
-__device__ __forceinline__ void dpp_entries_exact(float (&acc)[4], int n16, int roff, float rval,
+template <int VEC>
+__device__ __forceinline__ void dpp_entries_exact(float (&acc)[VEC], int n16, int roff, float rval,
                                                   const char* __restrict__ lane_base) {
   entry_pair e = make_entry(roff, rval);
   int left = n16;
