@@ -211,7 +211,7 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
                 float, __builtin_amdgcn_ds_bpermute(idx, __builtin_bit_cast(int, rval)));
           }
           dpp_entries_exact(acc[r], min(16, cnt), rcol * (BN * 4), rval, lane_base);
-          if (cnt > 16) {  // rare: the rest of a long segment, 16 entries at a time
+          if (cnt > 16) {  // rare: the rest of a long segment, 16 entries at a time  // rare: the rest of a long segment, 16 entries at a time
             const int start = s_ps[r];
             for (int q0 = 16; q0 < cnt; q0 += 16) {
               const int base = min(start + q0, last_window);
@@ -325,11 +325,9 @@ __global__ __launch_bounds__(Cfg::kThreads) void spmm_tiled_kernel(
 #pragma unroll
     for (int v = 0; v < VEC; ++v) acc[r][v] = 0.f;
 
-  {
-    spmm_tiled_body_dpp<Cfg, SPARSE>(acc, &tile[0][0], lane, wave, slot0, slots, nchunks, nonzeros, n, k,
-                             n0, values, column_indices, table, dense, dbg_no_compute,
-                             dbg_no_stage, dbg_no_barrier);
-  }
+  spmm_tiled_body_dpp<Cfg, SPARSE>(acc, &tile[0][0], lane, wave, slot0, slots, nchunks, nonzeros, n,
+                                   k, n0, values, column_indices, table, dense, dbg_no_compute,
+                                   dbg_no_stage, dbg_no_barrier);
 
 #pragma unroll
   for (int r = 0; r < RPW; ++r) {
@@ -450,7 +448,11 @@ inline Kernel choose_kernel(int m, int k, int n, int nonzeros, int replicas /* <
   if (tiled512_applicable(m, k, n, nonzeros)) {
     const int64_t tiles512 =
         static_cast<int64_t>(ceil_div(m, CfgWide512::kBM)) * (n / CfgWide512::kBN);
-    if (forced == -2 || (forced == 0 && tiles512 >= 192)) return Kernel::kWide512;
+    // ... and a row has more than about two entries per 32-row chunk (below that
+    // the 64-row chunks of the 256-column kernel win by 2 %: 4096^3 at density 0.05)
+    const bool long_enough = static_cast<int64_t>(nonzeros) * 5 >=
+                             int64_t{11} * m * ceil_div(k, CfgWide512::kBK);
+    if (forced == -2 || (forced == 0 && tiles512 >= 192 && long_enough)) return Kernel::kWide512;
   }
   const bool wide = tiled_applicable(m, k, n, nonzeros);
   const bool narrow = spmm_tiled64_applicable(m, k, n, nonzeros);
@@ -561,7 +563,13 @@ int spmm_tiled_exec(int m, int k, int n, int nonzeros, int replicas, const int* 
   }();
   // Mean number of entries of a row inside one K chunk picks the variant
   // (measured cross-over at 4096^3: between density 0.15 and 0.2).
-  const bool sparse = forced >= 0
+  // Mean number of entries of a row inside one K chunk picks the variant
+  // (measured cross-over at 4096^3, 64-row chunks: between density 0.15 and 0.2).
+  // The 512-column tile always takes the short-segment variant: its 32-row chunks
+  // hold at most 32 entries of a row, and it measured faster up to density 0.9
+  // (55.3 vs 52.5 TFLOP/s), so the long-segment form is not even built for it.
+  const bool sparse = w512 ? true
+                      : forced >= 0
                           ? forced != 0
                           : static_cast<int64_t>(nonzeros) < int64_t{12} * m * plan.nchunks;
   static const int force_tile = [] {
@@ -578,8 +586,7 @@ int spmm_tiled_exec(int m, int k, int n, int nonzeros, int replicas, const int* 
                      row_indices, values, values_stride, column_indices, table, dense,            \
                      dense_stride, out, out_stride, row_ok, row_offsets, debug, epi)
   if (w512) {
-    if (sparse) SPUTNIK_HIP_LAUNCH_TILED(CfgWide512, true);
-    else SPUTNIK_HIP_LAUNCH_TILED(CfgWide512, false);
+    SPUTNIK_HIP_LAUNCH_TILED(CfgWide512, true);
   } else if (tile == 0) {
     if (sparse) SPUTNIK_HIP_LAUNCH_TILED(CfgLarge, true);
     else SPUTNIK_HIP_LAUNCH_TILED(CfgLarge, false);

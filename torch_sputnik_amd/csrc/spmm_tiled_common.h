@@ -239,12 +239,6 @@ __device__ __forceinline__ void dpp_group4(float (&acc)[VEC], int roff, float rv
   b1.fma(acc, entry_val(e1));
   b2.fma(acc, entry_val(e2));
   b3.fma(acc, entry_val(e3));
-  if constexpr (VEC == 8) {
-    // all eight reads of the batch in flight before the first FMA: left alone the
-    // scheduler trades the 32 strip registers for three dependent LDS round trips
-    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);  // DS reads
-    __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);  // VALU: the 16 v_pk_fma_f32
-  }
 }
 
 // True iff every one of the workgroup's `rows` row slots (starting at
