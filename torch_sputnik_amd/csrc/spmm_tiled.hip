@@ -137,11 +137,10 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
   // quarter of the window traffic, and the entries are processed exactly
   // (rotating groups).  For short segments only: the rare segment with more
   // than 16 entries fetches the rest on demand, draining the wave's loads.
-  constexpr int kWindow = SPARSE ? 16 : kWave;
   const int* __restrict__ my_table = table + slot0;  // wave-uniform
   const int e16x4 = (lane & 15) * 4;
-  const unsigned lane4 = static_cast<unsigned>(SPARSE ? (lane & 15) : lane) * 4u;
-  const int last_window = nonzeros - kWindow;  // >= 0: the dispatcher requires >= 1024 nonzeros
+  const int window_lane = SPARSE ? (lane & 15) : lane;  // the window entry this lane loads
+  const int last_entry = nonzeros - 1;
   const float* lane_tile = tile0 + lane * 4;
   const unsigned b_lane_off = static_cast<unsigned>(n0 + lane * 4) * 4u;
 
@@ -154,19 +153,23 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
   wait_positions(s_ps);
   wait_positions(s_pe);
 
-  // Entry window of a row: 64 consecutive stream entries (lane = entry)
-  // starting at `start`, loaded with a wave-uniform base and a constant lane
-  // offset.  Near the end of the arrays the window is moved back so that it
-  // never reads past them; `shift` is then the position of the row's first
-  // entry inside the window.
+  // Entry window of a row: 64 (short-segment variant: 16) consecutive stream entries starting at
+  // `start` (lane = entry, or entry = lane % 16 in the short-segment variant).
+  // The per-lane byte offset is formed on the VALU -- the loop is bound by
+  // SCALAR instruction issue (about 45 scalar operations per (row, chunk) visit
+  // at 1.75 ns each per SIMD against 96 ns per visit), so
+  // nothing that a vector instruction can do is left to the scalar unit.  Lanes
+  // past the end of the arrays re-read the last entry; the counts are exact, so
+  // such entries are never used.
   int vcol[D];
   float vval[D];
-  int shift[D];
+  auto window_offset = [&](int start) {
+    return static_cast<unsigned>(min(start + window_lane, last_entry)) * 4u;
+  };
   auto request = [&](int slot, int start) {
-    const int base = min(start, last_window);
-    shift[slot] = start - base;
-    vcol[slot] = untracked_load_i32(column_indices + base, lane4);
-    vval[slot] = untracked_load_f32(values + base, lane4);
+    const unsigned off = window_offset(start);
+    vcol[slot] = untracked_load_i32(column_indices, off);
+    vval[slot] = untracked_load_f32(values, off);
   };
 #pragma unroll
   for (int r = 0; r < D; ++r) request(r, s_ps[r]);
@@ -199,33 +202,18 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
       } else {
         wait_vm<kWaitSameChunk>(wcol, wval);
       }
-      const int cnt = dbg_no_compute ? 0 : s_pe[r] - s_ps[r];
+      const int cnt = s_pe[r] - s_ps[r];
       if constexpr (SPARSE) {
         if (cnt > 0) {
-          int rcol = wcol;
-          float rval = wval;
-          if (shift[r % D] != 0) {  // window moved back at the end of the arrays: realign
-            const int idx = ((lane & 48) << 2) + ((e16x4 + (shift[r % D] << 2)) & 60);
-            rcol = __builtin_amdgcn_ds_bpermute(idx, rcol);
-            rval = __builtin_bit_cast(
-                float, __builtin_amdgcn_ds_bpermute(idx, __builtin_bit_cast(int, rval)));
-          }
-          dpp_entries_exact(acc[r], min(16, cnt), rcol * (BN * 4), rval, lane_base);
-          if (cnt > 16) {  // rare: the rest of a long segment, 16 entries at a time  // rare: the rest of a long segment, 16 entries at a time
+          dpp_entries_exact(acc[r], min(16, cnt), wcol * (BN * 4), wval, lane_base);
+          if (cnt > 16) {  // rare: the rest of a long segment, 16 entries at a time
             const int start = s_ps[r];
             for (int q0 = 16; q0 < cnt; q0 += 16) {
-              const int base = min(start + q0, last_window);
-              const int sh = start + q0 - base;
-              int c2 = untracked_load_i32(column_indices + base, lane4);
-              float v2 = untracked_load_f32(values + base, lane4);
+              const unsigned off = window_offset(start + q0);
+              int c2 = untracked_load_i32(column_indices, off);
+              float v2 = untracked_load_f32(values, off);
               wait_vm<0>();
               asm volatile("" : "+v"(c2), "+v"(v2));
-              if (sh != 0) {
-                const int idx = ((lane & 48) << 2) + ((e16x4 + (sh << 2)) & 60);
-                c2 = __builtin_amdgcn_ds_bpermute(idx, c2);
-                v2 = __builtin_bit_cast(
-                    float, __builtin_amdgcn_ds_bpermute(idx, __builtin_bit_cast(int, v2)));
-              }
               dpp_entries_exact(acc[r], min(16, cnt - q0), c2 * (BN * 4), v2, lane_base);
             }
           }
@@ -233,7 +221,7 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
       } else {
       for (int q0 = 0; q0 < cnt; q0 += 16) {
         // replicate entries q0 .. q0+15 of the row into every 16-lane row
-        const int idx = e16x4 + ((q0 + shift[r % D]) << 2);
+        const int idx = e16x4 + (q0 << 2);
         const int rcol = __builtin_amdgcn_ds_bpermute(idx, wcol);
         const float rval_all = __builtin_bit_cast(
             float, __builtin_amdgcn_ds_bpermute(idx, __builtin_bit_cast(int, wval)));
@@ -249,7 +237,7 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
     }
     wait_positions(s_pe_next);
     s_ps = s_pe;
-    s_pe = s_pe_next;
+    s_pe = dbg_no_compute ? s_pe : s_pe_next;  // timing experiment: every later segment is empty
     wait_vm<kWaitStage>();  // next B tile landed; windows and positions stay in flight
     if (!dbg_no_barrier) __syncthreads();
   }
@@ -398,7 +386,7 @@ inline bool tiled_applicable(int m, int k, int n, int nonzeros) {
   // Needs full column tiles, and enough work per row block to amortise staging
   // B (each workgroup stages k x 256 floats): mean row length >= 16.
   return n % CfgLarge::kBN == 0 && k >= CfgLarge::kBK && m >= 64 &&
-         nonzeros >= 16 * static_cast<int64_t>(m);
+         nonzeros >= 16 * static_cast<int64_t>(m) && nonzeros < (1 << 30);  // 32-bit byte offsets
 }
 
 // Which tiled kernel serves a call.  Both may be applicable (n a multiple of
@@ -412,7 +400,7 @@ enum class Kernel { kNone, kWide, kNarrow, kEither, kWide512 };
 
 inline bool tiled512_applicable(int m, int k, int n, int nonzeros) {
   return forced_kernel() <= 0 && n % CfgWide512::kBN == 0 && k >= CfgWide512::kBK && m >= 64 &&
-         nonzeros >= 16 * static_cast<int64_t>(m);
+         nonzeros >= 16 * static_cast<int64_t>(m) && nonzeros < (1 << 30);  // 32-bit byte offsets
 }
 
 inline size_t wide512_workspace_bytes(int m, int k, int n) {
