@@ -147,6 +147,28 @@ def test_spmm_full_size_linearity(capi, dev):
         assert rel_err(c1[r].cpu().numpy(), want) < TOL
 
 
+@pytest.mark.parametrize("density", [0.5, 0.1, 0.05])
+def test_spmm_full_size_whole_matrix(capi, dev, density):
+    """Every element of the 4096^3 product against a dense fp32 product on the GPU
+    (the CPU oracle would take minutes): the linearity test above cannot see a row
+    that is wrong in the same way in every call."""
+    from torch_sputnik_amd.synthetic import random_csr, uniform
+    m = k = n = 4096
+    ri, ro, ci, nnz = random_csr(m, k, density, dev, seed=int(density * 1000) + 11)
+    vals = uniform((nnz,), dev, 1) - 0.5
+    b = uniform((k, n), dev, 2) - 0.5
+    rows = torch.repeat_interleave(torch.arange(m, device=dev), (ro[1:] - ro[:-1]).long())
+    a = torch.zeros(m, k, device=dev)
+    a[rows, ci.long()] = vals
+    want = a @ b
+    ws = torch.empty(capi.spmm_workspace_bytes(m, k, n, nnz) + 16, dtype=torch.uint8, device=dev)
+    out = torch.full((m, n), float("nan"), device=dev)
+    capi.spmm_batched(m, k, n, 1, ri, vals, 0, ro, ci, b, out, ws)
+    assert not torch.isnan(out).any()
+    err = (out - want).abs().amax(dim=1) / want.abs().amax()
+    assert float(err.max()) < TOL, f"{int((err > TOL).sum())} rows off, worst {int(err.argmax())}"
+
+
 @pytest.mark.parametrize("replicas,shared,m,k,n", [
     (3, False, 130, 96, 136), (5, True, 130, 96, 136), (1, False, 130, 96, 136),
     (4, False, 512, 512, 64), (3, True, 300, 256, 128),       # 64-column tiled kernel

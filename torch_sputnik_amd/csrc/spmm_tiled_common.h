@@ -173,24 +173,28 @@ __device__ __forceinline__ void wait_positions(V& a) {
     (ACC)[2] = fmaf((A), (B).z, (ACC)[2]);   \
     (ACC)[3] = fmaf((A), (B).w, (ACC)[3]);   \
   } while (0)
+using v4f = float __attribute__((ext_vector_type(4)));
 template <int VEC>
 struct BStrip;
 template <>
 struct BStrip<4> {
-  float4 p0;
+  v4f p0;
   __device__ __forceinline__ void read(const char* __restrict__ at) {
-    p0 = *reinterpret_cast<const float4*>(at);
+    p0 = *reinterpret_cast<const v4f*>(at);
   }
-  __device__ __forceinline__ void fma(float (&acc)[4], float a) const { SPUTNIK_HIP_FMA4(acc, a, p0); }
+  __device__ __forceinline__ void fma(float (&acc)[4], float a) { SPUTNIK_HIP_FMA4(acc, a, p0); }
 };
 template <>
 struct BStrip<8> {
-  float4 p0, p1;
+  v4f p0, p1;
   __device__ __forceinline__ void read(const char* __restrict__ at) {
-    p0 = *reinterpret_cast<const float4*>(at);
-    p1 = *reinterpret_cast<const float4*>(at + 1024);
+    p0 = *reinterpret_cast<const v4f*>(at);
+    p1 = *reinterpret_cast<const v4f*>(at + 1024);
   }
-  __device__ __forceinline__ void fma(float (&acc)[8], float a) const {
+  __device__ __forceinline__ void fma(float (&acc)[8], float a) {
+    // one `s_waitcnt` per entry instead of one per piece: the loop around this is
+    // bound by scalar/issue slots, not by the LDS pipe
+    asm("" : "+v"(p0), "+v"(p1));
     SPUTNIK_HIP_FMA4(acc, a, p0);
     SPUTNIK_HIP_FMA4(acc + 4, a, p1);
   }
