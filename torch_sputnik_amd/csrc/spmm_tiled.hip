@@ -204,18 +204,18 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
       }
       const int cnt = s_pe[r] - s_ps[r];
       if constexpr (SPARSE) {
-        if (cnt > 0) {
-          dpp_entries_exact(acc[r], min(16, cnt), wcol * (BN * 4), wval, lane_base);
-          if (cnt > 16) {  // rare: the rest of a long segment, 16 entries at a time
-            const int start = s_ps[r];
-            for (int q0 = 16; q0 < cnt; q0 += 16) {
-              const unsigned off = window_offset(start + q0);
-              int c2 = untracked_load_i32(column_indices, off);
-              float v2 = untracked_load_f32(values, off);
-              wait_vm<0>();
-              asm volatile("" : "+v"(c2), "+v"(v2));
-              dpp_entries_exact(acc[r], min(16, cnt - q0), c2 * (BN * 4), v2, lane_base);
-            }
+        // (no test for an empty segment: it would cost every other visit a scalar
+        // compare and branch, and an empty one falls through three tests anyway)
+        dpp_entries_exact(acc[r], min(16, cnt), wcol * (BN * 4), wval, lane_base);
+        if (cnt > 16) {  // rare: the rest of a long segment, 16 entries at a time
+          const int start = s_ps[r];
+          for (int q0 = 16; q0 < cnt; q0 += 16) {
+            const unsigned off = window_offset(start + q0);
+            int c2 = untracked_load_i32(column_indices, off);
+            float v2 = untracked_load_f32(values, off);
+            wait_vm<0>();
+            asm volatile("" : "+v"(c2), "+v"(v2));
+            dpp_entries_exact(acc[r], min(16, cnt - q0), c2 * (BN * 4), v2, lane_base);
           }
         }
       } else {
