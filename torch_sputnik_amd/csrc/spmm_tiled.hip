@@ -550,16 +550,15 @@ int spmm_tiled_exec(int m, int k, int n, int nonzeros, int replicas, const int* 
     return e ? atoi(e) : 0;
   }();
   // Mean number of entries of a row inside one K chunk picks the variant
-  // (measured cross-over at 4096^3: between density 0.15 and 0.2).
-  // Mean number of entries of a row inside one K chunk picks the variant
-  // (measured cross-over at 4096^3, 64-row chunks: between density 0.15 and 0.2).
+  // (measured cross-over with 64-row chunks, 4096^3 and 2048^3 x 8: density 0.2
+  // short-segment form 7-9 % ahead, 0.25 a tie, 0.3 and above the long-segment form).
   // The 512-column tile always takes the short-segment variant: its 32-row chunks
   // hold at most 32 entries of a row, and it measured faster up to density 0.9
   // (55.3 vs 52.5 TFLOP/s), so the long-segment form is not even built for it.
   const bool sparse = w512 ? true
                       : forced >= 0
                           ? forced != 0
-                          : static_cast<int64_t>(nonzeros) < int64_t{12} * m * plan.nchunks;
+                          : static_cast<int64_t>(nonzeros) < int64_t{15} * m * plan.nchunks;
   static const int force_tile = [] {
     const char* e = getenv("SPUTNIK_HIP_SPMM_MEDIUM");  // developer knob: 1 = medium, 2 = small tile
     return e ? atoi(e) : 0;
