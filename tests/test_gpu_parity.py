@@ -169,6 +169,40 @@ def test_spmm_full_size_whole_matrix(capi, dev, density):
     assert float(err.max()) < TOL, f"{int((err > TOL).sum())} rows off, worst {int(err.argmax())}"
 
 
+def test_spmm_full_size_after_other_products(capi, dev):
+    """The 4096^3 product after three products of OTHER topologies have gone
+    through the same workspace, called three times back to back, every element
+    checked.  A layout of the tiled kernel's main loop that was a few scalar
+    instructions shorter per visit passed everything else and faulted in this
+    sequence in most runs: a change of that loop has to
+    pass this one, repeatedly (tools/repeat_primer.sh)."""
+    from torch_sputnik_amd.synthetic import random_csr, uniform
+    m = k = n = 4096
+    density, seed = 0.1, 5234
+    b = uniform((k, n), dev, 2) - 0.5
+    ri, ro, ci, nnz = random_csr(m, k, density, dev, seed=seed)
+    vals = uniform((nnz,), dev, 1) - 0.5
+    ws = torch.empty(capi.spmm_workspace_bytes(m, k, n, nnz) + 16, dtype=torch.uint8, device=dev)
+    for j in range(3):
+        ri2, ro2, ci2, nnz2 = random_csr(m, k, density, dev, seed=seed + 1 + j)
+        assert nnz2 == nnz
+        scratch_out = torch.empty(m, n, device=dev)
+        capi.spmm_batched(m, k, n, 1, ri2, vals, 0, ro2, ci2, b, scratch_out, ws)
+        torch.cuda.synchronize()
+    outs = []
+    for _ in range(3):
+        out = torch.full((m, n), float("nan"), device=dev)
+        capi.spmm_batched(m, k, n, 1, ri, vals, 0, ro, ci, b, out, ws)
+        outs.append(out)
+    rows = torch.repeat_interleave(torch.arange(m, device=dev), (ro[1:] - ro[:-1]).long())
+    a = torch.zeros(m, k, device=dev)
+    a[rows, ci.long()] = vals
+    want = a @ b
+    for out in outs:
+        err = (out - want).abs().amax(dim=1) / want.abs().amax()
+        assert float(err.max()) < TOL
+
+
 @pytest.mark.parametrize("replicas,shared,m,k,n", [
     (3, False, 130, 96, 136), (5, True, 130, 96, 136), (1, False, 130, 96, 136),
     (4, False, 512, 512, 64), (3, True, 300, 256, 128),       # 64-column tiled kernel
