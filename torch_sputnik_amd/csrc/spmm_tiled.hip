@@ -242,6 +242,19 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
     if (!dbg_no_barrier) __syncthreads();
   }
   wait_vm<0>();  // nothing may be in flight (LDS-DMA!) when the wave ends
+  // ... and the windows requested by the last rows (clamped, never used) must
+  // stay ALLOCATED up to this wait: the compiler takes an asm-issued load as
+  // complete where it is issued, so a register whose value is never read is free
+  // to it at once -- it put the output address of the epilogue into such a
+  // register pair ahead of the wait (one faster layout of the loop did; which one
+  // does is a matter of scheduling), the late load landed on it, and the store
+  // went to a wild address: an aperture violation in 40-75 % of the runs on a
+  // warmed-up GPU, none on a cold one.
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    tie_reg(vcol[i]);
+    tie_reg(vval[i]);
+  }
 }
 
 // SPARSE = false: 64-entry windows, groups of four entries with a padded last

@@ -233,6 +233,11 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled64_kernel(
     if (c0 + 2 < nchunks) chunk(std::integral_constant<int, 2>{}, c0 + 2);
   }
   wait_vm<0>();  // nothing may be in flight (LDS-DMA!) when the wave ends
+  // the windows of the two chunks past the end were requested and never read:
+  // keep their registers allocated up to the wait (see spmm_tiled.hip)
+  arrived(std::integral_constant<int, 0>{});
+  arrived(std::integral_constant<int, 1>{});
+  arrived(std::integral_constant<int, 2>{});
 
 #pragma unroll
   for (int t = 0; t < kRQ; ++t) {
