@@ -204,20 +204,38 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
       }
       const int cnt = s_pe[r] - s_ps[r];
       if constexpr (SPARSE) {
-        // (no test for an empty segment: it would cost every other visit a scalar
-        // compare and branch, and an empty one falls through three tests anyway)
-        dpp_entries_exact(acc[r], min(16, cnt), wcol * (BN * 4), wval, lane_base);
-        if (cnt > 16) {  // rare: the rest of a long segment, 16 entries at a time
-          const int start = s_ps[r];
-          for (int q0 = 16; q0 < cnt; q0 += 16) {
-            const unsigned off = window_offset(start + q0);
-            int c2 = untracked_load_i32(column_indices, off);
-            float v2 = untracked_load_f32(values, off);
-            wait_vm<0>();
-            asm volatile("" : "+v"(c2), "+v"(v2));
-            dpp_entries_exact(acc[r], min(16, cnt - q0), c2 * (BN * 4), v2, lane_base);
+        // Laid out for the fewest scalar compares and branches on the common
+        // short segment (the loop is bound by its serial instruction stream): an
+        // empty segment and one of 1..3 entries pass three tests (>= 4, bit 1,
+        // bit 0); the test for a segment longer than the window is only reached
+        // by segments of four or more.
+        entry_pair e = make_entry(wcol * (BN * 4), wval);
+        int tail = cnt;  // bits 0 and 1: the entries left after the batches of four
+        if (cnt >= 4) {
+          int left = min(16, cnt);
+          do {
+            dpp_group_at0<4>(acc[r], e, lane_base);
+            e = row_rotate_entry<4>(e);
+            left -= 4;
+          } while (left >= 4);
+          tail = left;
+          if (cnt > 16) {  // rare: the rest of a long segment, 16 entries at a time (tail = 0 here)
+            const int start = s_ps[r];
+            for (int q0 = 16; q0 < cnt; q0 += 16) {
+              const unsigned off = window_offset(start + q0);
+              int c2 = untracked_load_i32(column_indices, off);
+              float v2 = untracked_load_f32(values, off);
+              wait_vm<0>();
+              asm volatile("" : "+v"(c2), "+v"(v2));
+              dpp_entries_exact(acc[r], min(16, cnt - q0), c2 * (BN * 4), v2, lane_base);
+            }
           }
         }
+        if (tail & 2) {
+          dpp_group_at0<2>(acc[r], e, lane_base);
+          e = row_rotate_entry<2>(e);
+        }
+        if (tail & 1) dpp_group_at0<1>(acc[r], e, lane_base);
       } else {
       for (int q0 = 0; q0 < cnt; q0 += 16) {
         // replicate entries q0 .. q0+15 of the row into every 16-lane row
