@@ -104,6 +104,14 @@ __device__ __forceinline__ void lds_dma_row(const float* row_base /* wave-unifor
 
 // Vector load whose completion the compiler does not track (the main loop counts
 // vmcnt by hand, see the kernel).
+// RULE: the compiler takes the load as complete where it is issued.  Every
+// register such a load writes must therefore be READ (tie_reg, or a "+v"
+// operand of the wait) after the s_waitcnt that covers it, on EVERY path --
+// also where the value is not wanted (the clamped requests past the last
+// chunk).  A register that is never read again is free to the compiler at once:
+// it may be given to something else while the load is still in flight, and the
+// late data then lands on that something else (it was the epilogue's output
+// address once: DESIGN.md section 3.1).
 // (wave-uniform base in SGPRs + 32-bit per-lane byte offset: no 64-bit VGPR
 // address arithmetic, no VGPR pairs to keep alive.)
 __device__ __forceinline__ int untracked_load_i32(const int* base, unsigned byte_offset) {
