@@ -52,9 +52,10 @@ def spmm_bytes(nnz, m, k, n, replicas=1):
     return replicas * (8.0 * nnz + 4.0 * k * n + 4.0 * m * n) + 4.0 * (2 * m + 1)
 
 
-def event_time_ms(fn, iters, warmup=3):
-    """Median GPU time of one call: one HIP event pair per call on torch's current
-    stream (= the stream the C ABI launches on), so host launch gaps are not counted."""
+def event_time_ms(fn, iters, warmup=3, with_min=False):
+    """Median (and minimum) GPU time of one call: one HIP event pair per call on
+    torch's current stream (= the stream the C ABI launches on), so host launch
+    gaps are not counted."""
     for _ in range(warmup):
         fn()
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
@@ -66,7 +67,7 @@ def event_time_ms(fn, iters, warmup=3):
         e.record()
     torch.cuda.synchronize()
     times = sorted(s.elapsed_time(e) for s, e in zip(starts, ends))
-    return times[len(times) // 2]
+    return (times[len(times) // 2], times[0]) if with_min else times[len(times) // 2]
 
 
 class SpmmProblem:
@@ -452,9 +453,11 @@ def main():
             for d in DENSITIES:
                 p = problem if d == HEADLINE_DENSITY else SpmmProblem(dev, d, 1, seed=1234 + 1000 * DENSITIES.index(d))
                 p.step()
-                ms_full = event_time_ms(p.step, 10)
-                ms_kern = event_time_ms(p.kernel_only, 10)
-                sweep.append({"density": d, "nnz": p.nnz, "ms": ms_full, "kernel_ms": ms_kern,
+                # 20 warm-up + 100 timed launches, median and minimum
+                ms_full, ms_full_min = event_time_ms(p.step, 100, warmup=20, with_min=True)
+                ms_kern = event_time_ms(p.kernel_only, 100, warmup=20)
+                sweep.append({"density": d, "nnz": p.nnz, "ms": ms_full, "ms_min": ms_full_min,
+                              "kernel_ms": ms_kern,
                               "gflops": p.flops / ms_full / 1e6, "alg_gbs": p.bytes / ms_full / 1e6,
                               "hbm_frac": p.bytes / ms_kern / 1e6 / HBM_PEAK_GBS,
                               "valu_frac": p.flops / ms_kern / 1e9 / VALU_PEAK_TFLOPS})
