@@ -97,6 +97,9 @@ STRESS = [
     (128, 32, 512, 0.0),      # 512-column kernel: one chunk, fully dense
     (1000, 33, 1536, 0.5),    # 512-column kernel: three tiles, k % 32 = 1, row slots padded to 1024
     (384, 4096, 512, 0.97),   # 512-column kernel: 128 chunks, most segments empty, slots padded to 512
+    (256, 40, 512, 0.2),      # 512-column kernel: one full chunk and a quarter, long segments
+    (200, 41, 1024, 0.4),     # 512-column kernel: two tiles, last chunk 9 rows
+    (512, 1000, 512, 0.05),   # 512-column kernel: segments of ~30 entries (two windows), k % 32 = 8
 ]
 
 

@@ -331,7 +331,7 @@ int attention_exec(int m, int n, int d, int nonzeros, int replicas, const int* r
   int* table = reinterpret_cast<int*>(static_cast<char*>(workspace) + row_ok_bytes(slots));
   int st = 0;
   if (!planned) {
-    hipLaunchKernelGGL((spmm_chunk_table_kernel<ilog2(kBK)>), dim3(ceil_div(slots, 4)),
+    hipLaunchKernelGGL((spmm_chunk_table_kernel<kBK>), dim3(ceil_div(slots, 4)),
                        dim3(256), 0, stream, m, n, slots, kBM, nchunks, row_indices, row_offsets,
                        column_indices, table, row_ok);
     st = launch_status();
@@ -377,7 +377,7 @@ int sputnik_hip_sparse_attention_plan(int m, int n, int d, int nonzeros, const i
   const int slots = slots_of(m);
   int* row_ok = static_cast<int*>(workspace);
   int* table = reinterpret_cast<int*>(static_cast<char*>(workspace) + row_ok_bytes(slots));
-  hipLaunchKernelGGL((spmm_chunk_table_kernel<ilog2(kBK)>), dim3(ceil_div(slots, 4)), dim3(256),
+  hipLaunchKernelGGL((spmm_chunk_table_kernel<kBK>), dim3(ceil_div(slots, 4)), dim3(256),
                      0, stream, m, n, slots, kBM, chunks_of(n), row_indices, row_offsets,
                      column_indices, table, row_ok);
   return launch_status();

@@ -273,7 +273,7 @@ template <int KV>
 int plan(int m, int n, int slots, const int* row_indices, const int* row_offsets,
          const int* column_indices, int* table, int* row_ok, hipStream_t stream) {
   using S = Slab<KV>;
-  hipLaunchKernelGGL((spmm_chunk_table_kernel<ilog2(S::kRows)>), dim3(ceil_div(slots, 4)),
+  hipLaunchKernelGGL((spmm_chunk_table_kernel<S::kRows>), dim3(ceil_div(slots, 4)),
                      dim3(256), 0, stream, m, n, slots, kSGroups * kSRows, ceil_div(n, S::kRows),
                      row_indices, row_offsets, column_indices, table, row_ok);
   return launch_status();

@@ -69,31 +69,29 @@ struct TileConfig {
   static constexpr int kVec = BN / kWave;  // floats per lane: 4 per 256-column piece
   static constexpr int kPieces = BN / 256;  // 1 KiB LDS-DMA pieces (= ds_read_b128 per lane) per B row
   static constexpr int kThreads = WAVES * kWave;
-  static constexpr int kStageRowsPerWave = BK / WAVES;
-  static constexpr int kStageOps = kStageRowsPerWave * kPieces;  // LDS-DMA copies per wave and stage
+  static constexpr int kStageOps = BK * kPieces / WAVES;  // LDS-DMA copies per wave and stage
   static_assert(BN == 256 || BN == 512, "one or two 1 KiB LDS-DMA pieces per B row");
-  static_assert(BK % WAVES == 0, "stage rows split evenly over the waves");
+  static_assert((BK * kPieces) % WAVES == 0, "the pieces of a stage split evenly over the waves");
 };
 
 template <typename Cfg>
 __device__ __forceinline__ void stage_chunk(float* __restrict__ tile, const float* __restrict__ dense,
                                             int n, int k, int kc, int wave,
                                             unsigned lane_byte_offset) {
-  // Wave w copies B rows kc + w, kc + w + WAVES, ...; one wave instruction
-  // moves one 256-column piece of a row (lane_byte_offset = (n0 + lane*4) * 4
-  // selects the workgroup's column tile and the lane's 16 bytes) straight into
-  // the row-major tile row.  Rows past the end of B (last, partial chunk)
-  // re-read row k-1: no nonzero refers to them, and every wave then issues
-  // exactly kStageOps copies per stage, which the counted vmcnt waits of
-  // main loop rely on.
+  // The stage is BK * kPieces pieces of 1 KiB (256 columns of one B row); wave w
+  // copies pieces w, w + WAVES, ...: one wave instruction moves one piece
+  // (lane_byte_offset = (n0 + lane*4) * 4 selects the workgroup's column tile and
+  // the lane's 16 bytes) straight into the row-major tile row.  Rows past the end
+  // of B (last, partial chunk) re-read row k-1: no nonzero refers to them, and
+  // every wave then issues exactly kStageOps copies per stage, which the counted
+  // vmcnt waits of the main loop rely on.
 #pragma unroll
-  for (int i = 0; i < Cfg::kStageRowsPerWave; ++i) {
-    const int r = wave + i * Cfg::kWaves;
+  for (int i = 0; i < Cfg::kStageOps; ++i) {
+    const int piece = wave + i * Cfg::kWaves;
+    const int r = piece / Cfg::kPieces, h = piece % Cfg::kPieces;
     const int src_row = min(kc + r, k - 1);
-#pragma unroll
-    for (int h = 0; h < Cfg::kPieces; ++h)
-      lds_dma_row(dense + static_cast<int64_t>(src_row) * n + h * 256, lane_byte_offset,
-                  tile + r * Cfg::kBN + h * 256);
+    lds_dma_row(dense + static_cast<int64_t>(src_row) * n + h * 256, lane_byte_offset,
+                tile + r * Cfg::kBN + h * 256);
   }
 }
 
@@ -321,7 +319,9 @@ __global__ __launch_bounds__(Cfg::kThreads) void spmm_tiled_kernel(
 
   // Row blocks whose column indices do not ascend inside rows cannot be cut by
   // K chunk: they take the order-independent path (B gathered from L2).
-  if (!block_rows_ok(row_ok, mblock * Cfg::kBM, Cfg::kBM)) {
+  // (the 512-column tile has no LDS to spare for the workgroup-wide reduction)
+  if (!(BN == 512 ? block_rows_ok_wave(row_ok, mblock * Cfg::kBM, Cfg::kBM)
+                  : block_rows_ok(row_ok, mblock * Cfg::kBM, Cfg::kBM))) {
     for (int r = 0; r < RPW; ++r) {
       const int entry = dealt_index(slot0 + r, slots, kDealPer);
       if (entry >= m) continue;
@@ -398,6 +398,8 @@ using CfgSmall = TileConfig<256, 8, 8, 64>;
 // vs step_pair_v4).  The accumulators of 8 rows fill the registers that 16 rows
 // take above, and 32 rows of B are all that two LDS stages hold: a chunk table
 // of its own (BK = 32).  For problems large enough to give every CU a tile.
+// (40-row chunks -- all 160 KiB of LDS, a fifth fewer visits -- measured the same at
+// density 0.1 and 5 % slower at 0.5: longer segments cost LDS round trips.)
 using CfgWide512 = TileConfig<512, 16, 8, 32>;
 
 // Developer / test knob SPUTNIK_HIP_SPMM_KERNEL, read at every call: "wide" =
@@ -524,12 +526,12 @@ int spmm_tiled_plan(int m, int k, int n, int nonzeros, int replicas, const int* 
     int* row_ok = static_cast<int*>(workspace);
     int* table = reinterpret_cast<int*>(static_cast<char*>(workspace) + row_ok_bytes(plan.slots));
     if (w512) {
-      hipLaunchKernelGGL((spmm_chunk_table_kernel<ilog2(CfgWide512::kBK)>),
+      hipLaunchKernelGGL((spmm_chunk_table_kernel<CfgWide512::kBK>),
                          dim3(ceil_div(plan.slots, 4)), dim3(256), 0, stream, m, k, plan.slots,
                          kDealPer, plan.nchunks, row_indices, row_offsets, column_indices, table,
                          row_ok);
     } else {
-      hipLaunchKernelGGL((spmm_chunk_table_kernel<ilog2(CfgLarge::kBK)>),
+      hipLaunchKernelGGL((spmm_chunk_table_kernel<CfgLarge::kBK>),
                          dim3(ceil_div(plan.slots, 4)), dim3(256), 0, stream, m, k, plan.slots,
                          kDealPer, plan.nchunks, row_indices, row_offsets, column_indices, table,
                          row_ok);

@@ -271,7 +271,7 @@ int spmm_tiled64_plan(int m, int k, const int* row_indices, const int* row_offse
   const int slots = slots_of(m);
   int* row_ok = static_cast<int*>(workspace);
   int* table = reinterpret_cast<int*>(static_cast<char*>(workspace) + row_ok_bytes(slots));
-  hipLaunchKernelGGL((spmm_chunk_table_kernel<ilog2(kBK)>), dim3(ceil_div(slots, 4)), dim3(256),
+  hipLaunchKernelGGL((spmm_chunk_table_kernel<kBK>), dim3(ceil_div(slots, 4)), dim3(256),
                      0, stream, m, k, slots, kBM, chunks_of(k), row_indices, row_offsets,
                      column_indices, table, row_ok);
   return launch_status();

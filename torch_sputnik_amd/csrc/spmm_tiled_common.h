@@ -36,7 +36,7 @@ __device__ __forceinline__ int dealt_index(int slot, int slots, int per) {
   return (slot % per) * (slots / per) + slot / per;
 }
 
-template <int BK_LOG2>
+template <int BK>  // rows of B per chunk (any positive number; a power of two divides by shifting)
 __global__ __launch_bounds__(256) void spmm_chunk_table_kernel(
     int m, int k, int slots, int per, int nchunks, const int* __restrict__ row_indices,
     const int* __restrict__ row_offsets, const int* __restrict__ column_indices,
@@ -62,8 +62,8 @@ __global__ __launch_bounds__(256) void spmm_chunk_table_kernel(
       if (cur <= prev || cur >= k) {
         ok = false;
       } else {
-        const int cb = cur >> BK_LOG2;
-        const int pb = (prev < 0) ? -1 : (prev >> BK_LOG2);
+        const int cb = static_cast<int>(static_cast<unsigned>(cur) / BK);
+        const int pb = (prev < 0) ? -1 : static_cast<int>(static_cast<unsigned>(prev) / BK);
         for (int c = pb + 1; c <= cb; ++c) table[static_cast<int64_t>(c) * slots + slot] = p;
       }
     }
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void spmm_chunk_table_kernel(
   int last = -1;
   if (p1 > p0) {
     const int lc = column_indices[p1 - 1];
-    last = (lc >= 0 && lc < k) ? (lc >> BK_LOG2) : nchunks;
+    last = (lc >= 0 && lc < k) ? static_cast<int>(static_cast<unsigned>(lc) / BK) : nchunks;
   }
   for (int c = last + 1 + lane; c <= nchunks; c += kWave)
     table[static_cast<int64_t>(c) * slots + slot] = p1;
@@ -251,6 +251,16 @@ __device__ __forceinline__ void dpp_group4(float (&acc)[VEC], int roff, float rv
   b1.fma(acc, entry_val(e1));
   b2.fma(acc, entry_val(e2));
   b3.fma(acc, entry_val(e3));
+}
+
+// The same answer without LDS and without a barrier: every wave looks at all of
+// the workgroup's row slots itself (a few hundred words from L2) and reduces with
+// a ballot.  For the tile that needs all 160 KiB of the CU's LDS for B.
+__device__ __forceinline__ bool block_rows_ok_wave(const int* __restrict__ row_ok, int block_slot0,
+                                                   int rows) {
+  int ok = 1;
+  for (int s = threadIdx.x % kWave; s < rows; s += kWave) ok &= row_ok[block_slot0 + s];
+  return __builtin_amdgcn_ballot_w64(ok == 0) == 0;
 }
 
 // True iff every one of the workgroup's `rows` row slots (starting at
