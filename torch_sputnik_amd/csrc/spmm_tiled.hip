@@ -12,25 +12,36 @@
 //   * each wave owns RPW rows whose accumulators stay in registers for the
 //     whole K walk (RPW*BN/64 VGPRs), so C is written exactly once and no
 //     atomics or partial sums exist -> bitwise reproducible;
-//   * a row's (column, value) stream is wave-uniform.  Its next 64 entries are
-//     prefetched into two VGPRs (lane = entry) and handed out with DPP
-//     row_newbcast after one ds_bpermute pair per 16 entries: per nonzero one
-//     v_add_u32_dpp (LDS address), one ds_read_b128, one v_mov_b32_dpp (value)
-//     and two v_pk_fma_f32 -- no VGPR->SGPR traffic, no scalar loads.  (Two
-//     earlier forms, scalar loads of the stream and v_readlane hand-out, were
-//     measured slower and removed: DESIGN.md section 3.1.)
+//   * a row's (column, value) stream is wave-uniform.  Its next entries are
+//     prefetched into two VGPRs (a "window": 64 entries, lane = entry, replicated
+//     16 at a time with one ds_bpermute pair -- or, for short segments, 16
+//     entries that the load itself replicates into every 16-lane row) and
+//     handed out with DPP row_newbcast: per nonzero one v_mov_b64_dpp (tile
+//     offset and value as a register pair), one v_add_u32 (LDS address), one or
+//     two ds_read_b128 and two or four v_pk_fma_f32 -- no VGPR->SGPR traffic.
+//     (Two earlier forms, scalar loads of the stream and v_readlane hand-out,
+//     were measured slower and removed: DESIGN.md section 3.1.)
 //
-// The binding limit is LDS bandwidth: one B dword per FMA, 256 B/clk/CU
-// -> 64 FMA/clk/CU = 78.6 TFLOP/s chip-wide (= the plain v_fma_f32 rate).
+// Tiles: 128 x 512 (eight columns per lane: one broadcast and address feed two
+// LDS reads and eight FMAs, the best instruction mix; for problems that give
+// every CU a tile), 256 x 256, 128 x 256, 64 x 256 (TileConfig below).
 //
-// Rows are dealt to waves in `row_indices` order (similar lengths together).
-// Splitting a row's nonzeros by K chunk needs the column indices of a row to
-// ascend; a small pre-pass builds, per row and chunk boundary, the position
-// of the first nonzero at or past the boundary (the "chunk table", in the
-// caller's workspace) and records per row whether its columns ascend.  A
-// workgroup that finds a non-ascending row in its block takes an
-// order-independent path (B gathered from L2) inside the same launch: no host
-// synchronisation, no second kernel.
+// The roof is LDS bandwidth: one B dword per FMA, 256 B/clk/CU -> 64
+// FMA/clk/CU = 78.6 TFLOP/s chip-wide (= the plain v_fma_f32 rate).  What
+// binds in practice, at the densities of the headline benchmark, is the serial
+// instruction stream of a (row, chunk) visit -- see the comments in the main
+// loop: everything scalar that a vector instruction or no instruction can do
+// has been moved or removed.
+//
+// Rows are dealt to workgroups interleaved (dealt_index), so that every
+// workgroup gets the same mix of long and short rows whatever the order of the
+// caller's `row_indices`.  Splitting a row's nonzeros by K chunk needs the
+// column indices of a row to ascend; a small pre-pass builds, per row and chunk
+// boundary, the position of the first nonzero at or past the boundary (the
+// "chunk table", in the caller's workspace) and records per row whether its
+// columns ascend.  A workgroup that finds a non-ascending row in its block
+// takes an order-independent path (B gathered from L2) inside the same launch:
+// no host synchronisation, no second kernel.
 #include <stdlib.h>
 
 #include "spmm_tiled_common.h"
