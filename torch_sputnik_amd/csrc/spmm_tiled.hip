@@ -81,6 +81,10 @@ struct TileConfig {
   static constexpr int kPieces = BN / 256;  // 1 KiB LDS-DMA pieces (= ds_read_b128 per lane) per B row
   static constexpr int kThreads = WAVES * kWave;
   static constexpr int kStageOps = BK * kPieces / WAVES;  // LDS-DMA copies per wave and stage
+  // Entries per LDS round trip in the short-segment variant: the strips of a
+  // batch are 32 registers with 8 columns per lane and batches of four; the
+  // 8-row tiles with 4 columns per lane have the registers for batches of eight.
+  static constexpr int kBatch = (RPW == 8 && BN == 256) ? 8 : 4;
   static_assert(BN == 256 || BN == 512, "one or two 1 KiB LDS-DMA pieces per B row");
   static_assert((BK * kPieces) % WAVES == 0, "the pieces of a stage split evenly over the waves");
 };
@@ -215,18 +219,19 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
       if constexpr (SPARSE) {
         // Laid out for the fewest scalar compares and branches on the common
         // short segment (the loop is bound by its serial instruction stream): an
-        // empty segment and one of 1..3 entries pass three tests (>= 4, bit 1,
+        // empty segment and one of 1..3 entries pass three tests (>= B, bit 1,
         // bit 0); the test for a segment longer than the window is only reached
-        // by segments of four or more.
+        // by segments of a full batch or more.
         entry_pair e = make_entry(wcol * (BN * 4), wval);
         int tail = cnt;  // bits 0 and 1: the entries left after the batches of four
-        if (cnt >= 4) {
+        constexpr int B = Cfg::kBatch;
+        if (cnt >= B) {
           int left = min(16, cnt);
           do {
-            dpp_group_at0<4>(acc[r], e, lane_base);
-            e = row_rotate_entry<4>(e);
-            left -= 4;
-          } while (left >= 4);
+            dpp_group_at0<B>(acc[r], e, lane_base);
+            e = row_rotate_entry<B>(e);
+            left -= B;
+          } while (left >= B);
           tail = left;
           if (cnt > 16) {  // rare: the rest of a long segment, 16 entries at a time (tail = 0 here)
             const int start = s_ps[r];
@@ -238,6 +243,12 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
               asm volatile("" : "+v"(c2), "+v"(v2));
               dpp_entries_exact(acc[r], min(16, cnt - q0), c2 * (BN * 4), v2, lane_base);
             }
+          }
+        }
+        if constexpr (B == 8) {
+          if (tail & 4) {
+            dpp_group_at0<4>(acc[r], e, lane_base);
+            e = row_rotate_entry<4>(e);
           }
         }
         if (tail & 2) {

@@ -208,6 +208,18 @@ struct BStrip<8> {
   }
 };
 
+// Compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(<N-1>): a loop
+// whose body indexes register arrays by the counter must not be left to
+// `#pragma unroll` (a refused unroll turns the arrays into scratch memory).
+template <typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
 // DPP row_newbcast: every lane of a 16-lane row reads lane U of ITS row.  With
 // the same 16 entries replicated in all four rows this is a wave-wide
 // broadcast of entry U that costs one VALU op and no SGPR round trip.
@@ -329,20 +341,12 @@ __device__ __forceinline__ entry_pair row_rotate_entry(entry_pair e) {
 template <int COUNT, int VEC>
 __device__ __forceinline__ void dpp_group_at0(float (&acc)[VEC], entry_pair e,
                                               const char* __restrict__ lane_base) {
-  static_assert(COUNT == 1 || COUNT == 2 || COUNT == 4, "");
-  const entry_pair e0 = row_bcast_entry<0>(e);
-  const entry_pair e1 = COUNT > 1 ? row_bcast_entry<1>(e) : 0;
-  const entry_pair e2 = COUNT > 2 ? row_bcast_entry<2>(e) : 0;
-  const entry_pair e3 = COUNT > 2 ? row_bcast_entry<3>(e) : 0;
-  BStrip<VEC> b0, b1, b2, b3;
-  b0.read(lane_base + entry_off(e0));
-  if (COUNT > 1) b1.read(lane_base + entry_off(e1));
-  if (COUNT > 2) b2.read(lane_base + entry_off(e2));
-  if (COUNT > 2) b3.read(lane_base + entry_off(e3));
-  b0.fma(acc, entry_val(e0));
-  if (COUNT > 1) b1.fma(acc, entry_val(e1));
-  if (COUNT > 2) b2.fma(acc, entry_val(e2));
-  if (COUNT > 2) b3.fma(acc, entry_val(e3));
+  static_assert(COUNT == 1 || COUNT == 2 || COUNT == 4 || COUNT == 8, "");
+  entry_pair b[COUNT];
+  BStrip<VEC> strip[COUNT];
+  static_for<COUNT>([&](auto i) { b[i] = row_bcast_entry<decltype(i)::value>(e); });
+  static_for<COUNT>([&](auto i) { strip[i].read(lane_base + entry_off(b[i])); });
+  static_for<COUNT>([&](auto i) { strip[i].fma(acc, entry_val(b[i])); });
 }
 template <int VEC>
 __device__ __forceinline__ void dpp_entries_exact(float (&acc)[VEC], int n16, int roff, float rval,
@@ -358,18 +362,6 @@ __device__ __forceinline__ void dpp_entries_exact(float (&acc)[VEC], int n16, in
     e = row_rotate_entry<2>(e);
   }
   if (left & 1) dpp_group_at0<1>(acc, e, lane_base);
-}
-
-// Compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(<N-1>): a loop
-// whose body indexes register arrays by the counter must not be left to
-// `#pragma unroll` (a refused unroll turns the arrays into scratch memory).
-template <typename F, int... Is>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
-  (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
 }
 
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v / 2); }
