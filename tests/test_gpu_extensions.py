@@ -451,7 +451,8 @@ def test_sparse_attention_function_gradients(ts, dev):
 # static topologies: plan once, run many times
 # ----------------------------------------------------------------------------
 @pytest.mark.parametrize("m,k,n,replicas", [(512, 512, 256, 8), (256, 300, 64, 4), (100, 64, 18, 2),
-                                            (2048, 2048, 256, 4)])
+                                            (2048, 2048, 256, 4),
+                                            (2048, 256, 512, 12)])  # 512-column kernel by replica count
 def test_planned_ops_equal_the_per_call_ops(ts, dev, spmm_kernel, sddmm_kernel, m, k, n, replicas):
     rng = np.random.default_rng(m + n)
     _, vals, ri, ro, ci = make_csr(m, k, 0.8, seed=m, order="ascending")

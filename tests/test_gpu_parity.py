@@ -209,7 +209,8 @@ def test_spmm_full_size_after_other_products(capi, dev):
 @pytest.mark.parametrize("replicas,shared,m,k,n", [
     (3, False, 130, 96, 136), (5, True, 130, 96, 136), (1, False, 130, 96, 136),
     (4, False, 512, 512, 64), (3, True, 300, 256, 128),       # 64-column tiled kernel
-    (2, False, 512, 512, 256), (3, True, 256, 1024, 512)])    # 256-column tiled kernel
+    (2, False, 512, 512, 256), (3, True, 256, 1024, 512),     # 256-column tiled kernel
+    (12, False, 2048, 256, 512), (13, True, 2000, 300, 1024)])  # 512-column kernel by replica count
 def test_spmm_batched_capi(capi, dev, spmm_kernel, replicas, shared, m, k, n):
     _, vals, ri, ro, ci = make_csr(m, k, 0.85, seed=21)
     rng = np.random.default_rng(22)

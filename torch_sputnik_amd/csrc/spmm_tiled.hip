@@ -458,6 +458,23 @@ inline bool tiled512_applicable(int m, int k, int n, int nonzeros) {
          nonzeros >= 16 * static_cast<int64_t>(m) && nonzeros < (1 << 30);  // 32-bit byte offsets
 }
 
+inline int64_t tiles512(int m, int n) {
+  return static_cast<int64_t>(ceil_div(m, CfgWide512::kBM)) * (n / CfgWide512::kBN);
+}
+constexpr int64_t kTiles512From = 192;
+// A row has more than about two entries per 32-row chunk (below that the 64-row
+// chunks of the 256-column kernel win by 2 %: 4096^3 at density 0.05).
+inline bool long_enough_for_512(int m, int k, int nonzeros) {
+  return static_cast<int64_t>(nonzeros) * 5 >= int64_t{11} * m * ceil_div(k, CfgWide512::kBK);
+}
+// The 512-column kernel could serve this shape once enough replicas come in one
+// call, but the shape alone does not select it: a workspace that has to serve
+// any replica count carries its table BEHIND those of the other kernels.
+inline bool wide512_possible(int m, int k, int n, int nonzeros) {
+  return forced_kernel() == 0 && tiled512_applicable(m, k, n, nonzeros) &&
+         long_enough_for_512(m, k, nonzeros) && tiles512(m, n) < kTiles512From;
+}
+
 inline size_t wide512_workspace_bytes(int m, int k, int n) {
   const Plan plan = make_plan<CfgWide512>(m, k, n);
   return (row_ok_bytes(plan.slots) + plan.table_bytes + 15) / 16 * 16;
@@ -485,17 +502,14 @@ inline Kernel choose_kernel(int m, int k, int n, int nonzeros, int replicas /* <
     if (work < (int64_t{1} << 27) || (replicas < 8 && work < (int64_t{1} << 29)))
       return Kernel::kNone;
   }
-  // The 512-column kernel has one tile size: taken when the shape alone (whatever
-  // the replica count, so that a plan made ahead of the call knows) gives about
-  // one workgroup per CU.
+  // The 512-column kernel has one tile size: taken when the tiles of all replicas
+  // give about one workgroup per CU.  (A plan made ahead of the call does not
+  // know the replica count: when the shape alone does not decide, it builds this
+  // kernel's table next to the others', see wide512_possible.)
   if (tiled512_applicable(m, k, n, nonzeros)) {
-    const int64_t tiles512 =
-        static_cast<int64_t>(ceil_div(m, CfgWide512::kBM)) * (n / CfgWide512::kBN);
-    // ... and a row has more than about two entries per 32-row chunk (below that
-    // the 64-row chunks of the 256-column kernel win by 2 %: 4096^3 at density 0.05)
-    const bool long_enough = static_cast<int64_t>(nonzeros) * 5 >=
-                             int64_t{11} * m * ceil_div(k, CfgWide512::kBK);
-    if (forced == -2 || (forced == 0 && tiles512 >= 192 && long_enough)) return Kernel::kWide512;
+    const int64_t tiles = tiles512(m, n) * (replicas > 0 ? replicas : 1);
+    if (forced == -2 || (forced == 0 && tiles >= kTiles512From && long_enough_for_512(m, k, nonzeros)))
+      return Kernel::kWide512;
   }
   const bool wide = tiled_applicable(m, k, n, nonzeros);
   const bool narrow = spmm_tiled64_applicable(m, k, n, nonzeros);
@@ -511,7 +525,9 @@ inline Kernel choose_kernel(int m, int k, int n, int nonzeros, int replicas /* <
 
 }  // namespace
 
-size_t spmm_tiled_workspace_bytes(int m, int k, int n, int nonzeros) {
+namespace {
+// Bytes of the tables of the kernels that the shape alone admits (replica count unknown).
+size_t base_workspace_bytes(int m, int k, int n, int nonzeros) {
   switch (choose_kernel(m, k, n, nonzeros, -1)) {
     case Kernel::kWide: return wide_workspace_bytes(m, k, n);
     case Kernel::kWide512: return wide512_workspace_bytes(m, k, n);
@@ -519,6 +535,20 @@ size_t spmm_tiled_workspace_bytes(int m, int k, int n, int nonzeros) {
     case Kernel::kEither: return wide_workspace_bytes(m, k, n) + spmm_tiled64_workspace_bytes(m, k);
     default: return 0;
   }
+}
+// Where the 512-column kernel's tables start: at the front when the shape alone
+// selects it, behind the others' when only the replica count can.
+size_t wide512_offset(int m, int k, int n, int nonzeros) {
+  return wide512_possible(m, k, n, nonzeros)
+             ? (base_workspace_bytes(m, k, n, nonzeros) + 255) / 256 * 256
+             : 0;
+}
+}  // namespace
+
+size_t spmm_tiled_workspace_bytes(int m, int k, int n, int nonzeros) {
+  return wide512_possible(m, k, n, nonzeros)
+             ? wide512_offset(m, k, n, nonzeros) + wide512_workspace_bytes(m, k, n)
+             : base_workspace_bytes(m, k, n, nonzeros);
 }
 
 // Pre-pass only: topology -> per-row order status + chunk table in `workspace`.  Depends
@@ -530,7 +560,9 @@ int spmm_tiled_plan(int m, int k, int n, int nonzeros, int replicas, const int* 
                     size_t workspace_bytes, hipStream_t stream, bool* planned) {
   *planned = false;
   const Kernel which = choose_kernel(m, k, n, nonzeros, replicas);
-  if (which == Kernel::kNone || workspace == nullptr || !aligned_to(workspace, 16) ||
+  // replica count unknown: also the 512-column kernel's table when a later call may take it
+  const bool also512 = replicas < 0 && wide512_possible(m, k, n, nonzeros);
+  if ((which == Kernel::kNone && !also512) || workspace == nullptr || !aligned_to(workspace, 16) ||
       workspace_bytes < spmm_tiled_workspace_bytes(m, k, n, nonzeros))
     return 0;
   // the narrow kernel's tables follow the wide kernel's whenever both could be needed
@@ -542,22 +574,24 @@ int spmm_tiled_plan(int m, int k, int n, int nonzeros, int replicas, const int* 
         spmm_tiled64_plan(m, k, row_indices, row_offsets, column_indices, ws64, stream);
     if (st != 0) return st;
   }
-  if (which == Kernel::kWide || which == Kernel::kEither || which == Kernel::kWide512) {
-    const bool w512 = which == Kernel::kWide512;
-    const Plan plan = w512 ? make_plan<CfgWide512>(m, k, n) : make_plan<CfgLarge>(m, k, n);
+  if (which == Kernel::kWide || which == Kernel::kEither) {
+    const Plan plan = make_plan<CfgLarge>(m, k, n);
     int* row_ok = static_cast<int*>(workspace);
     int* table = reinterpret_cast<int*>(static_cast<char*>(workspace) + row_ok_bytes(plan.slots));
-    if (w512) {
-      hipLaunchKernelGGL((spmm_chunk_table_kernel<CfgWide512::kBK>),
-                         dim3(ceil_div(plan.slots, 4)), dim3(256), 0, stream, m, k, plan.slots,
-                         kDealPer, plan.nchunks, row_indices, row_offsets, column_indices, table,
-                         row_ok);
-    } else {
-      hipLaunchKernelGGL((spmm_chunk_table_kernel<CfgLarge::kBK>),
-                         dim3(ceil_div(plan.slots, 4)), dim3(256), 0, stream, m, k, plan.slots,
-                         kDealPer, plan.nchunks, row_indices, row_offsets, column_indices, table,
-                         row_ok);
-    }
+    hipLaunchKernelGGL((spmm_chunk_table_kernel<CfgLarge::kBK>), dim3(ceil_div(plan.slots, 4)),
+                       dim3(256), 0, stream, m, k, plan.slots, kDealPer, plan.nchunks, row_indices,
+                       row_offsets, column_indices, table, row_ok);
+    const int st = launch_status();
+    if (st != 0) return st;
+  }
+  if (which == Kernel::kWide512 || also512) {
+    const Plan plan = make_plan<CfgWide512>(m, k, n);
+    char* base = static_cast<char*>(workspace) + wide512_offset(m, k, n, nonzeros);
+    int* row_ok = reinterpret_cast<int*>(base);
+    int* table = reinterpret_cast<int*>(base + row_ok_bytes(plan.slots));
+    hipLaunchKernelGGL((spmm_chunk_table_kernel<CfgWide512::kBK>), dim3(ceil_div(plan.slots, 4)),
+                       dim3(256), 0, stream, m, k, plan.slots, kDealPer, plan.nchunks, row_indices,
+                       row_offsets, column_indices, table, row_ok);
     const int st = launch_status();
     if (st != 0) return st;
   }
@@ -591,9 +625,10 @@ int spmm_tiled_exec(int m, int k, int n, int nonzeros, int replicas, const int* 
   using Cfg = CfgLarge;
   const bool w512 = which == Kernel::kWide512;
   const Plan plan = w512 ? make_plan<CfgWide512>(m, k, n) : make_plan<Cfg>(m, k, n);
-  const int* row_ok = static_cast<const int*>(workspace);
-  const int* table = reinterpret_cast<const int*>(static_cast<const char*>(workspace) +
-                                                  row_ok_bytes(plan.slots));
+  const char* ws_base =
+      static_cast<const char*>(workspace) + (w512 ? wide512_offset(m, k, n, nonzeros) : 0);
+  const int* row_ok = reinterpret_cast<const int*>(ws_base);
+  const int* table = reinterpret_cast<const int*>(ws_base + row_ok_bytes(plan.slots));
 
   const int blocks = (plan.slots / Cfg::kBM) * plan.n_tiles;
   static const int forced = [] {
