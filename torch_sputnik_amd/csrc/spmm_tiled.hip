@@ -423,6 +423,10 @@ using CfgSmall = TileConfig<256, 8, 8, 64>;
 // (40-row chunks -- all 160 KiB of LDS, a fifth fewer visits -- measured the same at
 // density 0.1 and 5 % slower at 0.5: longer segments cost LDS round trips.)
 using CfgWide512 = TileConfig<512, 16, 8, 32>;
+// The same with four rows per wave (64 x 512 tiles, same chunk table): twice the
+// workgroups for grids that would leave CUs idle (config 5's left_spmm: 2048^2 x
+// 512 x 8 replicas = 128 tiles of 128 rows, 256 of 64).
+using CfgWide512Half = TileConfig<512, 16, 4, 32>;
 
 // Developer / test knob SPUTNIK_HIP_SPMM_KERNEL, read at every call: "wide" =
 // 256-column kernel whenever it applies, "wide512" = 512-column kernel whenever
@@ -472,7 +476,7 @@ inline bool long_enough_for_512(int m, int k, int nonzeros) {
 // any replica count carries its table BEHIND those of the other kernels.
 inline bool wide512_possible(int m, int k, int n, int nonzeros) {
   return forced_kernel() == 0 && tiled512_applicable(m, k, n, nonzeros) &&
-         long_enough_for_512(m, k, nonzeros) && tiles512(m, n) < kTiles512From;
+         long_enough_for_512(m, k, nonzeros) && 2 * tiles512(m, n) < kTiles512From;
 }
 
 inline size_t wide512_workspace_bytes(int m, int k, int n) {
@@ -507,7 +511,8 @@ inline Kernel choose_kernel(int m, int k, int n, int nonzeros, int replicas /* <
   // know the replica count: when the shape alone does not decide, it builds this
   // kernel's table next to the others', see wide512_possible.)
   if (tiled512_applicable(m, k, n, nonzeros)) {
-    const int64_t tiles = tiles512(m, n) * (replicas > 0 ? replicas : 1);
+    // (with its 64-row variant the count that matters is that of 64-row tiles)
+    const int64_t tiles = 2 * tiles512(m, n) * (replicas > 0 ? replicas : 1);
     if (forced == -2 || (forced == 0 && tiles >= kTiles512From && long_enough_for_512(m, k, nonzeros)))
       return Kernel::kWide512;
   }
@@ -663,7 +668,9 @@ int spmm_tiled_exec(int m, int k, int n, int nonzeros, int replicas, const int* 
                      row_indices, values, values_stride, column_indices, table, dense,            \
                      dense_stride, out, out_stride, row_ok, row_offsets, debug, epi)
   if (w512) {
-    SPUTNIK_HIP_LAUNCH_TILED(CfgWide512, true);
+    // 128-row tiles when they give about one workgroup per CU, else 64-row tiles
+    if (tiles512(m, n) * replicas >= kTiles512From) SPUTNIK_HIP_LAUNCH_TILED(CfgWide512, true);
+    else SPUTNIK_HIP_LAUNCH_TILED(CfgWide512Half, true);
   } else if (tile == 0) {
     if (sparse) SPUTNIK_HIP_LAUNCH_TILED(CfgLarge, true);
     else SPUTNIK_HIP_LAUNCH_TILED(CfgLarge, false);

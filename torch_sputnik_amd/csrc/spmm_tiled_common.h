@@ -166,6 +166,15 @@ struct Positions<8> {
     return v;
   }
 };
+template <>
+struct Positions<4> {
+  using type = int __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ type load(const int* p /* wave-uniform */) {
+    type v;
+    asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(v) : "s"(p) : "memory");
+    return v;
+  }
+};
 template <typename V>
 __device__ __forceinline__ void wait_positions(V& a) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a) : : "memory");
