@@ -669,7 +669,7 @@ int spmm_tiled_exec(int m, int k, int n, int nonzeros, int replicas, const int* 
                      dense_stride, out, out_stride, row_ok, row_offsets, debug, epi)
   if (w512) {
     // 128-row tiles when they give about one workgroup per CU, else 64-row tiles
-    if (tiles512(m, n) * replicas >= kTiles512From) SPUTNIK_HIP_LAUNCH_TILED(CfgWide512, true);
+    if (tiles512(m, n) * replicas >= kTiles512From && force_tile == 0) SPUTNIK_HIP_LAUNCH_TILED(CfgWide512, true);
     else SPUTNIK_HIP_LAUNCH_TILED(CfgWide512Half, true);
   } else if (tile == 0) {
     if (sparse) SPUTNIK_HIP_LAUNCH_TILED(CfgLarge, true);
