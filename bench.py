@@ -375,7 +375,7 @@ def main():
         main.wait_stream(side)
 
     # The GPU needs a few tens of milliseconds of load before its clocks settle
-    # (tools/sustain_test.py: the first 50 back-to-back steps average 0.433 ms,
+    # (tools/sustain_bench.py: the first 50 back-to-back steps average 0.433 ms,
     # every later batch 0.397-0.405 ms): bring it to its sustained state first,
     # untimed, so that K timed steps measure the steady rate whatever W is.
     t_ramp = time.perf_counter()

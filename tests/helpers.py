@@ -23,18 +23,73 @@ def make_csr(m, n, sparsity, seed, round_to=4, empty_rows=(), order="descending"
     return values.astype(np.float32), vals, row_indices, row_offsets, column_indices
 
 
-def rel_err(got, expected):
-    """max |got - want| / (|want| + mean|want|).
+def _row_view(a, row_offsets):
+    """(values as [rows, width] or flat, row id per element or None)."""
+    a = np.asarray(a, np.float64)
+    if row_offsets is None:
+        return (a.reshape(-1, a.shape[-1]) if a.ndim >= 2 else a.reshape(1, -1)), None
+    lengths = np.diff(np.asarray(row_offsets, np.int64))
+    ids = np.repeat(np.arange(len(lengths)), lengths)
+    return a.reshape(-1, a.shape[-1]), ids
 
-    The north star's bound is 1e-4 on fp32 outputs.  A float32 sum of K
-    products carries an absolute error of about 1e-7 * sum|a*b|, so outputs
-    that cancel to nearly zero cannot be held to a purely relative bound;
-    adding the mean magnitude of the expected tensor to the denominator is the
-    usual rtol*|want| + atol test with atol = rtol * mean|want|.
+
+def rel_err(got, expected, row_offsets=None):
+    """Worst violation of the fp32 parity bound, as a multiple of 1: the test
+    is ``rel_err(...) < 1e-4`` (the north star's tolerance).  Two criteria, both
+    PER ROW of the output (the unit one wavefront group accumulates):
+
+      (1) |got - want| / (|want| + rowmean|want|)       every element
+      (2) |got - want| / |want|                         elements with
+                                                         |want| > 1e-2 * rowmax|want|
+
+    (1) is rtol*|want| + atol with atol = rtol * mean magnitude of the SAME
+    row: a float32 sum of K products carries an absolute error ~1e-7*sum|a*b|,
+    so entries that cancel to nearly zero cannot be held to a purely relative
+    bound, but the slack they get comes from their own row, never from a
+    larger row elsewhere in the tensor.  (2) is a pure relative check on
+    every entry that is not a cancellation.
+
+    A "row" is the last dimension for dense outputs; for CSR-ordered outputs
+    ([nnz] or [R, nnz]) pass ``row_offsets`` and it is the CSR row.
     """
     got = np.asarray(got, np.float64)
     expected = np.asarray(expected, np.float64)
     if got.size == 0:
         return 0.0
-    scale = np.abs(expected) + max(1e-30, float(np.mean(np.abs(expected))))
-    return float(np.max(np.abs(got - expected) / scale))
+    assert got.shape == expected.shape, (got.shape, expected.shape)
+    w, ids = _row_view(expected, row_offsets)
+    g = got.reshape(w.shape)
+    aw = np.abs(w)
+    err = np.abs(g - w)
+    if ids is None:
+        rowmean = aw.mean(axis=1, keepdims=True)
+        rowmax = aw.max(axis=1, keepdims=True)
+    else:
+        rows = int(ids.max()) + 1 if ids.size else 0
+        count = np.maximum(np.bincount(ids, minlength=rows), 1)
+        rowmean = np.stack([np.bincount(ids, weights=r, minlength=rows) / count for r in aw])[:, ids]
+        rowmax = np.zeros((aw.shape[0], rows))
+        for r in range(aw.shape[0]):
+            np.maximum.at(rowmax[r], ids, aw[r])
+        rowmax = rowmax[:, ids]
+    worst = float(np.max(err / (aw + np.maximum(rowmean, 1e-30))))
+    significant = aw > 1e-2 * rowmax
+    if significant.any():
+        worst = max(worst, float(np.max(err[significant] / aw[significant])))
+    return worst
+
+
+def rel_err_torch(got, want):
+    """rel_err on device tensors (full-size checks): rows = last dimension,
+    ``want`` in float64."""
+    import torch
+    want = want.to(torch.float64)
+    err = (got.to(torch.float64) - want).abs()
+    aw = want.abs()
+    rowmean = aw.mean(dim=-1, keepdim=True).clamp_min(1e-30)
+    rowmax = aw.amax(dim=-1, keepdim=True)
+    worst = float((err / (aw + rowmean)).max())
+    significant = aw > 1e-2 * rowmax
+    if bool(significant.any()):
+        worst = max(worst, float((err[significant] / aw[significant]).max()))
+    return worst

@@ -109,13 +109,14 @@ def test_transpose_cache_gives_same_gradients(cpu_ops):
         cpu_ops.Spmm.apply(15, 11, v, *topo, d).square().sum().backward()
         return v.grad.clone(), d.grad.clone()
 
-    base = grads()
-    cache = functional.enable_transpose_cache(True)
+    functional.enable_transpose_cache(False)     # the reference's per-call transpose
     try:
+        base = grads()
+        cache = functional.enable_transpose_cache(True)
         first, second = grads(), grads()
         assert len(cache._entries) == 1
     finally:
-        functional.enable_transpose_cache(False)
+        functional.enable_transpose_cache(functional.TRANSPOSE_CACHE_DEFAULT)
     for got in (first, second):
         assert torch.equal(got[0], base[0]) and torch.equal(got[1], base[1])
 

@@ -11,48 +11,140 @@ Beyond the reference:
   * the transposed topology of a static mask can be cached
     (``TransposeCache``), so a backward is one gather instead of a transpose.
 """
+import collections
+
 import torch
 
 from . import ops
 from .topology import diffsort
 
 
+def _identity(*tensors):
+    """Key part naming these tensors' storage and contents: address, version
+    counter (bumped by every in-place write), size, device.  The caches below
+    keep a reference to the keyed tensors, so an address cannot be recycled
+    while its entry is alive."""
+    return tuple((t.data_ptr(), t._version, t.numel(), t.dtype, str(t.device)) for t in tensors)
+
+
+class _Lru:
+    """Small bounded map (static topologies are few: a model's layers and masks)."""
+
+    def __init__(self, capacity):
+        self.capacity = capacity
+        self._entries = collections.OrderedDict()
+
+    def get(self, key):
+        entry = self._entries.get(key)
+        if entry is not None:
+            self._entries.move_to_end(key)
+        return entry
+
+    def put(self, key, entry):
+        self._entries[key] = entry
+        while len(self._entries) > self.capacity:
+            self._entries.popitem(last=False)
+        return entry
+
+    def clear(self):
+        self._entries.clear()
+
+    def __len__(self):
+        return len(self._entries)
+
+
 class TransposeCache:
     """Memoises the transposed topology (and the value permutation) of static
-    CSR patterns, keyed by the identity and version of the index tensors."""
+    CSR patterns, keyed by the identity and version of the index tensors.  The
+    reference re-runs csr_transpose + diffsort in every backward although the
+    topology never changes (modules/spmm.py:59-64, modules/sddmm.py:60-65,
+    modules/sparse_linear.py:52-57); with the cache a backward is one gather of
+    the values through the stored permutation."""
 
-    def __init__(self):
-        self._entries = {}
-
-    @staticmethod
-    def _key(m, n, row_offsets, column_indices):
-        return (m, n, row_offsets.data_ptr(), column_indices.data_ptr(), row_offsets._version,
-                column_indices._version, column_indices.numel(), str(column_indices.device))
+    def __init__(self, capacity=128):
+        self._entries = _Lru(capacity)
 
     def lookup(self, m, n, row_offsets, column_indices, probe_values):
-        key = self._key(m, n, row_offsets, column_indices)
+        key = (m, n) + _identity(row_offsets, column_indices)
         entry = self._entries.get(key)
         if entry is None:
             _, row_offsets_t, column_indices_t, permutation = ops.csr_transpose_with_permutation(
                 m, n, probe_values.detach().reshape(-1, probe_values.shape[-1])[0].contiguous(),
                 row_offsets, column_indices)
-            entry = (diffsort(row_offsets_t), row_offsets_t, column_indices_t,
-                     permutation.to(torch.int64), row_offsets, column_indices)
-            self._entries[key] = entry
+            entry = self._entries.put(key, (diffsort(row_offsets_t), row_offsets_t,
+                                            column_indices_t, permutation.to(torch.int64),
+                                            row_offsets, column_indices))
         return entry[:4]
 
     def clear(self):
         self._entries.clear()
 
 
-_cache = None
+class PlanCache:
+    """Memoises the topology-only pre-pass of the LDS-tiled kernels
+    (ops.spmm_plan / ops.sddmm_plan) per static topology and operand width, so
+    that training steps launch kernels only.  Keyed like TransposeCache."""
+
+    def __init__(self, capacity=256):
+        self._entries = _Lru(capacity)
+
+    def spmm(self, m, k, n, row_indices, row_offsets, column_indices):
+        key = ("spmm", m, k, n) + _identity(row_indices, row_offsets, column_indices)
+        entry = self._entries.get(key)
+        if entry is None:
+            plan = ops.spmm_plan(m, k, n, row_indices, row_offsets, column_indices)
+            entry = self._entries.put(key, (plan, row_indices, row_offsets, column_indices))
+        return entry[0]
+
+    def sddmm(self, m, n, k, row_indices, row_offsets, column_indices):
+        key = ("sddmm", m, n, k) + _identity(row_indices, row_offsets, column_indices)
+        entry = self._entries.get(key)
+        if entry is None:
+            plan = ops.sddmm_plan(m, n, k, row_indices, row_offsets, column_indices)
+            entry = self._entries.put(key, (plan, row_indices, row_offsets, column_indices))
+        return entry[0]
+
+    def attention(self, m, n, d, row_indices, row_offsets, column_indices):
+        key = ("attention", m, n, d) + _identity(row_indices, row_offsets, column_indices)
+        entry = self._entries.get(key)
+        if entry is None:
+            plan = ops.sparse_attention_plan(m, n, d, row_indices, row_offsets, column_indices)
+            entry = self._entries.put(key, (plan, row_indices, row_offsets, column_indices))
+        return entry[0]
+
+    def clear(self):
+        self._entries.clear()
+
+
+# Both caches are ON by default: the topologies of a sparse model are static,
+# and the keys (address + version counter + size of every index tensor, with the
+# tensors kept alive by the entry) change whenever a topology is replaced or
+# written to.  `enable_transpose_cache(False)` / `enable_plan_cache(False)` give
+# the reference's per-call behaviour.
+TRANSPOSE_CACHE_DEFAULT = True
+PLAN_CACHE_DEFAULT = True
+_cache = TransposeCache() if TRANSPOSE_CACHE_DEFAULT else None
+_plans = PlanCache() if PLAN_CACHE_DEFAULT else None
 
 
 def enable_transpose_cache(enabled=True):
-    """Opt in to caching transposed topologies across backward calls."""
+    """Cache transposed topologies across backward calls (default: on)."""
     global _cache
     _cache = TransposeCache() if enabled else None
     return _cache
+
+
+def enable_plan_cache(enabled=True):
+    """Cache the kernels' topology pre-pass across calls (default: on)."""
+    global _plans
+    _plans = PlanCache() if enabled else None
+    return _plans
+
+
+def clear_caches():
+    for cache in (_cache, _plans):
+        if cache is not None:
+            cache.clear()
 
 
 def _transpose(m, n, values, row_offsets, column_indices):
@@ -67,6 +159,35 @@ def _transpose(m, n, values, row_offsets, column_indices):
     return values_t, diffsort(row_offsets_t), row_offsets_t, column_indices_t
 
 
+def _spmm(m, k, values, row_indices, row_offsets, column_indices, dense, left=False):
+    """spmm / left_spmm, through the cached plan of the topology when enabled."""
+    if _plans is None:
+        return (ops.left_spmm if left else ops.spmm)(m, k, values, row_indices, row_offsets,
+                                                     column_indices, dense)
+    plan = _plans.spmm(m, k, dense.size(-1), row_indices, row_offsets, column_indices)
+    return (ops.left_spmm_planned if left else ops.spmm_planned)(
+        m, k, values, row_indices, row_offsets, column_indices, dense, plan)
+
+
+def _sddmm(m, n, row_indices, row_offsets, column_indices, lhs_matrix, rhs_matrix):
+    if _plans is None:
+        return ops.sddmm(m, n, row_indices, row_offsets, column_indices, lhs_matrix, rhs_matrix)
+    plan = _plans.sddmm(m, n, lhs_matrix.size(-1), row_indices, row_offsets, column_indices)
+    return ops.sddmm_planned(m, n, row_indices, row_offsets, column_indices, lhs_matrix,
+                             rhs_matrix, plan)
+
+
+def _attention(query, key, value, row_indices, row_offsets, column_indices, scale):
+    """Fused attention forward, through the cached plan of the mask when enabled."""
+    if _plans is None:
+        return ops.sparse_attention(query, key, value, row_indices, row_offsets, column_indices,
+                                    scale)
+    plan = _plans.attention(query.size(-2), key.size(-2), query.size(-1), row_indices,
+                            row_offsets, column_indices)
+    return ops.sparse_attention_planned(query, key, value, row_indices, row_offsets,
+                                        column_indices, scale, plan)
+
+
 class Spmm(torch.autograd.Function):
     """sparse(values, CSR topology) @ dense.  ``apply(m, k, values, row_indices,
     row_offsets, column_indices, dense)``."""
@@ -76,7 +197,7 @@ class Spmm(torch.autograd.Function):
         ctx.shape = (m, k)
         ctx.topology = (row_indices, row_offsets, column_indices)
         ctx.save_for_backward(values, dense)
-        return ops.spmm(m, k, values, row_indices, row_offsets, column_indices, dense)
+        return _spmm(m, k, values, row_indices, row_offsets, column_indices, dense)
 
     @staticmethod
     def backward(ctx, grad_output):
@@ -87,14 +208,14 @@ class Spmm(torch.autograd.Function):
         grad_values = grad_dense = None
         if ctx.needs_input_grad[2]:
             # dL/dA sampled at the pattern: <dC[i,:], B[j,:]>
-            grad_values = ops.sddmm(m, k, row_indices, row_offsets, column_indices, grad_output,
-                                    dense.contiguous())
+            grad_values = _sddmm(m, k, row_indices, row_offsets, column_indices, grad_output,
+                                 dense.contiguous())
         if ctx.needs_input_grad[6]:
             # dL/dB = A^T @ dC
             values_t, row_indices_t, row_offsets_t, column_indices_t = _transpose(
                 m, k, values, row_offsets, column_indices)
-            grad_dense = ops.spmm(k, m, values_t, row_indices_t, row_offsets_t, column_indices_t,
-                                  grad_output)
+            grad_dense = _spmm(k, m, values_t, row_indices_t, row_offsets_t, column_indices_t,
+                               grad_output)
         return None, None, grad_values, None, None, None, grad_dense
 
 
@@ -107,7 +228,7 @@ class Sddmm(torch.autograd.Function):
         ctx.shape = (m, n)
         ctx.topology = (row_indices, row_offsets, column_indices)
         ctx.save_for_backward(lhs_matrix, rhs_matrix)
-        return ops.sddmm(m, n, row_indices, row_offsets, column_indices, lhs_matrix, rhs_matrix)
+        return _sddmm(m, n, row_indices, row_offsets, column_indices, lhs_matrix, rhs_matrix)
 
     @staticmethod
     def backward(ctx, grad_output):
@@ -118,14 +239,14 @@ class Sddmm(torch.autograd.Function):
         grad_lhs = grad_rhs = None
         if ctx.needs_input_grad[5]:
             # dL/dlhs = dS @ rhs, dS sparse with the mask's pattern
-            grad_lhs = ops.spmm(m, n, grad_output, row_indices, row_offsets, column_indices,
-                                rhs_matrix.contiguous())
+            grad_lhs = _spmm(m, n, grad_output, row_indices, row_offsets, column_indices,
+                             rhs_matrix.contiguous())
         if ctx.needs_input_grad[6]:
             # dL/drhs = dS^T @ lhs
             grad_t, row_indices_t, row_offsets_t, column_indices_t = _transpose(
                 m, n, grad_output, row_offsets, column_indices)
-            grad_rhs = ops.spmm(n, m, grad_t, row_indices_t, row_offsets_t, column_indices_t,
-                                lhs_matrix.contiguous())
+            grad_rhs = _spmm(n, m, grad_t, row_indices_t, row_offsets_t, column_indices_t,
+                             lhs_matrix.contiguous())
         return None, None, None, None, None, grad_lhs, grad_rhs
 
 
@@ -139,7 +260,7 @@ class SparseLinearFunction(torch.autograd.Function):
         ctx.shape = (m, k)
         ctx.topology = (row_indices, row_offsets, column_indices)
         ctx.save_for_backward(values, dense)
-        return ops.left_spmm(m, k, values, row_indices, row_offsets, column_indices, dense)
+        return _spmm(m, k, values, row_indices, row_offsets, column_indices, dense, left=True)
 
     @staticmethod
     def backward(ctx, grad_output):
@@ -150,15 +271,15 @@ class SparseLinearFunction(torch.autograd.Function):
         grad_values = grad_dense = None
         if ctx.needs_input_grad[2]:
             # [B,nnz]; autograd sums it over B to match the shared `values`.
-            grad_values = ops.sddmm(m, k, row_indices, row_offsets, column_indices, grad_output,
-                                    dense.contiguous())
+            grad_values = _sddmm(m, k, row_indices, row_offsets, column_indices, grad_output,
+                                 dense.contiguous())
             if grad_values.dim() == 2:
                 grad_values = grad_values.sum(dim=0)
         if ctx.needs_input_grad[6]:
             values_t, row_indices_t, row_offsets_t, column_indices_t = _transpose(
                 m, k, values, row_offsets, column_indices)
-            grad_dense = ops.left_spmm(k, m, values_t, row_indices_t, row_offsets_t,
-                                       column_indices_t, grad_output)
+            grad_dense = _spmm(k, m, values_t, row_indices_t, row_offsets_t, column_indices_t,
+                               grad_output, left=True)
             if dense.dim() == 2:
                 grad_dense = grad_dense[0]
         return None, None, grad_values, None, None, None, grad_dense
@@ -204,8 +325,7 @@ class SparseAttentionFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, query, key, value, row_indices, row_offsets, column_indices, scale):
-        out = ops.sparse_attention(query, key, value, row_indices, row_offsets, column_indices,
-                                   scale)
+        out = _attention(query, key, value, row_indices, row_offsets, column_indices, scale)
         ctx.scale = float(scale)
         ctx.save_for_backward(query, key, value, row_indices, row_offsets, column_indices)
         return out
@@ -216,24 +336,28 @@ class SparseAttentionFunction(torch.autograd.Function):
         topo = (row_indices, row_offsets, column_indices)
         m, n = query.size(-2), key.size(-2)
         grad_output = grad_output.contiguous()
-        scores = ops.sddmm(m, n, *topo, query, key)
+        scores = _sddmm(m, n, *topo, query, key)
         weights = ops.sparse_softmax_scaled(scores, *topo, ctx.scale)
-        grad_weights = ops.sddmm(m, n, *topo, grad_output, value)
+        grad_weights = _sddmm(m, n, *topo, grad_output, value)
         grad_scores = ops.sparse_softmax_backward(weights, grad_weights, row_offsets, ctx.scale)
         grad_query = grad_key = grad_value = None
         if ctx.needs_input_grad[0]:
-            grad_query = ops.spmm(m, n, grad_scores, *topo, key)
+            grad_query = _spmm(m, n, grad_scores, *topo, key)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            grad_scores_t, row_offsets_t, column_indices_t, perm = \
-                ops.csr_transpose_with_permutation(m, n, grad_scores, row_offsets, column_indices)
-            row_indices_t = diffsort(row_offsets_t)
+            if _cache is not None:
+                row_indices_t, row_offsets_t, column_indices_t, perm = _cache.lookup(
+                    m, n, row_offsets, column_indices, grad_scores)
+            else:
+                _, row_offsets_t, column_indices_t, perm = ops.csr_transpose_with_permutation(
+                    m, n, grad_scores.reshape(-1, grad_scores.shape[-1])[0].contiguous(),
+                    row_offsets, column_indices)
+                row_indices_t, perm = diffsort(row_offsets_t), perm.to(torch.int64)
             if ctx.needs_input_grad[1]:
-                grad_key = ops.spmm(n, m, grad_scores_t, row_indices_t, row_offsets_t,
-                                    column_indices_t, query)
+                grad_key = _spmm(n, m, grad_scores.index_select(-1, perm), row_indices_t,
+                                 row_offsets_t, column_indices_t, query)
             if ctx.needs_input_grad[2]:
-                weights_t = weights.index_select(-1, perm.to(torch.int64))
-                grad_value = ops.spmm(n, m, weights_t, row_indices_t, row_offsets_t,
-                                      column_indices_t, grad_output)
+                grad_value = _spmm(n, m, weights.index_select(-1, perm), row_indices_t,
+                                   row_offsets_t, column_indices_t, grad_output)
         return grad_query, grad_key, grad_value, None, None, None, None
 
 

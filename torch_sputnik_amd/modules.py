@@ -18,7 +18,7 @@ import math
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import functional, ops
 from .functional import SparseAttentionFunction, Sddmm, SparseLinearFunction, SparseSoftmax, Spmm
 from .topology import dense_to_sparse, generate_mask
 
@@ -39,24 +39,17 @@ class SparseLinear(nn.Module):
         self.row_indices = row_indices
         self.row_offsets = row_offsets
         self.column_indices = column_indices
-        self._plans = {}  # sequence length -> SpMM plan of this (static) topology
 
     def forward(self, x):
         dense = x.transpose(1, 2).contiguous()
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or self.values.requires_grad)
         if not needs_grad:
-            # forward only: the weight's pattern is static, so its topology pre-pass
-            # is run once per sequence length and reused (ops.spmm_plan)
-            n = (dense.size(-1), dense.device)
-            plan = getattr(self, "_plans", {}).get(n)
-            if plan is None:
-                plan = ops.spmm_plan(self.output_features, self.input_features, n[0],
-                                     self.row_indices, self.row_offsets, self.column_indices)
-                if hasattr(self, "_plans"):
-                    self._plans[n] = plan
-            return ops.left_spmm_planned(self.output_features, self.input_features,
-                                         self.values.detach(), self.row_indices, self.row_offsets,
-                                         self.column_indices, dense, plan)
+            # forward only: no autograd node.  (The weight's pattern is static: its
+            # topology pre-pass comes from the plan cache, functional.PlanCache,
+            # which is keyed on the identity and version of the index tensors.)
+            return functional._spmm(self.output_features, self.input_features,
+                                    self.values.detach(), self.row_indices, self.row_offsets,
+                                    self.column_indices, dense, left=True)
         return SparseLinearFunction.apply(
             self.output_features, self.input_features, self.values, self.row_indices,
             self.row_offsets, self.column_indices, dense)
@@ -97,7 +90,6 @@ class SparseAttention(nn.Module):
         # backward instead of being kept (and, unlike the reference's raw softmax
         # call, the gradient reaches Q and K)
         self.fused_training = fused_training
-        self._attention_plan = None
 
     def attention(self, query, key, value, mask):
         q3d = self.four_d_to_three_d(query)
@@ -108,13 +100,8 @@ class SparseAttention(nn.Module):
         needs_grad = torch.is_grad_enabled() and (
             q3d.requires_grad or k3d.requires_grad or v3d.requires_grad)
         if self.fused_inference and not needs_grad:
-            if self._attention_plan is None:  # the mask is static: plan once
-                self._attention_plan = ops.sparse_attention_plan(
-                    self.m, self.n, self.head_dim, self.row_indices, self.row_offsets,
-                    self.column_indices)
-            return ops.sparse_attention_planned(q3d, k3d, v3d, self.row_indices,
-                                                self.row_offsets, self.column_indices, scale,
-                                                self._attention_plan)
+            return functional._attention(q3d, k3d, v3d, self.row_indices, self.row_offsets,
+                                         self.column_indices, scale)
         if self.fused_training:
             return SparseAttentionFunction.apply(q3d, k3d, v3d, self.row_indices,
                                                  self.row_offsets, self.column_indices, scale)
