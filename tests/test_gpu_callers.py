@@ -132,7 +132,7 @@ def test_spmm_function_vs_dense_autograd(tsa, dev, transpose_mode, m, k, n, repl
     bd = b.detach().double().requires_grad_(True)
     rows = torch.repeat_interleave(torch.arange(m, device=dev), (d_ro[1:] - d_ro[:-1]).long())
     a = torch.zeros(shape_v[:-1] + (m, k), dtype=torch.float64, device=dev)
-    a = a.index_put((..., rows, d_ci.long()), vd)
+    a[..., rows, d_ci.long()] = vd          # in-place scatter, tracked by autograd
     want = torch.matmul(a, bd)
     want.backward(go.double())
     assert rel_err_torch(out.detach(), want.detach()) < TOL
@@ -196,7 +196,7 @@ def dense_attention_module(module, query, key, value):
 
 def build_attention(tsa, dev, heads, embed, seq, seed, **flags):
     module = tsa.SparseAttention(heads, embed, max_sequence_length=seq, device=dev,
-                                 mask_generator=np.random.default_rng(seed), **flags)
+                                 mask_generator=np.random.default_rng(seed), **flags).to(dev)
     rng = np.random.default_rng(seed + 1)
     for layer in module.linears:
         w = rng.uniform(-1, 1, (embed, embed)) / math.sqrt(embed * 0.3)
