@@ -12,11 +12,15 @@ that is already resident in HBM.
   N = 1  workload "C2": 2-D SpMM 4096^3, density 0.1 (BASELINE.json configs[1];
          the other densities of the sweep are reported in `sweep`).
   N > 1  workload "C4": batched SpMM, 16 replicas of the same problem per GPU
-         (128 replicas at 8 GPUs), replica dimension sharded over the ranks,
-         one launch per rank per step.  Per-GPU work is fixed -> "weak".
-         The shards are independent: no collective is on the data path.
-         `--allgather` adds the RCCL all-gather of C (north star's optional
-         exchange step) inside the timed step.
+         (128 replicas at 8 GPUs), replica dimension sharded over the ranks
+         (operands rank-local: no GPU holds another rank's B), one launch per
+         rank per step, THEN the all-gather of C over RCCL/xGMI that the north
+         star names, inside the timed step.  Per-GPU work is fixed -> "weak".
+         Seven schedules are timed with the same W + K steps each and printed
+         in the one JSON line: `compute_only`, `allgather` (collective / p2p),
+         `allgather_overlapped` (collective / p2p, chunked on a side stream),
+         `exchange` (the all-gather alone: bytes per rank, GB/s per link).
+         `value` is the fastest schedule that includes the all-gather.
 
 value = 2*nnz*N*replicas_total / time  (effective GFLOP/s of the whole job).
 Rank 0 prints ONE JSON line.  Extra keys: `roofline` (HBM roof, algorithmic
@@ -106,6 +110,117 @@ class SpmmProblem:
         self.capi.spmm_batched_planned(M, K, N, self.replicas, self.ri, self.values,
                                        self.nnz if self.replicas > 1 else 0, self.ro, self.ci,
                                        self.dense, self.out, self.ws)
+
+
+class Exchange:
+    """The all-gather of C for the replica-sharded product, on
+    preallocated buffers: every rank ends with all `world * replicas` output
+    matrices.  Two transports -- RCCL's all_gather_into_tensor, and direct
+    grouped send/recv to every peer (xGMI is a full mesh: all 7 links carry one
+    block each, no ring) -- each either after the launch or chunk by chunk on a
+    side stream while the next chunk is being computed."""
+
+    def __init__(self, problem, world, rank, dev, chunks):
+        import torch.distributed as dist
+        self.dist, self.problem, self.world, self.rank, self.dev = dist, problem, world, rank, dev
+        r = problem.replicas
+        self.local = problem.out.reshape(r, M, N)
+        self.flat = torch.empty(world * r * M * N, device=dev)
+        self.rank_major = self.flat.view(world, r, M, N)          # = global replica order
+        per = (r + chunks - 1) // chunks
+        self.bounds = [(a, min(a + per, r)) for a in range(0, r, per)]
+        # collective chunks land chunk-major ([chunk][rank][replicas of the chunk]):
+        # one contiguous all_gather_into_tensor each, in the same storage
+        self.chunk_major, off = [], 0
+        for a, b in self.bounds:
+            size = world * (b - a) * M * N
+            self.chunk_major.append(self.flat[off:off + size].view(world * (b - a), M, N))
+            off += size
+        self.side = torch.cuda.Stream(device=dev)
+        self.bytes_per_peer = r * M * N * 4.0
+
+    def collective(self):
+        self.dist.all_gather_into_tensor(self.rank_major.view(-1, M, N), self.local)
+
+    def collective_chunk(self, c):
+        a, b = self.bounds[c]
+        self.dist.all_gather_into_tensor(self.chunk_major[c], self.local[a:b])
+
+    def p2p_chunk(self, c):
+        a, b = self.bounds[c]
+        self.p2p(a, b)
+
+    def p2p(self, a=0, b=None):
+        dist = self.dist
+        b = self.problem.replicas if b is None else b
+        send = self.local[a:b]
+        ops = []
+        if self.world == 1:   # BENCH_FORCE_DIST: the block to itself, through RCCL
+            ops = [dist.P2POp(dist.isend, send, 0), dist.P2POp(dist.irecv, self.rank_major[0, a:b], 0)]
+        else:
+            self.rank_major[self.rank, a:b].copy_(send)
+            for step in range(1, self.world):
+                dst, src = (self.rank + step) % self.world, (self.rank - step) % self.world
+                ops.append(dist.P2POp(dist.isend, send, dst))
+                ops.append(dist.P2POp(dist.irecv, self.rank_major[src, a:b], src))
+        for work in dist.batch_isend_irecv(ops):
+            work.wait()
+
+    def overlapped(self, exchange_chunk):
+        """compute chunk i on the main stream; its exchange runs on the side stream
+        behind an event while the main stream computes chunk i + 1."""
+        main = torch.cuda.current_stream(self.dev)
+        for c, (a, b) in enumerate(self.bounds):
+            self.problem.step_range(a, b)
+            done = torch.cuda.Event()
+            done.record(main)
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(done)
+                exchange_chunk(c)
+        main.wait_stream(self.side)
+
+    def verify(self, schedule):
+        """After the timed steps: this rank's block must sit where the schedule put it."""
+        torch.cuda.synchronize()
+        if not schedule.startswith("allgather"):
+            return
+        if schedule == "allgather_overlapped_collective":
+            for c, (a, b) in enumerate(self.bounds):
+                got = self.chunk_major[c].view(self.world, b - a, M, N)[self.rank]
+                assert torch.equal(got, self.local[a:b]), "gathered chunk differs from the local block"
+        else:
+            assert torch.equal(self.rank_major[self.rank], self.local), \
+                "gathered block differs from the local block"
+
+    def report(self, timings, n_gpus):
+        flops = self.problem.flops * n_gpus
+
+        def line(name):
+            ms = timings.get(name)
+            return None if not ms else {"ms_per_step": ms, "gflops": flops / ms / 1e6}
+
+        def link(name):
+            ms = timings.get(name)
+            if not ms:
+                return None
+            return {"ms": ms, "gbs_per_link_per_direction": self.bytes_per_peer / ms / 1e6,
+                    "gbs_received_per_gpu": self.bytes_per_peer * max(1, self.world - 1) / ms / 1e6}
+
+        return {
+            "compute_only": line("compute_only"),
+            "allgather": {"collective": line("allgather_collective"), "p2p": line("allgather_p2p")},
+            "allgather_overlapped": {"collective": line("allgather_overlapped_collective"),
+                                     "p2p": line("allgather_overlapped_p2p"),
+                                     "chunks": len(self.bounds)},
+            "exchange_only": {"collective": link("exchange_only_collective"),
+                              "p2p": link("exchange_only_p2p")},
+            "bytes_sent_per_rank_per_peer": self.bytes_per_peer,
+            "bytes_received_per_rank": self.bytes_per_peer * (self.world - 1),
+            "gathered_bytes_per_rank": self.bytes_per_peer * self.world,
+            "xgmi_model": {"links_per_gpu": 7, "gbs_per_link": 153.0,
+                           "direct_exchange_floor_ms": self.bytes_per_peer / 153.0e6
+                           if self.world > 1 else 0.0},
+        }
 
 
 def cpu_baseline(problem):
@@ -244,8 +359,10 @@ def other_ops(dev):
     t = event_time_ms(lambda: capi.sddmm_batched(m, seq, n, batch, ri, ro, ci, gy, x, gw, sws), 10)
     res["sddmm_grad_values_c5"] = {"ms": t, "gflops": 2.0 * nnz * seq * batch / t / 1e6}
     # config 5 end to end: SparseLinear forward + backward through the torch ops and the
-    # autograd Function (left_spmm; sddmm + csr_transpose + left_spmm), fp32 and with the
-    # input stored in fp16 (widened once at the op layer, fp32 arithmetic: DESIGN.md section 7)
+    # autograd Function (left_spmm; sddmm + transposed topology + left_spmm), fp32 and with
+    # the input stored in fp16.  Default = transposed topology and kernel plans cached per
+    # static topology; `_per_call` = the reference's behaviour (csr_transpose + diffsort and
+    # the pre-passes in every call, modules/sparse_linear.py:52-57).
     try:
         from torch_sputnik_amd import SparseLinear
         layer = SparseLinear(n, m).to(dev)
@@ -263,15 +380,17 @@ def other_ops(dev):
 
             res[f"sparse_linear_fwd_bwd_c5_{name}"] = {"ms": event_time_ms(fwd_bwd, 10), "batch": batch,
                                                        "seq": seq}
-            if name == "fp32":  # static weights: transposed topology computed once (opt-in cache)
-                from torch_sputnik_amd.functional import enable_transpose_cache
-                enable_transpose_cache(True)
+            if name == "fp32":
+                from torch_sputnik_amd import functional
+                functional.enable_transpose_cache(False)
+                functional.enable_plan_cache(False)
                 try:
                     fwd_bwd()
-                    res["sparse_linear_fwd_bwd_c5_fp32_cached_transpose"] = {
+                    res["sparse_linear_fwd_bwd_c5_fp32_per_call"] = {
                         "ms": event_time_ms(fwd_bwd, 10)}
                 finally:
-                    enable_transpose_cache(False)
+                    functional.enable_transpose_cache(functional.TRANSPOSE_CACHE_DEFAULT)
+                    functional.enable_plan_cache(functional.PLAN_CACHE_DEFAULT)
     except Exception as e:  # noqa: BLE001 - extra metric, best effort
         res["sparse_linear_fwd_bwd_c5"] = {"error": str(e)[:200]}
     return res
@@ -296,11 +415,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--device-warmup-s", type=float, default=0.25,
                     help="seconds of untimed steps before the W warm-up steps (clock ramp)")
-    ap.add_argument("--allgather", action="store_true",
-                    help="N>1: all-gather C over RCCL inside the timed step")
-    ap.add_argument("--overlap-chunks", type=int, default=1,
-                    help="with --allgather: split the replicas into this many chunks and "
-                         "exchange chunk i (side stream) while chunk i+1 is computed")
+    ap.add_argument("--compute-only", action="store_true",
+                    help="N>1: time the local launches only (no all-gather of C)")
+    ap.add_argument("--overlap-chunks", type=int, default=4,
+                    help="N>1: the overlapped schedules split a rank's replicas into this many "
+                         "chunks and exchange chunk i (side stream) while chunk i+1 is computed")
     ap.add_argument("--replicas-per-gpu", type=int, default=0,
                     help="override (default 1 at --gpus 1, 16 otherwise)")
     ap.add_argument("--no-extras", action="store_true", help="skip sweep / cpu baseline / other ops")
@@ -337,6 +456,10 @@ def main():
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:   # BENCH_FORCE_DIST without a launcher
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", device_id=dev)
     n_gpus = world if distributed else 1
     if args.gpus != n_gpus and rank == 0:
@@ -345,34 +468,28 @@ def main():
     replicas = args.replicas_per_gpu or (1 if n_gpus == 1 else REPLICAS_PER_GPU_MULTI)
     problem = SpmmProblem(dev, HEADLINE_DENSITY, replicas, seed=1234 + 1000 * DENSITIES.index(HEADLINE_DENSITY) + rank)
 
-    gathered = None
-    chunks = max(1, min(args.overlap_chunks, replicas))
-    if distributed and args.allgather:
-        # [chunk][rank][replicas in chunk, M, N]: chunk-major so that every exchange
-        # is one contiguous all_gather_into_tensor
-        per = (replicas + chunks - 1) // chunks
-        bounds = [(a, min(a + per, replicas)) for a in range(0, replicas, per)]
-        gathered = [torch.empty((world, b - a, M, N), device=dev) for a, b in bounds]
-        side = torch.cuda.Stream(device=dev)
-
-    def step():
-        if gathered is None:
-            problem.step()
-            return
-        if len(gathered) == 1:
-            problem.step()
-            dist.all_gather_into_tensor(gathered[0], problem.out.reshape(replicas, M, N))
-            return
-        # pipelined: compute chunk i on the main stream, gather it on the side stream
-        main = torch.cuda.current_stream(dev)
-        for g, (a, b) in zip(gathered, bounds):
-            problem.step_range(a, b)
-            done = torch.cuda.Event()
-            done.record(main)
-            with torch.cuda.stream(side):
-                side.wait_event(done)
-                dist.all_gather_into_tensor(g, problem.out.reshape(replicas, M, N)[a:b])
-        main.wait_stream(side)
+    def run_timed(step_fn):
+        """W untimed steps, then EXACTLY K steps between barrier + synchronize on
+        both sides; the maximum over the ranks, in ms per step."""
+        for _ in range(args.warmup):
+            step_fn()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_fn()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed / args.steps * 1e3
 
     # The GPU needs a few tens of milliseconds of load before its clocks settle
     # (tools/sustain_bench.py: the first 50 back-to-back steps average 0.433 ms,
@@ -383,26 +500,44 @@ def main():
         for _ in range(10):
             problem.step()  # compute only: a time-based loop must not contain collectives
         torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-        torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-        torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
-    ms_per_step = elapsed / args.steps * 1e3
+    multi = None
+    if not distributed:
+        ms_per_step = run_timed(problem.step)
+        headline = "compute (one GPU: nothing to exchange)"
+    else:
+        # North star / SURVEY.md 8e: the replica-sharded product WITH the all-gather of
+        # C over RCCL.  Every schedule is timed the same way (W + K steps each):
+        #   compute_only                      the local launch, no exchange
+        #   exchange_only_{collective,p2p}    the all-gather alone (link bandwidth)
+        #   allgather_{collective,p2p}        launch, then exchange (unoverlapped)
+        #   allgather_overlapped_{...}        chunk i exchanged while chunk i+1 computes
+        # `value` is the best schedule that includes the all-gather.
+        ex = Exchange(problem, world, rank, dev, max(1, min(args.overlap_chunks, replicas)))
+        variants = {"compute_only": problem.step,
+                    "exchange_only_collective": ex.collective,
+                    "allgather_collective": lambda: (problem.step(), ex.collective()),
+                    "allgather_overlapped_collective": lambda: ex.overlapped(ex.collective_chunk)}
+        if os.environ.get("BENCH_NO_P2P") != "1":
+            variants.update({
+                "exchange_only_p2p": ex.p2p,
+                "allgather_p2p": lambda: (problem.step(), ex.p2p()),
+                "allgather_overlapped_p2p": lambda: ex.overlapped(ex.p2p_chunk)})
+        if args.compute_only:
+            variants = {"compute_only": problem.step}
+        timings = {}
+        for name, fn in variants.items():
+            try:
+                timings[name] = run_timed(fn)
+            except Exception as e:  # noqa: BLE001 - one schedule failing must not lose the others
+                timings[name] = None
+                print(f"[bench] rank {rank}: schedule {name} failed: {e}", file=sys.stderr)
+        gathered_names = [k for k, v in timings.items() if k.startswith("allgather") and v]
+        headline = min(gathered_names, key=lambda k: timings[k]) if gathered_names else "compute_only"
+        ms_per_step = timings[headline]
+        ex.verify(headline)
+        multi = ex.report(timings, n_gpus)
+
     total_flops = problem.flops * n_gpus
     value = total_flops / (ms_per_step * 1e-3) / 1e9
 
@@ -425,9 +560,9 @@ def main():
                 "replicas_per_gpu": replicas, "nnz": problem.nnz,
                 "device_warmup_s": args.device_warmup_s,
                 "step": "sputnik_hip_spmm_batched (pre-pass + kernel) via the C ABI",
-                "collective": ("none (independent shards)" if gathered is None else
-                               "all_gather(C) over RCCL" if len(gathered) == 1 else
-                               "all_gather(C) over RCCL, %d chunks overlapped with compute" % len(gathered)),
+                "collective": ("none (one GPU)" if multi is None else
+                               "all-gather of C over RCCL inside the step; schedule timed as `value`: "
+                               + headline),
                 "inputs": "uniform-random sparsity (tests/connectors.py distribution), U[0,1) values, resident in HBM",
             },
             "algorithmic_gbs": problem.bytes * n_gpus / (ms_per_step * 1e-3) / 1e9,
@@ -448,6 +583,13 @@ def main():
             },
             "a100_reference_sputnik_gflops": 3416.0,  # README.md:54 of the reference (other hardware)
         }
+        if multi is not None:
+            # SURVEY.md 8e's three figures (and both transports), each timed over the
+            # same K steps: compute only / compute + all-gather / overlapped
+            result["headline_schedule"] = headline
+            result.update({k: multi[k] for k in ("compute_only", "allgather", "allgather_overlapped")})
+            result["exchange"] = {k: multi[k] for k in multi
+                                  if k not in ("compute_only", "allgather", "allgather_overlapped")}
         if not args.no_extras and n_gpus == 1:
             sweep = []
             for d in DENSITIES:

@@ -56,6 +56,19 @@ def _worker(rank, world, port, replicas, results):
         a, z = sharding.local_range(replicas, world, rank)
         ok = all(torch.equal(t, full) for t in out.values()) and torch.equal(local, full[a:z])
 
+        # shard-at-origin: every rank passes ONLY its own block of the operands
+        for mode in ("collective", "p2p"):
+            got = sharding.spmm(m, k, v[a:z].contiguous(), *topo, b[a:z].contiguous(),
+                                gather_mode=mode, local_operands=True, replicas=replicas)
+            ok = ok and torch.equal(got, full)
+        mine = sharding.spmm(m, k, v[a:z].contiguous(), *topo, b[a:z].contiguous(),
+                             gather_output=False, local_operands=True, replicas=replicas)
+        ok = ok and torch.equal(mine, full[a:z])
+        if replicas % world == 0:
+            got = sharding.spmm(m, k, v[a:z].contiguous(), *topo, b[a:z].contiguous(),
+                                overlap_chunks=2, local_operands=True)
+            ok = ok and torch.equal(got, full)
+
         left = sharding.left_spmm(m, k, v[0].contiguous(), *topo, b)
         ok = ok and torch.equal(left, ops.left_spmm(m, k, v[0].contiguous(), *topo, b))
         lhs = torch.from_numpy(rng.uniform(-1, 1, (replicas, m, 4)).astype(np.float32))
