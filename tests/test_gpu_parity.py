@@ -345,6 +345,30 @@ def test_softmax_capi_vs_oracle(capi, dev, m, n, sparsity, replicas):
     assert rel_err(got, want, ro) < TOL
 
 
+@pytest.mark.parametrize("m,n,sparsity,replicas", [(300, 700, 0.85, 3), (64, 64, 0.3, 2),
+                                                   (100, 2000, 0.9, 2), (40, 3000, 0.5, 1)])
+@pytest.mark.parametrize("in_phase,out_phase", [(0, 0), (1, 1), (3, 2), (2, 0)])
+def test_softmax_unaligned_buffers(capi, dev, m, n, sparsity, replicas, in_phase, out_phase):
+    """The kernel moves rows as aligned 16-byte pieces: buffers that start 1-3
+    floats past a 16-byte boundary, replica strides that are not multiples of
+    four (nnz is odd here) and outputs aligned differently from the inputs must
+    give the same answer, and nothing outside the output may be written."""
+    _, vals, ri, ro, ci = make_csr(m, n, sparsity, seed=m + n, round_to=1, empty_rows=(0, m // 2))
+    nnz = len(vals)
+    rng = np.random.default_rng(m)
+    v = rng.uniform(-6, 6, size=(replicas, nnz)).astype(np.float32)
+    want = c_oracle.sparse_softmax(v, ro, ci)
+    src = torch.zeros(replicas * nnz + 8, device=dev)
+    src[in_phase:in_phase + replicas * nnz] = T(v, dev).reshape(-1)
+    dst = torch.full((replicas * nnz + 8,), 7.0, device=dev)
+    capi.sparse_softmax_batched(m, replicas, src[in_phase:in_phase + replicas * nnz].view(replicas, nnz),
+                                T(ri, dev), T(ro, dev), T(ci, dev),
+                                dst[out_phase:out_phase + replicas * nnz].view(replicas, nnz))
+    got = dst.cpu().numpy()
+    assert np.all(got[:out_phase] == 7.0) and np.all(got[out_phase + replicas * nnz:] == 7.0)
+    assert rel_err(got[out_phase:out_phase + replicas * nnz].reshape(replicas, nnz), want, ro) < TOL
+
+
 def test_softmax_op_golden(ts, dev, golden):
     g = golden("softmax_72x72")
     out = ts.sparse_softmax(T(g["values"], dev),

@@ -2,14 +2,16 @@
 //
 // Replaces sputnik::SparseSoftmax as driven by src/softmax_cuda.cu:35-43.
 //
-// A group of LPR lanes owns one row.
-// Rows of up to LPR*kRegs entries are read from HBM exactly once into
-// registers (coalesced, lane-strided), reduced with DPP (max, then sum of
-// exp) and written once: 8 bytes of HBM traffic per entry, the algorithmic
-// minimum.  Longer rows fall back to three streaming passes whose re-reads
-// are served by L2.  exp is the hardware v_exp_f32 path (__expf): relative error
-// about 5e-6 at |x - max| ~ 88, far inside the 1e-4 budget; the accurate
-// library expf made the kernel VALU-bound.
+// A group of 16 / 32 / 64 lanes owns a run of consecutive rows; a row moves
+// through registers once, as ALIGNED 16-byte pieces (one dwordx4 per lane and
+// instruction, whatever the row's start), with the next row's pieces in flight
+// while the current one is reduced with DPP (max, then sum of exp): 8 bytes of
+// HBM traffic per entry, the algorithmic minimum.  See the kernel's comment.
+#include <stdlib.h>
+
+#include <type_traits>
+#include <utility>
+
 #include "common.h"
 #include "wave_utils.h"
 
@@ -17,168 +19,286 @@ namespace sputnik_hip {
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kRegs = 8;
 
-template <int LPR>
-__global__ __launch_bounds__(kBlock) void sparse_softmax_kernel(
-    int m, const float* __restrict__ values, int64_t values_stride,
-    const int* __restrict__ row_indices, const int* __restrict__ row_offsets,
-    float* __restrict__ out, int64_t out_stride, float scale) {
-  constexpr int kRowsPerBlock = kBlock / LPR;
-  const int sub = threadIdx.x / LPR;
+using f4 = float __attribute__((ext_vector_type(4)));
+
+template <typename F, int... Is>
+__device__ __forceinline__ void unrolled_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+// f(integral_constant<0>), ..., f(integral_constant<N-1>): register arrays indexed
+// by the counter stay in registers.
+template <int N, typename F>
+__device__ __forceinline__ void unrolled(F&& f) {
+  unrolled_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+// 16 bytes at `base + byte_offset`: wave-uniform base (SGPR pair) plus a 32-bit
+// per-lane offset, the cheapest addressing form (no 64-bit VALU arithmetic).
+__device__ __forceinline__ f4 load_piece(const char* __restrict__ base, unsigned byte_offset) {
+  return *reinterpret_cast<const f4*>(base + byte_offset);
+}
+
+// Forward (BACKWARD = false): y = softmax(scale * x) over the stored entries of
+// each row.  Backward: dx = scale * y * (dy - sum_row(dy * y)).
+//
+// A group of LPR lanes owns `rows_per_group` CONSECUTIVE rows (neighbouring
+// groups stream neighbouring memory) and walks them with the next row's data
+// already in flight.  A row moves through registers exactly once -- 8 bytes of
+// HBM traffic per entry forward, 12 backward, the algorithmic minimum -- as
+// 16-byte pieces that are ALIGNED in memory: the first piece starts up to three
+// entries before the row, lane l owns pieces l, l + LPR, ... (V of them), so every
+// load is one unconditional `dwordx4` per lane (a piece outside the row is
+// clamped into the buffer and masked by index arithmetic, one unsigned compare
+// per entry) and every interior store is one `dwordx4`; only the two pieces a
+// row shares with its neighbours are stored entry by entry.  All index
+// arithmetic is 32-bit and relative to the replica's base; the loop has no
+// divergent branch.  Rows that do not fit the window (LPR * 4 * V - 3 entries),
+// rows that touch the partial first / last piece of the whole buffer, and
+// buffers whose inputs and output are aligned differently take three strided
+// passes (re-reads served by L2).  exp is the hardware v_exp_f32 path (__expf):
+// relative error about 5e-6 at |x - max| ~ 88, far inside the 1e-4 budget; the
+// accurate library expf made the kernel VALU-bound.
+template <int LPR, int V, bool BACKWARD, int DEPTH>
+__global__ __launch_bounds__(kBlock) void sparse_softmax_rows_kernel(
+    int m, int rows_per_group, int nonzeros, const float* __restrict__ a, int64_t a_stride,
+    const float* __restrict__ b, int64_t b_stride, const int* __restrict__ row_offsets,
+    float* __restrict__ out, int64_t out_stride, float scale, int same_phase) {
+  constexpr int kWindow = LPR * 4 * V;
   const int l = threadIdx.x % LPR;
-  const int slot = blockIdx.x * kRowsPerBlock + sub;
+  const int group = (blockIdx.x * kBlock + threadIdx.x) / LPR;
   const int replica = blockIdx.y;
-  values += replica * values_stride;
+  const int replicas = gridDim.y;
+  a += replica * a_stride;
+  if constexpr (BACKWARD) b += replica * b_stride;
   out += replica * out_stride;
 
-  // Rows are taken in storage order, not in row_indices order: neighbouring
-  // groups then read neighbouring memory (a row is only a few hundred bytes, so
-  // rows dealt by length touch partial cache lines at both ends), and the
-  // result never depends on the order.  Lanes of out-of-range slots keep an
-  // empty row so that every lane reaches the convergent reductions below.
-  (void)row_indices;
-  const int row = (slot < m) ? slot : 0;
-  const int p0 = (slot < m) ? row_offsets[row] : 0;
-  const int p1 = (slot < m) ? row_offsets[row + 1] : 0;
-  const int len = p1 - p0;
+  // This replica's alignment: its element e sits (e + phase) % 4 entries into a
+  // 16-byte piece.  [qmin, qmax]: first / last piece start that lies wholly
+  // inside the buffer (relative to this replica: the buffer begins `replica`
+  // strides earlier and ends `replicas - 1 - replica` strides + nonzeros later).
+  const int phase = static_cast<int>((reinterpret_cast<uintptr_t>(a) / sizeof(float)) % 4);
+  const int64_t before = static_cast<int64_t>(replica) * a_stride;
+  const int64_t after = static_cast<int64_t>(replicas - 1 - replica) * a_stride + nonzeros;
+  const int lo_lim = -static_cast<int>(before < (1 << 30) ? before : (1 << 30));
+  const int hi_lim = static_cast<int>(after < (1 << 30) ? after : (1 << 30));
+  const int qmin = lo_lim + ((-(lo_lim + phase)) & 3);
+  const int qmax = ((hi_lim - 4 + phase) & ~3) - phase;
+  // (pointers 16 bytes before the replica: byte offsets (q + 4) * 4 are never negative)
+  const char* a_bytes = reinterpret_cast<const char*>(a) - 16;
+  const char* b_bytes = reinterpret_cast<const char*>(b) - 16;
 
-  // Longest row handled by this wave decides the path (wave-uniform branch).
-  int wave_max_len = len;
-  if constexpr (LPR < kWave) {
-#pragma unroll
-    for (int off = LPR; off < kWave; off <<= 1)
-      wave_max_len = max(wave_max_len, __shfl_xor(wave_max_len, off, kWave));
-  }
-  wave_max_len = __builtin_amdgcn_readfirstlane(wave_max_len);
+  // A wave's 64 / LPR groups take ADJACENT rows in every step (row = first row of
+  // the wave + step * groups + group), so one store instruction of the wave
+  // covers one contiguous stretch of memory and the 16-byte pieces that two
+  // neighbouring rows share are written within the same instruction pair.
+  // Lanes of groups past the last row keep empty rows so that every lane reaches
+  // the convergent reductions below.
+  constexpr int kGroups = kWave / LPR;  // per wave
+  const int wave_index = (blockIdx.x * kBlock + threadIdx.x) / kWave;
+  const int g = (threadIdx.x % kWave) / LPR;
+  const int row0 = wave_index * (rows_per_group * kGroups) + g;
+  (void)group;
 
-  if (wave_max_len <= LPR * kRegs) {
-    float x[kRegs];
-    float mx = -INFINITY;
+  struct Row {
+    int p0, len, s;   // first entry, length, start of the first aligned piece
+    bool fast;
+    f4 x[V], y[V];
+  };
+  // The run's row bounds, loaded ONCE (lane i of the group holds those of its
+  // i-th row): inside the loop a row's bounds come from a lane broadcast, so no
+  // load of the loop depends on another one (a dependent load would also wait
+  // for the previous row's stores: vmcnt retires in order).
+  const int mine = row0 + l * kGroups;
+  const bool have = l < rows_per_group && mine < m;
+  const int o_lo = have ? row_offsets[mine] : 0;
+  const int o_hi = have ? row_offsets[mine + 1] : 0;
+  auto fetch = [&](int it, Row& w) {
+    const int p0 = it < rows_per_group ? __shfl(o_lo, it, LPR) : 0;
+    const int p1 = it < rows_per_group ? __shfl(o_hi, it, LPR) : 0;
+    w.p0 = p0;
+    w.len = p1 - p0;
+    w.s = p0 - ((p0 + phase) & 3);
+    const int last_piece = ((p1 - 1 + phase) & ~3) - phase;
+    w.fast = same_phase && p1 - w.s <= kWindow && w.s >= qmin && last_piece <= qmax;
 #pragma unroll
-    for (int i = 0; i < kRegs; ++i) {
-      const int q = p0 + i * LPR + l;
-      x[i] = (q < p1) ? values[q] * scale : -INFINITY;
-      mx = fmaxf(mx, x[i]);
+    for (int v = 0; v < V; ++v) {
+      const int q = w.s + 4 * l + v * (4 * LPR);
+      const unsigned off = static_cast<unsigned>(min(max(q, qmin), qmax) + 4) * 4u;
+      w.x[v] = load_piece(a_bytes, off);
+      if constexpr (BACKWARD) w.y[v] = load_piece(b_bytes, off);
     }
-    mx = group_max<LPR>(mx);
-    float sum = 0.f;
+  };
+
+  // DEPTH rows in flight ahead of the one being reduced: a statically indexed
+  // ring of DEPTH + 1 register sets (the loop body is unrolled once per set).
+  Row ring[DEPTH + 1];
 #pragma unroll
-    for (int i = 0; i < kRegs; ++i) {
-      const int q = p0 + i * LPR + l;
-      x[i] = (q < p1) ? __expf(x[i] - mx) : 0.f;
-      sum += x[i];
-    }
-    sum = group_sum<LPR>(sum);
-    const float inv = 1.f / sum;
+  for (int d = 0; d < DEPTH; ++d) fetch(d, ring[d]);
+  auto process = [&](Row& cur) {
+    const int p0 = cur.p0, len = cur.len;
+    if (cur.fast) {
+      // entry i of piece v belongs to the row iff 0 <= q + i - p0 < len
+      bool valid[V][4];
+      f4 res[V];
 #pragma unroll
-    for (int i = 0; i < kRegs; ++i) {
-      const int q = p0 + i * LPR + l;
-      if (q < p1) out[q] = x[i] * inv;
+      for (int v = 0; v < V; ++v) {
+        const int t = cur.s + 4 * l + v * (4 * LPR) - p0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          valid[v][i] = static_cast<unsigned>(t + i) < static_cast<unsigned>(len);
+      }
+      if constexpr (!BACKWARD) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            cur.x[v][i] = valid[v][i] ? cur.x[v][i] * scale : -INFINITY;
+            mx = fmaxf(mx, cur.x[v][i]);
+          }
+        mx = group_max<LPR>(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            cur.x[v][i] = __expf(cur.x[v][i] - mx);   // exp(-inf) = 0 for the masked slots
+            sum += cur.x[v][i];
+          }
+        sum = group_sum<LPR>(sum);
+        const float inv = __builtin_amdgcn_rcpf(sum);   // 1 ulp
+#pragma unroll
+        for (int v = 0; v < V; ++v) res[v] = cur.x[v] * inv;
+      } else {
+        float dot = 0.f;
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dot += valid[v][i] ? cur.x[v][i] * cur.y[v][i] : 0.f;
+        dot = group_sum<LPR>(dot);
+#pragma unroll
+        for (int v = 0; v < V; ++v) res[v] = scale * cur.x[v] * (cur.y[v] - dot);
+      }
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const int q = cur.s + 4 * l + v * (4 * LPR);
+        if (valid[v][0] && valid[v][3]) {
+          *reinterpret_cast<f4*>(out + q) = res[v];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (valid[v][i]) out[q + i] = res[v][i];
+        }
+      }
+    } else if (len > 0) {
+      // three strided passes (this group's lanes only)
+      const int p1 = p0 + len;
+      if constexpr (!BACKWARD) {
+        float mx = -INFINITY;
+        for (int q = p0 + l; q < p1; q += LPR) mx = fmaxf(mx, a[q] * scale);
+        mx = group_max<LPR>(mx);
+        float sum = 0.f;
+        for (int q = p0 + l; q < p1; q += LPR) sum += __expf(a[q] * scale - mx);
+        sum = group_sum<LPR>(sum);
+        const float inv = 1.f / sum;
+        for (int q = p0 + l; q < p1; q += LPR) out[q] = __expf(a[q] * scale - mx) * inv;
+      } else {
+        float dot = 0.f;
+        for (int q = p0 + l; q < p1; q += LPR) dot = fmaf(a[q], b[q], dot);
+        dot = group_sum<LPR>(dot);
+        for (int q = p0 + l; q < p1; q += LPR) out[q] = scale * a[q] * (b[q] - dot);
+      }
     }
-  } else {
-    float mx = -INFINITY;
-    for (int q = p0 + l; q < p1; q += LPR) mx = fmaxf(mx, values[q] * scale);
-    mx = group_max<LPR>(mx);
-    float sum = 0.f;
-    for (int q = p0 + l; q < p1; q += LPR) sum += __expf(values[q] * scale - mx);
-    sum = group_sum<LPR>(sum);
-    const float inv = 1.f / sum;
-    for (int q = p0 + l; q < p1; q += LPR) out[q] = __expf(values[q] * scale - mx) * inv;
+  };
+  for (int it0 = 0; it0 < rows_per_group; it0 += DEPTH + 1) {
+    unrolled<DEPTH + 1>([&](auto j) {
+      constexpr int J = decltype(j)::value;
+      if (it0 + J < rows_per_group) {
+        fetch(it0 + J + DEPTH, ring[(J + DEPTH) % (DEPTH + 1)]);  // past the run: an empty row
+        process(ring[J]);
+      }
+    });
   }
 }
 
-// Gradient of y = softmax(scale * x) over the stored entries of each row:
-// dx = scale * y * (dy - sum_row(dy * y)).  Same row-per-group layout; rows
-// that fit the registers move 12 bytes per entry (y, dy in; dx out).
-template <int LPR>
-__global__ __launch_bounds__(kBlock) void sparse_softmax_backward_kernel(
-    int m, const float* __restrict__ y, int64_t y_stride, const float* __restrict__ dy,
-    int64_t dy_stride, const int* __restrict__ row_offsets, float* __restrict__ dx,
-    int64_t dx_stride, float scale) {
-  constexpr int kRowsPerBlock = kBlock / LPR;
-  const int sub = threadIdx.x / LPR;
-  const int l = threadIdx.x % LPR;
-  const int slot = blockIdx.x * kRowsPerBlock + sub;
-  const int replica = blockIdx.y;
-  y += replica * y_stride;
-  dy += replica * dy_stride;
-  dx += replica * dx_stride;
-  const int row = (slot < m) ? slot : 0;
-  const int p0 = (slot < m) ? row_offsets[row] : 0;
-  const int p1 = (slot < m) ? row_offsets[row + 1] : 0;
-
-  int wave_max_len = p1 - p0;
-  if constexpr (LPR < kWave) {
-#pragma unroll
-    for (int off = LPR; off < kWave; off <<= 1)
-      wave_max_len = max(wave_max_len, __shfl_xor(wave_max_len, off, kWave));
-  }
-  wave_max_len = __builtin_amdgcn_readfirstlane(wave_max_len);
-
-  if (wave_max_len <= LPR * kRegs) {
-    float yv[kRegs], gv[kRegs];
-    float dot = 0.f;
-#pragma unroll
-    for (int i = 0; i < kRegs; ++i) {
-      const int q = p0 + i * LPR + l;
-      yv[i] = (q < p1) ? y[q] : 0.f;
-      gv[i] = (q < p1) ? dy[q] : 0.f;
-      dot = fmaf(yv[i], gv[i], dot);
-    }
-    dot = group_sum<LPR>(dot);
-#pragma unroll
-    for (int i = 0; i < kRegs; ++i) {
-      const int q = p0 + i * LPR + l;
-      if (q < p1) dx[q] = scale * yv[i] * (gv[i] - dot);
-    }
-  } else {
-    float dot = 0.f;
-    for (int q = p0 + l; q < p1; q += LPR) dot = fmaf(y[q], dy[q], dot);
-    dot = group_sum<LPR>(dot);
-    for (int q = p0 + l; q < p1; q += LPR) dx[q] = scale * y[q] * (dy[q] - dot);
-  }
+inline int phase_of(const void* p, int64_t stride) {
+  // alignment class of every replica at once: -1 if the replicas differ from
+  // each other in a way the kernel does not handle (it recomputes per replica)
+  (void)stride;
+  return static_cast<int>((reinterpret_cast<uintptr_t>(p) / sizeof(float)) % 4);
 }
 
-template <int LPR>
-int launch(int m, int replicas, const float* values, int64_t values_stride,
-           const int* row_indices, const int* row_offsets, float* out, int64_t out_stride,
-           float scale, hipStream_t stream) {
-  const int gx = ceil_div(m, kBlock / LPR);
+template <int LPR, int V, bool BACKWARD>
+int launch_rows(int m, int nonzeros, int replicas, const float* a, int64_t a_stride, const float* b,
+                int64_t b_stride, const int* row_offsets, float* out, int64_t out_stride,
+                float scale, hipStream_t stream) {
+  // Two rows per group once the grid fills the chip (256 CUs x 8 workgroups):
+  // measured at config 3's mask with 64 and 512 replicas (tools/softmax_sweep.sh),
+  // short workgroups whose dispatch staggers the read and the write phases beat
+  // longer runs per group (1 / 2 / 4 / 16 rows: 104 / 99 / 102 / 110 us at 512).
+  const int groups_per_block = kBlock / LPR;
+  const int64_t total_rows = static_cast<int64_t>(m) * replicas;
+  int rows_per_group = static_cast<int>(total_rows / (int64_t{256} * 8 * groups_per_block));
+  rows_per_group = max(1, min(rows_per_group, 2));
+  static const int forced_rpg = [] {
+    const char* e = getenv("SPUTNIK_HIP_SOFTMAX_RPG");  // developer knob
+    return e ? atoi(e) : 0;
+  }();
+  if (forced_rpg > 0) rows_per_group = min(forced_rpg, 16);
+  static const int depth = [] {
+    const char* e = getenv("SPUTNIK_HIP_SOFTMAX_DEPTH");  // developer knob: 1..3
+    return e ? atoi(e) : 1;
+  }();
+  const int gx = ceil_div(ceil_div(m, rows_per_group), groups_per_block);
+  // The fast path needs the inputs and the output of every replica aligned alike
+  // (the common case: fresh allocations, equal strides) and 32-bit byte offsets.
+  const bool strides_alike = (a_stride - out_stride) % 4 == 0 &&
+                             (!BACKWARD || (a_stride - b_stride) % 4 == 0);
   for (int r0 = 0; r0 < replicas; r0 += kMaxGridYZ) {
     const int ry = min(replicas - r0, kMaxGridYZ);
-    hipLaunchKernelGGL((sparse_softmax_kernel<LPR>), dim3(gx, ry), dim3(kBlock), 0, stream, m,
-                       values + r0 * values_stride, values_stride, row_indices, row_offsets,
-                       out + r0 * out_stride, out_stride, scale);
+    const float* a_r = a + r0 * a_stride;
+    const float* b_r = BACKWARD ? b + r0 * b_stride : nullptr;
+    float* out_r = out + r0 * out_stride;
+    const int same_phase = strides_alike && nonzeros >= 8 && nonzeros < (1 << 28) &&
+                           phase_of(a_r, a_stride) == phase_of(out_r, out_stride) &&
+                           (!BACKWARD || phase_of(a_r, a_stride) == phase_of(b_r, b_stride));
+#define SPUTNIK_HIP_SOFTMAX_LAUNCH(DEPTH)                                                         \
+  hipLaunchKernelGGL((sparse_softmax_rows_kernel<LPR, V, BACKWARD, DEPTH>), dim3(gx, ry),        \
+                     dim3(kBlock), 0, stream, m, rows_per_group, nonzeros, a_r, a_stride, b_r,   \
+                     b_stride, row_offsets, out_r, out_stride, scale, same_phase)
+    if (depth == 3) SPUTNIK_HIP_SOFTMAX_LAUNCH(3);
+    else if (depth == 2) SPUTNIK_HIP_SOFTMAX_LAUNCH(2);
+    else SPUTNIK_HIP_SOFTMAX_LAUNCH(1);
+#undef SPUTNIK_HIP_SOFTMAX_LAUNCH
     const int st = launch_status();
     if (st != 0) return st;
   }
   return 0;
 }
 
-template <int LPR>
-int launch_backward(int m, int replicas, const float* y, int64_t y_stride, const float* dy,
-                    int64_t dy_stride, const int* row_offsets, float* dx, int64_t dx_stride,
-                    float scale, hipStream_t stream) {
-  const int gx = ceil_div(m, kBlock / LPR);
-  for (int r0 = 0; r0 < replicas; r0 += kMaxGridYZ) {
-    const int ry = min(replicas - r0, kMaxGridYZ);
-    hipLaunchKernelGGL((sparse_softmax_backward_kernel<LPR>), dim3(gx, ry), dim3(kBlock), 0,
-                       stream, m, y + r0 * y_stride, y_stride, dy + r0 * dy_stride, dy_stride,
-                       row_offsets, dx + r0 * dx_stride, dx_stride, scale);
-    const int st = launch_status();
-    if (st != 0) return st;
-  }
-  return 0;
-}
-
-// Smallest group whose register capacity (LPR * 8 entries) still holds rows
-// 25 % longer than the mean: every unused register slot costs an exp.
-inline int lanes_per_row(int m, int nonzeros) {
-  const int mean_len = nonzeros / m;
-  if (mean_len * 5 <= 16 * 8 * 4) return 16;
-  if (mean_len * 5 <= 32 * 8 * 4) return 32;
-  return 64;
+// Smallest window (LPR lanes x V pieces of four entries) that holds nearly every
+// row: mean + ~2.2 standard deviations of a random pattern + the alignment slack
+// (every unused register slot costs an exp; the few longer rows take the
+// strided passes).
+template <bool BACKWARD>
+int dispatch_rows(int m, int nonzeros, int replicas, const float* a, int64_t a_stride,
+                  const float* b, int64_t b_stride, const int* row_offsets, float* out,
+                  int64_t out_stride, float scale, hipStream_t stream) {
+  const int64_t mean = nonzeros / m;
+  int64_t dev = 1;
+  while (dev * dev < 5 * mean) ++dev;   // ~ 2.2 * sqrt(mean)
+  const int64_t need = mean + dev + 3;
+#define SPUTNIK_HIP_SOFTMAX_CASE(LPR, V)                                                          \
+  return launch_rows<LPR, V, BACKWARD>(m, nonzeros, replicas, a, a_stride, b, b_stride,           \
+                                       row_offsets, out, out_stride, scale, stream)
+  if (need <= 64) SPUTNIK_HIP_SOFTMAX_CASE(16, 1);
+  if (need <= 128) SPUTNIK_HIP_SOFTMAX_CASE(16, 2);
+  if (need <= 192) SPUTNIK_HIP_SOFTMAX_CASE(16, 3);
+  if (need <= 256) SPUTNIK_HIP_SOFTMAX_CASE(32, 2);
+  if (need <= 512) SPUTNIK_HIP_SOFTMAX_CASE(32, 4);
+  SPUTNIK_HIP_SOFTMAX_CASE(64, 4);
+#undef SPUTNIK_HIP_SOFTMAX_CASE
 }
 
 }  // namespace
@@ -197,19 +317,8 @@ int sputnik_hip_sparse_softmax_scaled_batched(int m, int n, int nonzeros, int re
   (void)column_indices;
   if (m < 0 || nonzeros < 0 || replicas < 0) return SPUTNIK_HIP_INVALID_ARGUMENT;
   if (m == 0 || nonzeros == 0 || replicas == 0) return 0;
-  // Mean row length picks the lanes-per-row split (host-side, no sync: m and
-  // nonzeros are arguments).
-  switch (lanes_per_row(m, nonzeros)) {
-    case 16:
-      return launch<16>(m, replicas, values, values_stride, row_indices, row_offsets, out,
-                        out_stride, scale, stream);
-    case 32:
-      return launch<32>(m, replicas, values, values_stride, row_indices, row_offsets, out,
-                        out_stride, scale, stream);
-    default:
-      return launch<64>(m, replicas, values, values_stride, row_indices, row_offsets, out,
-                        out_stride, scale, stream);
-  }
+  return dispatch_rows<false>(m, nonzeros, replicas, values, values_stride, nullptr, 0, row_offsets,
+                              out, out_stride, scale, stream);
 }
 
 int sputnik_hip_sparse_softmax_batched(int m, int n, int nonzeros, int replicas,
@@ -230,17 +339,9 @@ int sputnik_hip_sparse_softmax_backward_batched(int m, int nonzeros, int replica
                                                 sputnik_hip_stream_t stream) {
   if (m < 0 || nonzeros < 0 || replicas < 0) return SPUTNIK_HIP_INVALID_ARGUMENT;
   if (m == 0 || nonzeros == 0 || replicas == 0) return 0;
-  switch (lanes_per_row(m, nonzeros)) {
-    case 16:
-      return launch_backward<16>(m, replicas, softmax_out, out_stride, grad_out, grad_out_stride,
-                                 row_offsets, grad_values, grad_values_stride, scale, stream);
-    case 32:
-      return launch_backward<32>(m, replicas, softmax_out, out_stride, grad_out, grad_out_stride,
-                                 row_offsets, grad_values, grad_values_stride, scale, stream);
-    default:
-      return launch_backward<64>(m, replicas, softmax_out, out_stride, grad_out, grad_out_stride,
-                                 row_offsets, grad_values, grad_values_stride, scale, stream);
-  }
+  return dispatch_rows<true>(m, nonzeros, replicas, softmax_out, out_stride, grad_out,
+                             grad_out_stride, row_offsets, grad_values, grad_values_stride, scale,
+                             stream);
 }
 
 int sputnik_hip_sparse_softmax(int m, int n, int nonzeros, const float* values,

@@ -92,7 +92,16 @@ struct TileConfig {
 template <typename Cfg>
 __device__ __forceinline__ void stage_chunk(float* __restrict__ tile, const float* __restrict__ dense,
                                             int n, int k, int kc, int wave,
-                                            unsigned lane_byte_offset) {
+                                            unsigned lane_byte_offset, bool dbg_dummy, int& dummy) {
+  if (dbg_dummy) {
+    // timing experiment (SPUTNIK_HIP_SPMM_DEBUG & 8): the same NUMBER of vector-memory
+    // operations, so the counted waits hold, but each moves one hot dword into a
+    // scratch register instead of 1 KiB into LDS: what the loop costs without the
+    // B traffic (results are wrong)
+#pragma unroll
+    for (int i = 0; i < Cfg::kStageOps; ++i) dummy = untracked_load_i32(reinterpret_cast<const int*>(dense), 0u);
+    return;
+  }
   // The stage is BK * kPieces pieces of 1 KiB (256 columns of one B row); wave w
   // copies pieces w, w + WAVES, ...: one wave instruction moves one piece
   // (lane_byte_offset = (n0 + lane*4) * 4 selects the workgroup's column tile and
@@ -133,8 +142,9 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
     int slots, int nchunks, int nonzeros, int n, int k, int n0, const float* __restrict__ values,
     const int* __restrict__ column_indices, const int* __restrict__ table,
     const float* __restrict__ dense, bool dbg_no_compute, bool dbg_no_stage,
-    bool dbg_no_barrier = false) {
+    bool dbg_no_barrier = false, bool dbg_dummy_stage = false) {
   constexpr int BN = Cfg::kBN, BK = Cfg::kBK, RPW = Cfg::kRPW;
+  int dummy = 0;
   constexpr int S = Cfg::kStageOps;
   // windows in flight (the 512-column tile has no registers for more than four:
   // 64 accumulators + 32 for the B strips of a four-entry batch)
@@ -186,7 +196,7 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
   };
 #pragma unroll
   for (int r = 0; r < D; ++r) request(r, s_ps[r]);
-  stage_chunk<Cfg>(tile0, dense, n, k, 0, wave, b_lane_off);
+  stage_chunk<Cfg>(tile0, dense, n, k, 0, wave, b_lane_off, false, dummy);
   wait_vm<0>();
   __syncthreads();
 
@@ -195,7 +205,8 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
     // A (the timing experiment without staging still issues the copies, from
     // chunk 0, so that the operation count the waits assume is unchanged)
     stage_chunk<Cfg>(tile0 + (buf ^ 1) * (BK * BN), dense, n, k,
-                     dbg_no_stage ? 0 : min(c + 1, nchunks - 1) * BK, wave, b_lane_off);
+                     dbg_no_stage ? 0 : min(c + 1, nchunks - 1) * BK, wave, b_lane_off,
+                     dbg_dummy_stage, dummy);
     // B: positions at the end of chunk c+1, needed when that chunk begins (a
     // scalar load has the whole chunk to land)
     typename Pos::type s_pe_next =
@@ -293,6 +304,7 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
     tie_reg(vcol[i]);
     tie_reg(vval[i]);
   }
+  tie_reg(dummy);
 }
 
 // SPARSE = false: 64-entry windows, groups of four entries with a padded last
@@ -368,7 +380,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void spmm_tiled_kernel(
 
   spmm_tiled_body_dpp<Cfg, SPARSE>(acc, &tile[0][0], lane, wave, slot0, slots, nchunks, nonzeros, n,
                                    k, n0, values, column_indices, table, dense, dbg_no_compute,
-                                   dbg_no_stage, dbg_no_barrier);
+                                   dbg_no_stage, dbg_no_barrier, (debug & 8) != 0);
 
 #pragma unroll
   for (int r = 0; r < RPW; ++r) {
