@@ -174,6 +174,13 @@ SPUTNIK_HIP_API int sputnik_hip_sparse_softmax_batched(int m, int n, int nonzero
  * share one permutation; the reference only ever has replicas = 1.
  * `out_permutation` (may be NULL) receives, for every output slot, the index
  * of the source nonzero, so a caller can reuse a static topology's transpose.
+ * Preconditions (as for cusparseCsr2cscEx2 on valid CSR): column indices in
+ * [0, n), a row stores a column at most once (order inside a row is free).
+ * Workspace: 4 * (2 * ceil(m / 32) * n + n) bytes -- it depends on the SHAPE,
+ * not on the number of nonzeros (2 MiB at 2048 x 2048, 33 MiB at 16384^2,
+ * 1 GiB at 65536^2): very sparse very large matrices are outside what this
+ * path is built for (the reference's callers transpose weight matrices and
+ * attention masks of a few thousand rows).
  * ---------------------------------------------------------------------- */
 SPUTNIK_HIP_API size_t sputnik_hip_csr_transpose_workspace_bytes(int m, int n, int nonzeros);
 

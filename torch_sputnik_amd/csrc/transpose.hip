@@ -8,74 +8,120 @@
 //
 // The slot of a nonzero (row r, column c) in the output is
 //     row_offsets_t[c] + #{nonzeros (r', c) with r' < r}.
-// The second term is split by chunks of R (8..32) consecutive source rows:
-// whole earlier chunks come from a [chunks][n] count table (scanned down the
-// chunks), and inside a chunk the rank is a popcount: a workgroup builds, in
-// LDS, one 32-bit mask per column with bit r-r0 set iff row r holds that
-// column (a CSR row holds a column at most once), so
+// The second term is split by chunks of 32 consecutive source rows: whole
+// earlier chunks come from a [chunks][n] count table (scanned down the chunks),
+// and inside a chunk the rank is a popcount: one 32-bit mask per column with
+// bit r-r0 set iff row r holds that column (a CSR row holds a column at most
+// once -- a PRECONDITION, as for every CSR consumer of the reference: a row that
+// stores a column twice would have both entries land on one slot), so
 //     rank inside chunk = popc(mask[c] & ((1 << (r - r0)) - 1)).
 // All nonzeros of a chunk are therefore independent: no ordered walk, no
 // returning atomics -- every phase is flat data-parallel work.
-//   1. count    masks in LDS (ds_or_b32), table[chunk][c] = popc(mask[c])
-//   2. scan     table[:, c] made exclusive down the chunks; column totals
-//               scanned into out_row_offsets
-//   3. scatter  masks rebuilt in LDS, every nonzero computes its slot and
-//               moves (value(s), row id, optionally its source index)
-// Matrices with more than 8192 columns are processed in column ranges of 8192
-// (64 KiB of masks + slot bases) by separate workgroups.  R is chosen so that
-// a few hundred workgroups exist (m/R >= 256 where m allows).
-// HBM traffic: 16 B per nonzero (values and indices read and written once)
-// + 12 B per nonzero of repeated column-index reads + the small table.
+//   1. masks    one workgroup per chunk builds the masks in LDS (ds_or_b32) and
+//               writes them out: gmask[chunk][c]
+//   2. scan     table[chunk][c] = number of entries of column c in earlier
+//               chunks (popcounts scanned down the chunks), totals[c]
+//   3. scatter  one workgroup per (chunk, group of 256 columns): masks and slot
+//               bases of its columns in LDS, every nonzero of the chunk's rows
+//               that falls into the group computes its slot; the entries are
+//               first put in OUTPUT order in LDS and then written as runs, so
+//               that a wave's store instruction covers a few contiguous runs
+//               instead of 64 different cache lines (see the kernel).  Up to
+//               8192 columns every workgroup derives the slot bases of its
+//               columns from the column totals itself instead of waiting for a
+//               fourth launch; wider matrices take that launch and a plain
+//               scatter over column ranges of 8192.
+// Three launches (four above 8192 columns).  HBM traffic: 16 B per nonzero
+// (values and indices read and written once) + the mask / count tables (8 B
+// per chunk and column).
+// Workspace: two int tables of [ceil(m / 32)][n] + [n] totals -- independent of
+// the number of nonzeros (include/sputnik_hip.h states the bound).
 #include "common.h"
 #include "wave_utils.h"
 
 namespace sputnik_hip {
 namespace {
 
-constexpr int kMaxRowsPerChunk = 32;  // one mask bit per row
-constexpr int kColsPerRange = 8192;   // 32 KiB of masks + 32 KiB of slot bases
+constexpr int kRowsPerChunk = 32;    // one mask bit per row
+constexpr int kColsPerRange = 8192;  // 32 KiB of masks + 32 KiB of slot bases
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / kWave;
 constexpr int kScanGroups = 16;  // chunk groups per column in the table scan
+constexpr int kGroupCols = 256;  // columns per scatter workgroup (<= kColsPerRange columns)
+
 
 typedef unsigned int mask_t;
 
-// Builds mask[c - c0] for the columns [c0, c1) of the rows [row0, row1).
-// One wave per row at a time, lanes over the row's nonzeros (coalesced).
-__device__ __forceinline__ void build_masks(mask_t* __restrict__ masks, int row0, int row1, int c0,
-                                            int c1, const int* __restrict__ row_offsets,
-                                            const int* __restrict__ column_indices) {
-  const int lane = threadIdx.x % kWave;
-  const int wave = threadIdx.x / kWave;
-  for (int c = threadIdx.x; c < c1 - c0; c += kBlock) masks[c] = 0;
-  __syncthreads();
-  for (int row = row0 + wave; row < row1; row += kWaves) {
-    const mask_t bit = mask_t{1} << (row - row0);
-    const int p1 = row_offsets[row + 1];
-    for (int p = row_offsets[row] + lane; p < p1; p += kWave) {
-      const int c = column_indices[p];
-      if (c >= c0 && c < c1) atomicOr(&masks[c - c0], bit);
-    }
-  }
-  __syncthreads();
-}
+// Column groups of a matrix with n <= kColsPerRange columns: a multiple of 8, so
+// that group g of every chunk has the same `workgroup id % 8` (see the scatter).
+inline int column_groups(int n) { return ceil_div(ceil_div(n, kGroupCols), 8) * 8; }
 
-__global__ __launch_bounds__(kBlock) void transpose_count_kernel(
-    int m, int n, int rows_per_chunk, const int* __restrict__ row_offsets,
-    const int* __restrict__ column_indices, int* __restrict__ table) {
+// A wave walks one row: lanes over the row's nonzeros (coalesced), kUnroll
+// requests per lane in flight before the first one is used -- a row of a few
+// hundred entries costs ONE memory latency, not one per 64 entries.
+constexpr int kUnroll = 8;
+
+// gmask[chunk][c] for the columns [c0, c1) of one chunk of rows.  16 waves, two
+// rows each; a wave requests the bounds of both rows, then the first kUnroll x 64
+// entries of both, before it touches the first answer: the kernel is a chain of
+// memory latencies, not of bytes.
+constexpr int kMaskBlock = 1024;
+constexpr int kRowsPerWave = kRowsPerChunk / (kMaskBlock / kWave);  // 2
+__global__ __launch_bounds__(kMaskBlock) void transpose_mask_kernel(
+    int m, int n, const int* __restrict__ row_offsets, const int* __restrict__ column_indices,
+    mask_t* __restrict__ gmask) {
   extern __shared__ mask_t masks[];
   const int chunk = blockIdx.x;
   const int c0 = blockIdx.y * kColsPerRange, c1 = min(n, c0 + kColsPerRange);
-  const int row0 = chunk * rows_per_chunk, row1 = min(m, row0 + rows_per_chunk);
-  build_masks(masks, row0, row1, c0, c1, row_offsets, column_indices);
-  int* __restrict__ my_table = table + static_cast<int64_t>(chunk) * n + c0;
-  for (int c = threadIdx.x; c < c1 - c0; c += kBlock) my_table[c] = __popc(masks[c]);
+  const int row0 = chunk * kRowsPerChunk;
+  const int lane = threadIdx.x % kWave;
+  const int wave = threadIdx.x / kWave;
+  int p0[kRowsPerWave], p1[kRowsPerWave];
+#pragma unroll
+  for (int j = 0; j < kRowsPerWave; ++j) {
+    const int row = row0 + wave + j * (kMaskBlock / kWave);
+    p0[j] = row < m ? row_offsets[row] : 0;
+    p1[j] = row < m ? row_offsets[row + 1] : 0;
+  }
+  int c[kRowsPerWave][kUnroll];
+#pragma unroll
+  for (int j = 0; j < kRowsPerWave; ++j)
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int p = p0[j] + lane + u * kWave;
+      c[j][u] = p < p1[j] ? column_indices[p] : -1;
+    }
+  for (int i = threadIdx.x; i < c1 - c0; i += kMaskBlock) masks[i] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kRowsPerWave; ++j) {
+    const mask_t bit = mask_t{1} << (wave + j * (kMaskBlock / kWave));
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u)
+      if (c[j][u] >= c0 && c[j][u] < c1) atomicOr(&masks[c[j][u] - c0], bit);
+    // rows longer than kUnroll x 64 entries: the rest, one batch at a time
+    for (int first = p0[j] + lane + kUnroll * kWave; first < p1[j]; first += kUnroll * kWave) {
+      int more[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        const int p = first + u * kWave;
+        more[u] = p < p1[j] ? column_indices[p] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u)
+        if (more[u] >= c0 && more[u] < c1) atomicOr(&masks[more[u] - c0], bit);
+    }
+  }
+  __syncthreads();
+  mask_t* __restrict__ mine = gmask + static_cast<int64_t>(chunk) * n + c0;
+  for (int i = threadIdx.x; i < c1 - c0; i += kMaskBlock) mine[i] = masks[i];
 }
 
-// table[:, c] -> exclusive prefix down the chunks; totals[c] = column count.
-// Block = 64 columns x kScanGroups chunk groups.
+// table[chunk][c] = sum of popc(gmask[chunk'][c]) over chunk' < chunk;
+// totals[c] = column count.  Block = 64 columns x kScanGroups chunk groups.
 __global__ __launch_bounds__(kWave* kScanGroups) void transpose_scan_table_kernel(
-    int n, int chunks, int* __restrict__ table, int* __restrict__ totals) {
+    int n, int chunks, const mask_t* __restrict__ gmask, int* __restrict__ table,
+    int* __restrict__ totals) {
   __shared__ int group_sum[kScanGroups][kWave];
   const int lane = threadIdx.x % kWave;
   const int group = threadIdx.x / kWave;
@@ -84,26 +130,42 @@ __global__ __launch_bounds__(kWave* kScanGroups) void transpose_scan_table_kerne
   const int ch0 = min(chunks, group * per_group);
   const int ch1 = min(chunks, ch0 + per_group);
 
+  // up to kKeep chunks per group (m <= 4096 rows) stay in registers between the
+  // two passes: one memory round trip instead of two
+  constexpr int kKeep = 8;
+  int kept[kKeep];
   int sum = 0;
   if (c < n) {
-    for (int ch = ch0; ch < ch1; ++ch) sum += table[static_cast<int64_t>(ch) * n + c];
+#pragma unroll
+    for (int i = 0; i < kKeep; ++i) {
+      const int ch = ch0 + i;
+      kept[i] = ch < ch1 ? __popc(gmask[static_cast<int64_t>(ch) * n + c]) : 0;
+      sum += kept[i];
+    }
+    for (int ch = ch0 + kKeep; ch < ch1; ++ch) sum += __popc(gmask[static_cast<int64_t>(ch) * n + c]);
   }
   group_sum[group][lane] = sum;
   __syncthreads();
   int running = 0;
   for (int g = 0; g < group; ++g) running += group_sum[g][lane];
   if (c < n) {
-    for (int ch = ch0; ch < ch1; ++ch) {
+#pragma unroll
+    for (int i = 0; i < kKeep; ++i) {
+      const int ch = ch0 + i;
+      if (ch < ch1) table[static_cast<int64_t>(ch) * n + c] = running;
+      running += kept[i];
+    }
+    for (int ch = ch0 + kKeep; ch < ch1; ++ch) {
       const int64_t idx = static_cast<int64_t>(ch) * n + c;
-      const int t = table[idx];
       table[idx] = running;
-      running += t;
+      running += __popc(gmask[idx]);
     }
     if (group == kScanGroups - 1) totals[c] = running;
   }
 }
 
-// Exclusive scan of totals[0..n) into offsets[0..n], single workgroup.
+// Exclusive scan of totals[0..n) into offsets[0..n], single workgroup
+// (matrices wider than kColsPerRange only).
 constexpr int kScanBlock = 1024;
 __global__ __launch_bounds__(kScanBlock) void transpose_scan_totals_kernel(
     int n, const int* __restrict__ totals, int* __restrict__ offsets) {
@@ -134,50 +196,226 @@ __global__ __launch_bounds__(kScanBlock) void transpose_scan_totals_kernel(
   if (tid == kScanBlock - 1) offsets[n] = running;
 }
 
+// Plain scatter over column ranges (matrices wider than kColsPerRange):
+// `parts` workgroups per chunk, a few rows each; out_row_offsets comes from the
+// scan kernel above.
 __global__ __launch_bounds__(kBlock) void transpose_scatter_kernel(
-    int m, int n, int rows_per_chunk, int replicas, const float* __restrict__ values,
-    int64_t values_stride,
-    const int* __restrict__ row_offsets, const int* __restrict__ column_indices,
+    int m, int n, int parts, int rows_per_part, int replicas, const float* __restrict__ values,
+    int64_t values_stride, const int* __restrict__ row_offsets,
+    const int* __restrict__ column_indices, const mask_t* __restrict__ gmask,
     const int* __restrict__ table, const int* __restrict__ out_row_offsets,
     float* __restrict__ out_values, int64_t out_values_stride,
     int* __restrict__ out_column_indices, int* __restrict__ out_permutation) {
   extern __shared__ mask_t masks[];
-  const int chunk = blockIdx.x;
+  const int chunk = blockIdx.x / parts, part = blockIdx.x % parts;
   const int c0 = blockIdx.y * kColsPerRange, c1 = min(n, c0 + kColsPerRange);
-  const int row0 = chunk * rows_per_chunk, row1 = min(m, row0 + rows_per_chunk);
-  build_masks(masks, row0, row1, c0, c1, row_offsets, column_indices);
-
-  // Slot base of every column of the range for this chunk (coalesced reads,
-  // instead of two dependent gathers per nonzero).
-  int* __restrict__ base = reinterpret_cast<int*>(masks + (c1 - c0));
-  const int* __restrict__ my_table = table + static_cast<int64_t>(chunk) * n + c0;
-  for (int c = threadIdx.x; c < c1 - c0; c += kBlock) base[c] = out_row_offsets[c0 + c] + my_table[c];
-  __syncthreads();
-
+  const int width = c1 - c0;
+  const int chunk_row0 = chunk * kRowsPerChunk;
+  const int row0 = chunk_row0 + part * rows_per_part;
+  const int row1 = min(min(m, chunk_row0 + kRowsPerChunk), row0 + rows_per_part);
   const int lane = threadIdx.x % kWave;
   const int wave = threadIdx.x / kWave;
+
+  int* __restrict__ base = reinterpret_cast<int*>(masks + width);
+  const mask_t* __restrict__ my_mask = gmask + static_cast<int64_t>(chunk) * n + c0;
+  const int* __restrict__ my_table = table + static_cast<int64_t>(chunk) * n + c0;
+  for (int c = threadIdx.x; c < width; c += kBlock) {
+    masks[c] = my_mask[c];
+    base[c] = out_row_offsets[c0 + c] + my_table[c];
+  }
+  __syncthreads();
+
   for (int row = row0 + wave; row < row1; row += kWaves) {
-    const mask_t below = (mask_t{1} << (row - row0)) - 1;
+    const mask_t below = (mask_t{1} << (row - chunk_row0)) - 1;
     const int p1 = row_offsets[row + 1];
-    for (int p = row_offsets[row] + lane; p < p1; p += kWave) {
-      const int c = column_indices[p];
-      if (c < c0 || c >= c1) continue;
-      const int pos = base[c - c0] + __popc(masks[c - c0] & below);
-      out_column_indices[pos] = row;
+    for (int first = row_offsets[row] + lane; first < p1; first += kWave * kUnroll) {
+      int c[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        const int p = first + u * kWave;
+        c[u] = p < p1 ? column_indices[p] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        if (c[u] < c0 || c[u] >= c1) continue;
+        const int p = first + u * kWave;
+        const int pos = base[c[u] - c0] + __popc(masks[c[u] - c0] & below);
+        out_column_indices[pos] = row;
+        if (out_permutation != nullptr) out_permutation[pos] = p;
+        for (int r = 0; r < replicas; ++r)
+          out_values[r * out_values_stride + pos] = values[r * values_stride + p];
+      }
+    }
+  }
+}
+
+// Exclusive scan over the first kGroupCols threads' values (one per thread; the
+// other threads pass 0); returns the prefix of the caller, *total = the sum.
+// Contains two workgroup barriers.
+constexpr int kGroupBlock = 512;  // 8 waves: four rows of the chunk each
+__device__ __forceinline__ int scan_group_columns(int value, int* __restrict__ wave_sums,
+                                                  int* __restrict__ total) {
+  const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+  int incl = value;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const int up = __shfl_up(incl, off, kWave);
+    if (lane >= off) incl += up;
+  }
+  __syncthreads();   // wave_sums may still be read from a previous scan
+  if (lane == kWave - 1) wave_sums[wave] = incl;
+  __syncthreads();
+  int before = 0, all = 0;
+  for (int w = 0; w < kGroupCols / kWave; ++w) {
+    if (w < wave) before += wave_sums[w];
+    all += wave_sums[w];
+  }
+  *total = all;
+  return before + incl - value;
+}
+
+// Scatter for matrices of up to kColsPerRange columns: workgroup b handles chunk
+// b / groups and the kGroupCols columns of group b % groups.  It reads all of its
+// chunk's entries (the reads of the `groups` workgroups of a chunk overlap in L2)
+// and moves those that fall into its columns.
+//
+// Why by column group: an output cache line (32 consecutive entries of one
+// output row) collects entries from many source rows.  With the writers of a
+// line spread over the chip, every XCD's L2 ends up holding a few bytes of
+// every line and writes them back one partial line at a time (measured at
+// 2048^2, density 0.2: 20.7 us for 6.7 MB of stores).  Workgroups are dealt
+// round-robin to the 8 XCDs and `groups` is a multiple of 8, so all writers of an
+// output line sit behind ONE L2, which merges them into whole lines (16 us;
+// 12.7 us with the staging below).
+// (Placement is a speed matter only: nothing depends on it for correctness.)
+//
+// Why staged: in source order the 64 lanes of a store instruction hit 64
+// different output rows -- 64 requests of 4 bytes to L2.  The workgroup
+// therefore first puts its entries in OUTPUT order in LDS (local slot = the
+// same rank arithmetic with local bases) and then writes them flat: consecutive
+// lanes then hold consecutive slots of an output row (a run of up to 32
+// entries per column and chunk), and an instruction covers a few contiguous
+// runs.  The staging area holds kStageCap entries (a chunk x group that is more
+// than half full writes the overflow directly).
+//
+// Latency: everything the workgroup needs that does not depend on another load
+// (column totals, masks, counts, the bounds of its rows) is requested at the
+// top; a wave then walks its four rows with kUnroll x 64 entries in flight.
+constexpr int kStageCap = 4096;
+__global__ __launch_bounds__(kGroupBlock) void transpose_scatter_grouped_kernel(
+    int m, int n, int groups, int replicas, const float* __restrict__ values,
+    int64_t values_stride, const int* __restrict__ row_offsets,
+    const int* __restrict__ column_indices, const mask_t* __restrict__ gmask,
+    const int* __restrict__ table, const int* __restrict__ totals,
+    int* __restrict__ out_row_offsets, float* __restrict__ out_values,
+    int64_t out_values_stride, int* __restrict__ out_column_indices,
+    int* __restrict__ out_permutation) {
+  __shared__ mask_t masks[kGroupCols];
+  __shared__ int base[kGroupCols];       // global slot of the first entry (this chunk, column)
+  __shared__ int lbase[kGroupCols];      // the same in the staging area
+  __shared__ int wave_sums[kGroupBlock / kWave];
+  __shared__ int st_pos[kStageCap], st_src[kStageCap];
+  __shared__ float st_val[kStageCap];
+  __shared__ unsigned char st_row[kStageCap];
+
+  const int chunk = blockIdx.x / groups, cg = blockIdx.x % groups;
+  const int c0 = cg * kGroupCols, c1 = min(n, c0 + kGroupCols);
+  const int width = c1 - c0;
+  if (width <= 0) return;
+  const int row0 = chunk * kRowsPerChunk;
+  const int lane = threadIdx.x % kWave;
+  const int wave = threadIdx.x / kWave;
+  const int t = threadIdx.x;
+  constexpr int kRows = kRowsPerChunk / (kGroupBlock / kWave);  // rows per wave: 2
+  const bool stage_values = replicas == 1;
+
+  // ---- independent requests first
+  int p0[kRows], p1[kRows];
+#pragma unroll
+  for (int j = 0; j < kRows; ++j) {
+    const int row = row0 + wave + j * (kGroupBlock / kWave);
+    p0[j] = row < m ? row_offsets[row] : 0;
+    p1[j] = row < m ? row_offsets[row + 1] : 0;
+  }
+  int before = 0;
+  for (int c = t; c < c0; c += kGroupBlock) before += totals[c];
+  const bool mine = t < width;
+  const int my_total = mine ? totals[c0 + t] : 0;
+  const mask_t my_mask = mine ? gmask[static_cast<int64_t>(chunk) * n + c0 + t] : 0;
+  const int my_count = mine ? table[static_cast<int64_t>(chunk) * n + c0 + t] : 0;
+  // slot base of column c = sum of totals[0..c) + entries of c in earlier chunks
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) before += __shfl_xor(before, off, kWave);
+  if (lane == 0) wave_sums[wave] = before;
+  __syncthreads();
+  before = 0;
+  for (int w = 0; w < kGroupBlock / kWave; ++w) before += wave_sums[w];
+  int sum_totals, sum_local;
+  const int prefix = scan_group_columns(my_total, wave_sums, &sum_totals);
+  const int lprefix = scan_group_columns(__popc(my_mask), wave_sums, &sum_local);
+  if (mine) {
+    masks[t] = my_mask;
+    base[t] = before + prefix + my_count;
+    lbase[t] = lprefix;
+    if (chunk == 0) out_row_offsets[c0 + t] = before + prefix;
+  }
+  if (chunk == 0 && c1 == n && t == 0) out_row_offsets[n] = before + sum_totals;
+  __syncthreads();
+
+  auto place = [&](int row_in_chunk, int p, int col, float val) {
+    const mask_t below = (mask_t{1} << row_in_chunk) - 1;
+    const int rank = __popc(masks[col - c0] & below);
+    const int pos = base[col - c0] + rank;
+    const int slot = lbase[col - c0] + rank;
+    if (slot < kStageCap) {
+      st_pos[slot] = pos;
+      st_src[slot] = p;
+      st_row[slot] = static_cast<unsigned char>(row_in_chunk);
+      if (stage_values) st_val[slot] = val;
+    } else {
+      out_column_indices[pos] = row0 + row_in_chunk;
       if (out_permutation != nullptr) out_permutation[pos] = p;
+      for (int r = 0; r < replicas; ++r)
+        out_values[r * out_values_stride + pos] = values[r * values_stride + p];
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < kRows; ++j) {
+    const int row_in_chunk = wave + j * (kGroupBlock / kWave);
+    for (int first = p0[j] + lane; first < p1[j]; first += kUnroll * kWave) {
+      int c[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        const int p = first + u * kWave;
+        c[u] = p < p1[j] ? column_indices[p] : -1;
+      }
+      // (the value is fetched for the entries that pass only: requesting all of
+      // them with the columns saves a round trip but reads 8x the bytes -- 15.0
+      // against 12.7 us)
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u)
+        if (c[u] >= c0 && c[u] < c1)
+          place(row_in_chunk, first + u * kWave, c[u],
+                stage_values ? values[first + u * kWave] : 0.f);
+    }
+  }
+  __syncthreads();
+  const int staged = min(sum_local, kStageCap);
+  for (int i = t; i < staged; i += kGroupBlock) {
+    const int pos = st_pos[i];
+    out_column_indices[pos] = row0 + st_row[i];
+    if (out_permutation != nullptr) out_permutation[pos] = st_src[i];
+    if (stage_values) {
+      out_values[pos] = st_val[i];
+    } else {
+      const int p = st_src[i];
       for (int r = 0; r < replicas; ++r)
         out_values[r * out_values_stride + pos] = values[r * values_stride + p];
     }
   }
 }
 
-// Rows per chunk: 8, 16 or 32, the largest that still leaves >= 256 chunks.
-inline int rows_per_chunk_of(int m) {
-  int r = kMaxRowsPerChunk;
-  while (r > 8 && m / r < 256) r /= 2;
-  return r;
-}
-inline int chunks_of(int m) { return ceil_div(m, rows_per_chunk_of(m)); }
+inline int chunks_of(int m) { return ceil_div(m, kRowsPerChunk); }
 
 }  // namespace
 }  // namespace sputnik_hip
@@ -189,7 +427,8 @@ extern "C" {
 size_t sputnik_hip_csr_transpose_workspace_bytes(int m, int n, int nonzeros) {
   (void)nonzeros;
   if (m <= 0 || n <= 0) return 0;
-  return sizeof(int) * (static_cast<size_t>(chunks_of(m)) * n + n);
+  // masks [chunks][n] + counts [chunks][n] + totals [n]
+  return sizeof(int) * (2 * static_cast<size_t>(chunks_of(m)) * n + n);
 }
 
 int sputnik_hip_csr_transpose(int m, int n, int nonzeros, int replicas, const float* values,
@@ -210,32 +449,46 @@ int sputnik_hip_csr_transpose(int m, int n, int nonzeros, int replicas, const fl
       workspace_bytes < sputnik_hip_csr_transpose_workspace_bytes(m, n, nonzeros))
     return SPUTNIK_HIP_INVALID_ARGUMENT;
 
-  const int rows_per_chunk = rows_per_chunk_of(m);
   const int chunks = chunks_of(m);
   const int ranges = ceil_div(n, kColsPerRange);
   if (ranges > kMaxGridYZ) return SPUTNIK_HIP_INVALID_ARGUMENT;
-  int* table = static_cast<int*>(workspace);
+  mask_t* gmask = static_cast<mask_t*>(workspace);
+  int* table = reinterpret_cast<int*>(gmask + static_cast<size_t>(chunks) * n);
   int* totals = table + static_cast<size_t>(chunks) * n;
   const size_t range_cols = static_cast<size_t>(min(n, kColsPerRange));
   const size_t lds_bytes = sizeof(mask_t) * range_cols;
+  const int groups = column_groups(n);
+  const bool grouped = ranges == 1 && chunks <= 0x7fffffff / groups;
 
-  hipLaunchKernelGGL(transpose_count_kernel, dim3(chunks, ranges), dim3(kBlock), lds_bytes, stream,
-                     m, n, rows_per_chunk, row_offsets, column_indices, table);
+  hipLaunchKernelGGL(transpose_mask_kernel, dim3(chunks, ranges), dim3(kMaskBlock), lds_bytes,
+                     stream, m, n, row_offsets, column_indices, gmask);
   int st = launch_status();
   if (st != 0) return st;
   hipLaunchKernelGGL(transpose_scan_table_kernel, dim3(ceil_div(n, kWave)),
-                     dim3(kWave * kScanGroups), 0, stream, n, chunks, table, totals);
+                     dim3(kWave * kScanGroups), 0, stream, n, chunks, gmask, table, totals);
   st = launch_status();
   if (st != 0) return st;
+  if (grouped) {
+    hipLaunchKernelGGL(transpose_scatter_grouped_kernel, dim3(chunks * groups), dim3(kGroupBlock),
+                       0, stream, m, n, groups, replicas, values, values_stride, row_offsets,
+                       column_indices, gmask, table, totals, out_row_offsets,
+                       out_values, out_values_stride, out_column_indices, out_permutation);
+    return launch_status();
+  }
   hipLaunchKernelGGL(transpose_scan_totals_kernel, dim3(1), dim3(kScanBlock), 0, stream, n,
                      totals, out_row_offsets);
   st = launch_status();
   if (st != 0) return st;
-  hipLaunchKernelGGL(transpose_scatter_kernel, dim3(chunks, ranges), dim3(kBlock),
-                     lds_bytes + sizeof(int) * range_cols, stream, m, n, rows_per_chunk, replicas,
-                     values, values_stride, row_offsets, column_indices,
-                     table, out_row_offsets, out_values, out_values_stride, out_column_indices,
-                     out_permutation);
+  // Workgroups per chunk in the plain scatter: enough for about two per CU (the
+  // chunk's 32 rows split into parts of 16 / 8 / 4).
+  int parts = 1;
+  while (parts < 8 && static_cast<int64_t>(chunks) * ranges * parts < 512) parts *= 2;
+  if (chunks > 0x7fffffff / parts) return SPUTNIK_HIP_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(transpose_scatter_kernel, dim3(chunks * parts, ranges), dim3(kBlock),
+                     lds_bytes + sizeof(int) * range_cols, stream, m, n, parts,
+                     kRowsPerChunk / parts, replicas, values, values_stride, row_offsets,
+                     column_indices, gmask, table, out_row_offsets, out_values, out_values_stride,
+                     out_column_indices, out_permutation);
   return launch_status();
 }
 
