@@ -335,6 +335,22 @@ def other_ops(dev):
                                               "projection_density": 0.1}
     except Exception as e:  # noqa: BLE001 - extra metric, best effort
         res["sparse_attention_forward_c3"] = {"error": str(e)[:200]}
+    # dense widths that are no multiple of a tile width (the reference takes any n,
+    # src/spmm_cuda.cu:32): 4096 x 4096 at density 0.1 against n columns
+    try:
+        mk = 4096
+        ri, ro, ci, nnz = random_csr(mk, mk, 0.1, dev, seed=21)
+        vals = uniform((nnz,), dev, 22)
+        sweep_n = []
+        for nn in (72, 200, 1000, 4000, 4096):
+            bmat = uniform((mk, nn), dev, 23)
+            cmat = torch.empty(mk, nn, device=dev)
+            wsn = torch.empty(capi.spmm_workspace_bytes(mk, mk, nn, nnz) + 16, dtype=torch.uint8, device=dev)
+            t = event_time_ms(lambda: capi.spmm_batched(mk, mk, nn, 1, ri, vals, 0, ro, ci, bmat, cmat, wsn), 20)
+            sweep_n.append({"n": nn, "ms": t, "gflops": 2.0 * nnz * nn / t / 1e6})
+        res["spmm_4096x4096_d010_by_n"] = sweep_n
+    except Exception as e:  # noqa: BLE001 - extra metric, best effort
+        res["spmm_4096x4096_d010_by_n"] = {"error": str(e)[:200]}
     m = n = 2048  # config 5: transpose of a 2048^2, density 0.2 weight
     ri, ro, ci, nnz = random_csr(m, n, 0.2, dev, seed=9)
     vals = uniform((nnz,), dev, 10)

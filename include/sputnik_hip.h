@@ -336,6 +336,29 @@ SPUTNIK_HIP_API int sputnik_hip_csr_transpose_many_mask(int masks, int m, int n,
                              void* workspace, size_t workspace_bytes,
                              sputnik_hip_stream_t stream);
 
+/*
+ * The library's developer / test knobs (SPUTNIK_HIP_* environment variables:
+ * kernel choice for small inputs, timing experiments) are read once, at first
+ * use, never on the launch path; this re-reads them.  Not to be called while
+ * other threads issue launches.  (tests/conftest.py steers the parity tests
+ * onto every kernel with it.)
+ */
+SPUTNIK_HIP_API void sputnik_hip_reload_options(void);
+
+/*
+ * Batched 2-D transpose  out[b][c][r] = in[b][r][c]  (row-major, fp32; batch
+ * strides in elements).  The layout pass of the reference's modules:
+ * `x.transpose(1, 2).contiguous()` in front of left_spmm
+ * (modules/sparse_linear.py:89), the same behind every projection and the head
+ * split / merge copies of modules/sparse_attention.py:108-126 are all this
+ * operation (the head split [B, H*D, S] -> [B*H, S, D] is a transpose of B*H
+ * matrices of D x S).  No workspace, no synchronisation.
+ */
+SPUTNIK_HIP_API int sputnik_hip_transpose_batched(int batches, int rows, int cols, const float* in,
+                                  int64_t in_batch_stride, float* out,
+                                  int64_t out_batch_stride,
+                                  sputnik_hip_stream_t stream);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

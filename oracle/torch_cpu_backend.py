@@ -139,6 +139,10 @@ def _csr_transpose_many_mask(b, m, n, nonzeros, values, row_offsets, column_indi
     return [_f32(v), torch.from_numpy(ro), torch.from_numpy(ci)]
 
 
+def _transpose_last2(x):
+    return x.transpose(-1, -2).contiguous()
+
+
 def _plan(*_args):
     return torch.zeros(16, dtype=torch.uint8)  # the CPU checker has nothing to pre-compute
 
@@ -192,3 +196,4 @@ def install():
     _lib.impl("sparse_softmax_many_mask_scaled", _sparse_softmax_many_mask_scaled, "CPU")
     _lib.impl("sparse_softmax_backward_many_mask", _sparse_softmax_backward_many_mask, "CPU")
     _lib.impl("csr_transpose_many_mask", _csr_transpose_many_mask, "CPU")
+    _lib.impl("transpose_last2", _transpose_last2, "CPU")

@@ -59,6 +59,13 @@ def cpu_ops():
     return torch_sputnik_amd
 
 
+def _reload_library_options():
+    """The kernel library reads its SPUTNIK_HIP_* knobs once; the fixtures below
+    change them per test and tell it to look again."""
+    from torch_sputnik_amd import capi
+    capi.reload_options()
+
+
 @pytest.fixture(params=["auto", "wide", "wide512", "narrow", "gather"])
 def spmm_kernel(request, monkeypatch):
     """Small inputs take the single-launch row-gather kernel on their own; the
@@ -68,7 +75,10 @@ def spmm_kernel(request, monkeypatch):
         monkeypatch.delenv("SPUTNIK_HIP_SPMM_KERNEL", raising=False)
     else:
         monkeypatch.setenv("SPUTNIK_HIP_SPMM_KERNEL", request.param)
-    return request.param
+    _reload_library_options()
+    yield request.param
+    monkeypatch.delenv("SPUTNIK_HIP_SPMM_KERNEL", raising=False)
+    _reload_library_options()
 
 
 @pytest.fixture(params=["auto", "tiled", "wave"])
@@ -78,4 +88,7 @@ def sddmm_kernel(request, monkeypatch):
         monkeypatch.delenv("SPUTNIK_HIP_SDDMM_KERNEL", raising=False)
     else:
         monkeypatch.setenv("SPUTNIK_HIP_SDDMM_KERNEL", request.param)
-    return request.param
+    _reload_library_options()
+    yield request.param
+    monkeypatch.delenv("SPUTNIK_HIP_SDDMM_KERNEL", raising=False)
+    _reload_library_options()

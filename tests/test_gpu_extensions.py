@@ -536,3 +536,28 @@ def test_hip_graph_replay_of_a_module_forward(dev):
     assert torch.equal(fast(x2, x2, x2), want2)
     with pytest.raises(ValueError):
         fast(x2[:1], x2[:1], x2[:1])
+
+
+# ----------------------------------------------------------------------------
+# layout pass: batched 2-D transpose (modules/sparse_linear.py:89,
+# modules/sparse_attention.py:108-126)
+# ----------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(3, 72, 128), (8, 512, 2048), (2, 4, 1024, 64), (5, 70, 33),
+                                   (1, 1, 7), (64, 64, 1024), (100, 260)])
+def test_transpose_last2_is_bit_exact(ts, dev, shape):
+    from torch_sputnik_amd import ops
+    x = torch.randn(*shape, device=dev)
+    got = ops.transpose_last2(x)
+    assert got.is_contiguous() and torch.equal(got, x.transpose(-1, -2).contiguous())
+    # a non-contiguous view in, other dtypes through ATen
+    view = x.transpose(-1, -2)
+    assert torch.equal(ops.transpose_last2(view), x.contiguous())
+    assert torch.equal(ops.transpose_last2(x.half()), x.half().transpose(-1, -2).contiguous())
+
+
+def test_transpose_last2_gradient(dev):
+    from torch_sputnik_amd import functional
+    x = torch.randn(4, 96, 40, device=dev, requires_grad=True)
+    g = torch.randn(4, 40, 96, device=dev)
+    functional.transpose_last2(x).backward(g)
+    assert torch.equal(x.grad, g.transpose(1, 2).contiguous())

@@ -120,6 +120,44 @@ def test_spmm_tiled_stress(capi, dev, spmm_kernel, m, k, n, sparsity, order):
     assert rel_err(got, want) < TOL
 
 
+TAIL_SHAPES = [
+    # m, k, n, sparsity, replicas: dense widths that are multiples of 4 but of no
+    # tile width -- the last column tile of the LDS-tiled kernels is partial
+    (72, 64, 72, 0.5, 1),        # tests/test_spmm.py:13: 64-column kernel, tiles of 64 + 8
+    (256, 300, 200, 0.8, 2),     # one 256-column tile, 200 used; 64-column kernel: 3 x 64 + 8
+    (512, 512, 1000, 0.9, 1),    # two 512-column tiles (512 + 488); four 256-column tiles
+    (300, 1024, 4000, 0.95, 1),  # eight 512-column tiles, the last with 416 columns
+    (640, 96, 260, 0.3, 3),      # 256 + 4: a tile whose lanes are nearly all clamped
+    (128, 2048, 68, 0.9, 2),     # 64 + 4
+    (1000, 777, 516, 0.7, 1),    # 512 + 4
+]
+
+
+@pytest.mark.parametrize("m,k,n,sparsity,replicas", TAIL_SHAPES)
+@pytest.mark.parametrize("order", ["ascending", "random"])
+def test_spmm_partial_column_tiles(capi, dev, spmm_kernel, m, k, n, sparsity, replicas, order):
+    """Any n that is a multiple of 4 stays on the LDS-tiled kernels (the reference
+    accepts any n, src/spmm_cuda.cu:32); nothing may be written past a row's end
+    or past the end of the output (the buffer carries a guard zone), and the last
+    B row's clamped copies must stay inside B (B is the last allocation made)."""
+    _, vals, ri, ro, ci = make_csr(m, k, sparsity, seed=m + n, round_to=1, order=order,
+                                   empty_rows=(m // 3,))
+    rng = np.random.default_rng(n)
+    v = vals if replicas == 1 else rng.uniform(-1, 1, (replicas, len(vals))).astype(np.float32)
+    b = rng.uniform(-1, 1, size=(replicas, k, n)).astype(np.float32)
+    want = c_oracle.spmm(m, k, v, ro, ci, b if replicas > 1 else b[0])
+    guard = 64
+    flat = torch.full((replicas * m * n + guard,), float("nan"), device=dev)
+    out = flat[:replicas * m * n].view(replicas, m, n)
+    ws = torch.empty(capi.spmm_workspace_bytes(m, k, n, len(ci)) + 16, dtype=torch.uint8, device=dev)
+    capi.spmm_batched(m, k, n, replicas, T(ri, dev), T(v, dev), 0 if replicas == 1 else len(vals),
+                      T(ro, dev), T(ci, dev), T(b, dev), out, ws)
+    got = out.cpu().numpy()
+    assert not np.isnan(got).any(), "some output elements were never written"
+    assert torch.isnan(flat[replicas * m * n:]).all(), "wrote past the end of the output"
+    assert rel_err(got.reshape(want.shape), want) < TOL
+
+
 def test_spmm_full_size_linearity(capi, dev):
     """BASELINE.json's headline size (4096^3, density 0.1), checked through
     size-independent properties: linearity in the values, agreement of the planned
@@ -207,6 +245,47 @@ def test_spmm_full_size_after_other_products(capi, dev):
     want = dense_fp64_product(m, k, ro, ci, vals, b)
     for out in outs:
         assert rel_err_torch(out, want) < TOL
+
+
+def test_spmm_full_size_soak_on_a_warm_gpu(capi, dev):
+    """tools/repeat_primer.sh as a test: the failure of DESIGN.md section 3.1 (a
+    register of an in-flight load reused by the compiler) never showed on a cold
+    GPU and in 40-75 % of the runs on a warm one.  One second of dense matmul
+    first, then 32 products at the headline size that alternate between four
+    topologies through ONE workspace, every one checked: the first of each
+    topology against the dense float64 product, the repeats bit for bit against
+    the first (the kernels are deterministic)."""
+    from torch_sputnik_amd.synthetic import random_csr, uniform
+    m = k = n = 4096
+    x = torch.randn(4096, 4096, device=dev)
+    t0 = torch.cuda.Event(enable_timing=True)
+    t1 = torch.cuda.Event(enable_timing=True)
+    t0.record()
+    elapsed = 0.0
+    while elapsed < 1000.0:    # ms of GPU time
+        for _ in range(20):
+            x = torch.tanh(x @ x) * 0.01
+        t1.record()
+        torch.cuda.synchronize()
+        elapsed = t0.elapsed_time(t1)
+    b = uniform((k, n), dev, 2) - 0.5
+    topologies = []
+    for j, density in enumerate((0.1, 0.1, 0.05, 0.25)):
+        ri, ro, ci, nnz = random_csr(m, k, density, dev, seed=900 + j)
+        topologies.append((ri, ro, ci, nnz, uniform((nnz,), dev, j) - 0.5))
+    ws_bytes = max(capi.spmm_workspace_bytes(m, k, n, t[3]) for t in topologies) + 16
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    first = {}
+    for rep in range(32):
+        j = rep % len(topologies)
+        ri, ro, ci, nnz, vals = topologies[j]
+        out = torch.full((m, n), float("nan"), device=dev)
+        capi.spmm_batched(m, k, n, 1, ri, vals, 0, ro, ci, b, out, ws)
+        if j not in first:
+            assert rel_err_torch(out, dense_fp64_product(m, k, ro, ci, vals, b)) < TOL
+            first[j] = out
+        else:
+            assert torch.equal(out, first[j]), f"repeat {rep} of topology {j} differs"
 
 
 @pytest.mark.parametrize("replicas,shared,m,k,n", [

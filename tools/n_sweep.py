@@ -21,6 +21,7 @@ for (m, k, n, d, R) in shapes:
     for kern in ("auto", "gather", "narrow", "wide"):
         if kern == "auto": os.environ.pop("SPUTNIK_HIP_SPMM_KERNEL", None)
         else: os.environ["SPUTNIK_HIP_SPMM_KERNEL"] = kern
+        capi.reload_options()  # the library reads its knobs once
         ws = torch.empty(capi.spmm_workspace_bytes(m, k, n, nnz) + (1 << 20), dtype=torch.uint8, device=dev)
         t = timeit(lambda: capi.spmm_batched(m, k, n, R, ri, vals, 0, ro, ci, b, o, ws))
         line += f"  {kern} {t*1e3:.1f}us"

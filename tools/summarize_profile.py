@@ -78,8 +78,11 @@ def main():
         traffic["dominant_kernel"] = args.kernel
         traffic["fetch_bytes_raw"] = fetch
         traffic["write_bytes"] = write
-        # gfx950: FETCH_SIZE counts 128-B requests of wide (16 B/lane) streaming reads at 64 B,
-        # i.e. reports half of them; B staging (global_load_lds_dwordx4) is that access shape.
+        # gfx950: FETCH_SIZE tallies the L2's 128-byte line fetches at 64 B, i.e. reports half
+        # of the bytes read.  Calibrated (tools/fetch_calib.hip, profiles/r2_fetch_calibration.json)
+        # on a known 512 MiB read in each access shape this kernel uses -- LDS-DMA dwordx4,
+        # dwordx4 to registers, dword, and the 16-dword replicated entry window: the ratio is
+        # 0.500 for all four, so the correction applies to the whole fetch.
         traffic["fetch_bytes_corrected_x2"] = 2 * fetch
         traffic["traffic_bytes_per_launch"] = 2 * fetch + write
         if args.algorithmic_bytes:

@@ -57,9 +57,25 @@ def build_torch_ops():
     return OPS_LIB
 
 
+def lint_kernels():
+    """Post-build ISA lint of the hand-counted kernels (tools/isa_lint.py): the
+    build fails if the compiler broke an assumption the counted waits rely on."""
+    import importlib.util
+    path = os.path.join(HERE, "..", "tools", "isa_lint.py")
+    spec = importlib.util.spec_from_file_location("_isa_lint", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if mod.lint(KERNEL_LIB, verbose=False) != 0:
+        raise SystemExit("isa_lint: libsputnik_hip.so violates the hand-counted vmcnt scheme")
+    print("isa_lint: ok", flush=True)
+
+
 def build_all():
     os.makedirs(LIB, exist_ok=True)
+    stamp = os.path.getmtime(KERNEL_LIB) if os.path.exists(KERNEL_LIB) else None
     build_kernels()
+    if stamp is None or os.path.getmtime(KERNEL_LIB) != stamp:
+        lint_kernels()   # (only when the library was relinked)
     build_torch_ops()
 
 

@@ -22,6 +22,7 @@ _c_float = ctypes.c_float
 # name -> (restype, argtypes); must list every symbol include/sputnik_hip.h declares.
 SIGNATURES = {
     "sputnik_hip_version": (ctypes.c_char_p, []),
+    "sputnik_hip_reload_options": (None, []),
     "sputnik_hip_spmm": (_c_int, [_c_int] * 4 + [_c_ptr] * 7),
     "sputnik_hip_spmm_workspace_bytes": (_c_size, [_c_int] * 4),
     "sputnik_hip_spmm_batched": (_c_int, [_c_int] * 5 + [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr,
@@ -74,6 +75,7 @@ SIGNATURES = {
         _c_ptr, _c_int, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_float, _c_ptr, _c_i64, _c_ptr]),
     "sputnik_hip_sparse_softmax_backward_many_mask": (_c_int, [_c_int] * 2 + [
         _c_ptr, _c_int, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_float, _c_ptr, _c_i64, _c_ptr]),
+    "sputnik_hip_transpose_batched": (_c_int, [_c_int] * 3 + [_c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr]),
     "sputnik_hip_csr_transpose_many_mask": (_c_int, [_c_int] * 3 + [
         _c_ptr, _c_int, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr,
         _c_ptr, _c_size, _c_ptr]),
@@ -96,6 +98,11 @@ def lib():
 
 def version():
     return lib().sputnik_hip_version().decode()
+
+
+def reload_options():
+    """Re-read the SPUTNIK_HIP_* knobs from the environment (read once otherwise)."""
+    lib().sputnik_hip_reload_options()
 
 
 def _ptr(t):
@@ -402,4 +409,14 @@ def sparse_attention_forward_planned(m, n, d, replicas, row_indices, row_offsets
         _ptr(q), m * d, _ptr(k), n * d, _ptr(v), n * d, float(scale), _ptr(out), m * d, _ptr(lse),
         m, _ptr(workspace), _ws_bytes(workspace), _stream(out)),
         "sputnik_hip_sparse_attention_forward_planned")
+    return out
+
+
+def transpose_batched(batches, rows, cols, inp, out):
+    """out[b][c][r] = inp[b][r][c] for contiguous [batches, rows, cols] fp32."""
+    _require(inp, torch.float32, "inp")
+    _require(out, torch.float32, "out")
+    _check(lib().sputnik_hip_transpose_batched(batches, rows, cols, _ptr(inp), rows * cols,
+                                               _ptr(out), rows * cols, _stream(out)),
+           "sputnik_hip_transpose_batched")
     return out

@@ -1,0 +1,21 @@
+// Developer / test knobs (SPUTNIK_HIP_* environment variables), read ONCE at
+// first use -- never on the launch path.  sputnik_hip_reload_options() re-reads
+// them (the parity tests steer small inputs onto each kernel in turn).
+#pragma once
+
+namespace sputnik_hip {
+
+struct Options {
+  int spmm_kernel = 0;    // SPUTNIK_HIP_SPMM_KERNEL: 0 auto, -1 "wide", -2 "wide512", 1 "narrow", 2 "gather"
+  int spmm_sparse = -1;   // SPUTNIK_HIP_SPMM_SPARSE: 0 / 1 forces the long- / short-segment variant
+  int spmm_debug = 0;     // SPUTNIK_HIP_SPMM_DEBUG: timing experiments only (wrong results)
+  int spmm_tile = 0;      // SPUTNIK_HIP_SPMM_MEDIUM: 1 = medium, 2 = small tile
+  int sddmm_kernel = 0;   // SPUTNIK_HIP_SDDMM_KERNEL: 0 auto, 1 "tiled", 2 "wave"
+  int sddmm_debug = 0;    // SPUTNIK_HIP_SDDMM_DEBUG: timing experiments only
+  int softmax_rpg = 0;    // SPUTNIK_HIP_SOFTMAX_RPG: rows per group (0 = automatic)
+  int softmax_depth = 1;  // SPUTNIK_HIP_SOFTMAX_DEPTH: rows in flight ahead (1..3)
+};
+
+const Options& options();
+
+}  // namespace sputnik_hip

@@ -11,9 +11,8 @@
 // (no LDS crossbar up to 16 lanes).  Lane t keeps result t, so the LPN
 // results leave as one coalesced store.  Long inner dimensions are walked in
 // panels of LPN*VEC*KSL elements; later panels add into the output.
-#include <stdlib.h>
-
 #include "common.h"
+#include "options.h"
 #include "wave_utils.h"
 
 namespace sputnik_hip {
@@ -161,13 +160,12 @@ namespace {
 // kernel that first stages its slab.  Measured cross-over
 // (tools/small_sddmm.py): about 2.7e8 multiply-adds at k = 64, 1.3e8 at k =
 // 128, 3e7 at k = 512, i.e. nnz * k^2 * replicas ~ 2^34.
-// Test knob SPUTNIK_HIP_SDDMM_KERNEL (read per call): "tiled" / "wave".
+// Test knob SPUTNIK_HIP_SDDMM_KERNEL (options.h: read once): "tiled" / "wave".
 bool takes_tiled(int m, int k, int n, int nonzeros, int replicas /* < 0: unknown */,
                  const float* lhs, int64_t lhs_stride, const float* rhs, int64_t rhs_stride,
                  const void* workspace, size_t workspace_bytes) {
-  const char* forced = getenv("SPUTNIK_HIP_SDDMM_KERNEL");
-  const bool force_tiled = forced != nullptr && forced[0] == 't';
-  const bool force_wave = forced != nullptr && forced[0] == 'w';
+  const bool force_tiled = options().sddmm_kernel == 1;
+  const bool force_wave = options().sddmm_kernel == 2;
   const bool small = replicas >= 0 &&
                      static_cast<double>(nonzeros) * k * k * replicas < 17179869184.0;  // 2^34
   return !force_wave && (force_tiled || !small) && workspace != nullptr &&

@@ -25,10 +25,9 @@
 //     leaves entry u's sum in lane u, so 16 results leave as one 64-byte store.
 // Needs ascending columns inside rows (checked per row by the pre-pass); a row
 // that fails is computed whole by slab 0 with rhs gathered from global memory.
-#include <stdlib.h>
-
 #include <type_traits>
 
+#include "options.h"
 #include "spmm_tiled_common.h"
 
 namespace sputnik_hip {
@@ -338,10 +337,7 @@ int sddmm_tiled_launch(int m, int k, int n, int nonzeros, int replicas, const in
                        const int* row_offsets, const int* column_indices, const float* lhs,
                        int64_t lhs_stride, const float* rhs, int64_t rhs_stride, float* out,
                        int64_t out_stride, const void* workspace, hipStream_t stream) {
-  static const int debug = [] {
-    const char* e = getenv("SPUTNIK_HIP_SDDMM_DEBUG");  // timing experiments only
-    return e ? atoi(e) : 0;
-  }();
+  const int debug = options().sddmm_debug;  // timing experiments only
   const int slots = slots_of(m);
   const int* row_ok = static_cast<const int*>(workspace);
   const int* table =

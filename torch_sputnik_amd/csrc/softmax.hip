@@ -7,12 +7,11 @@
 // instruction, whatever the row's start), with the next row's pieces in flight
 // while the current one is reduced with DPP (max, then sum of exp): 8 bytes of
 // HBM traffic per entry, the algorithmic minimum.  See the kernel's comment.
-#include <stdlib.h>
-
 #include <type_traits>
 #include <utility>
 
 #include "common.h"
+#include "options.h"
 #include "wave_utils.h"
 
 namespace sputnik_hip {
@@ -241,15 +240,8 @@ int launch_rows(int m, int nonzeros, int replicas, const float* a, int64_t a_str
   const int64_t total_rows = static_cast<int64_t>(m) * replicas;
   int rows_per_group = static_cast<int>(total_rows / (int64_t{256} * 8 * groups_per_block));
   rows_per_group = max(1, min(rows_per_group, 2));
-  static const int forced_rpg = [] {
-    const char* e = getenv("SPUTNIK_HIP_SOFTMAX_RPG");  // developer knob
-    return e ? atoi(e) : 0;
-  }();
-  if (forced_rpg > 0) rows_per_group = min(forced_rpg, 16);
-  static const int depth = [] {
-    const char* e = getenv("SPUTNIK_HIP_SOFTMAX_DEPTH");  // developer knob: 1..3
-    return e ? atoi(e) : 1;
-  }();
+  if (options().softmax_rpg > 0) rows_per_group = min(options().softmax_rpg, 16);  // developer knob
+  const int depth = options().softmax_depth;                                       // developer knob
   const int gx = ceil_div(ceil_div(m, rows_per_group), groups_per_block);
   // The fast path needs the inputs and the output of every replica aligned alike
   // (the common case: fresh allocations, equal strides) and 32-bit byte offsets.

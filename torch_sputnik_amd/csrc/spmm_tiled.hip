@@ -42,8 +42,7 @@
 // columns ascend.  A workgroup that finds a non-ascending row in its block
 // takes an order-independent path (B gathered from L2) inside the same launch:
 // no host synchronisation, no second kernel.
-#include <stdlib.h>
-
+#include "options.h"
 #include "spmm_tiled_common.h"
 
 namespace sputnik_hip {
@@ -92,20 +91,13 @@ struct TileConfig {
 template <typename Cfg>
 __device__ __forceinline__ void stage_chunk(float* __restrict__ tile, const float* __restrict__ dense,
                                             int n, int k, int kc, int wave,
-                                            unsigned lane_byte_offset, bool dbg_dummy, int& dummy) {
-  if (dbg_dummy) {
-    // timing experiment (SPUTNIK_HIP_SPMM_DEBUG & 8): the same NUMBER of vector-memory
-    // operations, so the counted waits hold, but each moves one hot dword into a
-    // scratch register instead of 1 KiB into LDS: what the loop costs without the
-    // B traffic (results are wrong)
-#pragma unroll
-    for (int i = 0; i < Cfg::kStageOps; ++i) dummy = untracked_load_i32(reinterpret_cast<const int*>(dense), 0u);
-    return;
-  }
+                                            const unsigned (&lane_byte_offset)[Cfg::kPieces]) {
   // The stage is BK * kPieces pieces of 1 KiB (256 columns of one B row); wave w
   // copies pieces w, w + WAVES, ...: one wave instruction moves one piece
-  // (lane_byte_offset = (n0 + lane*4) * 4 selects the workgroup's column tile and
-  // the lane's 16 bytes) straight into the row-major tile row.  Rows past the end
+  // (lane_byte_offset[h] = byte offset of the lane's 16 bytes of piece h inside a
+  // B row: (n0 + h*256 + lane*4) * 4, clamped to the row's last 16 bytes in the
+  // last, partial column tile -- such columns are never stored, and no copy
+  // leaves the row, let alone B) straight into the row-major tile row.  Rows past the end
   // of B (last, partial chunk) re-read row k-1: no nonzero refers to them, and
   // every wave then issues exactly kStageOps copies per stage, which the counted
   // vmcnt waits of the main loop rely on.
@@ -114,7 +106,7 @@ __device__ __forceinline__ void stage_chunk(float* __restrict__ tile, const floa
     const int piece = wave + i * Cfg::kWaves;
     const int r = piece / Cfg::kPieces, h = piece % Cfg::kPieces;
     const int src_row = min(kc + r, k - 1);
-    lds_dma_row(dense + static_cast<int64_t>(src_row) * n + h * 256, lane_byte_offset,
+    lds_dma_row(dense + static_cast<int64_t>(src_row) * n, lane_byte_offset[h],
                 tile + r * Cfg::kBN + h * 256);
   }
 }
@@ -142,9 +134,8 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
     int slots, int nchunks, int nonzeros, int n, int k, int n0, const float* __restrict__ values,
     const int* __restrict__ column_indices, const int* __restrict__ table,
     const float* __restrict__ dense, bool dbg_no_compute, bool dbg_no_stage,
-    bool dbg_no_barrier = false, bool dbg_dummy_stage = false) {
+    bool dbg_no_barrier = false) {
   constexpr int BN = Cfg::kBN, BK = Cfg::kBK, RPW = Cfg::kRPW;
-  int dummy = 0;
   constexpr int S = Cfg::kStageOps;
   // windows in flight (the 512-column tile has no registers for more than four:
   // 64 accumulators + 32 for the B strips of a four-entry batch)
@@ -165,7 +156,10 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
   const int window_lane = SPARSE ? (lane & 15) : lane;  // the window entry this lane loads
   const int last_entry = nonzeros - 1;
   const float* lane_tile = tile0 + lane * 4;
-  const unsigned b_lane_off = static_cast<unsigned>(n0 + lane * 4) * 4u;
+  unsigned b_lane_off[Cfg::kPieces];
+#pragma unroll
+  for (int h = 0; h < Cfg::kPieces; ++h)
+    b_lane_off[h] = static_cast<unsigned>(min(n0 + h * 256 + lane * 4, n - 4)) * 4u;
 
   // Stream positions of this wave's rows at the start of the current chunk and
   // at its end: SGPRs (scalar loads of RPW table entries; B in the comment above
@@ -196,7 +190,7 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
   };
 #pragma unroll
   for (int r = 0; r < D; ++r) request(r, s_ps[r]);
-  stage_chunk<Cfg>(tile0, dense, n, k, 0, wave, b_lane_off, false, dummy);
+  stage_chunk<Cfg>(tile0, dense, n, k, 0, wave, b_lane_off);
   wait_vm<0>();
   __syncthreads();
 
@@ -205,8 +199,7 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
     // A (the timing experiment without staging still issues the copies, from
     // chunk 0, so that the operation count the waits assume is unchanged)
     stage_chunk<Cfg>(tile0 + (buf ^ 1) * (BK * BN), dense, n, k,
-                     dbg_no_stage ? 0 : min(c + 1, nchunks - 1) * BK, wave, b_lane_off,
-                     dbg_dummy_stage, dummy);
+                     dbg_no_stage ? 0 : min(c + 1, nchunks - 1) * BK, wave, b_lane_off);
     // B: positions at the end of chunk c+1, needed when that chunk begins (a
     // scalar load has the whole chunk to land)
     typename Pos::type s_pe_next =
@@ -304,7 +297,6 @@ __device__ __forceinline__ void spmm_tiled_body_dpp(
     tie_reg(vcol[i]);
     tie_reg(vval[i]);
   }
-  tie_reg(dummy);
 }
 
 // SPARSE = false: 64-entry windows, groups of four entries with a padded last
@@ -363,6 +355,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void spmm_tiled_kernel(
 #pragma unroll
       for (int h = 0; h < Cfg::kPieces; ++h) {
         const int col = n0 + h * 256 + lane * 4;
+        if (col >= n) continue;   // last, partial column tile
         const float4 acc4 = gather_row_strip(values, column_indices, row_offsets[row],
                                              row_offsets[row + 1], dense + col, n);
         *reinterpret_cast<float4*>(out + static_cast<int64_t>(row) * n + col) =
@@ -380,7 +373,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void spmm_tiled_kernel(
 
   spmm_tiled_body_dpp<Cfg, SPARSE>(acc, &tile[0][0], lane, wave, slot0, slots, nchunks, nonzeros, n,
                                    k, n0, values, column_indices, table, dense, dbg_no_compute,
-                                   dbg_no_stage, dbg_no_barrier, (debug & 8) != 0);
+                                   dbg_no_stage, dbg_no_barrier);
 
 #pragma unroll
   for (int r = 0; r < RPW; ++r) {
@@ -389,10 +382,11 @@ __global__ __launch_bounds__(Cfg::kThreads) void spmm_tiled_kernel(
       const int row = row_indices[entry];
 #pragma unroll
       for (int h = 0; h < Cfg::kPieces; ++h)
-        *reinterpret_cast<float4*>(out + static_cast<int64_t>(row) * n + n0 + h * 256 + lane * 4) =
-            apply_epilogue(make_float4(acc[r][4 * h], acc[r][4 * h + 1], acc[r][4 * h + 2],
-                                       acc[r][4 * h + 3]),
-                           epi, row);
+        if (n0 + h * 256 + lane * 4 < n)   // (the last column tile may be partial)
+          *reinterpret_cast<float4*>(out + static_cast<int64_t>(row) * n + n0 + h * 256 + lane * 4) =
+              apply_epilogue(make_float4(acc[r][4 * h], acc[r][4 * h + 1], acc[r][4 * h + 2],
+                                         acc[r][4 * h + 3]),
+                             epi, row);
     }
   }
 }
@@ -412,7 +406,7 @@ Plan make_plan(int m, int k, int n) {
   constexpr int kUnit = Cfg::kBM > kDealPer ? Cfg::kBM : kDealPer;
   p.slots = ceil_div(m, kUnit) * kUnit;
   p.nchunks = ceil_div(k, Cfg::kBK);
-  p.n_tiles = n / Cfg::kBN;
+  p.n_tiles = ceil_div(n, Cfg::kBN);
   p.table_bytes = sizeof(int) * static_cast<size_t>(p.nchunks + 1) * p.slots;
   p.use = true;
   return p;
@@ -440,23 +434,27 @@ using CfgWide512 = TileConfig<512, 16, 8, 32>;
 // 512 x 8 replicas = 128 tiles of 128 rows, 256 of 64).
 using CfgWide512Half = TileConfig<512, 16, 4, 32>;
 
-// Developer / test knob SPUTNIK_HIP_SPMM_KERNEL, read at every call: "wide" =
+// Developer / test knob SPUTNIK_HIP_SPMM_KERNEL (options.h: read once): "wide" =
 // 256-column kernel whenever it applies, "wide512" = 512-column kernel whenever
 // it applies (else as "wide"), "narrow" = 64-column kernel whenever it applies,
 // "gather" = row-gather kernel; anything else = the automatic choice.
 // (The parity tests use it to reach every kernel with small inputs.)
-inline int forced_kernel() {
-  const char* e = getenv("SPUTNIK_HIP_SPMM_KERNEL");
-  if (e == nullptr) return 0;
-  if (e[0] == 'w') return (e[1] && e[2] && e[3] && e[4] == '5') ? -2 : -1;
-  return e[0] == 'n' ? 1 : e[0] == 'g' ? 2 : 0;
+inline int forced_kernel() { return options().spmm_kernel; }
+
+// Column tiles of BN columns serve any n that is a multiple of 4 (16-byte rows of
+// B and C): the last tile may be partial (its LDS copies are clamped into the
+// row, its stores predicated).  Taken when at most a quarter of the staged
+// columns is padding: n = 1000 -> two 512-column tiles, 4000 -> eight,
+// 200 -> one 256-column tile; n = 72 goes to the 64-column kernel.
+inline bool fits_tiles(int n, int bn) {
+  return n % 4 == 0 && static_cast<int64_t>(ceil_div(n, bn)) * bn * 3 <= static_cast<int64_t>(n) * 4;
 }
 
 inline bool tiled_applicable(int m, int k, int n, int nonzeros) {
   if (forced_kernel() > 0) return false;
-  // Needs full column tiles, and enough work per row block to amortise staging
-  // B (each workgroup stages k x 256 floats): mean row length >= 16.
-  return n % CfgLarge::kBN == 0 && k >= CfgLarge::kBK && m >= 64 &&
+  // Enough work per row block to amortise staging B (each workgroup stages
+  // k x 256 floats): mean row length >= 16.
+  return fits_tiles(n, CfgLarge::kBN) && k >= CfgLarge::kBK && m >= 64 &&
          nonzeros >= 16 * static_cast<int64_t>(m) && nonzeros < (1 << 30);  // 32-bit byte offsets
 }
 
@@ -470,12 +468,12 @@ inline bool tiled_applicable(int m, int k, int n, int nonzeros) {
 enum class Kernel { kNone, kWide, kNarrow, kEither, kWide512 };
 
 inline bool tiled512_applicable(int m, int k, int n, int nonzeros) {
-  return forced_kernel() <= 0 && n % CfgWide512::kBN == 0 && k >= CfgWide512::kBK && m >= 64 &&
+  return forced_kernel() <= 0 && fits_tiles(n, CfgWide512::kBN) && k >= CfgWide512::kBK && m >= 64 &&
          nonzeros >= 16 * static_cast<int64_t>(m) && nonzeros < (1 << 30);  // 32-bit byte offsets
 }
 
 inline int64_t tiles512(int m, int n) {
-  return static_cast<int64_t>(ceil_div(m, CfgWide512::kBM)) * (n / CfgWide512::kBN);
+  return static_cast<int64_t>(ceil_div(m, CfgWide512::kBM)) * ceil_div(n, CfgWide512::kBN);
 }
 constexpr int64_t kTiles512From = 192;
 // A row has more than about two entries per 32-row chunk (below that the 64-row
@@ -532,7 +530,7 @@ inline Kernel choose_kernel(int m, int k, int n, int nonzeros, int replicas /* <
   const bool narrow = spmm_tiled64_applicable(m, k, n, nonzeros);
   if (!wide) return narrow ? Kernel::kNarrow : Kernel::kNone;
   if (!narrow || forced < 0) return Kernel::kWide;
-  const int64_t small_tiles = static_cast<int64_t>(ceil_div(m, CfgSmall::kBM)) * (n / CfgSmall::kBN);
+  const int64_t small_tiles = static_cast<int64_t>(ceil_div(m, CfgSmall::kBM)) * ceil_div(n, CfgSmall::kBN);
   // cross-over measured between 256 (narrow 8-10 % ahead) and 512 (wide 20 % ahead) tiles
   constexpr int64_t kWideFrom = 384;
   if (small_tiles >= kWideFrom) return Kernel::kWide;  // whatever the replica count
@@ -648,14 +646,8 @@ int spmm_tiled_exec(int m, int k, int n, int nonzeros, int replicas, const int* 
   const int* table = reinterpret_cast<const int*>(ws_base + row_ok_bytes(plan.slots));
 
   const int blocks = (plan.slots / Cfg::kBM) * plan.n_tiles;
-  static const int forced = [] {
-    const char* e = getenv("SPUTNIK_HIP_SPMM_SPARSE");  // developer knob: 0 / 1 forces the variant
-    return e ? atoi(e) : -1;
-  }();
-  static const int debug = [] {
-    const char* e = getenv("SPUTNIK_HIP_SPMM_DEBUG");  // timing experiments only
-    return e ? atoi(e) : 0;
-  }();
+  const int forced = options().spmm_sparse;  // developer knob: 0 / 1 forces the variant
+  const int debug = options().spmm_debug;    // timing experiments only
   // Mean number of entries of a row inside one K chunk picks the variant
   // (measured cross-over with 64-row chunks, 4096^3 and 2048^3 x 8: density 0.2
   // short-segment form 7-9 % ahead, 0.25 a tie, 0.3 and above the long-segment form).
@@ -666,10 +658,7 @@ int spmm_tiled_exec(int m, int k, int n, int nonzeros, int replicas, const int* 
                       : forced >= 0
                           ? forced != 0
                           : static_cast<int64_t>(nonzeros) < int64_t{15} * m * plan.nchunks;
-  static const int force_tile = [] {
-    const char* e = getenv("SPUTNIK_HIP_SPMM_MEDIUM");  // developer knob: 1 = medium, 2 = small tile
-    return e ? atoi(e) : 0;
-  }();
+  const int force_tile = options().spmm_tile;  // developer knob: 1 = medium, 2 = small tile
   // Largest tile that still gives about one workgroup per CU (256 CUs).
   const int64_t large_blocks = static_cast<int64_t>(blocks) * replicas;
   const int tile = force_tile ? force_tile : large_blocks >= 192 ? 0 : 2 * large_blocks >= 192 ? 1 : 2;

@@ -1,6 +1,7 @@
-// LDS-tiled SpMM for NARROW dense operands (n a multiple of 64 that the
-// 256-column kernel of spmm_tiled.hip does not take): attention heads
-// (n = head_dim), SparseLinear with short sequences.
+// LDS-tiled SpMM for NARROW dense operands (any n >= 64 that is a multiple of 4
+// and that the 256- / 512-column kernels of spmm_tiled.hip do not take; the last
+// column tile may be partial): attention heads (n = head_dim), SparseLinear with
+// short sequences, the reference's own test shape n = 72 (tests/test_spmm.py:13).
 //
 // Same decomposition as spmm_tiled.hip -- B staged per K chunk into LDS by
 // direct global->LDS copies, C accumulators in registers for the whole K walk,
@@ -22,10 +23,9 @@
 // costs nothing.  Rows with more than 32 entries in one chunk fetch the rest on
 // demand.  The four row groups of a wave run their own number of steps
 // (EXEC-masked), so no LDS traffic is spent on the shorter rows' padding.
-#include <stdlib.h>
-
 #include <type_traits>
 
+#include "options.h"
 #include "spmm_tiled_common.h"
 
 namespace sputnik_hip {
@@ -55,8 +55,10 @@ __device__ __forceinline__ void stage_chunk64(float* __restrict__ tile,
   for (int j = 0; j < kCopiesPerWave; ++j) {
     const int r0 = (wave + j * kWaves) * 4;
     const int src_row = min(kc + r0 + g, k - 1);  // past the end of B: re-read the last row
+    // (last, partial column tile: lanes past the row's end re-read its last 16
+    // bytes -- never stored -- so that no copy leaves the row, let alone B)
     const unsigned off = static_cast<unsigned>(src_row) * static_cast<unsigned>(n) * 4u +
-                         static_cast<unsigned>(n0 + i * 4) * 4u;
+                         static_cast<unsigned>(min(n0 + i * 4, n - 4)) * 4u;
     lds_dma_row(dense, off, tile + r0 * kBN);
   }
 }
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled64_kernel(
   if (!block_rows_ok(row_ok, mblock * kBM, kBM)) {
     for (int t = 0; t < kRQ; ++t) {
       const int entry = dealt_index(slot0 + 4 * t + g, slots, kBM);
-      if (entry < m) {
+      if (entry < m && n0 + i * 4 < n) {
         const int row = row_indices[entry];
         const float4 acc4 = gather_row_strip(values, column_indices, row_offsets[row],
                                              row_offsets[row + 1], dense + n0 + i * 4, n);
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled64_kernel(
 #pragma unroll
   for (int t = 0; t < kRQ; ++t) {
     const int entry = dealt_index(slot0 + 4 * t + g, slots, kBM);
-    if (entry < m) {
+    if (entry < m && n0 + i * 4 < n) {   // (the last column tile may be partial)
       const int row = row_indices[entry];
       *reinterpret_cast<float4*>(out + static_cast<int64_t>(row) * n + n0 + i * 4) =
           apply_epilogue(make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]), epi, row);
@@ -257,7 +259,7 @@ inline int chunks_of(int k) { return ceil_div(k, kBK); }
 
 bool spmm_tiled64_applicable(int m, int k, int n, int nonzeros) {
   // B rows are addressed with 32-bit byte offsets; enough work per staged tile.
-  return n % kBN == 0 && k >= 32 && m >= 16 && nonzeros >= 4 * static_cast<int64_t>(m) &&
+  return n % 4 == 0 && n >= kBN && k >= 32 && m >= 16 && nonzeros >= 4 * static_cast<int64_t>(m) &&
          static_cast<int64_t>(k) * n * 4 < (int64_t{1} << 32);
 }
 
@@ -286,11 +288,8 @@ int spmm_tiled64_exec(int m, int k, int n, int nonzeros, int replicas, const int
   const int* row_ok = static_cast<const int*>(workspace);
   const int* table =
       reinterpret_cast<const int*>(static_cast<const char*>(workspace) + row_ok_bytes(slots));
-  const int n_tiles = n / kBN;
-  static const int debug = [] {
-    const char* e = getenv("SPUTNIK_HIP_SPMM_DEBUG");  // timing experiments only
-    return e ? atoi(e) : 0;
-  }();
+  const int n_tiles = ceil_div(n, kBN);
+  const int debug = options().spmm_debug;  // timing experiments only
   hipLaunchKernelGGL(spmm_tiled64_kernel, dim3((slots / kBM) * n_tiles, replicas), dim3(kThreads),
                      0, stream, m, k, n, nonzeros, slots, chunks_of(k), n_tiles, row_indices,
                      values, values_stride, column_indices, table, dense, dense_stride, out,

@@ -769,6 +769,28 @@ std::vector<Tensor> csr_transpose_many_mask(int64_t b, int64_t m64, int64_t n64,
   return {out_values, out_row_offsets, out_column_indices};
 }
 
+// Layout pass of the reference's modules (modules/sparse_linear.py:89,
+// modules/sparse_attention.py:108-126): x[..., R, C] -> contiguous [..., C, R],
+// i.e. `x.transpose(-1, -2).contiguous()` as ONE tiled kernel.  float32 moves
+// through the HIP kernel; other dtypes take ATen's strided copy.
+Tensor transpose_last2(const Tensor& x_in) {
+  TORCH_CHECK(x_in.is_cuda(), "transpose_last2: expected a GPU (HIP) tensor, got ", x_in.device());
+  TORCH_CHECK(x_in.dim() >= 2, "transpose_last2: expected at least 2 dimensions, got ", x_in.dim());
+  if (x_in.scalar_type() != at::kFloat) return x_in.transpose(-1, -2).contiguous();
+  const Tensor x = x_in.contiguous();
+  const c10::DeviceGuard guard(x.device());
+  std::vector<int64_t> sizes = x.sizes().vec();
+  const int rows = to_int(sizes[sizes.size() - 2], "rows"), cols = to_int(sizes.back(), "cols");
+  std::swap(sizes[sizes.size() - 2], sizes[sizes.size() - 1]);
+  Tensor out = at::empty(sizes, x.options());
+  const int64_t per = static_cast<int64_t>(rows) * cols;
+  const int batches = per == 0 ? 0 : to_int(x.numel() / per, "batches");
+  check_status(sputnik_hip_transpose_batched(batches, rows, cols, x.data_ptr<float>(), per,
+                                             out.data_ptr<float>(), per, current_stream(x)),
+               "transpose_last2");
+  return out;
+}
+
 }  // namespace
 
 TORCH_LIBRARY(torch_sputnik, m) {
@@ -848,6 +870,7 @@ TORCH_LIBRARY(torch_sputnik, m) {
   m.def(
       "csr_transpose_many_mask(int b, int m, int n, Tensor nonzeros, Tensor values, "
       "Tensor row_offsets, Tensor column_indices) -> Tensor[]");
+  m.def("transpose_last2(Tensor x) -> Tensor");
 }
 
 // "CUDA" is the dispatch key of HIP tensors in a ROCm build of PyTorch.
@@ -877,4 +900,5 @@ TORCH_LIBRARY_IMPL(torch_sputnik, CUDA, m) {
   m.impl("sparse_softmax_many_mask_scaled", &sparse_softmax_many_mask_scaled);
   m.impl("sparse_softmax_backward_many_mask", &sparse_softmax_backward_many_mask);
   m.impl("csr_transpose_many_mask", &csr_transpose_many_mask);
+  m.impl("transpose_last2", &transpose_last2);
 }

@@ -188,6 +188,27 @@ def _attention(query, key, value, row_indices, row_offsets, column_indices, scal
                                         column_indices, scale, plan)
 
 
+class TransposeLast2(torch.autograd.Function):
+    """``x.transpose(-1, -2).contiguous()`` as one tiled kernel (ops.transpose_last2):
+    the layout pass of modules/sparse_linear.py:89 and
+    modules/sparse_attention.py:108-126.  Its gradient is the same operation."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return ops.transpose_last2(x)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return ops.transpose_last2(grad_output)
+
+
+def transpose_last2(x):
+    """Differentiable ``x.transpose(-1, -2).contiguous()``."""
+    if torch.is_grad_enabled() and x.requires_grad:
+        return TransposeLast2.apply(x)
+    return ops.transpose_last2(x)
+
+
 class Spmm(torch.autograd.Function):
     """sparse(values, CSR topology) @ dense.  ``apply(m, k, values, row_indices,
     row_offsets, column_indices, dense)``."""

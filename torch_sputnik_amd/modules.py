@@ -41,8 +41,15 @@ class SparseLinear(nn.Module):
         self.column_indices = column_indices
 
     def forward(self, x):
-        dense = x.transpose(1, 2).contiguous()
-        needs_grad = torch.is_grad_enabled() and (x.requires_grad or self.values.requires_grad)
+        # [B, S, in] -> the k-major operand [B, in, S] of left_spmm: the reference's
+        # `x.transpose(1, 2).contiguous()` (modules/sparse_linear.py:89) as one tiled
+        # kernel (same values, same layout)
+        return self.project(functional.transpose_last2(x))
+
+    def project(self, dense):
+        """``W @ dense`` for an operand that is already k-major: [B, in, S] ->
+        [B, out, S].  (SparseAttention chains its layout passes and calls this.)"""
+        needs_grad = torch.is_grad_enabled() and (dense.requires_grad or self.values.requires_grad)
         if not needs_grad:
             # forward only: no autograd node.  (The weight's pattern is static: its
             # topology pre-pass comes from the plan cache, functional.PlanCache,
@@ -92,10 +99,11 @@ class SparseAttention(nn.Module):
         self.fused_training = fused_training
 
     def attention(self, query, key, value, mask):
-        q3d = self.four_d_to_three_d(query)
-        k3d = self.four_d_to_three_d(key)
-        v3d = self.four_d_to_three_d(value)
+        """[B, H, S, D] operands, as modules/sparse_attention.py:66-82."""
+        return self._attention3d(self.four_d_to_three_d(query), self.four_d_to_three_d(key),
+                                 self.four_d_to_three_d(value))
 
+    def _attention3d(self, q3d, k3d, v3d):
         scale = 1.0 / math.sqrt(self.head_dim)
         needs_grad = torch.is_grad_enabled() and (
             q3d.requires_grad or k3d.requires_grad or v3d.requires_grad)
@@ -125,15 +133,57 @@ class SparseAttention(nn.Module):
         return tensor.reshape(n * c, h, w)
 
     def forward(self, query, key, value, mask=None):
-        batch_size = query.size(0)
-        # SparseLinear returns [B, E, S]; bring it to [B, H, S, D]
-        query, key, value = [
-            net(x).transpose(1, 2).contiguous()
-            .view(batch_size, -1, self.num_heads, self.head_dim).transpose(1, 2)
-            for net, x in zip(self.linears, (query, key, value))]
-        b, h, s, d = value.size()
+        """Same values and layouts as modules/sparse_attention.py:105-128 ([B, S, E] in,
+        [B, S, E] out as a transposed view of [B, E, S]); the layout passes are chained:
 
-        context = self.attention(query, key, value, mask).reshape(b, h, s, d)
-        context = context.transpose(1, 2).contiguous().reshape(
-            batch_size, -1, self.num_heads * self.head_dim)
-        return self.linears[-1](context).transpose(1, 2)
+          reference, per projection      here
+          x^T copy (SparseLinear)        transpose_last2(x)            [B, E, S]
+          y^T copy                       (none)
+          head-split copy                transpose_last2(y as [B*H, D, S])  -> [B*H, S, D]
+          context: head-merge copy       transpose_last2(ctx)          -> [B*H, D, S] = [B, E, S],
+          + x^T copy of the last layer   which IS the last layer's k-major operand
+
+        i.e. 7 passes (5 when query, key and value are one tensor) instead of 11, each
+        one tiled kernel.  The three input projections are independent: without
+        autograd they run on side streams so that their small grids share the chip."""
+        batch_size, seq = query.size(0), query.size(1)
+        heads, dim = self.num_heads, self.head_dim
+        inputs = (query, key, value)
+        if query is key and key is value:
+            shared = functional.transpose_last2(query)
+            operands = (shared, shared, shared)
+        else:
+            operands = tuple(functional.transpose_last2(x) for x in inputs)
+
+        def head_split(projected):   # [B, H*D, S] -> [B*H, S, D]
+            return functional.transpose_last2(projected.reshape(batch_size * heads, dim, seq))
+
+        needs_grad = torch.is_grad_enabled() and (
+            any(x.requires_grad for x in inputs) or
+            any(layer.values.requires_grad for layer in self.linears))
+        if needs_grad or not query.is_cuda:
+            q3d, k3d, v3d = (head_split(net.project(d)) for net, d in zip(self.linears, operands))
+        else:
+            main = torch.cuda.current_stream(query.device)
+            results = [None, None, None]
+            results[0] = head_split(self.linears[0].project(operands[0]))
+            for i in (1, 2):
+                side = self._side_stream(i, query.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    results[i] = head_split(self.linears[i].project(operands[i]))
+                    results[i].record_stream(main)
+            for i in (1, 2):
+                main.wait_stream(self._side_stream(i, query.device))
+            q3d, k3d, v3d = results
+
+        context = self._attention3d(q3d, k3d, v3d)                      # [B*H, S, D]
+        merged = functional.transpose_last2(context).reshape(batch_size, heads * dim, seq)
+        return self.linears[-1].project(merged).transpose(1, 2)
+
+    def _side_stream(self, index, device):
+        streams = self.__dict__.setdefault("_streams", {})
+        key = (index, str(device))
+        if key not in streams:
+            streams[key] = torch.cuda.Stream(device=device)
+        return streams[key]

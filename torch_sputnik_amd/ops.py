@@ -188,3 +188,10 @@ def sparse_attention_planned(query, key, value, row_indices, row_offsets, column
                              plan):
     return _ops.sparse_attention_planned(query, key, value, row_indices, row_offsets,
                                          column_indices, float(scale), plan)
+
+
+def transpose_last2(x):
+    """``x.transpose(-1, -2).contiguous()`` as one tiled HIP kernel: the layout
+    pass in front of / behind every SparseLinear (modules/sparse_linear.py:89,
+    modules/sparse_attention.py:108-126)."""
+    return _ops.transpose_last2(x)
