@@ -359,6 +359,22 @@ SPUTNIK_HIP_API int sputnik_hip_transpose_batched(int batches, int rows, int col
                                   int64_t out_batch_stride,
                                   sputnik_hip_stream_t stream);
 
+/*
+ * The same with a change of storage type on the way (in_type / out_type:
+ * SPUTNIK_HIP_F32 / F16 / BF16; supported: equal types, half -> float,
+ * float -> half).  BASELINE.json's config 5 stores activations in fp16 while the
+ * operators compute and return fp32 (src/spmm_cuda.cu:42): the widening happens
+ * inside the layout pass in front of left_spmm, the narrowing of the gradient
+ * inside the pass behind it -- no pass of its own.
+ */
+#define SPUTNIK_HIP_F32 0
+#define SPUTNIK_HIP_F16 1
+#define SPUTNIK_HIP_BF16 2
+SPUTNIK_HIP_API int sputnik_hip_transpose_cast_batched(int batches, int rows, int cols, const void* in,
+                                       int in_type, int64_t in_batch_stride, void* out,
+                                       int out_type, int64_t out_batch_stride,
+                                       sputnik_hip_stream_t stream);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

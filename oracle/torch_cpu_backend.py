@@ -143,6 +143,11 @@ def _transpose_last2(x):
     return x.transpose(-1, -2).contiguous()
 
 
+def _transpose_last2_as(x, out_type):
+    t = x.transpose(-1, -2).contiguous()
+    return t if out_type < 0 else t.to({0: torch.float32, 1: torch.float16, 2: torch.bfloat16}[out_type])
+
+
 def _plan(*_args):
     return torch.zeros(16, dtype=torch.uint8)  # the CPU checker has nothing to pre-compute
 
@@ -197,3 +202,4 @@ def install():
     _lib.impl("sparse_softmax_backward_many_mask", _sparse_softmax_backward_many_mask, "CPU")
     _lib.impl("csr_transpose_many_mask", _csr_transpose_many_mask, "CPU")
     _lib.impl("transpose_last2", _transpose_last2, "CPU")
+    _lib.impl("transpose_last2_as", _transpose_last2_as, "CPU")

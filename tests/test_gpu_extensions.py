@@ -561,3 +561,17 @@ def test_transpose_last2_gradient(dev):
     g = torch.randn(4, 40, 96, device=dev)
     functional.transpose_last2(x).backward(g)
     assert torch.equal(x.grad, g.transpose(1, 2).contiguous())
+
+
+@pytest.mark.parametrize("src,dst", [(torch.float16, torch.float32), (torch.bfloat16, torch.float32),
+                                     (torch.float32, torch.float16), (torch.float32, torch.bfloat16),
+                                     (torch.float16, torch.float16)])
+@pytest.mark.parametrize("shape", [(8, 512, 2048), (3, 70, 33), (2, 4, 64, 128)])
+def test_transpose_last2_with_storage_change(dev, src, dst, shape):
+    """Half-precision activations are widened (and gradients narrowed) INSIDE the
+    layout pass: bit-identical to transposing and then converting."""
+    from torch_sputnik_amd import ops
+    x = torch.randn(*shape, device=dev).to(src)
+    got = ops.transpose_last2(x, dst)
+    want = x.transpose(-1, -2).contiguous().to(dst)
+    assert got.dtype == dst and got.is_contiguous() and torch.equal(got, want)

@@ -11,9 +11,14 @@
 // instances of this one operation (the head split [B, H*D, S] -> [B*H, S, D] is
 // a transpose of B*H matrices of D x S), which moves 64 x 64 tiles through LDS so
 // that both the reads and the writes are 16-byte accesses along the contiguous
-// dimension.  HBM-bound: 8 bytes per element.
+// dimension.  HBM-bound: 8 bytes per fp32 element.  The pass may also change
+// the storage type (fp16 / bf16 <-> fp32): BASELINE config 5 stores activations
+// in half precision, and widening them here costs no pass of its own.
 #include "common.h"
 #include "wave_utils.h"
+
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
 
 namespace sputnik_hip {
 namespace {
@@ -21,11 +26,36 @@ namespace {
 constexpr int kTile = 64;
 constexpr int kThreads = 256;
 
-// VEC = 4: rows, cols multiples of 4 and 16-byte aligned operands; VEC = 1: anything.
-template <int VEC>
+// Element types: float, __half, __hip_bfloat16 -- the pass may change the storage
+// type on the way (half-precision activations are widened to float HERE, on
+// their way into left_spmm, instead of in a pass of their own; gradients are
+// narrowed back the same way).  Arithmetic type of the tile: float.
+template <typename T>
+__device__ __forceinline__ float to_float(T v) { return static_cast<float>(v); }
+template <>
+__device__ __forceinline__ float to_float<__half>(__half v) { return __half2float(v); }
+template <>
+__device__ __forceinline__ float to_float<__hip_bfloat16>(__hip_bfloat16 v) { return __bfloat162float(v); }
+template <typename T>
+__device__ __forceinline__ T from_float(float v);
+template <>
+__device__ __forceinline__ float from_float<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ __half from_float<__half>(float v) { return __float2half(v); }
+template <>
+__device__ __forceinline__ __hip_bfloat16 from_float<__hip_bfloat16>(float v) { return __float2bfloat16(v); }
+
+template <typename T>
+struct alignas(4 * sizeof(T)) Quad {
+  T v[4];
+};
+
+// VEC = 4: rows, cols multiples of 4 and operands aligned to four elements;
+// VEC = 1: anything.
+template <typename TIn, typename TOut, int VEC>
 __global__ __launch_bounds__(kThreads) void transpose_tiles_kernel(
-    int rows, int cols, int tiles_c, const float* __restrict__ in, int64_t in_batch_stride,
-    float* __restrict__ out, int64_t out_batch_stride) {
+    int rows, int cols, int tiles_c, const TIn* __restrict__ in, int64_t in_batch_stride,
+    TOut* __restrict__ out, int64_t out_batch_stride) {
   __shared__ float tile[kTile][kTile + 1];
   const int tr = blockIdx.x / tiles_c, tc = blockIdx.x % tiles_c;
   const int r0 = tr * kTile, c0 = tc * kTile;
@@ -33,16 +63,14 @@ __global__ __launch_bounds__(kThreads) void transpose_tiles_kernel(
   out += blockIdx.y * out_batch_stride;
   const int t = threadIdx.x;
   if constexpr (VEC == 4) {
-    const int tx = t % 16, ty = t / 16;   // 16 float4 across, 16 rows per pass
+    const int tx = t % 16, ty = t / 16;   // 16 quads across, 16 rows per pass
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int r = r0 + ty + 16 * j, c = c0 + 4 * tx;
       if (r < rows && c < cols) {
-        const float4 v = *reinterpret_cast<const float4*>(in + static_cast<int64_t>(r) * cols + c);
-        tile[ty + 16 * j][4 * tx + 0] = v.x;
-        tile[ty + 16 * j][4 * tx + 1] = v.y;
-        tile[ty + 16 * j][4 * tx + 2] = v.z;
-        tile[ty + 16 * j][4 * tx + 3] = v.w;
+        const Quad<TIn> q = *reinterpret_cast<const Quad<TIn>*>(in + static_cast<int64_t>(r) * cols + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[ty + 16 * j][4 * tx + e] = to_float(q.v[e]);
       }
     }
     __syncthreads();
@@ -50,23 +78,52 @@ __global__ __launch_bounds__(kThreads) void transpose_tiles_kernel(
     for (int j = 0; j < 4; ++j) {
       const int c = c0 + ty + 16 * j, r = r0 + 4 * tx;   // output row c, columns r .. r+3
       if (c < cols && r < rows) {
-        const float4 v = make_float4(tile[4 * tx + 0][ty + 16 * j], tile[4 * tx + 1][ty + 16 * j],
-                                     tile[4 * tx + 2][ty + 16 * j], tile[4 * tx + 3][ty + 16 * j]);
-        *reinterpret_cast<float4*>(out + static_cast<int64_t>(c) * rows + r) = v;
+        Quad<TOut> q;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q.v[e] = from_float<TOut>(tile[4 * tx + e][ty + 16 * j]);
+        *reinterpret_cast<Quad<TOut>*>(out + static_cast<int64_t>(c) * rows + r) = q;
       }
     }
   } else {
     const int tx = t % kTile, ty = t / kTile;   // 64 across, 4 rows per pass
     for (int j = 0; j < kTile / 4; ++j) {
       const int r = r0 + ty + 4 * j, c = c0 + tx;
-      if (r < rows && c < cols) tile[ty + 4 * j][tx] = in[static_cast<int64_t>(r) * cols + c];
+      if (r < rows && c < cols) tile[ty + 4 * j][tx] = to_float(in[static_cast<int64_t>(r) * cols + c]);
     }
     __syncthreads();
     for (int j = 0; j < kTile / 4; ++j) {
       const int c = c0 + ty + 4 * j, r = r0 + tx;
-      if (c < cols && r < rows) out[static_cast<int64_t>(c) * rows + r] = tile[tx][ty + 4 * j];
+      if (c < cols && r < rows)
+        out[static_cast<int64_t>(c) * rows + r] = from_float<TOut>(tile[tx][ty + 4 * j]);
     }
   }
+}
+
+template <typename TIn, typename TOut>
+int launch_transpose(int batches, int rows, int cols, const void* in_v, int64_t in_batch_stride,
+                     void* out_v, int64_t out_batch_stride, hipStream_t stream) {
+  const TIn* in = static_cast<const TIn*>(in_v);
+  TOut* out = static_cast<TOut*>(out_v);
+  const int tiles_r = ceil_div(rows, kTile), tiles_c = ceil_div(cols, kTile);
+  if (static_cast<int64_t>(tiles_r) * tiles_c > 0x7fffffff) return SPUTNIK_HIP_INVALID_ARGUMENT;
+  const bool vec = rows % 4 == 0 && cols % 4 == 0 && aligned_to(in, 4 * sizeof(TIn)) &&
+                   aligned_to(out, 4 * sizeof(TOut)) && in_batch_stride % 4 == 0 &&
+                   out_batch_stride % 4 == 0;
+  for (int b0 = 0; b0 < batches; b0 += kMaxGridYZ) {
+    const int by = min(batches - b0, kMaxGridYZ);
+    const dim3 grid(tiles_r * tiles_c, by);
+    const TIn* in_b = in + b0 * in_batch_stride;
+    TOut* out_b = out + b0 * out_batch_stride;
+    if (vec)
+      hipLaunchKernelGGL((transpose_tiles_kernel<TIn, TOut, 4>), grid, dim3(kThreads), 0, stream,
+                         rows, cols, tiles_c, in_b, in_batch_stride, out_b, out_batch_stride);
+    else
+      hipLaunchKernelGGL((transpose_tiles_kernel<TIn, TOut, 1>), grid, dim3(kThreads), 0, stream,
+                         rows, cols, tiles_c, in_b, in_batch_stride, out_b, out_batch_stride);
+    const int st = launch_status();
+    if (st != 0) return st;
+  }
+  return 0;
 }
 
 }  // namespace
@@ -79,27 +136,30 @@ extern "C" {
 int sputnik_hip_transpose_batched(int batches, int rows, int cols, const float* in,
                                   int64_t in_batch_stride, float* out, int64_t out_batch_stride,
                                   sputnik_hip_stream_t stream) {
+  return sputnik_hip_transpose_cast_batched(batches, rows, cols, in, SPUTNIK_HIP_F32,
+                                            in_batch_stride, out, SPUTNIK_HIP_F32,
+                                            out_batch_stride, stream);
+}
+
+int sputnik_hip_transpose_cast_batched(int batches, int rows, int cols, const void* in,
+                                       int in_type, int64_t in_batch_stride, void* out,
+                                       int out_type, int64_t out_batch_stride,
+                                       sputnik_hip_stream_t stream) {
   if (batches < 0 || rows < 0 || cols < 0) return SPUTNIK_HIP_INVALID_ARGUMENT;
   if (batches == 0 || rows == 0 || cols == 0) return 0;
-  const int tiles_r = ceil_div(rows, kTile), tiles_c = ceil_div(cols, kTile);
-  if (static_cast<int64_t>(tiles_r) * tiles_c > 0x7fffffff) return SPUTNIK_HIP_INVALID_ARGUMENT;
-  const bool vec = rows % 4 == 0 && cols % 4 == 0 && aligned_to(in, 16) && aligned_to(out, 16) &&
-                   in_batch_stride % 4 == 0 && out_batch_stride % 4 == 0;
-  for (int b0 = 0; b0 < batches; b0 += kMaxGridYZ) {
-    const int by = min(batches - b0, kMaxGridYZ);
-    const dim3 grid(tiles_r * tiles_c, by);
-    const float* in_b = in + b0 * in_batch_stride;
-    float* out_b = out + b0 * out_batch_stride;
-    if (vec)
-      hipLaunchKernelGGL(transpose_tiles_kernel<4>, grid, dim3(kThreads), 0, stream, rows, cols,
-                         tiles_c, in_b, in_batch_stride, out_b, out_batch_stride);
-    else
-      hipLaunchKernelGGL(transpose_tiles_kernel<1>, grid, dim3(kThreads), 0, stream, rows, cols,
-                         tiles_c, in_b, in_batch_stride, out_b, out_batch_stride);
-    const int st = launch_status();
-    if (st != 0) return st;
-  }
-  return 0;
+#define SPUTNIK_HIP_TRANSPOSE_CASE(A, TA, B, TB)                                                \
+  if (in_type == A && out_type == B)                                                            \
+    return launch_transpose<TA, TB>(batches, rows, cols, in, in_batch_stride, out,              \
+                                    out_batch_stride, stream)
+  SPUTNIK_HIP_TRANSPOSE_CASE(SPUTNIK_HIP_F32, float, SPUTNIK_HIP_F32, float);
+  SPUTNIK_HIP_TRANSPOSE_CASE(SPUTNIK_HIP_F16, __half, SPUTNIK_HIP_F32, float);
+  SPUTNIK_HIP_TRANSPOSE_CASE(SPUTNIK_HIP_BF16, __hip_bfloat16, SPUTNIK_HIP_F32, float);
+  SPUTNIK_HIP_TRANSPOSE_CASE(SPUTNIK_HIP_F32, float, SPUTNIK_HIP_F16, __half);
+  SPUTNIK_HIP_TRANSPOSE_CASE(SPUTNIK_HIP_F32, float, SPUTNIK_HIP_BF16, __hip_bfloat16);
+  SPUTNIK_HIP_TRANSPOSE_CASE(SPUTNIK_HIP_F16, __half, SPUTNIK_HIP_F16, __half);
+  SPUTNIK_HIP_TRANSPOSE_CASE(SPUTNIK_HIP_BF16, __hip_bfloat16, SPUTNIK_HIP_BF16, __hip_bfloat16);
+#undef SPUTNIK_HIP_TRANSPOSE_CASE
+  return SPUTNIK_HIP_INVALID_ARGUMENT;
 }
 
 }  // extern "C"

@@ -771,25 +771,43 @@ std::vector<Tensor> csr_transpose_many_mask(int64_t b, int64_t m64, int64_t n64,
 
 // Layout pass of the reference's modules (modules/sparse_linear.py:89,
 // modules/sparse_attention.py:108-126): x[..., R, C] -> contiguous [..., C, R],
-// i.e. `x.transpose(-1, -2).contiguous()` as ONE tiled kernel.  float32 moves
-// through the HIP kernel; other dtypes take ATen's strided copy.
-Tensor transpose_last2(const Tensor& x_in) {
+// i.e. `x.transpose(-1, -2).contiguous()` as ONE tiled kernel, optionally
+// changing the storage type on the way (out_type: -1 keep, 0 float32, 1 float16,
+// 2 bfloat16; half <-> float and equal types).
+int type_code(at::ScalarType t) {
+  return t == at::kFloat ? SPUTNIK_HIP_F32 : t == at::kHalf ? SPUTNIK_HIP_F16
+         : t == at::kBFloat16 ? SPUTNIK_HIP_BF16 : -1;
+}
+
+Tensor transpose_last2_as(const Tensor& x_in, int64_t out_type) {
   TORCH_CHECK(x_in.is_cuda(), "transpose_last2: expected a GPU (HIP) tensor, got ", x_in.device());
   TORCH_CHECK(x_in.dim() >= 2, "transpose_last2: expected at least 2 dimensions, got ", x_in.dim());
-  if (x_in.scalar_type() != at::kFloat) return x_in.transpose(-1, -2).contiguous();
+  const int in_code = type_code(x_in.scalar_type());
+  const int out_code = out_type < 0 ? in_code : static_cast<int>(out_type);
+  const at::ScalarType out_dtype = out_code == SPUTNIK_HIP_F32 ? at::kFloat
+                                   : out_code == SPUTNIK_HIP_F16 ? at::kHalf : at::kBFloat16;
+  const bool native = in_code >= 0 && out_code >= 0 && out_code <= 2 &&
+                      (in_code == out_code || in_code == SPUTNIK_HIP_F32 || out_code == SPUTNIK_HIP_F32);
+  if (!native) {   // (other element types: ATen's strided copy)
+    Tensor t = x_in.transpose(-1, -2).contiguous();
+    return out_type < 0 ? t : t.to(out_dtype);
+  }
   const Tensor x = x_in.contiguous();
   const c10::DeviceGuard guard(x.device());
   std::vector<int64_t> sizes = x.sizes().vec();
   const int rows = to_int(sizes[sizes.size() - 2], "rows"), cols = to_int(sizes.back(), "cols");
   std::swap(sizes[sizes.size() - 2], sizes[sizes.size() - 1]);
-  Tensor out = at::empty(sizes, x.options());
+  Tensor out = at::empty(sizes, x.options().dtype(out_dtype));
   const int64_t per = static_cast<int64_t>(rows) * cols;
   const int batches = per == 0 ? 0 : to_int(x.numel() / per, "batches");
-  check_status(sputnik_hip_transpose_batched(batches, rows, cols, x.data_ptr<float>(), per,
-                                             out.data_ptr<float>(), per, current_stream(x)),
+  check_status(sputnik_hip_transpose_cast_batched(batches, rows, cols, x.data_ptr(), in_code, per,
+                                                  out.data_ptr(), out_code, per,
+                                                  current_stream(x)),
                "transpose_last2");
   return out;
 }
+
+Tensor transpose_last2(const Tensor& x) { return transpose_last2_as(x, -1); }
 
 }  // namespace
 
@@ -871,6 +889,7 @@ TORCH_LIBRARY(torch_sputnik, m) {
       "csr_transpose_many_mask(int b, int m, int n, Tensor nonzeros, Tensor values, "
       "Tensor row_offsets, Tensor column_indices) -> Tensor[]");
   m.def("transpose_last2(Tensor x) -> Tensor");
+  m.def("transpose_last2_as(Tensor x, int out_type) -> Tensor");
 }
 
 // "CUDA" is the dispatch key of HIP tensors in a ROCm build of PyTorch.
@@ -901,4 +920,5 @@ TORCH_LIBRARY_IMPL(torch_sputnik, CUDA, m) {
   m.impl("sparse_softmax_backward_many_mask", &sparse_softmax_backward_many_mask);
   m.impl("csr_transpose_many_mask", &csr_transpose_many_mask);
   m.impl("transpose_last2", &transpose_last2);
+  m.impl("transpose_last2_as", &transpose_last2_as);
 }

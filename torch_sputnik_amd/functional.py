@@ -191,22 +191,33 @@ def _attention(query, key, value, row_indices, row_offsets, column_indices, scal
 class TransposeLast2(torch.autograd.Function):
     """``x.transpose(-1, -2).contiguous()`` as one tiled kernel (ops.transpose_last2):
     the layout pass of modules/sparse_linear.py:89 and
-    modules/sparse_attention.py:108-126.  Its gradient is the same operation."""
+    modules/sparse_attention.py:108-126, optionally widening half-precision
+    storage to float32 on the way.  Its gradient is the same operation (narrowing
+    back to the input's storage type inside the pass)."""
 
     @staticmethod
-    def forward(ctx, x):
-        return ops.transpose_last2(x)
+    def forward(ctx, x, dtype=None):
+        ctx.in_dtype = x.dtype
+        return ops.transpose_last2(x, dtype)
 
     @staticmethod
     def backward(ctx, grad_output):
-        return ops.transpose_last2(grad_output)
+        return ops.transpose_last2(grad_output, ctx.in_dtype), None
 
 
-def transpose_last2(x):
-    """Differentiable ``x.transpose(-1, -2).contiguous()``."""
+def transpose_last2(x, dtype=None):
+    """Differentiable ``x.transpose(-1, -2).contiguous()`` (``.to(dtype)``)."""
     if torch.is_grad_enabled() and x.requires_grad:
-        return TransposeLast2.apply(x)
-    return ops.transpose_last2(x)
+        return TransposeLast2.apply(x, dtype)
+    return ops.transpose_last2(x, dtype)
+
+
+def _to_operand(x):
+    """[B, S, in] -> the k-major float32 operand [B, in, S] of left_spmm.  The
+    operators compute and return float32 whatever the storage type
+    (src/spmm_cuda.cu:42); half-precision activations are widened inside this
+    pass instead of in one of their own."""
+    return transpose_last2(x, torch.float32 if x.dtype in (torch.float16, torch.bfloat16) else None)
 
 
 class Spmm(torch.autograd.Function):

@@ -44,7 +44,7 @@ class SparseLinear(nn.Module):
         # [B, S, in] -> the k-major operand [B, in, S] of left_spmm: the reference's
         # `x.transpose(1, 2).contiguous()` (modules/sparse_linear.py:89) as one tiled
         # kernel (same values, same layout)
-        return self.project(functional.transpose_last2(x))
+        return self.project(functional._to_operand(x))
 
     def project(self, dense):
         """``W @ dense`` for an operand that is already k-major: [B, in, S] ->
@@ -150,10 +150,10 @@ class SparseAttention(nn.Module):
         heads, dim = self.num_heads, self.head_dim
         inputs = (query, key, value)
         if query is key and key is value:
-            shared = functional.transpose_last2(query)
+            shared = functional._to_operand(query)
             operands = (shared, shared, shared)
         else:
-            operands = tuple(functional.transpose_last2(x) for x in inputs)
+            operands = tuple(functional._to_operand(x) for x in inputs)
 
         def head_split(projected):   # [B, H*D, S] -> [B*H, S, D]
             return functional.transpose_last2(projected.reshape(batch_size * heads, dim, seq))

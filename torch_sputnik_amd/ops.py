@@ -190,8 +190,18 @@ def sparse_attention_planned(query, key, value, row_indices, row_offsets, column
                                          column_indices, float(scale), plan)
 
 
-def transpose_last2(x):
+_TYPE_CODES = None
+
+
+def transpose_last2(x, dtype=None):
     """``x.transpose(-1, -2).contiguous()`` as one tiled HIP kernel: the layout
     pass in front of / behind every SparseLinear (modules/sparse_linear.py:89,
-    modules/sparse_attention.py:108-126)."""
-    return _ops.transpose_last2(x)
+    modules/sparse_attention.py:108-126).  ``dtype`` (float32 / float16 /
+    bfloat16) changes the storage type inside the same pass."""
+    global _TYPE_CODES
+    if dtype is None or dtype == x.dtype:
+        return _ops.transpose_last2(x)
+    if _TYPE_CODES is None:
+        import torch
+        _TYPE_CODES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+    return _ops.transpose_last2_as(x, _TYPE_CODES[dtype])
