@@ -293,9 +293,29 @@ def other_ops(dev):
     t = event_time_ms(lambda: capi.sddmm_batched(s, d, s, reps, ri, ro, ci, q, kk, scores, sd_ws), 20)
     by = reps * (8.0 * s * d + 4.0 * nnz) + 4.0 * nnz + 4.0 * (2 * s + 1)
     res["sddmm_c3"] = {"ms": t, "gflops": 2.0 * nnz * d * reps / t / 1e6, "alg_gbs": by / t / 1e6}
-    t = event_time_ms(lambda: capi.sparse_softmax_batched(s, reps, scores, ri, ro, ci, probs), 20)
+    t = event_time_ms(lambda: capi.sparse_softmax_batched(s, reps, scores, ri, ro, ci, probs), 50)
     by = reps * 8.0 * nnz + 4.0 * (2 * s + 1)
-    res["softmax_c3"] = {"ms": t, "alg_gbs": by / t / 1e6, "hbm_frac": by / t / 1e6 / HBM_PEAK_GBS}
+    res["softmax_c3"] = {"ms": t, "alg_gbs": by / t / 1e6, "hbm_frac": by / t / 1e6 / HBM_PEAK_GBS,
+                         "replicas": reps}
+    # the same bytes through a device copy: what the memory system gives a perfectly
+    # streaming kernel of this size (53.7 MB is a 10 us kernel: the launch ramp counts)
+    t_copy = event_time_ms(lambda: probs.copy_(scores), 50)
+    res["softmax_c3"]["device_copy_same_bytes_ms"] = t_copy
+    res["softmax_c3"]["device_copy_hbm_frac"] = by / t_copy / 1e6 / HBM_PEAK_GBS
+    grad = torch.empty_like(scores)
+    t = event_time_ms(lambda: capi.sparse_softmax_backward_batched(s, reps, probs, scores, ro, 1.0, grad), 50)
+    res["softmax_backward_c3"] = {"ms": t, "alg_gbs": reps * 12.0 * nnz / t / 1e6,
+                                  "hbm_frac": reps * 12.0 * nnz / t / 1e6 / HBM_PEAK_GBS}
+    try:   # 512 replicas: the launch ramp amortised
+        big = uniform((512, nnz), dev, 31)
+        big_out = torch.empty_like(big)
+        t = event_time_ms(lambda: capi.sparse_softmax_batched(s, 512, big, ri, ro, ci, big_out), 20)
+        res["softmax_c3_r512"] = {"ms": t, "hbm_frac": 512 * 8.0 * nnz / t / 1e6 / HBM_PEAK_GBS}
+        t = event_time_ms(lambda: capi.sparse_softmax_backward_batched(s, 512, big_out, big, ro, 1.0, big), 20)
+        res["softmax_backward_c3_r512"] = {"ms": t, "hbm_frac": 512 * 12.0 * nnz / t / 1e6 / HBM_PEAK_GBS}
+        del big, big_out
+    except Exception as e:  # noqa: BLE001
+        res["softmax_c3_r512"] = {"error": str(e)[:200]}
     ws3 = torch.empty(capi.spmm_workspace_bytes(s, s, d, nnz) + 16, dtype=torch.uint8, device=dev)
     t = event_time_ms(lambda: capi.spmm_batched(s, s, d, reps, ri, probs, nnz, ro, ci, v, ctx, ws3), 20)
     by = reps * (4.0 * nnz + 8.0 * s * d) + 4.0 * nnz + 4.0 * (2 * s + 1)
@@ -333,6 +353,23 @@ def other_ops(dev):
         res["sparse_attention_forward_c3"] = {"ms": t, "batch": batch, "heads": heads, "seq": s,
                                               "head_dim": emb // heads, "mask_density": 0.1,
                                               "projection_density": 0.1}
+        # forward + backward of the whole module (gradients to the inputs and to every
+        # projection's values), through the one-kernel attention forward with the
+        # recomputing backward (fused_training) and through the separate operators
+        for key, flags in (("sparse_attention_fwd_bwd_c3_fused_training", {"fused_training": True}),
+                           ("sparse_attention_fwd_bwd_c3_separate_ops", {"differentiable_softmax": True})):
+            for name, value in {"fused_training": False, "differentiable_softmax": False, **flags}.items():
+                setattr(attn, name, value)
+            xg = x.clone().requires_grad_(True)
+            gout = torch.randn(batch, s, emb, device=dev)
+
+            def fwd_bwd():
+                xg.grad = None
+                for lin in attn.linears:
+                    lin.values.grad = None
+                attn(xg, xg, xg, None).backward(gout)
+
+            res[key] = {"ms": event_time_ms(fwd_bwd, 10)}
     except Exception as e:  # noqa: BLE001 - extra metric, best effort
         res["sparse_attention_forward_c3"] = {"error": str(e)[:200]}
     # dense widths that are no multiple of a tile width (the reference takes any n,

@@ -337,6 +337,18 @@ SPUTNIK_HIP_API int sputnik_hip_csr_transpose_many_mask(int masks, int m, int n,
                              sputnik_hip_stream_t stream);
 
 /*
+ * out[r][i] = in[r][permutation[i]], i < n, for `rows` value arrays (strides in
+ * elements) that share one permutation: the values of a static pattern in the
+ * order of its transpose, given the permutation sputnik_hip_csr_transpose
+ * returned once (out_permutation).  Replaces the per-backward csr_transpose of
+ * modules/spmm.py:59-62, modules/sddmm.py:60-63 and
+ * modules/sparse_linear.py:52-55 for topologies that do not change.
+ */
+SPUTNIK_HIP_API int sputnik_hip_permute_last_batched(int n, int rows, const float* in, int64_t in_stride,
+                                     const int* permutation, float* out,
+                                     int64_t out_stride, sputnik_hip_stream_t stream);
+
+/*
  * The library's developer / test knobs (SPUTNIK_HIP_* environment variables:
  * kernel choice for small inputs, timing experiments) are read once, at first
  * use, never on the launch path; this re-reads them.  Not to be called while

@@ -139,6 +139,10 @@ def _csr_transpose_many_mask(b, m, n, nonzeros, values, row_offsets, column_indi
     return [_f32(v), torch.from_numpy(ro), torch.from_numpy(ci)]
 
 
+def _permute_last(values, permutation):
+    return values.float().index_select(-1, permutation.long())
+
+
 def _transpose_last2(x):
     return x.transpose(-1, -2).contiguous()
 
@@ -201,5 +205,6 @@ def install():
     _lib.impl("sparse_softmax_many_mask_scaled", _sparse_softmax_many_mask_scaled, "CPU")
     _lib.impl("sparse_softmax_backward_many_mask", _sparse_softmax_backward_many_mask, "CPU")
     _lib.impl("csr_transpose_many_mask", _csr_transpose_many_mask, "CPU")
+    _lib.impl("permute_last", _permute_last, "CPU")
     _lib.impl("transpose_last2", _transpose_last2, "CPU")
     _lib.impl("transpose_last2_as", _transpose_last2_as, "CPU")

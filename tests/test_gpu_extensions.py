@@ -575,3 +575,13 @@ def test_transpose_last2_with_storage_change(dev, src, dst, shape):
     got = ops.transpose_last2(x, dst)
     want = x.transpose(-1, -2).contiguous().to(dst)
     assert got.dtype == dst and got.is_contiguous() and torch.equal(got, want)
+
+
+@pytest.mark.parametrize("rows,n", [(1, 1000), (64, 104860), (8, 838864), (3, 17)])
+def test_permute_last_matches_index_select(dev, rows, n):
+    from torch_sputnik_amd import ops
+    g = torch.Generator(device=dev).manual_seed(n)
+    values = torch.randn(rows, n, device=dev, generator=g)
+    perm = torch.randperm(n, device=dev, generator=g).to(torch.int32)
+    assert torch.equal(ops.permute_last(values, perm), values.index_select(-1, perm.long()))
+    assert torch.equal(ops.permute_last(values[0].contiguous(), perm), values[0][perm.long()])

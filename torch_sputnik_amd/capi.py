@@ -76,6 +76,7 @@ SIGNATURES = {
     "sputnik_hip_sparse_softmax_backward_many_mask": (_c_int, [_c_int] * 2 + [
         _c_ptr, _c_int, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_float, _c_ptr, _c_i64, _c_ptr]),
     "sputnik_hip_transpose_batched": (_c_int, [_c_int] * 3 + [_c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr]),
+    "sputnik_hip_permute_last_batched": (_c_int, [_c_int] * 2 + [_c_ptr, _c_i64, _c_ptr, _c_ptr, _c_i64, _c_ptr]),
     "sputnik_hip_transpose_cast_batched": (_c_int, [_c_int] * 3 + [_c_ptr, _c_int, _c_i64, _c_ptr, _c_int,
                                                                   _c_i64, _c_ptr]),
     "sputnik_hip_csr_transpose_many_mask": (_c_int, [_c_int] * 3 + [

@@ -99,6 +99,29 @@ __global__ __launch_bounds__(kThreads) void transpose_tiles_kernel(
   }
 }
 
+// out[r][i] = in[r][perm[i]] for R value rows sharing one permutation: the
+// transposed-topology values of a static pattern (functional.TransposeCache keeps
+// the permutation; the reference re-runs csr_transpose per backward,
+// modules/spmm.py:59-62).  A thread owns one output slot i for all rows: the
+// permutation entry is read once, the writes are coalesced; the reads are 4-byte
+// gathers inside one row of `in` at a time (a row of a few hundred KB: L2 hits).
+constexpr int kGatherRows = 8;   // value rows in flight per thread
+__global__ __launch_bounds__(kThreads) void permute_last_kernel(
+    int n, int rows, const float* __restrict__ in, int64_t in_stride,
+    const int* __restrict__ perm, float* __restrict__ out, int64_t out_stride) {
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n) return;
+  const int p = perm[i];
+  const int r0 = blockIdx.y * kGatherRows;
+  float v[kGatherRows];
+#pragma unroll
+  for (int j = 0; j < kGatherRows; ++j)
+    v[j] = r0 + j < rows ? in[(r0 + j) * in_stride + p] : 0.f;
+#pragma unroll
+  for (int j = 0; j < kGatherRows; ++j)
+    if (r0 + j < rows) out[(r0 + j) * out_stride + i] = v[j];
+}
+
 template <typename TIn, typename TOut>
 int launch_transpose(int batches, int rows, int cols, const void* in_v, int64_t in_batch_stride,
                      void* out_v, int64_t out_batch_stride, hipStream_t stream) {
@@ -139,6 +162,18 @@ int sputnik_hip_transpose_batched(int batches, int rows, int cols, const float* 
   return sputnik_hip_transpose_cast_batched(batches, rows, cols, in, SPUTNIK_HIP_F32,
                                             in_batch_stride, out, SPUTNIK_HIP_F32,
                                             out_batch_stride, stream);
+}
+
+int sputnik_hip_permute_last_batched(int n, int rows, const float* in, int64_t in_stride,
+                                     const int* permutation, float* out, int64_t out_stride,
+                                     sputnik_hip_stream_t stream) {
+  if (n < 0 || rows < 0) return SPUTNIK_HIP_INVALID_ARGUMENT;
+  if (n == 0 || rows == 0) return 0;
+  const int by = ceil_div(rows, kGatherRows);
+  if (by > kMaxGridYZ) return SPUTNIK_HIP_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(permute_last_kernel, dim3(ceil_div(n, kThreads), by), dim3(kThreads), 0,
+                     stream, n, rows, in, in_stride, permutation, out, out_stride);
+  return launch_status();
 }
 
 int sputnik_hip_transpose_cast_batched(int batches, int rows, int cols, const void* in,

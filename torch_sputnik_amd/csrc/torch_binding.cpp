@@ -809,6 +809,29 @@ Tensor transpose_last2_as(const Tensor& x_in, int64_t out_type) {
 
 Tensor transpose_last2(const Tensor& x) { return transpose_last2_as(x, -1); }
 
+// values[..., permutation] for value arrays [nnz] / [R, nnz] that share one int32
+// permutation (the transposed order of a static pattern): `index_select(-1, perm)`
+// as one kernel that reads the permutation once for all rows.
+Tensor permute_last(const Tensor& values_in, const Tensor& permutation) {
+  const Tensor values = as_float(values_in, "values");
+  TORCH_CHECK(values.dim() == 1 || values.dim() == 2, "values should have 1 or 2 dimensions, got ",
+              values.dim());
+  TORCH_CHECK(permutation.scalar_type() == at::kInt && permutation.dim() == 1 &&
+                  permutation.is_contiguous() && permutation.device() == values.device(),
+              "permutation must be a contiguous int32 vector on ", values.device());
+  TORCH_CHECK(permutation.size(0) == values.size(-1), "permutation has ", permutation.size(0),
+              " entries, values ", values.size(-1));
+  const c10::DeviceGuard guard(values.device());
+  const int n = to_int(values.size(-1), "n");
+  const int rows = values.dim() == 2 ? to_int(values.size(0), "rows") : 1;
+  Tensor out = at::empty_like(values);
+  check_status(sputnik_hip_permute_last_batched(n, rows, values.data_ptr<float>(), n,
+                                                permutation.data_ptr<int>(),
+                                                out.data_ptr<float>(), n, current_stream(values)),
+               "permute_last");
+  return out;
+}
+
 }  // namespace
 
 TORCH_LIBRARY(torch_sputnik, m) {
@@ -888,6 +911,7 @@ TORCH_LIBRARY(torch_sputnik, m) {
   m.def(
       "csr_transpose_many_mask(int b, int m, int n, Tensor nonzeros, Tensor values, "
       "Tensor row_offsets, Tensor column_indices) -> Tensor[]");
+  m.def("permute_last(Tensor values, Tensor permutation) -> Tensor");
   m.def("transpose_last2(Tensor x) -> Tensor");
   m.def("transpose_last2_as(Tensor x, int out_type) -> Tensor");
 }
@@ -919,6 +943,7 @@ TORCH_LIBRARY_IMPL(torch_sputnik, CUDA, m) {
   m.impl("sparse_softmax_many_mask_scaled", &sparse_softmax_many_mask_scaled);
   m.impl("sparse_softmax_backward_many_mask", &sparse_softmax_backward_many_mask);
   m.impl("csr_transpose_many_mask", &csr_transpose_many_mask);
+  m.impl("permute_last", &permute_last);
   m.impl("transpose_last2", &transpose_last2);
   m.impl("transpose_last2_as", &transpose_last2_as);
 }

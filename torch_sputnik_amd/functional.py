@@ -72,7 +72,7 @@ class TransposeCache:
                 m, n, probe_values.detach().reshape(-1, probe_values.shape[-1])[0].contiguous(),
                 row_offsets, column_indices)
             entry = self._entries.put(key, (diffsort(row_offsets_t), row_offsets_t,
-                                            column_indices_t, permutation.to(torch.int64),
+                                            column_indices_t, permutation.contiguous(),
                                             row_offsets, column_indices))
         return entry[:4]
 
@@ -153,7 +153,7 @@ def _transpose(m, n, values, row_offsets, column_indices):
     if _cache is not None:
         row_indices_t, row_offsets_t, column_indices_t, perm = _cache.lookup(
             m, n, row_offsets, column_indices, values)
-        return values.index_select(-1, perm), row_indices_t, row_offsets_t, column_indices_t
+        return ops.permute_last(values, perm), row_indices_t, row_offsets_t, column_indices_t
     values_t, row_offsets_t, column_indices_t = ops.csr_transpose(
         m, n, values, row_offsets, column_indices)
     return values_t, diffsort(row_offsets_t), row_offsets_t, column_indices_t
@@ -383,12 +383,12 @@ class SparseAttentionFunction(torch.autograd.Function):
                 _, row_offsets_t, column_indices_t, perm = ops.csr_transpose_with_permutation(
                     m, n, grad_scores.reshape(-1, grad_scores.shape[-1])[0].contiguous(),
                     row_offsets, column_indices)
-                row_indices_t, perm = diffsort(row_offsets_t), perm.to(torch.int64)
+                row_indices_t = diffsort(row_offsets_t)
             if ctx.needs_input_grad[1]:
-                grad_key = _spmm(n, m, grad_scores.index_select(-1, perm), row_indices_t,
+                grad_key = _spmm(n, m, ops.permute_last(grad_scores, perm), row_indices_t,
                                  row_offsets_t, column_indices_t, query)
             if ctx.needs_input_grad[2]:
-                grad_value = _spmm(n, m, weights.index_select(-1, perm), row_indices_t,
+                grad_value = _spmm(n, m, ops.permute_last(weights, perm), row_indices_t,
                                    row_offsets_t, column_indices_t, grad_output)
         return grad_query, grad_key, grad_value, None, None, None, None
 

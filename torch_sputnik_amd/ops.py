@@ -205,3 +205,10 @@ def transpose_last2(x, dtype=None):
         import torch
         _TYPE_CODES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
     return _ops.transpose_last2_as(x, _TYPE_CODES[dtype])
+
+
+def permute_last(values, permutation):
+    """``values[..., permutation]`` for value arrays [nnz] / [R, nnz] sharing one
+    int32 permutation (a static pattern's transposed order): one kernel, the
+    permutation read once for all rows.  float32 out."""
+    return _ops.permute_last(values, permutation)
