@@ -97,6 +97,10 @@ class SparseAttention(nn.Module):
         # backward instead of being kept (and, unlike the reference's raw softmax
         # call, the gradient reaches Q and K)
         self.fused_training = fused_training
+        # The three input projections on side streams (their grids are small).  Off:
+        # measured at config 3, the event traffic costs more than the overlap gives
+        # (forward 0.253 ms on one stream, 0.28-0.30 ms on three; fwd+bwd 1.04 / 1.11).
+        self.parallel_projections = False
 
     def attention(self, query, key, value, mask):
         """[B, H, S, D] operands, as modules/sparse_attention.py:66-82."""
@@ -144,8 +148,8 @@ class SparseAttention(nn.Module):
           + x^T copy of the last layer   which IS the last layer's k-major operand
 
         i.e. 7 passes (5 when query, key and value are one tensor) instead of 11, each
-        one tiled kernel.  The three input projections are independent: without
-        autograd they run on side streams so that their small grids share the chip."""
+        one tiled kernel.  (`parallel_projections` runs the three input projections on
+        side streams; measured slower at config 3, off by default.)"""
         batch_size, seq = query.size(0), query.size(1)
         heads, dim = self.num_heads, self.head_dim
         inputs = (query, key, value)
@@ -158,12 +162,11 @@ class SparseAttention(nn.Module):
         def head_split(projected):   # [B, H*D, S] -> [B*H, S, D]
             return functional.transpose_last2(projected.reshape(batch_size * heads, dim, seq))
 
-        needs_grad = torch.is_grad_enabled() and (
-            any(x.requires_grad for x in inputs) or
-            any(layer.values.requires_grad for layer in self.linears))
-        if needs_grad or not query.is_cuda:
+        if not (query.is_cuda and self.parallel_projections):
             q3d, k3d, v3d = (head_split(net.project(d)) for net, d in zip(self.linears, operands))
         else:
+            # (under autograd the backward of each projection runs on the stream its
+            # forward ran on, so the three weight / input gradients overlap as well)
             main = torch.cuda.current_stream(query.device)
             results = [None, None, None]
             results[0] = head_split(self.linears[0].project(operands[0]))
