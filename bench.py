@@ -179,18 +179,28 @@ class Exchange:
                 exchange_chunk(c)
         main.wait_stream(self.side)
 
+    def poison(self):
+        """Before a schedule runs: the first row of every block of the gathered buffer
+        is overwritten, so that verify() cannot pass on what an earlier schedule left."""
+        self.flat.view(-1, N)[::M].fill_(float("nan"))
+
     def verify(self, schedule):
-        """After the timed steps: this rank's block must sit where the schedule put it."""
+        """After a schedule's timed steps: EVERY rank's block must sit where the schedule
+        puts it.  Checked through a fingerprint of each block (its first row), which
+        all ranks exchange separately with a small all_gather."""
         torch.cuda.synchronize()
         if not schedule.startswith("allgather"):
             return
+        r = self.problem.replicas
+        mine = self.local[:, 0, :].contiguous()                       # [r, N]
+        prints = torch.empty((self.world, r, N), device=self.dev)
+        self.dist.all_gather_into_tensor(prints.view(-1, N), mine)
         if schedule == "allgather_overlapped_collective":
             for c, (a, b) in enumerate(self.bounds):
-                got = self.chunk_major[c].view(self.world, b - a, M, N)[self.rank]
-                assert torch.equal(got, self.local[a:b]), "gathered chunk differs from the local block"
+                got = self.chunk_major[c].view(self.world, b - a, M, N)[:, :, 0, :]
+                assert torch.equal(got, prints[:, a:b]), f"{schedule}: gathered chunk {c} is wrong"
         else:
-            assert torch.equal(self.rank_major[self.rank], self.local), \
-                "gathered block differs from the local block"
+            assert torch.equal(self.rank_major[:, :, 0, :], prints), f"{schedule}: gathered blocks are wrong"
 
     def report(self, timings, n_gpus):
         flops = self.problem.flops * n_gpus
@@ -581,14 +591,17 @@ def main():
         timings = {}
         for name, fn in variants.items():
             try:
+                ex.poison()
                 timings[name] = run_timed(fn)
+                # (the schedules share one gathered buffer in different layouts: each is
+                # checked right after its own run)
+                ex.verify(name)
             except Exception as e:  # noqa: BLE001 - one schedule failing must not lose the others
                 timings[name] = None
                 print(f"[bench] rank {rank}: schedule {name} failed: {e}", file=sys.stderr)
         gathered_names = [k for k, v in timings.items() if k.startswith("allgather") and v]
         headline = min(gathered_names, key=lambda k: timings[k]) if gathered_names else "compute_only"
         ms_per_step = timings[headline]
-        ex.verify(headline)
         multi = ex.report(timings, n_gpus)
 
     total_flops = problem.flops * n_gpus
