@@ -58,7 +58,7 @@ __device__ __forceinline__ f4 load_piece(const char* __restrict__ base, unsigned
 // passes (re-reads served by L2).  exp is the hardware v_exp_f32 path (__expf):
 // relative error about 5e-6 at |x - max| ~ 88, far inside the 1e-4 budget; the
 // accurate library expf made the kernel VALU-bound.
-template <int LPR, int V, bool BACKWARD, int DEPTH>
+template <int LPR, int BASE, int V, bool BACKWARD, int DEPTH>
 __global__ __launch_bounds__(kBlock) void sparse_softmax_rows_kernel(
     int m, int rows_per_group, int nonzeros, const float* __restrict__ a, int64_t a_stride,
     const float* __restrict__ b, int64_t b_stride, const int* __restrict__ row_offsets,
@@ -102,6 +102,7 @@ __global__ __launch_bounds__(kBlock) void sparse_softmax_rows_kernel(
   struct Row {
     int p0, len, s;   // first entry, length, start of the first aligned piece
     bool fast;
+    bool extra;       // wave-uniform: some row of this step reaches past BASE pieces
     f4 x[V], y[V];
   };
   // The run's row bounds, loaded ONCE (lane i of the group holds those of its
@@ -120,8 +121,14 @@ __global__ __launch_bounds__(kBlock) void sparse_softmax_rows_kernel(
     w.s = p0 - ((p0 + phase) & 3);
     const int last_piece = ((p1 - 1 + phase) & ~3) - phase;
     w.fast = same_phase && p1 - w.s <= kWindow && w.s >= qmin && last_piece <= qmax;
+    // Pieces BASE .. V-1 exist for the few rows that are much longer than the
+    // mean: they are requested and worked on only in the steps in which some row
+    // of the wave needs them (a wave-uniform branch: no exp, no load and no store
+    // is spent on them otherwise).
+    w.extra = BASE < V && __builtin_amdgcn_ballot_w64(w.fast && p1 - w.s > BASE * 4 * LPR) != 0;
 #pragma unroll
     for (int v = 0; v < V; ++v) {
+      if (v >= BASE && !w.extra) continue;
       const int q = w.s + 4 * l + v * (4 * LPR);
       const unsigned off = static_cast<unsigned>(min(max(q, qmin), qmax) + 4) * 4u;
       w.x[v] = load_piece(a_bytes, off);
@@ -142,6 +149,7 @@ __global__ __launch_bounds__(kBlock) void sparse_softmax_rows_kernel(
       f4 res[V];
 #pragma unroll
       for (int v = 0; v < V; ++v) {
+        if (v >= BASE && !cur.extra) continue;
         const int t = cur.s + 4 * l + v * (4 * LPR) - p0;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -150,37 +158,46 @@ __global__ __launch_bounds__(kBlock) void sparse_softmax_rows_kernel(
       if constexpr (!BACKWARD) {
         float mx = -INFINITY;
 #pragma unroll
-        for (int v = 0; v < V; ++v)
+        for (int v = 0; v < V; ++v) {
+          if (v >= BASE && !cur.extra) continue;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             cur.x[v][i] = valid[v][i] ? cur.x[v][i] * scale : -INFINITY;
             mx = fmaxf(mx, cur.x[v][i]);
           }
+        }
         mx = group_max<LPR>(mx);
         float sum = 0.f;
 #pragma unroll
-        for (int v = 0; v < V; ++v)
+        for (int v = 0; v < V; ++v) {
+          if (v >= BASE && !cur.extra) continue;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             cur.x[v][i] = __expf(cur.x[v][i] - mx);   // exp(-inf) = 0 for the masked slots
             sum += cur.x[v][i];
           }
+        }
         sum = group_sum<LPR>(sum);
         const float inv = __builtin_amdgcn_rcpf(sum);   // 1 ulp
 #pragma unroll
-        for (int v = 0; v < V; ++v) res[v] = cur.x[v] * inv;
+        for (int v = 0; v < V; ++v)
+          if (v < BASE || cur.extra) res[v] = cur.x[v] * inv;
       } else {
         float dot = 0.f;
 #pragma unroll
-        for (int v = 0; v < V; ++v)
+        for (int v = 0; v < V; ++v) {
+          if (v >= BASE && !cur.extra) continue;
 #pragma unroll
           for (int i = 0; i < 4; ++i) dot += valid[v][i] ? cur.x[v][i] * cur.y[v][i] : 0.f;
+        }
         dot = group_sum<LPR>(dot);
 #pragma unroll
-        for (int v = 0; v < V; ++v) res[v] = scale * cur.x[v] * (cur.y[v] - dot);
+        for (int v = 0; v < V; ++v)
+          if (v < BASE || cur.extra) res[v] = scale * cur.x[v] * (cur.y[v] - dot);
       }
 #pragma unroll
       for (int v = 0; v < V; ++v) {
+        if (v >= BASE && !cur.extra) continue;
         const int q = cur.s + 4 * l + v * (4 * LPR);
         if (valid[v][0] && valid[v][3]) {
           *reinterpret_cast<f4*>(out + q) = res[v];
@@ -228,7 +245,7 @@ inline int phase_of(const void* p, int64_t stride) {
   return static_cast<int>((reinterpret_cast<uintptr_t>(p) / sizeof(float)) % 4);
 }
 
-template <int LPR, int V, bool BACKWARD>
+template <int LPR, int BASE, int V, bool BACKWARD>
 int launch_rows(int m, int nonzeros, int replicas, const float* a, int64_t a_stride, const float* b,
                 int64_t b_stride, const int* row_offsets, float* out, int64_t out_stride,
                 float scale, hipStream_t stream) {
@@ -256,7 +273,7 @@ int launch_rows(int m, int nonzeros, int replicas, const float* a, int64_t a_str
                            phase_of(a_r, a_stride) == phase_of(out_r, out_stride) &&
                            (!BACKWARD || phase_of(a_r, a_stride) == phase_of(b_r, b_stride));
 #define SPUTNIK_HIP_SOFTMAX_LAUNCH(DEPTH)                                                         \
-  hipLaunchKernelGGL((sparse_softmax_rows_kernel<LPR, V, BACKWARD, DEPTH>), dim3(gx, ry),        \
+  hipLaunchKernelGGL((sparse_softmax_rows_kernel<LPR, BASE, V, BACKWARD, DEPTH>), dim3(gx, ry),  \
                      dim3(kBlock), 0, stream, m, rows_per_group, nonzeros, a_r, a_stride, b_r,   \
                      b_stride, row_offsets, out_r, out_stride, scale, same_phase)
     if (depth == 3) SPUTNIK_HIP_SOFTMAX_LAUNCH(3);
@@ -269,10 +286,11 @@ int launch_rows(int m, int nonzeros, int replicas, const float* a, int64_t a_str
   return 0;
 }
 
-// Smallest window (LPR lanes x V pieces of four entries) that holds nearly every
-// row: mean + ~2.2 standard deviations of a random pattern + the alignment slack
-// (every unused register slot costs an exp; the few longer rows take the
-// strided passes).
+// BASE pieces of four entries per lane cover the typical row (mean + ~2.2
+// standard deviations of a random pattern + the alignment slack: every register
+// slot costs an exp); up to V pieces are there for the few longer rows and are
+// paid for only in the steps that need them.  Rows beyond LPR * 4 * V take the
+// strided passes.
 template <bool BACKWARD>
 int dispatch_rows(int m, int nonzeros, int replicas, const float* a, int64_t a_stride,
                   const float* b, int64_t b_stride, const int* row_offsets, float* out,
@@ -281,15 +299,15 @@ int dispatch_rows(int m, int nonzeros, int replicas, const float* a, int64_t a_s
   int64_t dev = 1;
   while (dev * dev < 5 * mean) ++dev;   // ~ 2.2 * sqrt(mean)
   const int64_t need = mean + dev + 3;
-#define SPUTNIK_HIP_SOFTMAX_CASE(LPR, V)                                                          \
-  return launch_rows<LPR, V, BACKWARD>(m, nonzeros, replicas, a, a_stride, b, b_stride,           \
-                                       row_offsets, out, out_stride, scale, stream)
-  if (need <= 64) SPUTNIK_HIP_SOFTMAX_CASE(16, 1);
-  if (need <= 128) SPUTNIK_HIP_SOFTMAX_CASE(16, 2);
-  if (need <= 192) SPUTNIK_HIP_SOFTMAX_CASE(16, 3);
-  if (need <= 256) SPUTNIK_HIP_SOFTMAX_CASE(32, 2);
-  if (need <= 512) SPUTNIK_HIP_SOFTMAX_CASE(32, 4);
-  SPUTNIK_HIP_SOFTMAX_CASE(64, 4);
+#define SPUTNIK_HIP_SOFTMAX_CASE(LPR, BASE, V)                                                    \
+  return launch_rows<LPR, BASE, V, BACKWARD>(m, nonzeros, replicas, a, a_stride, b, b_stride,     \
+                                             row_offsets, out, out_stride, scale, stream)
+  if (need <= 64) SPUTNIK_HIP_SOFTMAX_CASE(16, 1, 2);
+  if (need <= 128) SPUTNIK_HIP_SOFTMAX_CASE(16, 2, 3);
+  if (need <= 192) SPUTNIK_HIP_SOFTMAX_CASE(16, 3, 4);
+  if (need <= 256) SPUTNIK_HIP_SOFTMAX_CASE(32, 2, 4);
+  if (need <= 512) SPUTNIK_HIP_SOFTMAX_CASE(32, 4, 4);
+  SPUTNIK_HIP_SOFTMAX_CASE(64, 4, 4);
 #undef SPUTNIK_HIP_SOFTMAX_CASE
 }
 
