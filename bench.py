@@ -124,23 +124,26 @@ class Exchange:
         import torch.distributed as dist
         self.dist, self.problem, self.world, self.rank, self.dev = dist, problem, world, rank, dev
         r = problem.replicas
-        self.local = problem.out.reshape(r, M, N)
-        self.flat = torch.empty(world * r * M * N, device=dev)
-        self.rank_major = self.flat.view(world, r, M, N)          # = global replica order
+        m, n = problem.out.shape[-2:]            # (4096 x 4096 in the benchmark)
+        self.m, self.n = m, n
+        self.local = problem.out.reshape(r, m, n)
+        self.flat = torch.empty(world * r * m * n, device=dev)
+        self.rank_major = self.flat.view(world, r, m, n)          # = global replica order
         per = (r + chunks - 1) // chunks
         self.bounds = [(a, min(a + per, r)) for a in range(0, r, per)]
         # collective chunks land chunk-major ([chunk][rank][replicas of the chunk]):
         # one contiguous all_gather_into_tensor each, in the same storage
         self.chunk_major, off = [], 0
         for a, b in self.bounds:
-            size = world * (b - a) * M * N
-            self.chunk_major.append(self.flat[off:off + size].view(world * (b - a), M, N))
+            size = world * (b - a) * m * n
+            self.chunk_major.append(self.flat[off:off + size].view(world * (b - a), m, n))
             off += size
-        self.side = torch.cuda.Stream(device=dev)
-        self.bytes_per_peer = r * M * N * 4.0
+        # (tests/test_bench_exchange.py drives this class on CPU tensors over gloo)
+        self.side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self.bytes_per_peer = r * m * n * 4.0
 
     def collective(self):
-        self.dist.all_gather_into_tensor(self.rank_major.view(-1, M, N), self.local)
+        self.dist.all_gather_into_tensor(self.rank_major.view(-1, self.m, self.n), self.local)
 
     def collective_chunk(self, c):
         a, b = self.bounds[c]
@@ -169,6 +172,11 @@ class Exchange:
     def overlapped(self, exchange_chunk):
         """compute chunk i on the main stream; its exchange runs on the side stream
         behind an event while the main stream computes chunk i + 1."""
+        if self.side is None:          # CPU (tests): the same order, no streams
+            for c, (a, b) in enumerate(self.bounds):
+                self.problem.step_range(a, b)
+                exchange_chunk(c)
+            return
         main = torch.cuda.current_stream(self.dev)
         for c, (a, b) in enumerate(self.bounds):
             self.problem.step_range(a, b)
@@ -182,22 +190,23 @@ class Exchange:
     def poison(self):
         """Before a schedule runs: the first row of every block of the gathered buffer
         is overwritten, so that verify() cannot pass on what an earlier schedule left."""
-        self.flat.view(-1, N)[::M].fill_(float("nan"))
+        self.flat.view(-1, self.n)[::self.m].fill_(float("nan"))
 
     def verify(self, schedule):
         """After a schedule's timed steps: EVERY rank's block must sit where the schedule
         puts it.  Checked through a fingerprint of each block (its first row), which
         all ranks exchange separately with a small all_gather."""
-        torch.cuda.synchronize()
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize()
         if not schedule.startswith("allgather"):
             return
-        r = self.problem.replicas
-        mine = self.local[:, 0, :].contiguous()                       # [r, N]
-        prints = torch.empty((self.world, r, N), device=self.dev)
-        self.dist.all_gather_into_tensor(prints.view(-1, N), mine)
+        r, m, n = self.problem.replicas, self.m, self.n
+        mine = self.local[:, 0, :].contiguous()                       # [r, n]
+        prints = torch.empty((self.world, r, n), device=self.dev)
+        self.dist.all_gather_into_tensor(prints.view(-1, n), mine)
         if schedule == "allgather_overlapped_collective":
             for c, (a, b) in enumerate(self.bounds):
-                got = self.chunk_major[c].view(self.world, b - a, M, N)[:, :, 0, :]
+                got = self.chunk_major[c].view(self.world, b - a, m, n)[:, :, 0, :]
                 assert torch.equal(got, prints[:, a:b]), f"{schedule}: gathered chunk {c} is wrong"
         else:
             assert torch.equal(self.rank_major[:, :, 0, :], prints), f"{schedule}: gathered blocks are wrong"
