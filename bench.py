@@ -242,6 +242,44 @@ class Exchange:
         }
 
 
+class Watchdog:
+    """arm(make_line, fd): unless disarm() comes within `seconds`, the process writes
+    make_line() (bytes or None) to fd and exits -- from a daemon thread, because the
+    main thread of a hung run sits inside a blocking runtime call."""
+
+    def __init__(self, seconds):
+        import threading
+        self.seconds = seconds
+        self._lock = threading.Lock()
+        self._deadline = None
+        self._make_line = None
+        self._fd = None
+        threading.Thread(target=self._run, daemon=True).start()
+
+    def arm(self, make_line, fd):
+        with self._lock:
+            self._deadline, self._make_line, self._fd = time.time() + self.seconds, make_line, fd
+
+    def disarm(self):
+        with self._lock:
+            self._deadline = None
+
+    def _run(self):
+        while True:
+            time.sleep(1.0)
+            with self._lock:
+                expired = self._deadline is not None and time.time() > self._deadline
+                make_line, fd = self._make_line, self._fd
+            if expired:
+                line = None
+                try:
+                    line = make_line()
+                    if line:
+                        os.write(fd, line)
+                finally:
+                    os._exit(0 if line else 3)
+
+
 def cpu_baseline(problem):
     """Oracle (C restatement, CSR, OpenMP) timed on the host cores; bounded sample."""
     import numpy as np
@@ -495,6 +533,9 @@ def main():
     ap.add_argument("--replicas-per-gpu", type=int, default=0,
                     help="override (default 1 at --gpus 1, 16 otherwise)")
     ap.add_argument("--no-extras", action="store_true", help="skip sweep / cpu baseline / other ops")
+    ap.add_argument("--schedule-timeout-s", type=float, default=240.0,
+                    help="N>1: a schedule that has not finished after this long ends the run; "
+                         "rank 0 prints the line with the schedules measured so far")
     args = ap.parse_args()
     # Contract: stdout carries ONE JSON line.  Libraries print there too (RCCL's
     # version banner at communicator creation, for one), so stdout is pointed at
@@ -573,55 +614,14 @@ def main():
             problem.step()  # compute only: a time-based loop must not contain collectives
         torch.cuda.synchronize()
 
-    multi = None
-    if not distributed:
-        ms_per_step = run_timed(problem.step)
-        headline = "compute (one GPU: nothing to exchange)"
-    else:
-        # North star / SURVEY.md 8e: the replica-sharded product WITH the all-gather of
-        # C over RCCL.  Every schedule is timed the same way (W + K steps each):
-        #   compute_only                      the local launch, no exchange
-        #   exchange_only_{collective,p2p}    the all-gather alone (link bandwidth)
-        #   allgather_{collective,p2p}        launch, then exchange (unoverlapped)
-        #   allgather_overlapped_{...}        chunk i exchanged while chunk i+1 computes
-        # `value` is the best schedule that includes the all-gather.
-        ex = Exchange(problem, world, rank, dev, max(1, min(args.overlap_chunks, replicas)))
-        variants = {"compute_only": problem.step,
-                    "exchange_only_collective": ex.collective,
-                    "allgather_collective": lambda: (problem.step(), ex.collective()),
-                    "allgather_overlapped_collective": lambda: ex.overlapped(ex.collective_chunk)}
-        if os.environ.get("BENCH_NO_P2P") != "1":
-            variants.update({
-                "exchange_only_p2p": ex.p2p,
-                "allgather_p2p": lambda: (problem.step(), ex.p2p()),
-                "allgather_overlapped_p2p": lambda: ex.overlapped(ex.p2p_chunk)})
-        if args.compute_only:
-            variants = {"compute_only": problem.step}
-        timings = {}
-        for name, fn in variants.items():
-            try:
-                ex.poison()
-                timings[name] = run_timed(fn)
-                # (the schedules share one gathered buffer in different layouts: each is
-                # checked right after its own run)
-                ex.verify(name)
-            except Exception as e:  # noqa: BLE001 - one schedule failing must not lose the others
-                timings[name] = None
-                print(f"[bench] rank {rank}: schedule {name} failed: {e}", file=sys.stderr)
-        gathered_names = [k for k, v in timings.items() if k.startswith("allgather") and v]
-        headline = min(gathered_names, key=lambda k: timings[k]) if gathered_names else "compute_only"
-        ms_per_step = timings[headline]
-        multi = ex.report(timings, n_gpus)
+    # Dominant kernel alone (HIP events on the launch stream = torch's current stream);
+    # before the schedules so that a partial result can carry it (see the watchdog).
+    problem.step()
+    kernel_ms = event_time_ms(problem.kernel_only, max(10, args.steps))
+    achieved_gbs = problem.bytes / (kernel_ms * 1e-3) / 1e9
 
-    total_flops = problem.flops * n_gpus
-    value = total_flops / (ms_per_step * 1e-3) / 1e9
-
-    result = None
-    if rank == 0:
-        # Dominant kernel alone (HIP events on the launch stream = torch's current stream).
-        problem.step()
-        kernel_ms = event_time_ms(problem.kernel_only, max(10, args.steps))
-        achieved_gbs = problem.bytes / (kernel_ms * 1e-3) / 1e9
+    def core_result(headline, ms_per_step, multi):
+        value = problem.flops * n_gpus / (ms_per_step * 1e-3) / 1e9
         result = {
             "metric": "SpMM effective GFLOP/s (2*nnz*N/t), M=N=K=4096 fp32, density 0.1",
             "value": value, "unit": "GFLOP/s", "n_gpus": n_gpus, "steps": args.steps,
@@ -665,6 +665,71 @@ def main():
             result.update({k: multi[k] for k in ("compute_only", "allgather", "allgather_overlapped")})
             result["exchange"] = {k: multi[k] for k in multi
                                   if k not in ("compute_only", "allgather", "allgather_overlapped")}
+        return result
+
+    def pick_headline(timings):
+        gathered = [k for k, v in timings.items() if k.startswith("allgather") and v]
+        return min(gathered, key=lambda k: timings[k]) if gathered else "compute_only"
+
+    multi = None
+    if not distributed:
+        ms_per_step = run_timed(problem.step)
+        headline = "compute (one GPU: nothing to exchange)"
+    else:
+        # North star / SURVEY.md 8e: the replica-sharded product WITH the all-gather of
+        # C over RCCL.  Every schedule is timed the same way (W + K steps each):
+        #   compute_only                      the local launch, no exchange
+        #   exchange_only_{collective,p2p}    the all-gather alone (link bandwidth)
+        #   allgather_{collective,p2p}        launch, then exchange (unoverlapped)
+        #   allgather_overlapped_{...}        chunk i exchanged while chunk i+1 computes
+        # `value` is the best schedule that includes the all-gather.
+        ex = Exchange(problem, world, rank, dev, max(1, min(args.overlap_chunks, replicas)))
+        variants = {"compute_only": problem.step,
+                    "exchange_only_collective": ex.collective,
+                    "allgather_collective": lambda: (problem.step(), ex.collective()),
+                    "allgather_overlapped_collective": lambda: ex.overlapped(ex.collective_chunk)}
+        if os.environ.get("BENCH_NO_P2P") != "1":
+            variants.update({
+                "exchange_only_p2p": ex.p2p,
+                "allgather_p2p": lambda: (problem.step(), ex.p2p()),
+                "allgather_overlapped_p2p": lambda: ex.overlapped(ex.p2p_chunk)})
+        if args.compute_only:
+            variants = {"compute_only": problem.step}
+        timings = {}
+        # A schedule that never returns (a transport that hangs on some fabric) must not
+        # lose the schedules already measured: past the deadline rank 0 prints the line
+        # with what it has and every rank leaves.  (A thread, not a signal: the main
+        # thread would be inside a blocking runtime call.)
+        watchdog = Watchdog(args.schedule_timeout_s)
+        for name, fn in variants.items():
+            def partial_line(name=name):
+                if rank != 0 or not timings.get("compute_only"):
+                    return None
+                done = dict(timings)
+                head = pick_headline(done)
+                line = core_result(head, done[head], ex.report(done, n_gpus))
+                line["watchdog"] = f"schedule {name} did not finish in {args.schedule_timeout_s:.0f} s"
+                return (json.dumps(line) + "\n").encode()
+            watchdog.arm(partial_line, result_fd)
+            try:
+                if os.environ.get("BENCH_TEST_HANG") == name:   # (test of the watchdog)
+                    time.sleep(1e6)
+                ex.poison()
+                timings[name] = run_timed(fn)
+                # (the schedules share one gathered buffer in different layouts: each is
+                # checked right after its own run)
+                ex.verify(name)
+            except Exception as e:  # noqa: BLE001 - one schedule failing must not lose the others
+                timings[name] = None
+                print(f"[bench] rank {rank}: schedule {name} failed: {e}", file=sys.stderr)
+            watchdog.disarm()
+        headline = pick_headline(timings)
+        ms_per_step = timings[headline]
+        multi = ex.report(timings, n_gpus)
+
+    result = None
+    if rank == 0:
+        result = core_result(headline, ms_per_step, multi)
         if not args.no_extras and n_gpus == 1:
             sweep = []
             for d in DENSITIES:
