@@ -247,9 +247,10 @@ class Watchdog:
     make_line() (bytes or None) to fd and exits -- from a daemon thread, because the
     main thread of a hung run sits inside a blocking runtime call."""
 
-    def __init__(self, seconds):
+    def __init__(self, seconds, printer=True):
         import threading
         self.seconds = seconds
+        self.printer = printer   # rank 0: the rank whose line is the result
         self._lock = threading.Lock()
         self._deadline = None
         self._make_line = None
@@ -277,7 +278,9 @@ class Watchdog:
                     if line:
                         os.write(fd, line)
                 finally:
-                    os._exit(0 if line else 3)
+                    # (the other ranks leave quietly: a non-zero exit would make the
+                    # launcher report the whole run as failed although the line is out)
+                    os._exit(0 if (line or not self.printer) else 3)
 
 
 def cpu_baseline(problem):
@@ -700,7 +703,7 @@ def main():
         # lose the schedules already measured: past the deadline rank 0 prints the line
         # with what it has and every rank leaves.  (A thread, not a signal: the main
         # thread would be inside a blocking runtime call.)
-        watchdog = Watchdog(args.schedule_timeout_s)
+        watchdog = Watchdog(args.schedule_timeout_s, printer=(rank == 0))
         for name, fn in variants.items():
             def partial_line(name=name):
                 if rank != 0 or not timings.get("compute_only"):
