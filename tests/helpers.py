@@ -55,7 +55,8 @@ def rel_err(got, expected, row_offsets=None):
     ([nnz] or [R, nnz]) pass ``row_offsets`` and it is the CSR row.  Dense
     outputs narrower than 16 columns (n = 1, 7 ...) have no row to speak of: a
     single cancelling element would be its own scale, so there the scale is
-    taken over the whole [m, n] matrix of the replica.
+    taken over the whole [m, n] matrix of the replica; likewise CSR rows of fewer
+    than 16 entries take the scale of their replica.
     """
     got = np.asarray(got, np.float64)
     expected = np.asarray(expected, np.float64)
@@ -72,11 +73,17 @@ def rel_err(got, expected, row_offsets=None):
     else:
         rows = int(ids.max()) + 1 if ids.size else 0
         count = np.maximum(np.bincount(ids, minlength=rows), 1)
-        rowmean = np.stack([np.bincount(ids, weights=r, minlength=rows) / count for r in aw])[:, ids]
+        rowmean = np.stack([np.bincount(ids, weights=r, minlength=rows) / count for r in aw])
         rowmax = np.zeros((aw.shape[0], rows))
         for r in range(aw.shape[0]):
             np.maximum.at(rowmax[r], ids, aw[r])
-        rowmax = rowmax[:, ids]
+        # CSR rows of fewer than 16 entries are no scale either (a row of ONE entry
+        # that cancels to nearly zero would be held to a relative bound of itself):
+        # such rows take the replica's mean / maximum, like narrow dense outputs
+        short = count < 16
+        rowmean[:, short] = aw.mean(axis=1, keepdims=True)
+        rowmax[:, short] = aw.max(axis=1, keepdims=True)
+        rowmean, rowmax = rowmean[:, ids], rowmax[:, ids]
     worst = float(np.max(err / (aw + np.maximum(rowmean, 1e-30))))
     significant = aw > 1e-2 * rowmax
     if significant.any():
