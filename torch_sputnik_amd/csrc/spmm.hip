@@ -13,6 +13,7 @@
 // LPR*VEC*4-byte segment.  It needs no workspace and places no requirement
 // on the order of column indices inside a row.
 #include "common.h"
+#include "options.h"
 #include "wave_utils.h"
 
 namespace sputnik_hip {
@@ -26,6 +27,13 @@ int spmm_tiled_exec(int m, int k, int n, int nonzeros, int replicas, const int* 
                     float* out, int64_t out_stride, const void* workspace,
                     size_t workspace_bytes, hipStream_t stream, Epilogue epi, bool* handled);
 size_t spmm_tiled_workspace_bytes(int m, int k, int n, int nonzeros);
+int spmm_tiled_choice(int m, int k, int n, int nonzeros, int replicas);
+bool spmm_panel_applicable(int m, int k, int n, int nonzeros, const float* dense,
+                           int64_t dense_stride, const float* out, int64_t out_stride);
+int spmm_panel_launch(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
+                      const float* values, int64_t values_stride, const int* row_offsets,
+                      const int* column_indices, const float* dense, int64_t dense_stride,
+                      float* out, int64_t out_stride, hipStream_t stream, Epilogue epi);
 
 namespace {
 
@@ -173,6 +181,24 @@ int sputnik_hip_spmm_plan(int m, int k, int n, int nonzeros, const int* row_indi
 
 namespace {
 
+// The panel-resident kernel (spmm_panel.hip, k <= 512: B panel copied to LDS once,
+// no pre-pass) is taken where the chunked kernels would be mostly skeleton: when
+// they would pick the 64-column kernel, or nothing although the call is not
+// tiny.  Wide shapes (many 256 / 512-column tiles) stay with the wide kernels,
+// whose inner step does twice the FMAs per broadcast.  Knob: "panel" forces it.
+bool takes_panel(int m, int k, int n, int nonzeros, int replicas, const float* dense,
+                 int64_t dense_stride, const float* out, int64_t out_stride) {
+  const int forced = options().spmm_kernel;
+  if (forced != 0 && forced != 3) return false;
+  if (nonzeros == 0 ||
+      !spmm_panel_applicable(m, k, n, nonzeros, dense, dense_stride, out, out_stride))
+    return false;
+  if (forced == 3) return true;
+  const int choice = spmm_tiled_choice(m, k, n, nonzeros, replicas);
+  const int64_t work = static_cast<int64_t>(nonzeros) * n * replicas;
+  return choice == 2 || choice == 3 || (choice == 0 && work >= (int64_t{1} << 24));
+}
+
 int spmm_exec(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
               const float* values, int64_t values_stride, const int* row_offsets,
               const int* column_indices, const float* dense, int64_t dense_stride, float* out,
@@ -180,6 +206,10 @@ int spmm_exec(int m, int k, int n, int nonzeros, int replicas, const int* row_in
               hipStream_t stream, Epilogue epi) {
   if (m < 0 || k < 0 || n < 0 || nonzeros < 0 || replicas < 0) return SPUTNIK_HIP_INVALID_ARGUMENT;
   if (m == 0 || n == 0 || replicas == 0) return 0;
+  if (takes_panel(m, k, n, nonzeros, replicas, dense, dense_stride, out, out_stride))
+    return spmm_panel_launch(m, k, n, nonzeros, replicas, row_indices, values, values_stride,
+                             row_offsets, column_indices, dense, dense_stride, out, out_stride,
+                             stream, epi);
   bool handled = false;
   const int st = spmm_tiled_exec(m, k, n, nonzeros, replicas, row_indices, values, values_stride,
                                  row_offsets, column_indices, dense, dense_stride, out,
@@ -225,13 +255,17 @@ int sputnik_hip_spmm_bias_batched(int m, int k, int n, int nonzeros, int replica
                                   sputnik_hip_stream_t stream) {
   if (m < 0 || k < 0 || n < 0 || nonzeros < 0 || replicas < 0) return SPUTNIK_HIP_INVALID_ARGUMENT;
   if (m == 0 || n == 0 || replicas == 0) return 0;
+  Epilogue epi;
+  epi.bias = bias;
+  epi.relu = relu != 0;
+  if (takes_panel(m, k, n, nonzeros, replicas, dense, dense_stride, out, out_stride))
+    return spmm_panel_launch(m, k, n, nonzeros, replicas, row_indices, values, values_stride,
+                             row_offsets, column_indices, dense, dense_stride, out, out_stride,
+                             stream, epi);   // no pre-pass
   bool planned = false;
   const int st = spmm_tiled_plan(m, k, n, nonzeros, replicas, row_indices, row_offsets,
                                  column_indices, workspace, workspace_bytes, stream, &planned);
   if (st != 0) return st;
-  Epilogue epi;
-  epi.bias = bias;
-  epi.relu = relu != 0;
   return spmm_exec(m, k, n, nonzeros, replicas, row_indices, values, values_stride, row_offsets,
                    column_indices, dense, dense_stride, out, out_stride, workspace,
                    workspace_bytes, stream, epi);

@@ -1,0 +1,166 @@
+// Panel-resident SpMM for SMALL inner dimensions (k <= 512): C[m,n] = A_csr[m,k] * B[k,n].
+//
+// The LDS-tiled kernels walk K in chunks with a workgroup rendezvous and a B-tile
+// copy per chunk; with k <= 512 that is four to sixteen chunks, and at the shapes
+// this serves -- the 512 x 512 projection weights of the attention block against
+// [512, 1024] x 8 activations (modules/sparse_attention.py:108-126) -- more than
+// half of the launch was the skeleton of those few chunks (37 us for 0.43 GFLOP).
+// Here a workgroup's whole B panel, k rows x 64 columns (<= 128 KiB), is copied
+// to LDS ONCE (direct global->LDS copies, one rendezvous), and every row then
+// runs its whole (column, value) stream against it: no chunk table, no pre-pass,
+// no workspace, and no requirement that a row's columns ascend.
+//
+// Compute mapping as in spmm_tiled64.hip: a wavefront works on four rows at a
+// time, each 16-lane group owning one row and its 64 output columns (4 per lane);
+// the group holds 16 consecutive entries of its row (lane i = entry i) and hands
+// entry u out with DPP row_newbcast: per nonzero one v_mov_b64_dpp, one
+// v_add_u32, one ds_read_b128 and four FMAs.  The four groups run their own
+// number of steps (EXEC-masked).  Rows are dealt to workgroups interleaved
+// (dealt_index), neighbours in the caller's length-sorted row_indices share a
+// quad.  The last column tile may be partial (n a multiple of 4).
+#include <atomic>
+
+#include "options.h"
+#include "spmm_tiled_common.h"
+
+namespace sputnik_hip {
+
+namespace {
+
+using namespace tiled;
+
+constexpr int kPBN = 64;      // columns of C per workgroup
+constexpr int kPWaves = 16;   // waves per workgroup
+constexpr int kPQuads = 4;    // row quads (4 rows) per wave
+constexpr int kPBM = kPWaves * kPQuads * 4;   // 256 rows per workgroup
+constexpr int kPThreads = kPWaves * kWave;
+constexpr int kPMaxK = 512;   // 512 rows x 256 B = 128 KiB of LDS
+
+__global__ __launch_bounds__(kPThreads) void spmm_panel64_kernel(
+    int m, int k, int n, int nonzeros, int slots, int n_tiles,
+    const int* __restrict__ row_indices, const float* __restrict__ values,
+    int64_t values_stride, const int* __restrict__ row_offsets,
+    const int* __restrict__ column_indices, const float* __restrict__ dense,
+    int64_t dense_stride, float* __restrict__ out, int64_t out_stride, Epilogue epi) {
+  extern __shared__ float panel[];   // [k][64]
+
+  const int lane = threadIdx.x % kWave;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int g = lane >> 4, i = lane & 15;
+  const int ntile = blockIdx.x % n_tiles;
+  const int mblock = blockIdx.x / n_tiles;
+  const int replica = blockIdx.y;
+  values += replica * values_stride;
+  dense += replica * dense_stride;
+  out += replica * out_stride;
+  const int n0 = ntile * kPBN;
+  const int last = nonzeros - 1;
+
+  // the rows' bounds first: their latency overlaps the panel copy
+  int row[kPQuads], p0[kPQuads], cnt[kPQuads];
+#pragma unroll
+  for (int t = 0; t < kPQuads; ++t) {
+    const int slot = mblock * kPBM + wave * (kPQuads * 4) + 4 * t + g;
+    const int entry = dealt_index(slot, slots, kPBM);
+    const bool live = entry < m;
+    row[t] = row_indices[live ? entry : 0];
+    p0[t] = row_offsets[row[t]];
+    cnt[t] = live ? row_offsets[row[t] + 1] - p0[t] : 0;
+    if (!live) row[t] = -1;
+  }
+
+  // panel: one wave instruction copies rows 4j .. 4j+3 (4 x 256 B; lane l -> row
+  // l / 16, bytes (l % 16) * 16).  Lanes past the end of a row of B (partial last
+  // column tile) or past the last row re-read valid bytes that are never used.
+  const int col = min(n0 + i * 4, n - 4);
+  for (int j = wave; j * 4 < k; j += kPWaves) {
+    const int src_row = min(4 * j + g, k - 1);
+    const unsigned off = static_cast<unsigned>(src_row) * static_cast<unsigned>(n) * 4u +
+                         static_cast<unsigned>(col) * 4u;
+    lds_dma_row(dense, off, panel + 4 * j * kPBN);
+  }
+  wait_vm<0>();
+  __syncthreads();
+
+  const char* __restrict__ lane_base = reinterpret_cast<const char*>(panel + i * 4);
+#pragma unroll
+  for (int t = 0; t < kPQuads; ++t) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int n_here = cnt[t];
+    const int longest =
+        max(max(__builtin_amdgcn_readlane(n_here, 0), __builtin_amdgcn_readlane(n_here, 16)),
+            max(__builtin_amdgcn_readlane(n_here, 32), __builtin_amdgcn_readlane(n_here, 48)));
+    // window w0: entries w0 .. w0+15 of this group's row, the next one requested
+    // before the current one is worked on
+    int idx = min(p0[t] + i, last);
+    int ecol = nonzeros > 0 ? column_indices[max(idx, 0)] : 0;
+    float eval = nonzeros > 0 ? values[max(idx, 0)] : 0.f;
+    for (int w0 = 0; w0 < longest; w0 += 16) {
+      const int cur_col = ecol;
+      const float cur_val = eval;
+      if (w0 + 16 < longest) {
+        idx = min(p0[t] + w0 + 16 + i, last);
+        ecol = column_indices[idx];
+        eval = values[idx];
+      }
+      const int left = n_here - w0;   // entries of this group's row at or after the window start
+      const bool valid = i < left;
+      const int roff = valid ? cur_col * (kPBN * 4) : 0;
+      const float rval = valid ? cur_val : 0.f;
+      if (left > 0) dpp_group4<0>(acc, roff, rval, lane_base);
+      if (left > 4) dpp_group4<4>(acc, roff, rval, lane_base);
+      if (left > 8) dpp_group4<8>(acc, roff, rval, lane_base);
+      if (left > 12) dpp_group4<12>(acc, roff, rval, lane_base);
+    }
+    if (row[t] >= 0 && n0 + i * 4 < n)
+      *reinterpret_cast<float4*>(out + static_cast<int64_t>(row[t]) * n + n0 + i * 4) =
+          apply_epilogue(make_float4(acc[0], acc[1], acc[2], acc[3]), epi, row[t]);
+  }
+}
+
+}  // namespace
+
+// Shapes the panel kernel serves.  (Column indices must lie in [0, k): as for
+// every kernel of the library, an out-of-range index is the caller's error.)
+bool spmm_panel_applicable(int m, int k, int n, int nonzeros, const float* dense,
+                           int64_t dense_stride, const float* out, int64_t out_stride) {
+  return k >= 1 && k <= kPMaxK && n % 4 == 0 && n >= kPBN && m >= 16 &&
+         static_cast<int64_t>(k) * n * 4 < (int64_t{1} << 32) && aligned_to(dense, 16) &&
+         aligned_to(out, 16) && dense_stride % 4 == 0 && out_stride % 4 == 0 && nonzeros >= 0;
+}
+
+int spmm_panel_launch(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
+                      const float* values, int64_t values_stride, const int* row_offsets,
+                      const int* column_indices, const float* dense, int64_t dense_stride,
+                      float* out, int64_t out_stride, hipStream_t stream, Epilogue epi) {
+  const int slots = ceil_div(m, kPBM) * kPBM;
+  const int n_tiles = ceil_div(n, kPBN);
+  const int64_t blocks = static_cast<int64_t>(slots / kPBM) * n_tiles;
+  if (blocks > 0x7fffffff) return SPUTNIK_HIP_INVALID_ARGUMENT;
+  const size_t lds = static_cast<size_t>(ceil_div(k, 4) * 4) * kPBN * sizeof(float);
+  // more than 64 KiB of dynamic LDS has to be asked for, once per device
+  static std::atomic<uint64_t> asked{0};
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) return launch_status();
+  const uint64_t bit = uint64_t{1} << (device & 63);
+  if (!(asked.load(std::memory_order_acquire) & bit)) {
+    const hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_panel64_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              kPMaxK * kPBN * sizeof(float));
+    if (st != hipSuccess) return static_cast<int>(st);
+    asked.fetch_or(bit, std::memory_order_release);
+  }
+  for (int r0 = 0; r0 < replicas; r0 += kMaxGridYZ) {
+    const int ry = min(replicas - r0, kMaxGridYZ);
+    hipLaunchKernelGGL(spmm_panel64_kernel, dim3(static_cast<unsigned>(blocks), ry), dim3(kPThreads),
+                       lds, stream, m, k, n, nonzeros, slots, n_tiles, row_indices,
+                       values + r0 * values_stride, values_stride, row_offsets, column_indices,
+                       dense + r0 * dense_stride, dense_stride, out + r0 * out_stride, out_stride,
+                       epi);
+    const int st = launch_status();
+    if (st != 0) return st;
+  }
+  return 0;
+}
+
+}  // namespace sputnik_hip

@@ -439,7 +439,7 @@ using CfgWide512Half = TileConfig<512, 16, 4, 32>;
 // it applies (else as "wide"), "narrow" = 64-column kernel whenever it applies,
 // "gather" = row-gather kernel; anything else = the automatic choice.
 // (The parity tests use it to reach every kernel with small inputs.)
-inline int forced_kernel() { return options().spmm_kernel; }
+inline int forced_kernel() { return options().spmm_kernel == 3 ? 0 : options().spmm_kernel; }
 
 // Column tiles of BN columns serve any n that is a multiple of 4 (16-byte rows of
 // B and C): the last tile may be partial (its LDS copies are clamped into the
@@ -559,6 +559,11 @@ size_t wide512_offset(int m, int k, int n, int nonzeros) {
              : 0;
 }
 }  // namespace
+
+// 0 = row gather, 1 = 256-column, 2 = 64-column, 3 = either (by replica count), 4 = 512-column
+int spmm_tiled_choice(int m, int k, int n, int nonzeros, int replicas) {
+  return static_cast<int>(choose_kernel(m, k, n, nonzeros, replicas));
+}
 
 size_t spmm_tiled_workspace_bytes(int m, int k, int n, int nonzeros) {
   return wide512_possible(m, k, n, nonzeros)
