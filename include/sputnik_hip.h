@@ -144,6 +144,34 @@ SPUTNIK_HIP_API int sputnik_hip_sddmm_batched_planned(int m, int k, int n, int n
                               float* out, int64_t out_stride, const void* workspace,
                               size_t workspace_bytes, sputnik_hip_stream_t stream);
 
+/* Sum of the replicas' products, out[nonzeros] = sum_r sddmm(lhs_r, rhs_r): the
+ * gradient of sparse values shared by a batch.  The reference returns the
+ * [replicas, nonzeros] products (tests/test_linear_3d.py:64-69,
+ * tests/test_left_spmm.py:57-64) and leaves the sum over the batch to autograd;
+ * here the (replica, k-panel) pairs of the tiled kernel run in ONE launch into
+ * `scratch` and a second kernel adds them up in index order (deterministic).
+ * `scratch` holds sputnik_hip_sddmm_sum_scratch_bytes(...) bytes (0: not
+ * needed), 16-byte aligned; `workspace` as for sputnik_hip_sddmm_batched /
+ * _batched_planned. */
+SPUTNIK_HIP_API size_t sputnik_hip_sddmm_sum_scratch_bytes(int m, int k, int n, int nonzeros,
+                                                           int replicas);
+
+SPUTNIK_HIP_API int sputnik_hip_sddmm_sum_batched(int m, int k, int n, int nonzeros,
+                              int replicas, const int* row_indices, const int* row_offsets,
+                              const int* column_indices, const float* lhs,
+                              int64_t lhs_stride, const float* rhs, int64_t rhs_stride,
+                              float* out, void* workspace, size_t workspace_bytes,
+                              void* scratch, size_t scratch_bytes,
+                              sputnik_hip_stream_t stream);
+
+SPUTNIK_HIP_API int sputnik_hip_sddmm_sum_batched_planned(int m, int k, int n, int nonzeros,
+                              int replicas, const int* row_indices, const int* row_offsets,
+                              const int* column_indices, const float* lhs,
+                              int64_t lhs_stride, const float* rhs, int64_t rhs_stride,
+                              float* out, const void* workspace, size_t workspace_bytes,
+                              void* scratch, size_t scratch_bytes,
+                              sputnik_hip_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Sparse softmax: per CSR row, exp(x - max) / sum(exp(x - max)) over the
  * stored entries.  `n` is unused (the reference passes -1,

@@ -168,6 +168,15 @@ def _sddmm_planned(m, n, row_indices, row_offsets, column_indices, lhs, rhs, pla
     return _sddmm(m, n, row_indices, row_offsets, column_indices, lhs, rhs)
 
 
+def _sddmm_sum(m, n, row_indices, row_offsets, column_indices, lhs, rhs):
+    out = _sddmm(m, n, row_indices, row_offsets, column_indices, lhs, rhs)
+    return out.sum(dim=0) if out.dim() == 2 else out
+
+
+def _sddmm_sum_planned(m, n, row_indices, row_offsets, column_indices, lhs, rhs, plan):
+    return _sddmm_sum(m, n, row_indices, row_offsets, column_indices, lhs, rhs)
+
+
 def _sparse_attention_planned(q, k, v, row_indices, row_offsets, column_indices, scale, plan):
     return _sparse_attention(q, k, v, row_indices, row_offsets, column_indices, scale)
 
@@ -198,6 +207,8 @@ def install():
     _lib.impl("spmm_planned", _spmm_planned, "CPU")
     _lib.impl("left_spmm_planned", _left_spmm_planned, "CPU")
     _lib.impl("sddmm_planned", _sddmm_planned, "CPU")
+    _lib.impl("sddmm_sum", _sddmm_sum, "CPU")
+    _lib.impl("sddmm_sum_planned", _sddmm_sum_planned, "CPU")
     _lib.impl("sparse_attention_planned", _sparse_attention_planned, "CPU")
     _lib.impl("spmm_many_mask", _spmm_many_mask, "CPU")
     _lib.impl("sddmm_many_mask", _sddmm_many_mask, "CPU")

@@ -396,6 +396,61 @@ def test_sddmm_capi_vs_oracle(capi, dev, sddmm_kernel, m, k, n, sparsity, replic
     assert rel_err(got, want, ro) < TOL    # rows = the mask's CSR rows
 
 
+# sum over the replicas inside the call (the gradient of values shared by a batch):
+# against the oracle's per-replica products added in float64
+SDDMM_SUM_SHAPES = [
+    (512, 1024, 512, 0.9, 8),   # attention projection weight gradient: 2 panels x 8 replicas, one launch
+    (512, 512, 512, 0.8, 3),    # one panel per replica
+    (256, 1024, 96, 0.7, 1),    # one replica, two panels: still summed from partials
+    (200, 768, 130, 0.8, 2),    # three panels of 256
+    (100, 40, 60, 0.5, 5),      # row-wave kernel ([R, nnz] partials)
+    (64, 64, 64, 0.0, 1),       # nothing to sum
+    (33, 100, 47, 0.6, 4),      # odd sizes: scalar reduction
+]
+
+
+@pytest.mark.parametrize("planned", [False, True])
+@pytest.mark.parametrize("m,k,n,sparsity,replicas", SDDMM_SUM_SHAPES)
+def test_sddmm_sum_capi_vs_oracle(capi, dev, sddmm_kernel, m, k, n, sparsity, replicas, planned):
+    round_to = 1 if m == 33 else 4
+    _, _, ri, ro, ci = make_csr(m, n, sparsity, seed=m + k + n, round_to=round_to,
+                                empty_rows=(m // 2,))
+    rng = np.random.default_rng(k + 1)
+    lhs = rng.uniform(-1, 1, size=(replicas, m, k)).astype(np.float32)
+    rhs = rng.uniform(-1, 1, size=(replicas, n, k)).astype(np.float32)
+    want = c_oracle.sddmm(m, n, ro, ci, lhs, rhs).astype(np.float64).sum(axis=0)
+    out = torch.full((len(ci),), float("nan"), device=dev)
+    ws = torch.empty(capi.sddmm_workspace_bytes(m, k, n, len(ci)) + 16, dtype=torch.uint8, device=dev)
+    scratch = torch.empty(capi.sddmm_sum_scratch_bytes(m, k, n, len(ci), replicas) + 16,
+                          dtype=torch.uint8, device=dev)
+    topo = (T(ri, dev), T(ro, dev), T(ci, dev))
+    if planned:
+        capi.sddmm_plan(m, k, n, *topo, ws)
+    capi.sddmm_sum_batched(m, k, n, replicas, *topo, T(lhs, dev), T(rhs, dev), out, ws, scratch,
+                           planned=planned)
+    got = out.cpu().numpy()
+    assert not np.isnan(got).any()
+    # one row of `replicas * k` products per entry: the tolerance scales as for one long row
+    assert rel_err(got[None, :], want[None, :].astype(np.float32), ro) < TOL
+
+
+def test_sddmm_sum_op_equals_the_summed_op(ts, dev):
+    m, k, n, replicas = 512, 1024, 512, 8
+    _, _, ri, ro, ci = make_csr(m, n, 0.9, seed=5)
+    topo = [T(x, dev) for x in (ri, ro, ci)]
+    rng = np.random.default_rng(1)
+    lhs = T(rng.uniform(-1, 1, (replicas, m, k)).astype(np.float32), dev)
+    rhs = T(rng.uniform(-1, 1, (replicas, n, k)).astype(np.float32), dev)
+    each = ts.sddmm(m, n, *topo, lhs, rhs)
+    total = ts.sddmm_sum(m, n, *topo, lhs, rhs)
+    assert total.shape == (len(ci),)
+    torch.testing.assert_close(total, each.double().sum(0).float(), rtol=2e-5, atol=2e-4)
+    plan = ts.sddmm_plan(m, n, k, *topo)
+    assert torch.equal(ts.sddmm_sum_planned(m, n, *topo, lhs, rhs, plan), total)   # deterministic
+    assert torch.equal(ts.sddmm_sum(m, n, *topo, lhs[0], rhs[0]).reshape(-1)[:8].isfinite(),
+                       torch.ones(8, dtype=torch.bool, device=dev))
+
+
 @pytest.mark.parametrize("name", ["sddmm_2d_dense_mask", "sddmm_3d_r8"])
 def test_sddmm_op_golden(ts, dev, golden, name):
     g = golden(name)

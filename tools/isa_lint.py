@@ -194,6 +194,10 @@ def lint_kernel(name, instrs):
     for off, mn, ops, _t in instrs:
         if mn.startswith(("scratch_", "flat_")):
             errors.append(f"{mn} at +0x{off:x}: scratch / flat access in a hand-counted kernel")
+    if "spmm_panel" in name:
+        # its one hand-written wait is the vmcnt(0) behind the panel copy, which
+        # drains everything; all other loads are the compiler's, with its waits
+        return errors
     cfg = Cfg(instrs)
     loop = cfg.main_loop()
     if loop is None:
@@ -226,7 +230,7 @@ def lint_kernel(name, instrs):
         if key in seen:
             continue
         seen.add(key)
-        if len(seen) > 200000:
+        if len(seen) > 50000:
             errors.append("path explosion in the vmcnt model (kernel structure changed?)")
             break
         outstanding = list(state)

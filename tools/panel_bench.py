@@ -27,7 +27,9 @@ def main():
 
     shapes = [(512, 512, 1024, 8, 0.1), (512, 512, 1024, 8, 0.5), (512, 512, 512, 16, 0.1),
               (2048, 512, 1024, 1, 0.1), (4096, 512, 4096, 1, 0.1), (512, 64, 512, 64, 0.1),
-              (1024, 256, 256, 8, 0.25), (4096, 4096, 4096, 1, 0.1)]
+              (1024, 256, 256, 8, 0.25), (1024, 1024, 64, 64, 0.1), (1024, 1024, 64, 64, 0.3),
+              (2048, 2048, 64, 16, 0.1), (4096, 4096, 64, 8, 0.1), (4096, 4096, 72, 1, 0.1),
+              (2048, 1024, 1024, 1, 0.1), (1024, 1024, 128, 32, 0.1)]
     if len(sys.argv) > 1:   # e.g. "4096,4096,4096,1,0.1"
         f = sys.argv[1].split(",")
         shapes = [(int(f[0]), int(f[1]), int(f[2]), int(f[3]), float(f[4]))]

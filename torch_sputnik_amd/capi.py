@@ -41,6 +41,14 @@ SIGNATURES = {
     "sputnik_hip_sddmm_batched_planned": (_c_int, [_c_int] * 5 + [_c_ptr, _c_ptr, _c_ptr, _c_ptr,
                                                                  _c_i64, _c_ptr, _c_i64, _c_ptr,
                                                                  _c_i64, _c_ptr, _c_size, _c_ptr]),
+    "sputnik_hip_sddmm_sum_scratch_bytes": (_c_size, [_c_int] * 5),
+    "sputnik_hip_sddmm_sum_batched": (_c_int, [_c_int] * 5 + [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64,
+                                                             _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_size,
+                                                             _c_ptr, _c_size, _c_ptr]),
+    "sputnik_hip_sddmm_sum_batched_planned": (_c_int, [_c_int] * 5 + [_c_ptr, _c_ptr, _c_ptr, _c_ptr,
+                                                                     _c_i64, _c_ptr, _c_i64, _c_ptr,
+                                                                     _c_ptr, _c_size, _c_ptr, _c_size,
+                                                                     _c_ptr]),
     "sputnik_hip_sparse_softmax": (_c_int, [_c_int] * 3 + [_c_ptr] * 6),
     "sputnik_hip_sparse_softmax_batched": (_c_int, [_c_int] * 4 + [_c_ptr, _c_i64, _c_ptr, _c_ptr,
                                                                   _c_ptr, _c_ptr, _c_i64, _c_ptr]),
@@ -393,6 +401,22 @@ def sddmm_batched_planned(m, k, n, replicas, row_indices, row_offsets, column_in
         m, k, n, nonzeros, replicas, _ptr(row_indices), _ptr(row_offsets), _ptr(column_indices),
         _ptr(lhs), m * k, _ptr(rhs), n * k, _ptr(out), nonzeros, _ptr(workspace),
         _ws_bytes(workspace), _stream(out)), "sputnik_hip_sddmm_batched_planned")
+    return out
+
+
+def sddmm_sum_scratch_bytes(m, k, n, nonzeros, replicas):
+    return lib().sputnik_hip_sddmm_sum_scratch_bytes(m, k, n, nonzeros, replicas)
+
+
+def sddmm_sum_batched(m, k, n, replicas, row_indices, row_offsets, column_indices, lhs, rhs, out,
+                      workspace, scratch, planned=False):
+    """out[nnz] = sum over the replicas of sddmm(lhs_r, rhs_r)."""
+    nonzeros = column_indices.numel()
+    fn = lib().sputnik_hip_sddmm_sum_batched_planned if planned else lib().sputnik_hip_sddmm_sum_batched
+    _check(fn(m, k, n, nonzeros, replicas, _ptr(row_indices), _ptr(row_offsets),
+              _ptr(column_indices), _ptr(lhs), m * k, _ptr(rhs), n * k, _ptr(out), _ptr(workspace),
+              _ws_bytes(workspace), _ptr(scratch), _ws_bytes(scratch), _stream(out)),
+           "sputnik_hip_sddmm_sum_batched")
     return out
 
 

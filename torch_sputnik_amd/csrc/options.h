@@ -13,6 +13,7 @@ struct Options {
   int sddmm_kernel = 0;   // SPUTNIK_HIP_SDDMM_KERNEL: 0 auto, 1 "tiled", 2 "wave"
   int sddmm_debug = 0;    // SPUTNIK_HIP_SDDMM_DEBUG: timing experiments only
   int softmax_rpg = 0;    // SPUTNIK_HIP_SOFTMAX_RPG: rows per group (0 = automatic)
+  int softmax_nt = -1;    // SPUTNIK_HIP_SOFTMAX_NT (developer): nontemporal 0 none, 1 loads, 2 stores, 3 both; -1 default
   int softmax_depth = 1;  // SPUTNIK_HIP_SOFTMAX_DEPTH: rows in flight ahead (1..3)
 };
 

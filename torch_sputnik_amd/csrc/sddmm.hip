@@ -27,6 +27,13 @@ int sddmm_tiled_launch(int m, int k, int n, int nonzeros, int replicas, const in
                        int64_t lhs_stride, const float* rhs, int64_t rhs_stride, float* out,
                        int64_t out_stride, const void* workspace, hipStream_t stream);
 
+int sddmm_tiled_panels(int k);
+int sddmm_tiled_launch_partials(int m, int k, int n, int nonzeros, int replicas,
+                                const int* row_indices, const int* row_offsets,
+                                const int* column_indices, const float* lhs, int64_t lhs_stride,
+                                const float* rhs, int64_t rhs_stride, float* partials,
+                                const void* workspace, hipStream_t stream);
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -141,6 +148,27 @@ int launch_vec(int m, int k, int replicas, const int* row_indices, const int* ro
 #undef SPUTNIK_HIP_SD
 }
 
+// out[i] = partials[0][i] + partials[1][i] + ... in that order (deterministic).
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void sum_partials_kernel(int count /* of VEC-wide pieces */,
+                                                              int parts, int64_t stride,
+                                                              const float* __restrict__ partials,
+                                                              float* __restrict__ out) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= count) return;
+  float acc[VEC];
+  load_vec<VEC>(acc, partials + static_cast<int64_t>(i) * VEC);
+#pragma unroll 4
+  for (int z = 1; z < parts; ++z) {
+    float v[VEC];
+    load_vec<VEC>(v, partials + z * stride + static_cast<int64_t>(i) * VEC);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] += v[e];
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) out[static_cast<int64_t>(i) * VEC + e] = acc[e];
+}
+
 }  // namespace
 }  // namespace sputnik_hip
 
@@ -226,6 +254,96 @@ int sputnik_hip_sddmm_batched(int m, int k, int n, int nonzeros, int replicas,
   return sddmm_exec(m, k, n, nonzeros, replicas, row_indices, row_offsets, column_indices, lhs,
                     lhs_stride, rhs, rhs_stride, out, out_stride, workspace, workspace_bytes,
                     /*planned=*/false, stream);
+}
+
+namespace {
+
+// Partial vectors a summed call needs: one per (replica, panel) on the tiled path.
+int64_t sum_parts(int m, int k, int n, int nonzeros, int replicas) {
+  const bool tiled_shape = sddmm_tiled_workspace_bytes(m, k, n, nonzeros) != 0;
+  return static_cast<int64_t>(replicas) * (tiled_shape ? sddmm_tiled_panels(k) : 1);
+}
+
+int sddmm_sum_exec(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
+                   const int* row_offsets, const int* column_indices, const float* lhs,
+                   int64_t lhs_stride, const float* rhs, int64_t rhs_stride, float* out,
+                   void* workspace, size_t workspace_bytes, bool planned, void* scratch,
+                   size_t scratch_bytes, hipStream_t stream) {
+  if (m < 0 || k < 0 || n < 0 || nonzeros < 0 || replicas < 0) return SPUTNIK_HIP_INVALID_ARGUMENT;
+  if (m == 0 || nonzeros == 0) return 0;
+  if (k == 0 || replicas == 0) {
+    const hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * static_cast<size_t>(nonzeros), stream);
+    return static_cast<int>(e);
+  }
+  const bool tiled = takes_tiled(m, k, n, nonzeros, replicas, lhs, lhs_stride, rhs, rhs_stride,
+                                 workspace, workspace_bytes);
+  const int panels = tiled ? sddmm_tiled_panels(k) : 1;
+  const int64_t parts = static_cast<int64_t>(replicas) * panels;
+  if (parts == 1)
+    return sddmm_exec(m, k, n, nonzeros, 1, row_indices, row_offsets, column_indices, lhs,
+                      lhs_stride, rhs, rhs_stride, out, 0, workspace, workspace_bytes, planned,
+                      stream);
+  if (scratch == nullptr || !aligned_to(scratch, 16) ||
+      scratch_bytes < sizeof(float) * static_cast<size_t>(parts) * nonzeros)
+    return SPUTNIK_HIP_INVALID_ARGUMENT;
+  float* partials = static_cast<float*>(scratch);
+  int st;
+  if (tiled && parts <= kMaxGridYZ) {
+    if (!planned) {
+      st = sddmm_tiled_plan(m, k, n, row_indices, row_offsets, column_indices, workspace, stream);
+      if (st != 0) return st;
+    }
+    st = sddmm_tiled_launch_partials(m, k, n, nonzeros, replicas, row_indices, row_offsets,
+                                     column_indices, lhs, lhs_stride, rhs, rhs_stride, partials,
+                                     workspace, stream);
+  } else {
+    st = sddmm_exec(m, k, n, nonzeros, replicas, row_indices, row_offsets, column_indices, lhs,
+                    lhs_stride, rhs, rhs_stride, partials, nonzeros, workspace, workspace_bytes,
+                    planned, stream);
+  }
+  if (st != 0) return st;
+  const int nparts = static_cast<int>(tiled && parts <= kMaxGridYZ ? parts : replicas);
+  if (nonzeros % 4 == 0 && aligned_to(out, 16)) {
+    hipLaunchKernelGGL(sum_partials_kernel<4>, dim3(ceil_div(nonzeros / 4, kBlock)), dim3(kBlock),
+                       0, stream, nonzeros / 4, nparts, static_cast<int64_t>(nonzeros), partials,
+                       out);
+  } else {
+    hipLaunchKernelGGL(sum_partials_kernel<1>, dim3(ceil_div(nonzeros, kBlock)), dim3(kBlock), 0,
+                       stream, nonzeros, nparts, static_cast<int64_t>(nonzeros), partials, out);
+  }
+  return launch_status();
+}
+
+}  // namespace
+
+size_t sputnik_hip_sddmm_sum_scratch_bytes(int m, int k, int n, int nonzeros, int replicas) {
+  if (m <= 0 || k <= 0 || n <= 0 || nonzeros <= 0 || replicas <= 0) return 0;
+  const int64_t parts = sum_parts(m, k, n, nonzeros, replicas);
+  return parts <= 1 ? 0 : sizeof(float) * static_cast<size_t>(parts) * nonzeros;
+}
+
+int sputnik_hip_sddmm_sum_batched(int m, int k, int n, int nonzeros, int replicas,
+                                  const int* row_indices, const int* row_offsets,
+                                  const int* column_indices, const float* lhs,
+                                  int64_t lhs_stride, const float* rhs, int64_t rhs_stride,
+                                  float* out, void* workspace, size_t workspace_bytes,
+                                  void* scratch, size_t scratch_bytes,
+                                  sputnik_hip_stream_t stream) {
+  return sddmm_sum_exec(m, k, n, nonzeros, replicas, row_indices, row_offsets, column_indices,
+                        lhs, lhs_stride, rhs, rhs_stride, out, workspace, workspace_bytes,
+                        /*planned=*/false, scratch, scratch_bytes, stream);
+}
+
+int sputnik_hip_sddmm_sum_batched_planned(int m, int k, int n, int nonzeros, int replicas,
+                                          const int* row_indices, const int* row_offsets,
+                                          const int* column_indices, const float* lhs,
+                                          int64_t lhs_stride, const float* rhs,
+                                          int64_t rhs_stride, float* out, const void* workspace,
+                                          size_t workspace_bytes, void* scratch,
+                                          size_t scratch_bytes, sputnik_hip_stream_t stream) {
+  return sddmm_sum_exec(m, k, n, nonzeros, replicas, row_indices, row_offsets, column_indices,
+                        lhs, lhs_stride, rhs, rhs_stride, out, const_cast<void*>(workspace),
+                        workspace_bytes, /*planned=*/true, scratch, scratch_bytes, stream);
 }
 
 int sputnik_hip_sddmm_plan(int m, int k, int n, int nonzeros, const int* row_indices,

@@ -62,7 +62,8 @@ void sddmm_stationary_kernel(
     const int* __restrict__ table, const int* __restrict__ row_ok,
     const float* __restrict__ lhs, int64_t lhs_stride, const float* __restrict__ rhs,
     int64_t rhs_stride, int ld /* floats between rows of lhs / rhs */, int accumulate,
-    float* __restrict__ out, int64_t out_stride, int debug) {
+    float* __restrict__ out, int64_t out_stride, int panels /* of one replica along grid z */,
+    int debug) {
   using S = Slab<KV>;
   constexpr int kdim = S::kdim;  // panel width; lhs / rhs point at the panel's first column
   constexpr int kRowBytes = kdim * 4;
@@ -72,10 +73,15 @@ void sddmm_stationary_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int g = lane >> 4, i = lane & 15;
   const int slab = blockIdx.x;
-  const int replica = blockIdx.z;
-  lhs += replica * lhs_stride;
-  rhs += replica * rhs_stride;
-  out += replica * out_stride;
+  // grid z = replica * panels + panel (panels == 1: the launch is one panel of
+  // every replica; > 1: all panels at once, each into its own output, see
+  // sddmm_tiled_launch_partials)
+  const int z = blockIdx.z;
+  const int replica = panels > 1 ? z / panels : z;
+  const int panel = z - replica * panels;
+  lhs += replica * lhs_stride + panel * kdim;
+  rhs += replica * rhs_stride + panel * kdim;
+  out += z * out_stride;
   const int jc = slab * S::kRows;
   const int last = nonzeros - 1;
 
@@ -295,7 +301,7 @@ int launch(int m, int k, int n, int nonzeros, int replicas, int slots, const int
                          dim3(kSThreads), 0, stream, m, n, nonzeros, slots, row_indices,
                          row_offsets, column_indices, table, row_ok, lhs + r0 * lhs_stride + k0,
                          lhs_stride, rhs + r0 * rhs_stride + k0, rhs_stride, k, k0 != 0,
-                         out + r0 * out_stride, out_stride, debug);
+                         out + r0 * out_stride, out_stride, 1, debug);
       st = launch_status();
       if (st != 0) return st;
     }
@@ -303,7 +309,56 @@ int launch(int m, int k, int n, int nonzeros, int replicas, int slots, const int
   return 0;
 }
 
+// Every (replica, panel) pair in ONE launch, each writing its own [nonzeros]
+// vector of `partials` (z = replica * panels + panel): for callers that sum the
+// replicas anyway (the gradient of a weight shared by a batch), so that the
+// panels need not run one after the other.
+template <int KV>
+int launch_partials(int m, int k, int n, int nonzeros, int replicas, int slots,
+                    const int* row_indices, const int* row_offsets, const int* column_indices,
+                    const int* table, const int* row_ok, const float* lhs, int64_t lhs_stride,
+                    const float* rhs, int64_t rhs_stride, float* partials, int debug,
+                    hipStream_t stream) {
+  using S = Slab<KV>;
+  const int slabs = ceil_div(n, S::kRows);
+  const int row_blocks = slots / (kSGroups * kSRows);
+  const int panels = k / S::kdim;
+  if (row_blocks > kMaxGridYZ || static_cast<int64_t>(replicas) * panels > kMaxGridYZ)
+    return SPUTNIK_HIP_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(sddmm_stationary_kernel<KV>, dim3(slabs, row_blocks, replicas * panels),
+                     dim3(kSThreads), 0, stream, m, n, nonzeros, slots, row_indices, row_offsets,
+                     column_indices, table, row_ok, lhs, lhs_stride, rhs, rhs_stride, k, 0,
+                     partials, static_cast<int64_t>(nonzeros), panels, debug);
+  return launch_status();
+}
+
 }  // namespace
+
+int sddmm_tiled_panels(int k) { return served(k) ? k / panel_width(k) : 1; }
+
+int sddmm_tiled_launch_partials(int m, int k, int n, int nonzeros, int replicas,
+                                const int* row_indices, const int* row_offsets,
+                                const int* column_indices, const float* lhs, int64_t lhs_stride,
+                                const float* rhs, int64_t rhs_stride, float* partials,
+                                const void* workspace, hipStream_t stream) {
+  const int debug = options().sddmm_debug;
+  const int slots = slots_of(m);
+  const int* row_ok = static_cast<const int*>(workspace);
+  const int* table =
+      reinterpret_cast<const int*>(static_cast<const char*>(workspace) + row_ok_bytes(slots));
+#define SPUTNIK_HIP_SD(KV)                                                                  \
+  return launch_partials<KV>(m, k, n, nonzeros, replicas, slots, row_indices, row_offsets, \
+                             column_indices, table, row_ok, lhs, lhs_stride, rhs,          \
+                             rhs_stride, partials, debug, stream)
+  switch (panel_width(k)) {
+    case 64: SPUTNIK_HIP_SD(1);
+    case 128: SPUTNIK_HIP_SD(2);
+    case 256: SPUTNIK_HIP_SD(4);
+    case 512: SPUTNIK_HIP_SD(8);
+    default: return SPUTNIK_HIP_INVALID_ARGUMENT;
+  }
+#undef SPUTNIK_HIP_SD
+}
 
 bool sddmm_tiled_applicable(int m, int k, int n, int nonzeros, const float* lhs,
                             int64_t lhs_stride, const float* rhs, int64_t rhs_stride) {

@@ -34,7 +34,9 @@ __device__ __forceinline__ void unrolled(F&& f) {
 
 // 16 bytes at `base + byte_offset`: wave-uniform base (SGPR pair) plus a 32-bit
 // per-lane offset, the cheapest addressing form (no 64-bit VALU arithmetic).
+template <bool NT>
 __device__ __forceinline__ f4 load_piece(const char* __restrict__ base, unsigned byte_offset) {
+  if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const f4*>(base + byte_offset));
   return *reinterpret_cast<const f4*>(base + byte_offset);
 }
 
@@ -58,7 +60,7 @@ __device__ __forceinline__ f4 load_piece(const char* __restrict__ base, unsigned
 // passes (re-reads served by L2).  exp is the hardware v_exp_f32 path (__expf):
 // relative error about 5e-6 at |x - max| ~ 88, far inside the 1e-4 budget; the
 // accurate library expf made the kernel VALU-bound.
-template <int LPR, int BASE, int V, bool BACKWARD, int DEPTH>
+template <int LPR, int BASE, int V, bool BACKWARD, int DEPTH, int NT>
 __global__ __launch_bounds__(kBlock) void sparse_softmax_rows_kernel(
     int m, int rows_per_group, int nonzeros, const float* __restrict__ a, int64_t a_stride,
     const float* __restrict__ b, int64_t b_stride, const int* __restrict__ row_offsets,
@@ -131,8 +133,8 @@ __global__ __launch_bounds__(kBlock) void sparse_softmax_rows_kernel(
       if (v >= BASE && !w.extra) continue;
       const int q = w.s + 4 * l + v * (4 * LPR);
       const unsigned off = static_cast<unsigned>(min(max(q, qmin), qmax) + 4) * 4u;
-      w.x[v] = load_piece(a_bytes, off);
-      if constexpr (BACKWARD) w.y[v] = load_piece(b_bytes, off);
+      w.x[v] = load_piece<(NT & 1) != 0>(a_bytes, off);
+      if constexpr (BACKWARD) w.y[v] = load_piece<(NT & 1) != 0>(b_bytes, off);
     }
   };
 
@@ -200,7 +202,8 @@ __global__ __launch_bounds__(kBlock) void sparse_softmax_rows_kernel(
         if (v >= BASE && !cur.extra) continue;
         const int q = cur.s + 4 * l + v * (4 * LPR);
         if (valid[v][0] && valid[v][3]) {
-          *reinterpret_cast<f4*>(out + q) = res[v];
+          if constexpr ((NT & 2) != 0) __builtin_nontemporal_store(res[v], reinterpret_cast<f4*>(out + q));
+          else *reinterpret_cast<f4*>(out + q) = res[v];
         } else {
 #pragma unroll
           for (int i = 0; i < 4; ++i)
@@ -272,13 +275,25 @@ int launch_rows(int m, int nonzeros, int replicas, const float* a, int64_t a_str
     const int same_phase = strides_alike && nonzeros >= 8 && nonzeros < (1 << 28) &&
                            phase_of(a_r, a_stride) == phase_of(out_r, out_stride) &&
                            (!BACKWARD || phase_of(a_r, a_stride) == phase_of(b_r, b_stride));
-#define SPUTNIK_HIP_SOFTMAX_LAUNCH(DEPTH)                                                         \
-  hipLaunchKernelGGL((sparse_softmax_rows_kernel<LPR, BASE, V, BACKWARD, DEPTH>), dim3(gx, ry),  \
+#define SPUTNIK_HIP_SOFTMAX_LAUNCH(DEPTH, NT)                                                     \
+  hipLaunchKernelGGL((sparse_softmax_rows_kernel<LPR, BASE, V, BACKWARD, DEPTH, NT>), dim3(gx, ry), \
                      dim3(kBlock), 0, stream, m, rows_per_group, nonzeros, a_r, a_stride, b_r,   \
                      b_stride, row_offsets, out_r, out_stride, scale, same_phase)
-    if (depth == 3) SPUTNIK_HIP_SOFTMAX_LAUNCH(3);
-    else if (depth == 2) SPUTNIK_HIP_SOFTMAX_LAUNCH(2);
-    else SPUTNIK_HIP_SOFTMAX_LAUNCH(1);
+    // Nontemporal STORES in the forward pass when the output is larger than the
+    // caches can hand to the next kernel anyway (measured, 1024^2 mask at density
+    // 0.1: 512 replicas, 215 MB out, 88.4 -> 75.8 us; 64 replicas 12.5 -> 12.2 us
+    // alone but +8 us on the attention step that reads the 27 MB straight back).
+    // In the backward pass they cost 4-5 %, nontemporal loads 15-35 % in both.
+    // Developer knob: 0 = none, 1 = loads, 2 = stores, 3 = both.
+    const bool large_out = static_cast<int64_t>(ry) * nonzeros * 4 >= (int64_t{128} << 20);
+    const int nt = options().softmax_nt >= 0 ? options().softmax_nt
+                                            : (!BACKWARD && large_out) ? 2 : 0;
+    if (depth == 3) SPUTNIK_HIP_SOFTMAX_LAUNCH(3, 0);
+    else if (depth == 2) SPUTNIK_HIP_SOFTMAX_LAUNCH(2, 0);
+    else if (nt == 1) SPUTNIK_HIP_SOFTMAX_LAUNCH(1, 1);
+    else if (nt == 2) SPUTNIK_HIP_SOFTMAX_LAUNCH(1, 2);
+    else if (nt == 3) SPUTNIK_HIP_SOFTMAX_LAUNCH(1, 3);
+    else SPUTNIK_HIP_SOFTMAX_LAUNCH(1, 0);
 #undef SPUTNIK_HIP_SOFTMAX_LAUNCH
     const int st = launch_status();
     if (st != 0) return st;

@@ -194,6 +194,10 @@ bool takes_panel(int m, int k, int n, int nonzeros, int replicas, const float* d
       !spmm_panel_applicable(m, k, n, nonzeros, dense, dense_stride, out, out_stride))
     return false;
   if (forced == 3) return true;
+  // More than one panel (k > 512): every pass walks the rows' whole streams, which
+  // pays for two panels of short rows only (1024^2 x 64 x 64 replicas: density 0.1
+  // 43 vs 48 us, 0.3 96 vs 89 us; four panels, 2048^2: 100 vs 60 us).
+  if (k > 1024 || (k > 512 && nonzeros > 128 * static_cast<int64_t>(m))) return false;
   const int choice = spmm_tiled_choice(m, k, n, nonzeros, replicas);
   const int64_t work = static_cast<int64_t>(nonzeros) * n * replicas;
   return choice == 2 || choice == 3 || (choice == 0 && work >= (int64_t{1} << 24));

@@ -34,15 +34,22 @@ constexpr int kPWaves = 16;   // waves per workgroup
 constexpr int kPQuads = 4;    // row quads (4 rows) per wave
 constexpr int kPBM = kPWaves * kPQuads * 4;   // 256 rows per workgroup
 constexpr int kPThreads = kPWaves * kWave;
-constexpr int kPMaxK = 512;   // 512 rows x 256 B = 128 KiB of LDS
+constexpr int kPMaxK = 512;   // rows of B per panel: 512 x 256 B = 128 KiB of LDS
+constexpr int kPMaxPasses = 8;
 
+// PASSES > 1 (k > 512): the panel is replaced every 512 rows of B; the C
+// accumulators of a wave's 16 rows stay in registers, and every pass walks each
+// row's whole stream again, working only on the groups of four entries that have
+// a column inside the resident panel (a row with ascending columns pays each
+// group once, plus the few that straddle a boundary; nothing has to be sorted).
+template <bool MULTI>
 __global__ __launch_bounds__(kPThreads) void spmm_panel64_kernel(
     int m, int k, int n, int nonzeros, int slots, int n_tiles,
     const int* __restrict__ row_indices, const float* __restrict__ values,
     int64_t values_stride, const int* __restrict__ row_offsets,
     const int* __restrict__ column_indices, const float* __restrict__ dense,
     int64_t dense_stride, float* __restrict__ out, int64_t out_stride, Epilogue epi) {
-  extern __shared__ float panel[];   // [k][64]
+  extern __shared__ float panel[];   // [min(k, 512)][64]
 
   const int lane = threadIdx.x % kWave;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -69,53 +76,75 @@ __global__ __launch_bounds__(kPThreads) void spmm_panel64_kernel(
     if (!live) row[t] = -1;
   }
 
-  // panel: one wave instruction copies rows 4j .. 4j+3 (4 x 256 B; lane l -> row
-  // l / 16, bytes (l % 16) * 16).  Lanes past the end of a row of B (partial last
-  // column tile) or past the last row re-read valid bytes that are never used.
-  const int col = min(n0 + i * 4, n - 4);
-  for (int j = wave; j * 4 < k; j += kPWaves) {
-    const int src_row = min(4 * j + g, k - 1);
-    const unsigned off = static_cast<unsigned>(src_row) * static_cast<unsigned>(n) * 4u +
-                         static_cast<unsigned>(col) * 4u;
-    lds_dma_row(dense, off, panel + 4 * j * kPBN);
-  }
-  wait_vm<0>();
-  __syncthreads();
-
-  const char* __restrict__ lane_base = reinterpret_cast<const char*>(panel + i * 4);
+  float acc[kPQuads][4];
 #pragma unroll
-  for (int t = 0; t < kPQuads; ++t) {
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    const int n_here = cnt[t];
-    const int longest =
-        max(max(__builtin_amdgcn_readlane(n_here, 0), __builtin_amdgcn_readlane(n_here, 16)),
-            max(__builtin_amdgcn_readlane(n_here, 32), __builtin_amdgcn_readlane(n_here, 48)));
-    // window w0: entries w0 .. w0+15 of this group's row, the next one requested
-    // before the current one is worked on
-    int idx = min(p0[t] + i, last);
-    int ecol = nonzeros > 0 ? column_indices[max(idx, 0)] : 0;
-    float eval = nonzeros > 0 ? values[max(idx, 0)] : 0.f;
-    for (int w0 = 0; w0 < longest; w0 += 16) {
-      const int cur_col = ecol;
-      const float cur_val = eval;
-      if (w0 + 16 < longest) {
-        idx = min(p0[t] + w0 + 16 + i, last);
-        ecol = column_indices[idx];
-        eval = values[idx];
-      }
-      const int left = n_here - w0;   // entries of this group's row at or after the window start
-      const bool valid = i < left;
-      const int roff = valid ? cur_col * (kPBN * 4) : 0;
-      const float rval = valid ? cur_val : 0.f;
-      if (left > 0) dpp_group4<0>(acc, roff, rval, lane_base);
-      if (left > 4) dpp_group4<4>(acc, roff, rval, lane_base);
-      if (left > 8) dpp_group4<8>(acc, roff, rval, lane_base);
-      if (left > 12) dpp_group4<12>(acc, roff, rval, lane_base);
+  for (int t = 0; t < kPQuads; ++t) acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0.f;
+  const int col = min(n0 + i * 4, n - 4);
+  const char* __restrict__ lane_base = reinterpret_cast<const char*>(panel + i * 4);
+
+  for (int kbase = 0; kbase < k; kbase += kPMaxK) {
+    // panel: one wave instruction copies rows 4j .. 4j+3 (4 x 256 B; lane l -> row
+    // l / 16, bytes (l % 16) * 16).  Lanes past the end of a row of B (partial last
+    // column tile) or past the last row re-read valid bytes that are never used.
+    if (MULTI && kbase > 0) __syncthreads();   // every wave is done with the previous panel
+    const int rows_here = min(k - kbase, kPMaxK);
+    for (int j = wave; j * 4 < rows_here; j += kPWaves) {
+      const int src_row = min(kbase + 4 * j + g, k - 1);
+      const unsigned off = static_cast<unsigned>(src_row) * static_cast<unsigned>(n) * 4u +
+                           static_cast<unsigned>(col) * 4u;
+      lds_dma_row(dense, off, panel + 4 * j * kPBN);
     }
+    wait_vm<0>();
+    __syncthreads();
+
+#pragma unroll
+    for (int t = 0; t < kPQuads; ++t) {
+      const int n_here = cnt[t];
+      const int longest =
+          max(max(__builtin_amdgcn_readlane(n_here, 0), __builtin_amdgcn_readlane(n_here, 16)),
+              max(__builtin_amdgcn_readlane(n_here, 32), __builtin_amdgcn_readlane(n_here, 48)));
+      // window w0: entries w0 .. w0+15 of this group's row, the next one requested
+      // before the current one is worked on
+      int idx = max(min(p0[t] + i, last), 0);
+      int ecol = column_indices[idx];
+      float eval = values[idx];
+      for (int w0 = 0; w0 < longest; w0 += 16) {
+        const int cur_col = ecol - kbase;
+        const float cur_val = eval;
+        if (w0 + 16 < longest) {
+          idx = min(p0[t] + w0 + 16 + i, last);
+          ecol = column_indices[idx];
+          eval = values[idx];
+        }
+        const int left = n_here - w0;   // entries of this group's row at or after the window start
+        if (!MULTI) {
+          const bool valid = i < left;
+          const int roff = valid ? cur_col * (kPBN * 4) : 0;
+          const float rval = valid ? cur_val : 0.f;
+          if (left > 0) dpp_group4<0>(acc[t], roff, rval, lane_base);
+          if (left > 4) dpp_group4<4>(acc[t], roff, rval, lane_base);
+          if (left > 8) dpp_group4<8>(acc[t], roff, rval, lane_base);
+          if (left > 12) dpp_group4<12>(acc[t], roff, rval, lane_base);
+        } else {
+          const bool valid = i < left && static_cast<unsigned>(cur_col) < static_cast<unsigned>(kPMaxK);
+          const int roff = valid ? cur_col * (kPBN * 4) : 0;
+          const float rval = valid ? cur_val : 0.f;
+          // which of this group's 16 entries are in the panel (bit u = entry u)
+          const unsigned in_panel =
+              static_cast<unsigned>(__builtin_amdgcn_ballot_w64(valid) >> (g * 16)) & 0xffffu;
+          if (in_panel & 0x000fu) dpp_group4<0>(acc[t], roff, rval, lane_base);
+          if (in_panel & 0x00f0u) dpp_group4<4>(acc[t], roff, rval, lane_base);
+          if (in_panel & 0x0f00u) dpp_group4<8>(acc[t], roff, rval, lane_base);
+          if (in_panel & 0xf000u) dpp_group4<12>(acc[t], roff, rval, lane_base);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < kPQuads; ++t)
     if (row[t] >= 0 && n0 + i * 4 < n)
       *reinterpret_cast<float4*>(out + static_cast<int64_t>(row[t]) * n + n0 + i * 4) =
-          apply_epilogue(make_float4(acc[0], acc[1], acc[2], acc[3]), epi, row[t]);
-  }
+          apply_epilogue(make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]), epi, row[t]);
 }
 
 }  // namespace
@@ -124,7 +153,7 @@ __global__ __launch_bounds__(kPThreads) void spmm_panel64_kernel(
 // every kernel of the library, an out-of-range index is the caller's error.)
 bool spmm_panel_applicable(int m, int k, int n, int nonzeros, const float* dense,
                            int64_t dense_stride, const float* out, int64_t out_stride) {
-  return k >= 1 && k <= kPMaxK && n % 4 == 0 && n >= kPBN && m >= 16 &&
+  return k >= 1 && k <= kPMaxK * kPMaxPasses && n % 4 == 0 && n >= kPBN && m >= 16 &&
          static_cast<int64_t>(k) * n * 4 < (int64_t{1} << 32) && aligned_to(dense, 16) &&
          aligned_to(out, 16) && dense_stride % 4 == 0 && out_stride % 4 == 0 && nonzeros >= 0;
 }
@@ -137,26 +166,29 @@ int spmm_panel_launch(int m, int k, int n, int nonzeros, int replicas, const int
   const int n_tiles = ceil_div(n, kPBN);
   const int64_t blocks = static_cast<int64_t>(slots / kPBM) * n_tiles;
   if (blocks > 0x7fffffff) return SPUTNIK_HIP_INVALID_ARGUMENT;
-  const size_t lds = static_cast<size_t>(ceil_div(k, 4) * 4) * kPBN * sizeof(float);
+  const size_t lds = static_cast<size_t>(ceil_div(min(k, kPMaxK), 4) * 4) * kPBN * sizeof(float);
+  const bool multi = k > kPMaxK;
   // more than 64 KiB of dynamic LDS has to be asked for, once per device
   static std::atomic<uint64_t> asked{0};
   int device = 0;
   if (hipGetDevice(&device) != hipSuccess) return launch_status();
   const uint64_t bit = uint64_t{1} << (device & 63);
   if (!(asked.load(std::memory_order_acquire) & bit)) {
-    const hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_panel64_kernel),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              kPMaxK * kPBN * sizeof(float));
-    if (st != hipSuccess) return static_cast<int>(st);
+    for (const void* f : {reinterpret_cast<const void*>(spmm_panel64_kernel<false>),
+                          reinterpret_cast<const void*>(spmm_panel64_kernel<true>)}) {
+      const hipError_t st = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                kPMaxK * kPBN * sizeof(float));
+      if (st != hipSuccess) return static_cast<int>(st);
+    }
     asked.fetch_or(bit, std::memory_order_release);
   }
   for (int r0 = 0; r0 < replicas; r0 += kMaxGridYZ) {
     const int ry = min(replicas - r0, kMaxGridYZ);
-    hipLaunchKernelGGL(spmm_panel64_kernel, dim3(static_cast<unsigned>(blocks), ry), dim3(kPThreads),
-                       lds, stream, m, k, n, nonzeros, slots, n_tiles, row_indices,
-                       values + r0 * values_stride, values_stride, row_offsets, column_indices,
-                       dense + r0 * dense_stride, dense_stride, out + r0 * out_stride, out_stride,
-                       epi);
+    hipLaunchKernelGGL(multi ? spmm_panel64_kernel<true> : spmm_panel64_kernel<false>,
+                       dim3(static_cast<unsigned>(blocks), ry), dim3(kPThreads), lds, stream, m, k,
+                       n, nonzeros, slots, n_tiles, row_indices, values + r0 * values_stride,
+                       values_stride, row_offsets, column_indices, dense + r0 * dense_stride,
+                       dense_stride, out + r0 * out_stride, out_stride, epi);
     const int st = launch_status();
     if (st != 0) return st;
   }

@@ -192,7 +192,7 @@ Tensor left_spmm(int64_t m, int64_t k, const Tensor& values, const Tensor& row_i
 
 Tensor sddmm_impl(int64_t m64, int64_t n64, const Tensor& row_indices, const Tensor& row_offsets,
                   const Tensor& column_indices, const Tensor& lhs_in, const Tensor& rhs_in,
-                  const c10::optional<Tensor>& plan) {
+                  const c10::optional<Tensor>& plan, bool sum_replicas = false) {
   const int m = to_int(m64, "m"), n = to_int(n64, "n");
   const Tensor lhs = as_float(lhs_in, "lhs_matrix");
   const Tensor rhs = as_float(rhs_in, "rhs_matrix");
@@ -216,9 +216,43 @@ Tensor sddmm_impl(int64_t m64, int64_t n64, const Tensor& row_indices, const Ten
               "first dim of lhs_matrix and rhs_matrix must match");
 
   // 1-D whenever there is a single replica, as src/sddmm_cuda.cu:43 does.
-  Tensor out = replicas == 1 ? at::empty({topo.nonzeros}, lhs.options())
-                             : at::empty({replicas, topo.nonzeros}, lhs.options());
+  Tensor out = (replicas == 1 || sum_replicas)
+                   ? at::empty({topo.nonzeros}, lhs.options())
+                   : at::empty({replicas, topo.nonzeros}, lhs.options());
   const size_t ws_bytes = sputnik_hip_sddmm_workspace_bytes(m, k, n, topo.nonzeros);
+  if (sum_replicas) {
+    // sum over the batch inside the call (sputnik_hip.h: sddmm_sum_batched)
+    const size_t scratch_bytes =
+        sputnik_hip_sddmm_sum_scratch_bytes(m, k, n, topo.nonzeros, replicas);
+    Tensor scratch, workspace;
+    if (scratch_bytes > 0)
+      scratch = at::empty({static_cast<int64_t>(scratch_bytes)}, lhs.options().dtype(at::kByte));
+    if (plan.has_value()) {
+      check_plan(*plan, ws_bytes, lhs);
+      check_status(sputnik_hip_sddmm_sum_batched_planned(
+                       m, k, n, topo.nonzeros, replicas, topo.row_indices.data_ptr<int>(),
+                       topo.row_offsets.data_ptr<int>(), topo.column_indices.data_ptr<int>(),
+                       lhs.data_ptr<float>(), static_cast<int64_t>(m) * k, rhs.data_ptr<float>(),
+                       static_cast<int64_t>(n) * k, out.data_ptr<float>(),
+                       ws_bytes ? plan->data_ptr() : nullptr, ws_bytes,
+                       scratch_bytes ? scratch.data_ptr() : nullptr, scratch_bytes,
+                       current_stream(lhs)),
+                   "sddmm_sum_planned");
+      return out;
+    }
+    if (ws_bytes > 0)
+      workspace = at::empty({static_cast<int64_t>(ws_bytes)}, lhs.options().dtype(at::kByte));
+    check_status(sputnik_hip_sddmm_sum_batched(
+                     m, k, n, topo.nonzeros, replicas, topo.row_indices.data_ptr<int>(),
+                     topo.row_offsets.data_ptr<int>(), topo.column_indices.data_ptr<int>(),
+                     lhs.data_ptr<float>(), static_cast<int64_t>(m) * k, rhs.data_ptr<float>(),
+                     static_cast<int64_t>(n) * k, out.data_ptr<float>(),
+                     ws_bytes ? workspace.data_ptr() : nullptr, ws_bytes,
+                     scratch_bytes ? scratch.data_ptr() : nullptr, scratch_bytes,
+                     current_stream(lhs)),
+                 "sddmm_sum");
+    return out;
+  }
   if (plan.has_value()) {
     check_plan(*plan, ws_bytes, lhs);
     check_status(sputnik_hip_sddmm_batched_planned(
@@ -310,6 +344,18 @@ Tensor sddmm_planned(int64_t m, int64_t n, const Tensor& row_indices, const Tens
                      const Tensor& column_indices, const Tensor& lhs, const Tensor& rhs,
                      const Tensor& plan) {
   return sddmm_impl(m, n, row_indices, row_offsets, column_indices, lhs, rhs, plan);
+}
+
+// sum over the replicas of sddmm: the gradient of values shared by a batch
+Tensor sddmm_sum(int64_t m, int64_t n, const Tensor& row_indices, const Tensor& row_offsets,
+                 const Tensor& column_indices, const Tensor& lhs, const Tensor& rhs) {
+  return sddmm_impl(m, n, row_indices, row_offsets, column_indices, lhs, rhs, c10::nullopt, true);
+}
+
+Tensor sddmm_sum_planned(int64_t m, int64_t n, const Tensor& row_indices,
+                         const Tensor& row_offsets, const Tensor& column_indices,
+                         const Tensor& lhs, const Tensor& rhs, const Tensor& plan) {
+  return sddmm_impl(m, n, row_indices, row_offsets, column_indices, lhs, rhs, plan, true);
 }
 
 Tensor sparse_softmax_scaled(const Tensor& values_in, const Tensor& row_indices,
@@ -888,6 +934,12 @@ TORCH_LIBRARY(torch_sputnik, m) {
       "sddmm_planned(int m, int n, Tensor row_indices, Tensor row_offsets, Tensor column_indices, "
       "Tensor lhs_matrix, Tensor rhs_matrix, Tensor plan) -> Tensor");
   m.def(
+      "sddmm_sum(int m, int n, Tensor row_indices, Tensor row_offsets, Tensor column_indices, "
+      "Tensor lhs_matrix, Tensor rhs_matrix) -> Tensor");
+  m.def(
+      "sddmm_sum_planned(int m, int n, Tensor row_indices, Tensor row_offsets, "
+      "Tensor column_indices, Tensor lhs_matrix, Tensor rhs_matrix, Tensor plan) -> Tensor");
+  m.def(
       "sparse_attention_plan(int m, int n, int d, Tensor row_indices, Tensor row_offsets, "
       "Tensor column_indices) -> Tensor");
   m.def(
@@ -935,6 +987,8 @@ TORCH_LIBRARY_IMPL(torch_sputnik, CUDA, m) {
   m.impl("left_spmm_planned", &left_spmm_planned);
   m.impl("sddmm_plan", &sddmm_plan);
   m.impl("sddmm_planned", &sddmm_planned);
+  m.impl("sddmm_sum", &sddmm_sum);
+  m.impl("sddmm_sum_planned", &sddmm_sum_planned);
   m.impl("sparse_attention_plan", &sparse_attention_plan);
   m.impl("sparse_attention_planned", &sparse_attention_planned);
   m.impl("spmm_many_mask", &spmm_many_mask);

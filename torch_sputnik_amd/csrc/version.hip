@@ -27,6 +27,7 @@ Options read_options() {
   o.sddmm_debug = num("SPUTNIK_HIP_SDDMM_DEBUG", 0);
   o.softmax_rpg = num("SPUTNIK_HIP_SOFTMAX_RPG", 0);
   o.softmax_depth = num("SPUTNIK_HIP_SOFTMAX_DEPTH", 1);
+  o.softmax_nt = num("SPUTNIK_HIP_SOFTMAX_NT", -1);
   return o;
 }
 

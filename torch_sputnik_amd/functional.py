@@ -169,12 +169,14 @@ def _spmm(m, k, values, row_indices, row_offsets, column_indices, dense, left=Fa
         m, k, values, row_indices, row_offsets, column_indices, dense, plan)
 
 
-def _sddmm(m, n, row_indices, row_offsets, column_indices, lhs_matrix, rhs_matrix):
+def _sddmm(m, n, row_indices, row_offsets, column_indices, lhs_matrix, rhs_matrix,
+           sum_replicas=False):
     if _plans is None:
-        return ops.sddmm(m, n, row_indices, row_offsets, column_indices, lhs_matrix, rhs_matrix)
+        return (ops.sddmm_sum if sum_replicas else ops.sddmm)(
+            m, n, row_indices, row_offsets, column_indices, lhs_matrix, rhs_matrix)
     plan = _plans.sddmm(m, n, lhs_matrix.size(-1), row_indices, row_offsets, column_indices)
-    return ops.sddmm_planned(m, n, row_indices, row_offsets, column_indices, lhs_matrix,
-                             rhs_matrix, plan)
+    return (ops.sddmm_sum_planned if sum_replicas else ops.sddmm_planned)(
+        m, n, row_indices, row_offsets, column_indices, lhs_matrix, rhs_matrix, plan)
 
 
 def _attention(query, key, value, row_indices, row_offsets, column_indices, scale):
@@ -302,11 +304,10 @@ class SparseLinearFunction(torch.autograd.Function):
         grad_output = grad_output.contiguous()
         grad_values = grad_dense = None
         if ctx.needs_input_grad[2]:
-            # [B,nnz]; autograd sums it over B to match the shared `values`.
+            # the [B,nnz] products summed over B (what autograd makes of the
+            # reference's result for the shared `values`), inside the call
             grad_values = _sddmm(m, k, row_indices, row_offsets, column_indices, grad_output,
-                                 dense.contiguous())
-            if grad_values.dim() == 2:
-                grad_values = grad_values.sum(dim=0)
+                                 dense.contiguous(), sum_replicas=True)
         if ctx.needs_input_grad[6]:
             values_t, row_indices_t, row_offsets_t, column_indices_t = _transpose(
                 m, k, values, row_offsets, column_indices)

@@ -178,6 +178,20 @@ def sddmm_planned(m, n, row_indices, row_offsets, column_indices, lhs_matrix, rh
                               lhs_matrix, rhs_matrix, plan)
 
 
+def sddmm_sum(m, n, row_indices, row_offsets, column_indices, lhs_matrix, rhs_matrix):
+    """sum over the replicas of sddmm(...) -> [nnz]: the gradient of sparse values
+    shared by a batch (what autograd makes of the [R, nnz] result of
+    tests/test_linear_3d.py:64-69), summed inside the call in replica order."""
+    return _ops.sddmm_sum(int(m), int(n), row_indices, row_offsets, column_indices, lhs_matrix,
+                          rhs_matrix)
+
+
+def sddmm_sum_planned(m, n, row_indices, row_offsets, column_indices, lhs_matrix, rhs_matrix,
+                      plan):
+    return _ops.sddmm_sum_planned(int(m), int(n), row_indices, row_offsets, column_indices,
+                                  lhs_matrix, rhs_matrix, plan)
+
+
 def sparse_attention_plan(m, n, d, row_indices, row_offsets, column_indices):
     """Pre-pass for the fused attention over an m x n mask with head dimension d."""
     return _ops.sparse_attention_plan(int(m), int(n), int(d), row_indices, row_offsets,
