@@ -245,6 +245,30 @@ SPUTNIK_HIP_API int sputnik_hip_spmm_bias_batched(int m, int k, int n, int nonze
                              size_t workspace_bytes, sputnik_hip_stream_t stream);
 
 /*
+ * SpMM over a topology whose values are stored in ANOTHER order of the same
+ * entries: entry p of (row_offsets, column_indices) takes
+ * values[value_permutation[p]].  This is the product with the TRANSPOSE of a
+ * matrix whose transposed topology and permutation are known (cached), as the
+ * backward passes need it (modules/spmm.py:59-66 transposes the values per
+ * call): the gather happens inside the kernel, no permuted copy is made.
+ * Served by the panel kernel only (k <= 4096, n a multiple of 4 and >= 64,
+ * m >= 16, 16-byte aligned operands); anything else returns
+ * SPUTNIK_HIP_UNSUPPORTED and the caller permutes first
+ * (sputnik_hip_permute_last_batched / _banded_batched) and calls
+ * sputnik_hip_spmm_batched.  `_supported` answers 1 where the gather inside the
+ * kernel is also the FASTER form: one panel, k <= 512 (with two panels every
+ * value is gathered twice: 162 us against 41 + 50 us at the attention shapes).
+ */
+SPUTNIK_HIP_API int sputnik_hip_spmm_permuted_supported(int m, int k, int n, int nonzeros);
+
+SPUTNIK_HIP_API int sputnik_hip_spmm_permuted_batched(int m, int k, int n, int nonzeros,
+                             int replicas, const int* row_indices, const float* values,
+                             int64_t values_stride, const int* value_permutation,
+                             const int* row_offsets, const int* column_indices,
+                             const float* dense, int64_t dense_stride, float* out,
+                             int64_t out_stride, sputnik_hip_stream_t stream);
+
+/*
  * softmax(scale * x) per CSR row: folds the 1/sqrt(d) of
  * modules/sparse_attention.py:72 into the softmax pass.
  */
@@ -374,6 +398,24 @@ SPUTNIK_HIP_API int sputnik_hip_csr_transpose_many_mask(int masks, int m, int n,
  */
 SPUTNIK_HIP_API int sputnik_hip_permute_last_batched(int n, int rows, const float* in, int64_t in_stride,
                                      const int* permutation, float* out,
+                                     int64_t out_stride, sputnik_hip_stream_t stream);
+
+/*
+ * The same permutation for MANY rows (attention weights: one row per batch x
+ * head), through LDS.  The caller regroups the permutation once per topology by
+ * the band of B = sputnik_hip_permute_band_size() consecutive SOURCE entries a
+ * value comes from: `dest_list` holds the output positions i, band after band
+ * (band b = list positions [b*B, min((b+1)*B, n)): exactly the positions whose
+ * source permutation[i] lies in [b*B, (b+1)*B)), ascending inside a band, and
+ * `source_in_band[t] = permutation[dest_list[t]] - (t / B) * B`.  (A stable sort
+ * of the positions by permutation[i] / B, or one counting pass on the host.)
+ *   out[r][dest_list[t]] = in[r][(t / B) * B + source_in_band[t]]
+ */
+SPUTNIK_HIP_API int sputnik_hip_permute_band_size(void);
+
+SPUTNIK_HIP_API int sputnik_hip_permute_banded_batched(int n, int rows, const float* in,
+                                     int64_t in_stride, const int* dest_list,
+                                     const int* source_in_band, float* out,
                                      int64_t out_stride, sputnik_hip_stream_t stream);
 
 /*

@@ -168,6 +168,28 @@ def _sddmm_planned(m, n, row_indices, row_offsets, column_indices, lhs, rhs, pla
     return _sddmm(m, n, row_indices, row_offsets, column_indices, lhs, rhs)
 
 
+def _spmm_permuted(m, k, values, permutation, row_indices, row_offsets, column_indices, dense,
+                   plan=None):
+    return _spmm(m, k, values[..., permutation.long()].contiguous(), row_indices, row_offsets,
+                 column_indices, dense)
+
+
+def _left_spmm_permuted(m, k, values, permutation, row_indices, row_offsets, column_indices,
+                        dense, plan=None):
+    return _left_spmm(m, k, values[permutation.long()].contiguous(), row_indices, row_offsets,
+                      column_indices, dense)
+
+
+def _permute_last_banded(values, dest_list, source_in_band):
+    import torch_sputnik_amd.ops as product_ops
+    band = product_ops.permute_band_size()
+    t = torch.arange(dest_list.numel())
+    source = torch.div(t, band, rounding_mode="floor") * band + source_in_band.long()
+    out = torch.empty_like(values)
+    out[..., dest_list.long()] = values[..., source]
+    return out
+
+
 def _sddmm_sum(m, n, row_indices, row_offsets, column_indices, lhs, rhs):
     out = _sddmm(m, n, row_indices, row_offsets, column_indices, lhs, rhs)
     return out.sum(dim=0) if out.dim() == 2 else out
@@ -208,6 +230,9 @@ def install():
     _lib.impl("left_spmm_planned", _left_spmm_planned, "CPU")
     _lib.impl("sddmm_planned", _sddmm_planned, "CPU")
     _lib.impl("sddmm_sum", _sddmm_sum, "CPU")
+    _lib.impl("permute_last_banded", _permute_last_banded, "CPU")
+    _lib.impl("spmm_permuted", _spmm_permuted, "CPU")
+    _lib.impl("left_spmm_permuted", _left_spmm_permuted, "CPU")
     _lib.impl("sddmm_sum_planned", _sddmm_sum_planned, "CPU")
     _lib.impl("sparse_attention_planned", _sparse_attention_planned, "CPU")
     _lib.impl("spmm_many_mask", _spmm_many_mask, "CPU")

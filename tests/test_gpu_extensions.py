@@ -479,6 +479,58 @@ def test_planned_ops_equal_the_per_call_ops(ts, dev, spmm_kernel, sddmm_kernel, 
             ts.spmm_planned(m, k, v, *topo, b, torch.zeros(4, dtype=torch.uint8, device=dev))
 
 
+@pytest.mark.parametrize("m,n,width,replicas", [
+    (1024, 1024, 64, 8),    # attention dV / dK: two panels, gathered values
+    (512, 512, 1024, 3),    # projection dX: one panel
+    (300, 200, 72, 2),      # ragged, partial column tile
+    (256, 100, 18, 2),      # not served by the panel kernel: permuted copy + the usual product
+    (128, 5000, 64, 1),     # transposed k = 5000 > 4096: permuted copy as well
+])
+def test_spmm_permuted_is_the_product_with_the_transpose(ts, dev, m, n, width, replicas):
+    """A^T @ X through the transposed topology and the permutation, values kept in
+    A's order, against the dense product in float64."""
+    a, vals, ri, ro, ci = make_csr(m, n, 0.9, seed=m + width)
+    rng = np.random.default_rng(width)
+    v = rng.uniform(-1, 1, (replicas, len(ci))).astype(np.float32)
+    x = rng.uniform(-1, 1, (replicas, m, width)).astype(np.float32)
+    _, ro_t, ci_t, perm = ts.csr_transpose_with_permutation(m, n, T(v[0], dev), T(ro, dev), T(ci, dev))
+    from torch_sputnik_amd.topology import diffsort
+    ri_t = diffsort(ro_t)
+    got = ts.spmm_permuted(n, m, T(v, dev), perm, ri_t, ro_t, ci_t, T(x, dev))
+    dense = np.zeros((replicas, m, n))
+    rows = np.repeat(np.arange(m), np.diff(ro))
+    dense[:, rows, ci] = v
+    want = np.einsum("rmn,rmw->rnw", dense, x.astype(np.float64))
+    got = got.reshape(replicas, n, width)   # one replica comes back 2-D (src/spmm_cuda.cu:42)
+    assert rel_err(got.cpu().numpy(), want.astype(np.float32)) < TOL
+    # the shared-values (left) form
+    left = ts.spmm_permuted(n, m, T(v[0], dev), perm, ri_t, ro_t, ci_t, T(x, dev), left=True)
+    want_left = np.einsum("mn,rmw->rnw", dense[0], x.astype(np.float64))
+    assert rel_err(left.cpu().numpy(), want_left.astype(np.float32)) < TOL
+    # same numbers as the two-step form
+    two_step = ts.spmm(n, m, ts.permute_last(T(v, dev), perm), ri_t, ro_t, ci_t, T(x, dev))
+    assert rel_err(got.cpu().numpy(), two_step.reshape(replicas, n, width).cpu().numpy()) < TOL
+
+
+@pytest.mark.parametrize("n,rows", [(104857, 64), (16384, 3), (16385, 2), (50001, 5), (100, 4), (40000, 1)])
+def test_permute_last_banded_equals_the_plain_gather(dev, n, rows):
+    from torch_sputnik_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(n)
+    perm = torch.randperm(n, generator=g).to(torch.int32).to(dev)
+    values = torch.rand(rows, n, generator=g).to(dev)
+    lists = ops.banded_lists(perm)
+    band = ops.permute_band_size()
+    # the lists are what the header says they are
+    t = torch.arange(n, device=dev)
+    assert torch.equal(perm.long()[lists[0].long()], (t // band) * band + lists[1].long())
+    got = ops.permute_last_banded(values, *lists)
+    assert torch.equal(got, values[:, perm.long()])
+    assert torch.equal(got, ops.permute_last(values, perm))
+    # rows that are not 16-byte aligned take the scalar copy
+    shifted = torch.rand(rows * n + 1, generator=g).to(dev)[1:].reshape(rows, n)
+    assert torch.equal(ops.permute_last_banded(shifted, *lists), shifted[:, perm.long()])
+
+
 def test_planned_attention_and_modules(ts, dev):
     from torch_sputnik_amd.modules import SparseAttention
     rng = np.random.default_rng(8)

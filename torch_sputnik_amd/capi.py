@@ -41,6 +41,13 @@ SIGNATURES = {
     "sputnik_hip_sddmm_batched_planned": (_c_int, [_c_int] * 5 + [_c_ptr, _c_ptr, _c_ptr, _c_ptr,
                                                                  _c_i64, _c_ptr, _c_i64, _c_ptr,
                                                                  _c_i64, _c_ptr, _c_size, _c_ptr]),
+    "sputnik_hip_permute_band_size": (_c_int, []),
+    "sputnik_hip_permute_banded_batched": (_c_int, [_c_int, _c_int, _c_ptr, _c_i64, _c_ptr, _c_ptr,
+                                                   _c_ptr, _c_i64, _c_ptr]),
+    "sputnik_hip_spmm_permuted_supported": (_c_int, [_c_int] * 4),
+    "sputnik_hip_spmm_permuted_batched": (_c_int, [_c_int] * 5 + [_c_ptr, _c_ptr, _c_i64, _c_ptr,
+                                                                 _c_ptr, _c_ptr, _c_ptr, _c_i64,
+                                                                 _c_ptr, _c_i64, _c_ptr]),
     "sputnik_hip_sddmm_sum_scratch_bytes": (_c_size, [_c_int] * 5),
     "sputnik_hip_sddmm_sum_batched": (_c_int, [_c_int] * 5 + [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64,
                                                              _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_size,
@@ -402,6 +409,20 @@ def sddmm_batched_planned(m, k, n, replicas, row_indices, row_offsets, column_in
         _ptr(lhs), m * k, _ptr(rhs), n * k, _ptr(out), nonzeros, _ptr(workspace),
         _ws_bytes(workspace), _stream(out)), "sputnik_hip_sddmm_batched_planned")
     return out
+
+
+def spmm_permuted_batched(m, k, n, replicas, row_indices, values, values_stride, permutation,
+                          row_offsets, column_indices, dense, out):
+    """out = A @ dense with A's values taken as values[permutation[p]]; returns the
+    status (SPUTNIK_HIP_UNSUPPORTED = -2 when the shape is not served)."""
+    nonzeros = column_indices.numel()
+    st = lib().sputnik_hip_spmm_permuted_batched(
+        m, k, n, nonzeros, replicas, _ptr(row_indices), _ptr(values), values_stride,
+        _ptr(permutation), _ptr(row_offsets), _ptr(column_indices), _ptr(dense), k * n, _ptr(out),
+        m * n, _stream(out))
+    if st != -2:
+        _check(st, "sputnik_hip_spmm_permuted_batched")
+    return st
 
 
 def sddmm_sum_scratch_bytes(m, k, n, nonzeros, replicas):

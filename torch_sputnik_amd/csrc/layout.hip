@@ -122,6 +122,68 @@ __global__ __launch_bounds__(kThreads) void permute_last_kernel(
     if (r0 + j < rows) out[(r0 + j) * out_stride + i] = v[j];
 }
 
+// The same permutation through LDS, for MANY rows of values (attention weights:
+// one row per batch x head).  The plain kernel's 4-byte gathers each pull a whole
+// 64-byte sector out of L2 (16 x the useful bytes: 41 us for 64 rows of 105 k
+// entries, the L2 -> L1 rate).  Here the positions are processed grouped by the
+// BAND of kPermuteBand consecutive source entries their value comes from
+// (`dest_list`: output positions, band after band, ascending inside a band;
+// `source_in_band`: the source's offset inside its band).  A workgroup copies one
+// band of one row into LDS with coalesced reads, gathers from LDS, and writes
+// runs of consecutive output positions (a band of a transposed CSR pattern holds
+// a run of every column's entries).  The lists depend on the permutation alone
+// and are reused for kRowsPerGroup rows per workgroup.
+constexpr int kPermuteBand = 16384;       // 64 KiB of LDS
+constexpr int kBandThreads = 1024;
+constexpr int kBandPerThread = kPermuteBand / kBandThreads;
+constexpr int kRowsPerGroup = 2;
+
+template <bool VEC>
+__global__ __launch_bounds__(kBandThreads) void permute_banded_kernel(
+    int n, int rows, const float* __restrict__ in, int64_t in_stride,
+    const int* __restrict__ dest_list, const int* __restrict__ source_in_band,
+    float* __restrict__ out, int64_t out_stride) {
+  __shared__ float band[kPermuteBand];
+  const int tid = threadIdx.x;
+  const int base = blockIdx.x * kPermuteBand;
+  const int count = min(kPermuteBand, n - base);
+  const int r0 = blockIdx.y * kRowsPerGroup;
+  int dest[kBandPerThread], src[kBandPerThread];
+#pragma unroll
+  for (int j = 0; j < kBandPerThread; ++j) {
+    const int t = j * kBandThreads + tid;
+    dest[j] = t < count ? dest_list[base + t] : -1;
+    src[j] = t < count ? source_in_band[base + t] : 0;
+  }
+  for (int r = r0; r < min(r0 + kRowsPerGroup, rows); ++r) {
+    const float* __restrict__ row_in = in + r * in_stride + base;
+    if (r > r0) __syncthreads();   // the previous row's gathers are done
+    if (VEC) {
+#pragma unroll
+      for (int j = 0; j < kBandPerThread / 4; ++j) {
+        const int t = (j * kBandThreads + tid) * 4;
+        if (t + 3 < count) {
+          *reinterpret_cast<float4*>(band + t) = *reinterpret_cast<const float4*>(row_in + t);
+        } else {
+          for (int e = 0; e < 4; ++e)
+            if (t + e < count) band[t + e] = row_in[t + e];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < kBandPerThread; ++j) {
+        const int t = j * kBandThreads + tid;
+        if (t < count) band[t] = row_in[t];
+      }
+    }
+    __syncthreads();
+    float* __restrict__ row_out = out + r * out_stride;
+#pragma unroll
+    for (int j = 0; j < kBandPerThread; ++j)
+      if (dest[j] >= 0) row_out[dest[j]] = band[src[j]];
+  }
+}
+
 template <typename TIn, typename TOut>
 int launch_transpose(int batches, int rows, int cols, const void* in_v, int64_t in_batch_stride,
                      void* out_v, int64_t out_batch_stride, hipStream_t stream) {
@@ -173,6 +235,27 @@ int sputnik_hip_permute_last_batched(int n, int rows, const float* in, int64_t i
   if (by > kMaxGridYZ) return SPUTNIK_HIP_INVALID_ARGUMENT;
   hipLaunchKernelGGL(permute_last_kernel, dim3(ceil_div(n, kThreads), by), dim3(kThreads), 0,
                      stream, n, rows, in, in_stride, permutation, out, out_stride);
+  return launch_status();
+}
+
+int sputnik_hip_permute_band_size(void) { return kPermuteBand; }
+
+int sputnik_hip_permute_banded_batched(int n, int rows, const float* in, int64_t in_stride,
+                                       const int* dest_list, const int* source_in_band,
+                                       float* out, int64_t out_stride,
+                                       sputnik_hip_stream_t stream) {
+  if (n < 0 || rows < 0) return SPUTNIK_HIP_INVALID_ARGUMENT;
+  if (n == 0 || rows == 0) return 0;
+  const int by = ceil_div(rows, kRowsPerGroup);
+  if (by > kMaxGridYZ) return SPUTNIK_HIP_INVALID_ARGUMENT;
+  const dim3 grid(ceil_div(n, kPermuteBand), by);
+  // (a band starts at a multiple of 16384 entries: rows aligned alike are enough)
+  if (aligned_to(in, 16) && in_stride % 4 == 0)
+    hipLaunchKernelGGL(permute_banded_kernel<true>, grid, dim3(kBandThreads), 0, stream, n, rows,
+                       in, in_stride, dest_list, source_in_band, out, out_stride);
+  else
+    hipLaunchKernelGGL(permute_banded_kernel<false>, grid, dim3(kBandThreads), 0, stream, n, rows,
+                       in, in_stride, dest_list, source_in_band, out, out_stride);
   return launch_status();
 }
 

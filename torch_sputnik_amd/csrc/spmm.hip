@@ -33,7 +33,8 @@ bool spmm_panel_applicable(int m, int k, int n, int nonzeros, const float* dense
 int spmm_panel_launch(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
                       const float* values, int64_t values_stride, const int* row_offsets,
                       const int* column_indices, const float* dense, int64_t dense_stride,
-                      float* out, int64_t out_stride, hipStream_t stream, Epilogue epi);
+                      float* out, int64_t out_stride, hipStream_t stream, Epilogue epi,
+                      const int* value_permutation = nullptr);
 
 namespace {
 
@@ -273,6 +274,29 @@ int sputnik_hip_spmm_bias_batched(int m, int k, int n, int nonzeros, int replica
   return spmm_exec(m, k, n, nonzeros, replicas, row_indices, values, values_stride, row_offsets,
                    column_indices, dense, dense_stride, out, out_stride, workspace,
                    workspace_bytes, stream, epi);
+}
+
+int sputnik_hip_spmm_permuted_supported(int m, int k, int n, int nonzeros) {
+  // (operand alignment is checked by the call itself)
+  return m > 0 && nonzeros > 0 && k <= 512 &&
+         spmm_panel_applicable(m, k, n, nonzeros, nullptr, 0, nullptr, 0) ? 1 : 0;
+}
+
+int sputnik_hip_spmm_permuted_batched(int m, int k, int n, int nonzeros, int replicas,
+                                      const int* row_indices, const float* values,
+                                      int64_t values_stride, const int* value_permutation,
+                                      const int* row_offsets, const int* column_indices,
+                                      const float* dense, int64_t dense_stride, float* out,
+                                      int64_t out_stride, sputnik_hip_stream_t stream) {
+  if (m < 0 || k < 0 || n < 0 || nonzeros < 0 || replicas < 0 || value_permutation == nullptr)
+    return SPUTNIK_HIP_INVALID_ARGUMENT;
+  if (m == 0 || n == 0 || replicas == 0) return 0;
+  if (nonzeros == 0 ||
+      !spmm_panel_applicable(m, k, n, nonzeros, dense, dense_stride, out, out_stride))
+    return SPUTNIK_HIP_UNSUPPORTED;
+  return spmm_panel_launch(m, k, n, nonzeros, replicas, row_indices, values, values_stride,
+                           row_offsets, column_indices, dense, dense_stride, out, out_stride,
+                           stream, Epilogue{}, value_permutation);
 }
 
 int sputnik_hip_spmm(int m, int k, int n, int nonzeros, const int* row_indices,

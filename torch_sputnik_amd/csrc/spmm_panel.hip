@@ -37,18 +37,23 @@ constexpr int kPThreads = kPWaves * kWave;
 constexpr int kPMaxK = 512;   // rows of B per panel: 512 x 256 B = 128 KiB of LDS
 constexpr int kPMaxPasses = 8;
 
+// PERM: entry p of the stream takes its value from values[value_permutation[p]]
+// (a transposed topology over the values of the original one: the gather that
+// a separate pass would do, 4-byte reads across a row of values that L2 holds,
+// overlaps the arithmetic here).
 // PASSES > 1 (k > 512): the panel is replaced every 512 rows of B; the C
 // accumulators of a wave's 16 rows stay in registers, and every pass walks each
 // row's whole stream again, working only on the groups of four entries that have
 // a column inside the resident panel (a row with ascending columns pays each
 // group once, plus the few that straddle a boundary; nothing has to be sorted).
-template <bool MULTI>
+template <bool MULTI, bool PERM>
 __global__ __launch_bounds__(kPThreads) void spmm_panel64_kernel(
     int m, int k, int n, int nonzeros, int slots, int n_tiles,
     const int* __restrict__ row_indices, const float* __restrict__ values,
     int64_t values_stride, const int* __restrict__ row_offsets,
-    const int* __restrict__ column_indices, const float* __restrict__ dense,
-    int64_t dense_stride, float* __restrict__ out, int64_t out_stride, Epilogue epi) {
+    const int* __restrict__ column_indices, const int* __restrict__ value_permutation,
+    const float* __restrict__ dense, int64_t dense_stride, float* __restrict__ out,
+    int64_t out_stride, Epilogue epi) {
   extern __shared__ float panel[];   // [min(k, 512)][64]
 
   const int lane = threadIdx.x % kWave;
@@ -107,14 +112,14 @@ __global__ __launch_bounds__(kPThreads) void spmm_panel64_kernel(
       // before the current one is worked on
       int idx = max(min(p0[t] + i, last), 0);
       int ecol = column_indices[idx];
-      float eval = values[idx];
+      float eval = values[PERM ? value_permutation[idx] : idx];
       for (int w0 = 0; w0 < longest; w0 += 16) {
         const int cur_col = ecol - kbase;
         const float cur_val = eval;
         if (w0 + 16 < longest) {
           idx = min(p0[t] + w0 + 16 + i, last);
           ecol = column_indices[idx];
-          eval = values[idx];
+          eval = values[PERM ? value_permutation[idx] : idx];
         }
         const int left = n_here - w0;   // entries of this group's row at or after the window start
         if (!MULTI) {
@@ -161,7 +166,8 @@ bool spmm_panel_applicable(int m, int k, int n, int nonzeros, const float* dense
 int spmm_panel_launch(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
                       const float* values, int64_t values_stride, const int* row_offsets,
                       const int* column_indices, const float* dense, int64_t dense_stride,
-                      float* out, int64_t out_stride, hipStream_t stream, Epilogue epi) {
+                      float* out, int64_t out_stride, hipStream_t stream, Epilogue epi,
+                      const int* value_permutation) {
   const int slots = ceil_div(m, kPBM) * kPBM;
   const int n_tiles = ceil_div(n, kPBN);
   const int64_t blocks = static_cast<int64_t>(slots / kPBM) * n_tiles;
@@ -174,8 +180,10 @@ int spmm_panel_launch(int m, int k, int n, int nonzeros, int replicas, const int
   if (hipGetDevice(&device) != hipSuccess) return launch_status();
   const uint64_t bit = uint64_t{1} << (device & 63);
   if (!(asked.load(std::memory_order_acquire) & bit)) {
-    for (const void* f : {reinterpret_cast<const void*>(spmm_panel64_kernel<false>),
-                          reinterpret_cast<const void*>(spmm_panel64_kernel<true>)}) {
+    for (const void* f : {reinterpret_cast<const void*>(spmm_panel64_kernel<false, false>),
+                          reinterpret_cast<const void*>(spmm_panel64_kernel<true, false>),
+                          reinterpret_cast<const void*>(spmm_panel64_kernel<false, true>),
+                          reinterpret_cast<const void*>(spmm_panel64_kernel<true, true>)}) {
       const hipError_t st = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                 kPMaxK * kPBN * sizeof(float));
       if (st != hipSuccess) return static_cast<int>(st);
@@ -184,11 +192,14 @@ int spmm_panel_launch(int m, int k, int n, int nonzeros, int replicas, const int
   }
   for (int r0 = 0; r0 < replicas; r0 += kMaxGridYZ) {
     const int ry = min(replicas - r0, kMaxGridYZ);
-    hipLaunchKernelGGL(multi ? spmm_panel64_kernel<true> : spmm_panel64_kernel<false>,
-                       dim3(static_cast<unsigned>(blocks), ry), dim3(kPThreads), lds, stream, m, k,
-                       n, nonzeros, slots, n_tiles, row_indices, values + r0 * values_stride,
-                       values_stride, row_offsets, column_indices, dense + r0 * dense_stride,
-                       dense_stride, out + r0 * out_stride, out_stride, epi);
+    const auto kernel = value_permutation != nullptr
+                            ? (multi ? spmm_panel64_kernel<true, true> : spmm_panel64_kernel<false, true>)
+                            : (multi ? spmm_panel64_kernel<true, false> : spmm_panel64_kernel<false, false>);
+    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(blocks), ry), dim3(kPThreads), lds,
+                       stream, m, k, n, nonzeros, slots, n_tiles, row_indices,
+                       values + r0 * values_stride, values_stride, row_offsets, column_indices,
+                       value_permutation, dense + r0 * dense_stride, dense_stride,
+                       out + r0 * out_stride, out_stride, epi);
     const int st = launch_status();
     if (st != 0) return st;
   }

@@ -103,13 +103,16 @@ void check_plan(const Tensor& plan, size_t bytes, const Tensor& like) {
               " bytes): it was made for other sizes");
 }
 
+Tensor permute_last(const Tensor& values_in, const Tensor& permutation);
+
 // Shared by spmm (values [nnz] / [R,nnz]) and left_spmm (values [nnz], shared).
 Tensor spmm_impl(int64_t m64, int64_t k64, const Tensor& values_in, const Tensor& row_indices,
                  const Tensor& row_offsets, const Tensor& column_indices, const Tensor& dense_in,
                  bool left, const char* what, const c10::optional<Tensor>& bias_in = c10::nullopt,
-                 bool relu = false, const c10::optional<Tensor>& plan = c10::nullopt) {
+                 bool relu = false, const c10::optional<Tensor>& plan = c10::nullopt,
+                 const c10::optional<Tensor>& permutation = c10::nullopt) {
   const int m = to_int(m64, "m"), k = to_int(k64, "k");
-  const Tensor values = as_float(values_in, "values");
+  Tensor values = as_float(values_in, "values");
   const Tensor dense = as_float(dense_in, "dense");
   TORCH_CHECK(dense.device() == values.device(), "values and dense must be on one device");
   TORCH_CHECK(dense.dim() == 2 || dense.dim() == 3, "dense should have 2 or 3 dimensions, got ",
@@ -143,6 +146,30 @@ Tensor spmm_impl(int64_t m64, int64_t k64, const Tensor& values_in, const Tensor
   Tensor out = (replicas == 1 && !left) ? at::empty({m, n}, options)
                                         : at::empty({replicas, m, n}, options);
   const int64_t values_stride = (left || values.dim() == 1) ? 0 : topo.nonzeros;
+  if (permutation.has_value()) {
+    // values are those of ANOTHER ordering of the same entries (the topology here
+    // is its transpose): entry p takes values[permutation[p]].  One kernel where
+    // the panel kernel serves the shape in one pass; otherwise the values are
+    // permuted first and the call goes on as usual.
+    TORCH_CHECK(permutation->scalar_type() == at::kInt && permutation->dim() == 1 &&
+                    permutation->is_contiguous() && permutation->device() == values.device() &&
+                    permutation->size(0) == topo.nonzeros,
+                "permutation must be a contiguous int32 vector of ", topo.nonzeros,
+                " entries on ", values.device());
+    int st = SPUTNIK_HIP_UNSUPPORTED;
+    if (sputnik_hip_spmm_permuted_supported(m, k, n, topo.nonzeros))
+      st = sputnik_hip_spmm_permuted_batched(
+          m, k, n, topo.nonzeros, replicas, topo.row_indices.data_ptr<int>(),
+          values.data_ptr<float>(), values_stride, permutation->data_ptr<int>(),
+          topo.row_offsets.data_ptr<int>(), topo.column_indices.data_ptr<int>(),
+          dense.data_ptr<float>(), static_cast<int64_t>(k) * n, out.data_ptr<float>(),
+          static_cast<int64_t>(m) * n, current_stream(values));
+    if (st != SPUTNIK_HIP_UNSUPPORTED) {
+      check_status(st, what);
+      return out;
+    }
+    values = permute_last(values, *permutation);
+  }
   const size_t ws_bytes = sputnik_hip_spmm_workspace_bytes(m, k, n, topo.nonzeros);
   if (plan.has_value()) {
     // static topology: the pre-pass ran once (spmm_plan); kernels only
@@ -182,6 +209,25 @@ Tensor spmm_impl(int64_t m64, int64_t k64, const Tensor& values_in, const Tensor
 Tensor spmm(int64_t m, int64_t k, const Tensor& values, const Tensor& row_indices,
             const Tensor& row_offsets, const Tensor& column_indices, const Tensor& dense) {
   return spmm_impl(m, k, values, row_indices, row_offsets, column_indices, dense, false, "spmm");
+}
+
+// spmm / left_spmm over a topology whose values are given in another order
+// (values_here[p] = values[permutation[p]]): the transposed products of the
+// backward passes, modules/spmm.py:59-66, without the permuted copy.
+Tensor spmm_permuted(int64_t m, int64_t k, const Tensor& values, const Tensor& permutation,
+                     const Tensor& row_indices, const Tensor& row_offsets,
+                     const Tensor& column_indices, const Tensor& dense,
+                     const c10::optional<Tensor>& plan) {
+  return spmm_impl(m, k, values, row_indices, row_offsets, column_indices, dense, false,
+                   "spmm_permuted", c10::nullopt, false, plan, permutation);
+}
+
+Tensor left_spmm_permuted(int64_t m, int64_t k, const Tensor& values, const Tensor& permutation,
+                          const Tensor& row_indices, const Tensor& row_offsets,
+                          const Tensor& column_indices, const Tensor& dense,
+                          const c10::optional<Tensor>& plan) {
+  return spmm_impl(m, k, values, row_indices, row_offsets, column_indices, dense, true,
+                   "left_spmm_permuted", c10::nullopt, false, plan, permutation);
 }
 
 Tensor left_spmm(int64_t m, int64_t k, const Tensor& values, const Tensor& row_indices,
@@ -878,6 +924,32 @@ Tensor permute_last(const Tensor& values_in, const Tensor& permutation) {
   return out;
 }
 
+// permute_last through LDS for many rows; the lists come from
+// torch_sputnik_amd.functional (one stable sort per cached permutation)
+Tensor permute_last_banded(const Tensor& values_in, const Tensor& dest_list,
+                           const Tensor& source_in_band) {
+  const Tensor values = as_float(values_in, "values");
+  TORCH_CHECK(values.dim() == 1 || values.dim() == 2, "values should have 1 or 2 dimensions, got ",
+              values.dim());
+  for (const Tensor* t : {&dest_list, &source_in_band})
+    TORCH_CHECK(t->scalar_type() == at::kInt && t->dim() == 1 && t->is_contiguous() &&
+                    t->device() == values.device() && t->size(0) == values.size(-1),
+                "dest_list / source_in_band must be contiguous int32 vectors of ",
+                values.size(-1), " entries on ", values.device());
+  const c10::DeviceGuard guard(values.device());
+  const int n = to_int(values.size(-1), "n");
+  const int rows = values.dim() == 2 ? to_int(values.size(0), "rows") : 1;
+  Tensor out = at::empty_like(values);
+  check_status(sputnik_hip_permute_banded_batched(
+                   n, rows, values.data_ptr<float>(), n, dest_list.data_ptr<int>(),
+                   source_in_band.data_ptr<int>(), out.data_ptr<float>(), n,
+                   current_stream(values)),
+               "permute_last_banded");
+  return out;
+}
+
+int64_t permute_band_size() { return sputnik_hip_permute_band_size(); }
+
 }  // namespace
 
 TORCH_LIBRARY(torch_sputnik, m) {
@@ -964,6 +1036,14 @@ TORCH_LIBRARY(torch_sputnik, m) {
       "csr_transpose_many_mask(int b, int m, int n, Tensor nonzeros, Tensor values, "
       "Tensor row_offsets, Tensor column_indices) -> Tensor[]");
   m.def("permute_last(Tensor values, Tensor permutation) -> Tensor");
+  m.def("permute_last_banded(Tensor values, Tensor dest_list, Tensor source_in_band) -> Tensor");
+  m.def("permute_band_size() -> int", &permute_band_size);
+  m.def(
+      "spmm_permuted(int m, int k, Tensor values, Tensor permutation, Tensor row_indices, "
+      "Tensor row_offsets, Tensor column_indices, Tensor dense_matrix, Tensor? plan) -> Tensor");
+  m.def(
+      "left_spmm_permuted(int m, int k, Tensor values, Tensor permutation, Tensor row_indices, "
+      "Tensor row_offsets, Tensor column_indices, Tensor dense_matrix, Tensor? plan) -> Tensor");
   m.def("transpose_last2(Tensor x) -> Tensor");
   m.def("transpose_last2_as(Tensor x, int out_type) -> Tensor");
 }
@@ -998,6 +1078,9 @@ TORCH_LIBRARY_IMPL(torch_sputnik, CUDA, m) {
   m.impl("sparse_softmax_backward_many_mask", &sparse_softmax_backward_many_mask);
   m.impl("csr_transpose_many_mask", &csr_transpose_many_mask);
   m.impl("permute_last", &permute_last);
+  m.impl("permute_last_banded", &permute_last_banded);
+  m.impl("spmm_permuted", &spmm_permuted);
+  m.impl("left_spmm_permuted", &left_spmm_permuted);
   m.impl("transpose_last2", &transpose_last2);
   m.impl("transpose_last2_as", &transpose_last2_as);
 }

@@ -147,16 +147,56 @@ def clear_caches():
             cache.clear()
 
 
+# From this many values on (several rows of them) a cached permutation goes
+# through the LDS-banded kernel; its two index lists are made once per cached
+# permutation and kept on the permutation tensor (the cache entry owns it).
+BANDED_PERMUTE_FROM = 1 << 21
+
+
+def _permute_cached(values, perm):
+    """values[..., perm] for a permutation held by the transpose cache."""
+    if values.dim() == 2 and values.size(0) > 1 and values.numel() >= BANDED_PERMUTE_FROM \
+            and values.is_cuda:
+        lists = getattr(perm, "_sputnik_banded_lists", None)
+        if lists is None:
+            lists = ops.banded_lists(perm)
+            perm._sputnik_banded_lists = lists
+        return ops.permute_last_banded(values, *lists)
+    return ops.permute_last(values, perm)
+
+
 def _transpose(m, n, values, row_offsets, column_indices):
     """(values_t, row_indices_t, row_offsets_t, column_indices_t)."""
     values = values.contiguous()
     if _cache is not None:
         row_indices_t, row_offsets_t, column_indices_t, perm = _cache.lookup(
             m, n, row_offsets, column_indices, values)
-        return ops.permute_last(values, perm), row_indices_t, row_offsets_t, column_indices_t
+        return _permute_cached(values, perm), row_indices_t, row_offsets_t, column_indices_t
     values_t, row_offsets_t, column_indices_t = ops.csr_transpose(
         m, n, values, row_offsets, column_indices)
     return values_t, diffsort(row_offsets_t), row_offsets_t, column_indices_t
+
+
+def _spmm_transposed(m, n, values, row_offsets, column_indices, dense, left=False):
+    """(A^T) @ dense for the m x n CSR matrix A: with the transposed-topology cache
+    the values stay in A's order and the kernel gathers them through the cached
+    permutation (ops.spmm_permuted); without it the reference's per-call
+    csr_transpose (modules/spmm.py:59-62)."""
+    if _cache is None:
+        values_t, row_indices_t, row_offsets_t, column_indices_t = _transpose(
+            m, n, values, row_offsets, column_indices)
+        return _spmm(n, m, values_t, row_indices_t, row_offsets_t, column_indices_t, dense,
+                     left=left)
+    values = values.contiguous()
+    row_indices_t, row_offsets_t, column_indices_t, perm = _cache.lookup(
+        m, n, row_offsets, column_indices, values)
+    if ops.spmm_permuted_fused(n, m, dense.size(-1), perm.numel()):
+        plan = None if _plans is None else _plans.spmm(n, m, dense.size(-1), row_indices_t,
+                                                       row_offsets_t, column_indices_t)
+        return ops.spmm_permuted(n, m, values, perm, row_indices_t, row_offsets_t,
+                                 column_indices_t, dense, plan, left=left)
+    return _spmm(n, m, _permute_cached(values, perm), row_indices_t, row_offsets_t,
+                 column_indices_t, dense, left=left)
 
 
 def _spmm(m, k, values, row_indices, row_offsets, column_indices, dense, left=False):
@@ -246,10 +286,7 @@ class Spmm(torch.autograd.Function):
                                  dense.contiguous())
         if ctx.needs_input_grad[6]:
             # dL/dB = A^T @ dC
-            values_t, row_indices_t, row_offsets_t, column_indices_t = _transpose(
-                m, k, values, row_offsets, column_indices)
-            grad_dense = _spmm(k, m, values_t, row_indices_t, row_offsets_t, column_indices_t,
-                               grad_output)
+            grad_dense = _spmm_transposed(m, k, values, row_offsets, column_indices, grad_output)
         return None, None, grad_values, None, None, None, grad_dense
 
 
@@ -277,10 +314,8 @@ class Sddmm(torch.autograd.Function):
                              rhs_matrix.contiguous())
         if ctx.needs_input_grad[6]:
             # dL/drhs = dS^T @ lhs
-            grad_t, row_indices_t, row_offsets_t, column_indices_t = _transpose(
-                m, n, grad_output, row_offsets, column_indices)
-            grad_rhs = _spmm(n, m, grad_t, row_indices_t, row_offsets_t, column_indices_t,
-                             lhs_matrix.contiguous())
+            grad_rhs = _spmm_transposed(m, n, grad_output, row_offsets, column_indices,
+                                        lhs_matrix.contiguous())
         return None, None, None, None, None, grad_lhs, grad_rhs
 
 
@@ -309,10 +344,8 @@ class SparseLinearFunction(torch.autograd.Function):
             grad_values = _sddmm(m, k, row_indices, row_offsets, column_indices, grad_output,
                                  dense.contiguous(), sum_replicas=True)
         if ctx.needs_input_grad[6]:
-            values_t, row_indices_t, row_offsets_t, column_indices_t = _transpose(
-                m, k, values, row_offsets, column_indices)
-            grad_dense = _spmm(k, m, values_t, row_indices_t, row_offsets_t, column_indices_t,
-                               grad_output, left=True)
+            grad_dense = _spmm_transposed(m, k, values, row_offsets, column_indices,
+                                          grad_output, left=True)
             if dense.dim() == 2:
                 grad_dense = grad_dense[0]
         return None, None, grad_values, None, None, None, grad_dense
@@ -385,12 +418,18 @@ class SparseAttentionFunction(torch.autograd.Function):
                     m, n, grad_scores.reshape(-1, grad_scores.shape[-1])[0].contiguous(),
                     row_offsets, column_indices)
                 row_indices_t = diffsort(row_offsets_t)
+            def transposed_product(values, dense):
+                if ops.spmm_permuted_fused(n, m, dense.size(-1), perm.numel()):
+                    return ops.spmm_permuted(n, m, values, perm, row_indices_t, row_offsets_t,
+                                             column_indices_t, dense)
+                values_t = (_permute_cached(values, perm) if _cache is not None
+                            else ops.permute_last(values, perm))
+                return _spmm(n, m, values_t, row_indices_t, row_offsets_t, column_indices_t, dense)
+
             if ctx.needs_input_grad[1]:
-                grad_key = _spmm(n, m, ops.permute_last(grad_scores, perm), row_indices_t,
-                                 row_offsets_t, column_indices_t, query)
+                grad_key = transposed_product(grad_scores, query)
             if ctx.needs_input_grad[2]:
-                grad_value = _spmm(n, m, ops.permute_last(weights, perm), row_indices_t,
-                                   row_offsets_t, column_indices_t, grad_output)
+                grad_value = transposed_product(weights, grad_output)
         return grad_query, grad_key, grad_value, None, None, None, None
 
 

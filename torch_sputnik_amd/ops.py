@@ -6,6 +6,8 @@ the extensions whose call sites exist only in the reference's tests
 
 GPU only: a CPU tensor raises from the dispatcher; there is no fallback.
 """
+import torch
+
 from ._native import load_ops
 
 _ops = load_ops()
@@ -176,6 +178,43 @@ def sddmm_plan(m, n, k, row_indices, row_offsets, column_indices):
 def sddmm_planned(m, n, row_indices, row_offsets, column_indices, lhs_matrix, rhs_matrix, plan):
     return _ops.sddmm_planned(int(m), int(n), row_indices, row_offsets, column_indices,
                               lhs_matrix, rhs_matrix, plan)
+
+
+def permute_band_size():
+    return _ops.permute_band_size()
+
+
+def banded_lists(permutation):
+    """(dest_list, source_in_band) of sputnik_hip_permute_banded_batched for a
+    permutation (out[i] = in[permutation[i]]): the output positions grouped by the
+    band of their source, ascending inside a band."""
+    band = permute_band_size()
+    perm = permutation.long()
+    order = torch.argsort(torch.div(perm, band, rounding_mode="floor"), stable=True)
+    return (order.to(torch.int32).contiguous(),
+            torch.remainder(perm[order], band).to(torch.int32).contiguous())
+
+
+def permute_last_banded(values, dest_list, source_in_band):
+    """permute_last for many rows of values, through LDS (lists: banded_lists)."""
+    return _ops.permute_last_banded(values, dest_list, source_in_band)
+
+
+def spmm_permuted_fused(m, k, n, nonzeros):
+    """True where spmm_permuted runs as one kernel (and that is the faster form)."""
+    from . import capi
+    return bool(capi.lib().sputnik_hip_spmm_permuted_supported(int(m), int(k), int(n), int(nonzeros)))
+
+
+def spmm_permuted(m, k, values, permutation, row_indices, row_offsets, column_indices,
+                  dense_matrix, plan=None, left=False):
+    """spmm / left_spmm over a topology whose values are stored in another order of
+    the same entries (entry p takes ``values[..., permutation[p]]``): the product
+    with a transpose whose topology and permutation are cached.  One kernel where
+    the panel kernel serves the shape, else permute_last + the planned product."""
+    op = _ops.left_spmm_permuted if left else _ops.spmm_permuted
+    return op(int(m), int(k), values, permutation, row_indices, row_offsets, column_indices,
+              dense_matrix, plan)
 
 
 def sddmm_sum(m, n, row_indices, row_offsets, column_indices, lhs_matrix, rhs_matrix):
