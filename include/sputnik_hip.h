@@ -151,8 +151,18 @@ SPUTNIK_HIP_API int sputnik_hip_sddmm_batched_planned(int m, int k, int n, int n
  * here the (replica, k-panel) pairs of the tiled kernel run in ONE launch into
  * `scratch` and a second kernel adds them up in index order (deterministic).
  * `scratch` holds sputnik_hip_sddmm_sum_scratch_bytes(...) bytes (0: not
- * needed), 16-byte aligned; `workspace` as for sputnik_hip_sddmm_batched /
- * _batched_planned. */
+ * needed), 16-byte aligned.  `workspace` holds
+ * sputnik_hip_sddmm_sum_workspace_bytes(...) bytes; the planned form takes one
+ * that sputnik_hip_sddmm_sum_plan filled -- NOT a plan of sputnik_hip_sddmm_plan:
+ * with its panels side by side the summed product may cut k (and with it the
+ * mask's column slabs) differently from the plain one. */
+SPUTNIK_HIP_API size_t sputnik_hip_sddmm_sum_workspace_bytes(int m, int k, int n, int nonzeros);
+
+SPUTNIK_HIP_API int sputnik_hip_sddmm_sum_plan(int m, int k, int n, int nonzeros,
+                              const int* row_indices, const int* row_offsets,
+                              const int* column_indices, void* workspace,
+                              size_t workspace_bytes, sputnik_hip_stream_t stream);
+
 SPUTNIK_HIP_API size_t sputnik_hip_sddmm_sum_scratch_bytes(int m, int k, int n, int nonzeros,
                                                            int replicas);
 

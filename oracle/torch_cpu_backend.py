@@ -225,6 +225,7 @@ def install():
     _lib.impl("sparse_attention_with_lse", _sparse_attention_with_lse, "CPU")
     _lib.impl("spmm_plan", _plan, "CPU")
     _lib.impl("sddmm_plan", _plan, "CPU")
+    _lib.impl("sddmm_sum_plan", _plan, "CPU")
     _lib.impl("sparse_attention_plan", _plan, "CPU")
     _lib.impl("spmm_planned", _spmm_planned, "CPU")
     _lib.impl("left_spmm_planned", _left_spmm_planned, "CPU")

@@ -406,6 +406,9 @@ SDDMM_SUM_SHAPES = [
     (100, 40, 60, 0.5, 5),      # row-wave kernel ([R, nnz] partials)
     (64, 64, 64, 0.0, 1),       # nothing to sum
     (33, 100, 47, 0.6, 4),      # odd sizes: scalar reduction
+    (512, 512, 512, 0.9, 8),    # sparse mask: the summed form cuts k into 128-wide panels
+    (300, 2048, 260, 0.95, 2),  # k = 2048 sparse: 256-wide panels, 8 per replica
+    (256, 4096, 256, 0.95, 2),  # k = 4096: 16 panels of 256 would be too many, stays at 512
 ]
 
 
@@ -420,12 +423,13 @@ def test_sddmm_sum_capi_vs_oracle(capi, dev, sddmm_kernel, m, k, n, sparsity, re
     rhs = rng.uniform(-1, 1, size=(replicas, n, k)).astype(np.float32)
     want = c_oracle.sddmm(m, n, ro, ci, lhs, rhs).astype(np.float64).sum(axis=0)
     out = torch.full((len(ci),), float("nan"), device=dev)
-    ws = torch.empty(capi.sddmm_workspace_bytes(m, k, n, len(ci)) + 16, dtype=torch.uint8, device=dev)
+    ws = torch.empty(capi.sddmm_sum_workspace_bytes(m, k, n, len(ci)) + 16, dtype=torch.uint8,
+                     device=dev)
     scratch = torch.empty(capi.sddmm_sum_scratch_bytes(m, k, n, len(ci), replicas) + 16,
                           dtype=torch.uint8, device=dev)
     topo = (T(ri, dev), T(ro, dev), T(ci, dev))
     if planned:
-        capi.sddmm_plan(m, k, n, *topo, ws)
+        capi.sddmm_sum_plan(m, k, n, *topo, ws)
     capi.sddmm_sum_batched(m, k, n, replicas, *topo, T(lhs, dev), T(rhs, dev), out, ws, scratch,
                            planned=planned)
     got = out.cpu().numpy()
@@ -445,7 +449,7 @@ def test_sddmm_sum_op_equals_the_summed_op(ts, dev):
     total = ts.sddmm_sum(m, n, *topo, lhs, rhs)
     assert total.shape == (len(ci),)
     torch.testing.assert_close(total, each.double().sum(0).float(), rtol=2e-5, atol=2e-4)
-    plan = ts.sddmm_plan(m, n, k, *topo)
+    plan = ts.sddmm_sum_plan(m, n, k, *topo)
     assert torch.equal(ts.sddmm_sum_planned(m, n, *topo, lhs, rhs, plan), total)   # deterministic
     assert torch.equal(ts.sddmm_sum(m, n, *topo, lhs[0], rhs[0]).reshape(-1)[:8].isfinite(),
                        torch.ones(8, dtype=torch.bool, device=dev))

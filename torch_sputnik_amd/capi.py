@@ -49,6 +49,8 @@ SIGNATURES = {
                                                                  _c_ptr, _c_ptr, _c_ptr, _c_i64,
                                                                  _c_ptr, _c_i64, _c_ptr]),
     "sputnik_hip_sddmm_sum_scratch_bytes": (_c_size, [_c_int] * 5),
+    "sputnik_hip_sddmm_sum_workspace_bytes": (_c_size, [_c_int] * 4),
+    "sputnik_hip_sddmm_sum_plan": (_c_int, [_c_int] * 4 + [_c_ptr] * 4 + [_c_size, _c_ptr]),
     "sputnik_hip_sddmm_sum_batched": (_c_int, [_c_int] * 5 + [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64,
                                                              _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_size,
                                                              _c_ptr, _c_size, _c_ptr]),
@@ -423,6 +425,20 @@ def spmm_permuted_batched(m, k, n, replicas, row_indices, values, values_stride,
     if st != -2:
         _check(st, "sputnik_hip_spmm_permuted_batched")
     return st
+
+
+def sddmm_sum_workspace_bytes(m, k, n, nonzeros):
+    return lib().sputnik_hip_sddmm_sum_workspace_bytes(m, k, n, nonzeros)
+
+
+def sddmm_sum_plan(m, k, n, row_indices, row_offsets, column_indices, workspace):
+    """Topology-only pre-pass of the SUMMED tiled SDDMM into `workspace`."""
+    _check(lib().sputnik_hip_sddmm_sum_plan(m, k, n, column_indices.numel(), _ptr(row_indices),
+                                            _ptr(row_offsets), _ptr(column_indices),
+                                            _ptr(workspace), _ws_bytes(workspace),
+                                            _stream(row_offsets)),
+           "sputnik_hip_sddmm_sum_plan")
+    return workspace
 
 
 def sddmm_sum_scratch_bytes(m, k, n, nonzeros, replicas):

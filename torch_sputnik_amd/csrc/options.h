@@ -11,6 +11,7 @@ struct Options {
   int spmm_debug = 0;     // SPUTNIK_HIP_SPMM_DEBUG: timing experiments only (wrong results)
   int spmm_tile = 0;      // SPUTNIK_HIP_SPMM_MEDIUM: 1 = medium, 2 = small tile
   int sddmm_kernel = 0;   // SPUTNIK_HIP_SDDMM_KERNEL: 0 auto, 1 "tiled", 2 "wave"
+  int sddmm_panel = 0;    // SPUTNIK_HIP_SDDMM_PANEL (developer): forces the k-panel width of the tiled SDDMM
   int sddmm_debug = 0;    // SPUTNIK_HIP_SDDMM_DEBUG: timing experiments only
   int softmax_rpg = 0;    // SPUTNIK_HIP_SOFTMAX_RPG: rows per group (0 = automatic)
   int softmax_nt = -1;    // SPUTNIK_HIP_SOFTMAX_NT (developer): nontemporal 0 none, 1 loads, 2 stores, 3 both; -1 default

@@ -19,15 +19,16 @@ namespace sputnik_hip {
 
 bool sddmm_tiled_applicable(int m, int k, int n, int nonzeros, const float* lhs,
                             int64_t lhs_stride, const float* rhs, int64_t rhs_stride);
-size_t sddmm_tiled_workspace_bytes(int m, int k, int n, int nonzeros);
-int sddmm_tiled_plan(int m, int k, int n, const int* row_indices, const int* row_offsets,
-                     const int* column_indices, void* workspace, hipStream_t stream);
+size_t sddmm_tiled_workspace_bytes(int m, int k, int n, int nonzeros, bool summed = false);
+int sddmm_tiled_plan(int m, int k, int n, int nonzeros, const int* row_indices,
+                     const int* row_offsets, const int* column_indices, void* workspace,
+                     hipStream_t stream, bool summed = false);
 int sddmm_tiled_launch(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
                        const int* row_offsets, const int* column_indices, const float* lhs,
                        int64_t lhs_stride, const float* rhs, int64_t rhs_stride, float* out,
                        int64_t out_stride, const void* workspace, hipStream_t stream);
 
-int sddmm_tiled_panels(int k);
+int sddmm_tiled_panels(int m, int k, int n, int nonzeros);
 int sddmm_tiled_launch_partials(int m, int k, int n, int nonzeros, int replicas,
                                 const int* row_indices, const int* row_offsets,
                                 const int* column_indices, const float* lhs, int64_t lhs_stride,
@@ -191,7 +192,7 @@ namespace {
 // Test knob SPUTNIK_HIP_SDDMM_KERNEL (options.h: read once): "tiled" / "wave".
 bool takes_tiled(int m, int k, int n, int nonzeros, int replicas /* < 0: unknown */,
                  const float* lhs, int64_t lhs_stride, const float* rhs, int64_t rhs_stride,
-                 const void* workspace, size_t workspace_bytes) {
+                 const void* workspace, size_t workspace_bytes, bool summed = false) {
   const bool force_tiled = options().sddmm_kernel == 1;
   const bool force_wave = options().sddmm_kernel == 2;
   const bool small = replicas >= 0 &&
@@ -199,7 +200,7 @@ bool takes_tiled(int m, int k, int n, int nonzeros, int replicas /* < 0: unknown
   return !force_wave && (force_tiled || !small) && workspace != nullptr &&
          aligned_to(workspace, 16) &&
          sddmm_tiled_applicable(m, k, n, nonzeros, lhs, lhs_stride, rhs, rhs_stride) &&
-         workspace_bytes >= sddmm_tiled_workspace_bytes(m, k, n, nonzeros);
+         workspace_bytes >= sddmm_tiled_workspace_bytes(m, k, n, nonzeros, summed);
 }
 
 int sddmm_exec(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
@@ -220,8 +221,8 @@ int sddmm_exec(int m, int k, int n, int nonzeros, int replicas, const int* row_i
   if (takes_tiled(m, k, n, nonzeros, replicas, lhs, lhs_stride, rhs, rhs_stride, workspace,
                   workspace_bytes)) {
     if (!planned) {
-      const int st = sddmm_tiled_plan(m, k, n, row_indices, row_offsets, column_indices,
-                                      workspace, stream);
+      const int st = sddmm_tiled_plan(m, k, n, nonzeros, row_indices, row_offsets,
+                                      column_indices, workspace, stream);
       if (st != 0) return st;
     }
     return sddmm_tiled_launch(m, k, n, nonzeros, replicas, row_indices, row_offsets,
@@ -261,7 +262,7 @@ namespace {
 // Partial vectors a summed call needs: one per (replica, panel) on the tiled path.
 int64_t sum_parts(int m, int k, int n, int nonzeros, int replicas) {
   const bool tiled_shape = sddmm_tiled_workspace_bytes(m, k, n, nonzeros) != 0;
-  return static_cast<int64_t>(replicas) * (tiled_shape ? sddmm_tiled_panels(k) : 1);
+  return static_cast<int64_t>(replicas) * (tiled_shape ? sddmm_tiled_panels(m, k, n, nonzeros) : 1);
 }
 
 int sddmm_sum_exec(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
@@ -276,10 +277,10 @@ int sddmm_sum_exec(int m, int k, int n, int nonzeros, int replicas, const int* r
     return static_cast<int>(e);
   }
   const bool tiled = takes_tiled(m, k, n, nonzeros, replicas, lhs, lhs_stride, rhs, rhs_stride,
-                                 workspace, workspace_bytes);
-  const int panels = tiled ? sddmm_tiled_panels(k) : 1;
+                                 workspace, workspace_bytes, /*summed=*/true);
+  const int panels = tiled ? sddmm_tiled_panels(m, k, n, nonzeros) : 1;
   const int64_t parts = static_cast<int64_t>(replicas) * panels;
-  if (parts == 1)
+  if (parts == 1)   // (one panel: the summed form's plan is the plain one)
     return sddmm_exec(m, k, n, nonzeros, 1, row_indices, row_offsets, column_indices, lhs,
                       lhs_stride, rhs, rhs_stride, out, 0, workspace, workspace_bytes, planned,
                       stream);
@@ -287,22 +288,24 @@ int sddmm_sum_exec(int m, int k, int n, int nonzeros, int replicas, const int* r
       scratch_bytes < sizeof(float) * static_cast<size_t>(parts) * nonzeros)
     return SPUTNIK_HIP_INVALID_ARGUMENT;
   float* partials = static_cast<float*>(scratch);
+  if (tiled && parts > kMaxGridYZ) return SPUTNIK_HIP_INVALID_ARGUMENT;
   int st;
-  if (tiled && parts <= kMaxGridYZ) {
+  if (tiled) {
     if (!planned) {
-      st = sddmm_tiled_plan(m, k, n, row_indices, row_offsets, column_indices, workspace, stream);
+      st = sddmm_tiled_plan(m, k, n, nonzeros, row_indices, row_offsets, column_indices,
+                            workspace, stream, /*summed=*/true);
       if (st != 0) return st;
     }
     st = sddmm_tiled_launch_partials(m, k, n, nonzeros, replicas, row_indices, row_offsets,
                                      column_indices, lhs, lhs_stride, rhs, rhs_stride, partials,
                                      workspace, stream);
   } else {
+    // (row-wave kernel: the workspace, planned for the summed form or not, is not used)
     st = sddmm_exec(m, k, n, nonzeros, replicas, row_indices, row_offsets, column_indices, lhs,
-                    lhs_stride, rhs, rhs_stride, partials, nonzeros, workspace, workspace_bytes,
-                    planned, stream);
+                    lhs_stride, rhs, rhs_stride, partials, nonzeros, nullptr, 0, false, stream);
   }
   if (st != 0) return st;
-  const int nparts = static_cast<int>(tiled && parts <= kMaxGridYZ ? parts : replicas);
+  const int nparts = static_cast<int>(parts);
   if (nonzeros % 4 == 0 && aligned_to(out, 16)) {
     hipLaunchKernelGGL(sum_partials_kernel<4>, dim3(ceil_div(nonzeros / 4, kBlock)), dim3(kBlock),
                        0, stream, nonzeros / 4, nparts, static_cast<int64_t>(nonzeros), partials,
@@ -315,6 +318,24 @@ int sddmm_sum_exec(int m, int k, int n, int nonzeros, int replicas, const int* r
 }
 
 }  // namespace
+
+size_t sputnik_hip_sddmm_sum_workspace_bytes(int m, int k, int n, int nonzeros) {
+  if (m <= 0 || k <= 0 || n <= 0 || nonzeros <= 0) return 0;
+  return sddmm_tiled_workspace_bytes(m, k, n, nonzeros, /*summed=*/true);
+}
+
+int sputnik_hip_sddmm_sum_plan(int m, int k, int n, int nonzeros, const int* row_indices,
+                               const int* row_offsets, const int* column_indices,
+                               void* workspace, size_t workspace_bytes,
+                               sputnik_hip_stream_t stream) {
+  if (m < 0 || k < 0 || n < 0 || nonzeros < 0) return SPUTNIK_HIP_INVALID_ARGUMENT;
+  if (m == 0 || nonzeros == 0 || k == 0) return 0;
+  const size_t need = sddmm_tiled_workspace_bytes(m, k, n, nonzeros, /*summed=*/true);
+  if (workspace == nullptr || !aligned_to(workspace, 16) || need == 0 || workspace_bytes < need)
+    return 0;  // nothing to plan: the row-wave kernel needs no workspace
+  return sddmm_tiled_plan(m, k, n, nonzeros, row_indices, row_offsets, column_indices, workspace,
+                          stream, /*summed=*/true);
+}
 
 size_t sputnik_hip_sddmm_sum_scratch_bytes(int m, int k, int n, int nonzeros, int replicas) {
   if (m <= 0 || k <= 0 || n <= 0 || nonzeros <= 0 || replicas <= 0) return 0;
@@ -356,7 +377,8 @@ int sputnik_hip_sddmm_plan(int m, int k, int n, int nonzeros, const int* row_ind
       sddmm_tiled_workspace_bytes(m, k, n, nonzeros) == 0 ||
       workspace_bytes < sddmm_tiled_workspace_bytes(m, k, n, nonzeros))
     return 0;  // nothing to plan: the row-wave kernel needs no workspace
-  return sddmm_tiled_plan(m, k, n, row_indices, row_offsets, column_indices, workspace, stream);
+  return sddmm_tiled_plan(m, k, n, nonzeros, row_indices, row_offsets, column_indices, workspace,
+                          stream);
 }
 
 int sputnik_hip_sddmm_batched_planned(int m, int k, int n, int nonzeros, int replicas,

@@ -264,13 +264,34 @@ inline int slots_of(int m) { return ceil_div(m, kSGroups * kSRows) * (kSGroups *
 constexpr int kMaxPanels = 8;
 // Widest panel that divides k (0 if k is not a multiple of 64).
 inline int panel_width(int k) {
+  const int forced = options().sddmm_panel;   // developer knob: a width that divides k
+  if (forced > 0 && k > 0 && k % forced == 0 && (forced == 64 || forced == 128 || forced == 256 || forced == 512))
+    return forced;
   return k <= 0 ? 0 : k % 512 == 0 ? 512 : k % 256 == 0 ? 256 : k % 128 == 0 ? 128 : k % 64 == 0 ? 64 : 0;
 }
-inline bool served(int k) { return panel_width(k) != 0 && k / panel_width(k) <= kMaxPanels; }
-inline int slab_rows(int k) {
+inline int slab_rows_of_width(int w) { return (w <= 128 ? 64 * 1024 : 128 * 1024) / (w * 4); }
+// Panel width of the SUMMED product (sddmm_tiled_launch_partials), whose panels
+// run side by side, so a narrower panel costs no extra launch.  What it buys: a
+// narrower panel means a taller slab, hence more entries of a mask row per slab
+// visit; below about ten the 16-entry windows run mostly empty.  Measured
+// (tools/sddmm_panel_bench.py, 8 replicas, widths 512 / 256 / 128):
+//   512^2   x k 1024, density 0.1 (6.4 per visit at 512):   39 / 32 / 36 us
+//   4096^2  x k 512,  density 0.1:                          809 / 665 / 636 us
+//   4096^2  x k 512,  density 0.05:                         668 / 578 / 527 us
+//   2048^2  x k 512,  density 0.2 (12.8):                   252 / 259 / 242 us
+//   1024^2  x k 1024, density 0.3 (19):                     173 / 180 / 175 us
+inline int sum_panel_width(int m, int k, int n, int nonzeros) {
   const int w = panel_width(k);
-  return (w <= 128 ? 64 * 1024 : 128 * 1024) / (w * 4);
+  if (options().sddmm_panel > 0 || w <= 128 || m <= 0 || n <= 0) return w;
+  const double per_visit = static_cast<double>(nonzeros) / m * slab_rows_of_width(w) / n;
+  if (per_visit >= 10.0) return w;
+  const int narrow = (k >= 1024 && k % 256 == 0) ? 256 : 128;
+  return (narrow < w && k / narrow <= 8) ? narrow : w;
 }
+inline int width_for(int m, int k, int n, int nonzeros, bool summed) {
+  return summed ? sum_panel_width(m, k, n, nonzeros) : panel_width(k);
+}
+inline bool served(int k) { return panel_width(k) != 0 && k / panel_width(k) <= kMaxPanels; }
 
 // The chunk table is the SpMM one with the mask's columns (n) in the role of k,
 // cut at slab boundaries.  Topology only: a caller with a static mask runs it once.
@@ -334,7 +355,9 @@ int launch_partials(int m, int k, int n, int nonzeros, int replicas, int slots,
 
 }  // namespace
 
-int sddmm_tiled_panels(int k) { return served(k) ? k / panel_width(k) : 1; }
+int sddmm_tiled_panels(int m, int k, int n, int nonzeros) {
+  return served(k) ? k / sum_panel_width(m, k, n, nonzeros) : 1;
+}
 
 int sddmm_tiled_launch_partials(int m, int k, int n, int nonzeros, int replicas,
                                 const int* row_indices, const int* row_offsets,
@@ -350,7 +373,7 @@ int sddmm_tiled_launch_partials(int m, int k, int n, int nonzeros, int replicas,
   return launch_partials<KV>(m, k, n, nonzeros, replicas, slots, row_indices, row_offsets, \
                              column_indices, table, row_ok, lhs, lhs_stride, rhs,          \
                              rhs_stride, partials, debug, stream)
-  switch (panel_width(k)) {
+  switch (sum_panel_width(m, k, n, nonzeros)) {
     case 64: SPUTNIK_HIP_SD(1);
     case 128: SPUTNIK_HIP_SD(2);
     case 256: SPUTNIK_HIP_SD(4);
@@ -367,18 +390,22 @@ bool sddmm_tiled_applicable(int m, int k, int n, int nonzeros, const float* lhs,
          aligned_to(rhs, 16) && lhs_stride % 4 == 0 && rhs_stride % 4 == 0;
 }
 
-size_t sddmm_tiled_workspace_bytes(int m, int k, int n, int nonzeros) {
+// `summed`: for sddmm_tiled_launch_partials (its panel width, hence its slabs and
+// its chunk table, can differ from the plain product's).
+size_t sddmm_tiled_workspace_bytes(int m, int k, int n, int nonzeros, bool summed) {
   if (!served(k) || n < 16 || m < 16 || nonzeros < 4 * static_cast<int64_t>(m)) return 0;
+  const int rows = slab_rows_of_width(width_for(m, k, n, nonzeros, summed));
   return row_ok_bytes(slots_of(m)) +
-         sizeof(int) * static_cast<size_t>(ceil_div(n, slab_rows(k)) + 1) * slots_of(m);
+         sizeof(int) * static_cast<size_t>(ceil_div(n, rows) + 1) * slots_of(m);
 }
 
-int sddmm_tiled_plan(int m, int k, int n, const int* row_indices, const int* row_offsets,
-                     const int* column_indices, void* workspace, hipStream_t stream) {
+int sddmm_tiled_plan(int m, int k, int n, int nonzeros, const int* row_indices,
+                     const int* row_offsets, const int* column_indices, void* workspace,
+                     hipStream_t stream, bool summed) {
   const int slots = slots_of(m);
   int* row_ok = static_cast<int*>(workspace);
   int* table = reinterpret_cast<int*>(static_cast<char*>(workspace) + row_ok_bytes(slots));
-  switch (panel_width(k)) {
+  switch (width_for(m, k, n, nonzeros, summed)) {
     case 64: return plan<1>(m, n, slots, row_indices, row_offsets, column_indices, table, row_ok, stream);
     case 128: return plan<2>(m, n, slots, row_indices, row_offsets, column_indices, table, row_ok, stream);
     case 256: return plan<4>(m, n, slots, row_indices, row_offsets, column_indices, table, row_ok, stream);

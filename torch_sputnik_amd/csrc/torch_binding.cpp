@@ -265,7 +265,9 @@ Tensor sddmm_impl(int64_t m64, int64_t n64, const Tensor& row_indices, const Ten
   Tensor out = (replicas == 1 || sum_replicas)
                    ? at::empty({topo.nonzeros}, lhs.options())
                    : at::empty({replicas, topo.nonzeros}, lhs.options());
-  const size_t ws_bytes = sputnik_hip_sddmm_workspace_bytes(m, k, n, topo.nonzeros);
+  const size_t ws_bytes = sum_replicas
+                              ? sputnik_hip_sddmm_sum_workspace_bytes(m, k, n, topo.nonzeros)
+                              : sputnik_hip_sddmm_workspace_bytes(m, k, n, topo.nonzeros);
   if (sum_replicas) {
     // sum over the batch inside the call (sputnik_hip.h: sddmm_sum_batched)
     const size_t scratch_bytes =
@@ -383,6 +385,25 @@ Tensor sddmm_plan(int64_t m64, int64_t n64, int64_t k64, const Tensor& row_indic
                                       bytes ? plan.data_ptr() : nullptr, bytes,
                                       current_stream(row_offsets)),
                "sddmm_plan");
+  return plan;
+}
+
+// the summed product has a plan of its own (sputnik_hip.h: sddmm_sum_plan)
+Tensor sddmm_sum_plan(int64_t m64, int64_t n64, int64_t k64, const Tensor& row_indices,
+                      const Tensor& row_offsets, const Tensor& column_indices) {
+  const int m = to_int(m64, "m"), n = to_int(n64, "n"), k = to_int(k64, "k");
+  TORCH_CHECK(row_offsets.is_cuda(), "row_offsets must be a GPU (HIP) tensor");
+  const c10::DeviceGuard guard(row_offsets.device());
+  const Topology topo = check_topology(m, row_indices, row_offsets, column_indices, row_offsets);
+  const size_t bytes = sputnik_hip_sddmm_sum_workspace_bytes(m, k, n, topo.nonzeros);
+  Tensor plan = make_plan_tensor(bytes, row_offsets);
+  check_status(sputnik_hip_sddmm_sum_plan(m, k, n, topo.nonzeros,
+                                          topo.row_indices.data_ptr<int>(),
+                                          topo.row_offsets.data_ptr<int>(),
+                                          topo.column_indices.data_ptr<int>(),
+                                          bytes ? plan.data_ptr() : nullptr, bytes,
+                                          current_stream(row_offsets)),
+               "sddmm_sum_plan");
   return plan;
 }
 
@@ -1006,6 +1027,9 @@ TORCH_LIBRARY(torch_sputnik, m) {
       "sddmm_planned(int m, int n, Tensor row_indices, Tensor row_offsets, Tensor column_indices, "
       "Tensor lhs_matrix, Tensor rhs_matrix, Tensor plan) -> Tensor");
   m.def(
+      "sddmm_sum_plan(int m, int n, int k, Tensor row_indices, Tensor row_offsets, "
+      "Tensor column_indices) -> Tensor");
+  m.def(
       "sddmm_sum(int m, int n, Tensor row_indices, Tensor row_offsets, Tensor column_indices, "
       "Tensor lhs_matrix, Tensor rhs_matrix) -> Tensor");
   m.def(
@@ -1068,6 +1092,7 @@ TORCH_LIBRARY_IMPL(torch_sputnik, CUDA, m) {
   m.impl("sddmm_plan", &sddmm_plan);
   m.impl("sddmm_planned", &sddmm_planned);
   m.impl("sddmm_sum", &sddmm_sum);
+  m.impl("sddmm_sum_plan", &sddmm_sum_plan);
   m.impl("sddmm_sum_planned", &sddmm_sum_planned);
   m.impl("sparse_attention_plan", &sparse_attention_plan);
   m.impl("sparse_attention_planned", &sparse_attention_planned);

@@ -225,6 +225,11 @@ def sddmm_sum(m, n, row_indices, row_offsets, column_indices, lhs_matrix, rhs_ma
                           rhs_matrix)
 
 
+def sddmm_sum_plan(m, n, k, row_indices, row_offsets, column_indices):
+    """Pre-pass for sddmm_sum_planned (its own: not interchangeable with sddmm_plan)."""
+    return _ops.sddmm_sum_plan(int(m), int(n), int(k), row_indices, row_offsets, column_indices)
+
+
 def sddmm_sum_planned(m, n, row_indices, row_offsets, column_indices, lhs_matrix, rhs_matrix,
                       plan):
     return _ops.sddmm_sum_planned(int(m), int(n), row_indices, row_offsets, column_indices,
