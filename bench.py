@@ -380,6 +380,35 @@ def other_ops(dev):
     t = event_time_ms(lambda: capi.spmm_batched(s, s, d, reps, ri, probs, nnz, ro, ci, v, ctx, ws3), 20)
     by = reps * (4.0 * nnz + 8.0 * s * d) + 4.0 * nnz + 4.0 * (2 * s + 1)
     res["spmm_c3"] = {"ms": t, "gflops": 2.0 * nnz * d * reps / t / 1e6, "alg_gbs": by / t / 1e6}
+    try:
+        # config 3's projections (modules/sparse_attention.py:108-126): a 512 x 512 weight at
+        # density 0.1 against [512, 1024] x batch 8 (panel-resident kernel), its transposed
+        # product through the permutation, and the weight gradient summed over the batch
+        e, b3 = 512, 8
+        wri, wro, wci, wnnz = random_csr(e, e, 0.1, dev, seed=17)
+        wv = uniform((wnnz,), dev, 18)
+        xs = uniform((b3, e, s), dev, 19)
+        ys = torch.empty(b3, e, s, device=dev)
+        pws = torch.empty(capi.spmm_workspace_bytes(e, e, s, wnnz) + 16, dtype=torch.uint8, device=dev)
+        t = event_time_ms(lambda: capi.spmm_batched(e, e, s, b3, wri, wv, 0, wro, wci, xs, ys, pws), 20)
+        res["spmm_projection_c3"] = {"ms": t, "gflops": 2.0 * wnnz * s * b3 / t / 1e6,
+                                     "alg_gbs": (8.0 * b3 * e * s + 8.0 * wnnz) / t / 1e6}
+        gw = torch.empty(wnnz, device=dev)
+        sws = torch.empty(capi.sddmm_sum_workspace_bytes(e, s, e, wnnz) + 16, dtype=torch.uint8, device=dev)
+        scr = torch.empty(capi.sddmm_sum_scratch_bytes(e, s, e, wnnz, b3) + 16, dtype=torch.uint8, device=dev)
+        t = event_time_ms(lambda: capi.sddmm_sum_batched(e, s, e, b3, wri, wro, wci, ys, xs, gw, sws, scr), 20)
+        res["sddmm_sum_weight_gradient_c3"] = {"ms": t, "gflops": 2.0 * wnnz * s * b3 / t / 1e6}
+        big = uniform((reps, nnz), dev, 33)
+        from torch_sputnik_amd import ops as _ops
+        perm = _ops.csr_transpose_with_permutation(s, s, big[0].contiguous(), ro, ci)[3]
+        lists = _ops.banded_lists(perm)
+        t_plain = event_time_ms(lambda: _ops.permute_last(big, perm), 20)
+        t_band = event_time_ms(lambda: _ops.permute_last_banded(big, *lists), 20)
+        res["permute_values_c3"] = {"plain_ms": t_plain, "banded_ms": t_band,
+                                    "note": "64 x nnz attention weights into the order of the mask's transpose"}
+        del big
+    except Exception as e2:  # noqa: BLE001 - extra metric, best effort
+        res["spmm_projection_c3"] = {"error": str(e2)[:200]}
     # the same chain as ONE kernel (online softmax; scores / weights never reach HBM)
     aws = torch.empty(capi.sparse_attention_workspace_bytes(s, s, d, nnz), dtype=torch.uint8,
                       device=dev)

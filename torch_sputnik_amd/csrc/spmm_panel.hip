@@ -36,6 +36,40 @@ constexpr int kPBM = kPWaves * kPQuads * 4;   // 256 rows per workgroup
 constexpr int kPThreads = kPWaves * kWave;
 constexpr int kPMaxK = 512;   // rows of B per panel: 512 x 256 B = 128 KiB of LDS
 constexpr int kPMaxPasses = 8;
+#ifndef SPUTNIK_HIP_PANEL_PAIR
+#define SPUTNIK_HIP_PANEL_PAIR 1
+#endif
+constexpr bool kPairQuads = SPUTNIK_HIP_PANEL_PAIR != 0;   // two row quads side by side (one panel only)
+
+// Two independent row quads side by side: eight B strips in flight before the
+// first FMA, so that one quad's LDS latency is covered by the other's arithmetic.
+template <int G>
+__device__ __forceinline__ void dpp_group4_pair(float (&acc_a)[4], float (&acc_b)[4], int roff_a,
+                                                float rval_a, int roff_b, float rval_b,
+                                                const char* __restrict__ lane_base) {
+  const entry_pair ea = make_entry(roff_a, rval_a), eb = make_entry(roff_b, rval_b);
+  const entry_pair a0 = row_bcast_entry<G + 0>(ea), a1 = row_bcast_entry<G + 1>(ea);
+  const entry_pair a2 = row_bcast_entry<G + 2>(ea), a3 = row_bcast_entry<G + 3>(ea);
+  const entry_pair b0 = row_bcast_entry<G + 0>(eb), b1 = row_bcast_entry<G + 1>(eb);
+  const entry_pair b2 = row_bcast_entry<G + 2>(eb), b3 = row_bcast_entry<G + 3>(eb);
+  BStrip<4> sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3;
+  sa0.read(lane_base + entry_off(a0));
+  sa1.read(lane_base + entry_off(a1));
+  sa2.read(lane_base + entry_off(a2));
+  sa3.read(lane_base + entry_off(a3));
+  sb0.read(lane_base + entry_off(b0));
+  sb1.read(lane_base + entry_off(b1));
+  sb2.read(lane_base + entry_off(b2));
+  sb3.read(lane_base + entry_off(b3));
+  sa0.fma(acc_a, entry_val(a0));
+  sa1.fma(acc_a, entry_val(a1));
+  sa2.fma(acc_a, entry_val(a2));
+  sa3.fma(acc_a, entry_val(a3));
+  sb0.fma(acc_b, entry_val(b0));
+  sb1.fma(acc_b, entry_val(b1));
+  sb2.fma(acc_b, entry_val(b2));
+  sb3.fma(acc_b, entry_val(b3));
+}
 
 // PERM: entry p of the stream takes its value from values[value_permutation[p]]
 // (a transposed topology over the values of the original one: the gather that
@@ -102,6 +136,42 @@ __global__ __launch_bounds__(kPThreads) void spmm_panel64_kernel(
     wait_vm<0>();
     __syncthreads();
 
+    if constexpr (!MULTI && kPairQuads) {
+#pragma unroll
+      for (int t = 0; t < kPQuads; t += 2) {
+        const int n_a = cnt[t], n_b = cnt[t + 1];
+        const int n_max = max(n_a, n_b);
+        const int longest =
+            max(max(__builtin_amdgcn_readlane(n_max, 0), __builtin_amdgcn_readlane(n_max, 16)),
+                max(__builtin_amdgcn_readlane(n_max, 32), __builtin_amdgcn_readlane(n_max, 48)));
+        int idx_a = max(min(p0[t] + i, last), 0), idx_b = max(min(p0[t + 1] + i, last), 0);
+        int ecol_a = column_indices[idx_a], ecol_b = column_indices[idx_b];
+        float eval_a = values[PERM ? value_permutation[idx_a] : idx_a];
+        float eval_b = values[PERM ? value_permutation[idx_b] : idx_b];
+        for (int w0 = 0; w0 < longest; w0 += 16) {
+          const int col_a = ecol_a, col_b = ecol_b;
+          const float val_a = eval_a, val_b = eval_b;
+          if (w0 + 16 < longest) {
+            idx_a = min(p0[t] + w0 + 16 + i, last);
+            idx_b = min(p0[t + 1] + w0 + 16 + i, last);
+            ecol_a = column_indices[idx_a];
+            ecol_b = column_indices[idx_b];
+            eval_a = values[PERM ? value_permutation[idx_a] : idx_a];
+            eval_b = values[PERM ? value_permutation[idx_b] : idx_b];
+          }
+          const int left_a = n_a - w0, left_b = n_b - w0;
+          const int roff_a = i < left_a ? col_a * (kPBN * 4) : 0;
+          const int roff_b = i < left_b ? col_b * (kPBN * 4) : 0;
+          const float rval_a = i < left_a ? val_a : 0.f;
+          const float rval_b = i < left_b ? val_b : 0.f;
+          const int left = max(left_a, left_b);   // (entries past a row's end carry a zero value)
+          if (left > 0) dpp_group4_pair<0>(acc[t], acc[t + 1], roff_a, rval_a, roff_b, rval_b, lane_base);
+          if (left > 4) dpp_group4_pair<4>(acc[t], acc[t + 1], roff_a, rval_a, roff_b, rval_b, lane_base);
+          if (left > 8) dpp_group4_pair<8>(acc[t], acc[t + 1], roff_a, rval_a, roff_b, rval_b, lane_base);
+          if (left > 12) dpp_group4_pair<12>(acc[t], acc[t + 1], roff_a, rval_a, roff_b, rval_b, lane_base);
+        }
+      }
+    } else {
 #pragma unroll
     for (int t = 0; t < kPQuads; ++t) {
       const int n_here = cnt[t];
@@ -143,6 +213,7 @@ __global__ __launch_bounds__(kPThreads) void spmm_panel64_kernel(
           if (in_panel & 0xf000u) dpp_group4<12>(acc[t], roff, rval, lane_base);
         }
       }
+    }
     }
   }
 #pragma unroll
