@@ -279,6 +279,34 @@ SPUTNIK_HIP_API int sputnik_hip_spmm_permuted_batched(int m, int k, int n, int n
                              int64_t out_stride, sputnik_hip_stream_t stream);
 
 /*
+ * SpMM whose product C[m, n] is STORED TRANSPOSED in blocks of `block_rows` rows:
+ *   out[(row / block_rows) * n * block_rows + col * block_rows + row % block_rows]
+ * per replica, i.e. every block of block_rows rows of C as its transpose
+ * [n][block_rows].  With block_rows = head_dim this is the head split that
+ * follows every projection (`four_d_to_three_d` on a transposed view,
+ * modules/sparse_attention.py:38-45,108-126); with block_rows = m it is C^T, the
+ * head merge in front of the output projection -- layout passes that the
+ * reference runs as separate strided copies.  The panel kernel writes its
+ * 256 x 64 tile through LDS in that order.  `value_permutation` may be NULL or
+ * as in sputnik_hip_spmm_permuted_batched; bias / relu as in
+ * sputnik_hip_spmm_bias_batched.  Rows are processed in natural order (no
+ * row_indices).  Served: what the panel kernel serves, with block_rows a
+ * multiple of 64 that divides m and divides or is a multiple of 256; otherwise
+ * SPUTNIK_HIP_UNSUPPORTED (the caller runs the product and
+ * sputnik_hip_transpose_batched).  `_supported` also requires k <= 1024.
+ */
+SPUTNIK_HIP_API int sputnik_hip_spmm_transposed_out_supported(int m, int k, int n, int nonzeros,
+                                                              int block_rows);
+
+SPUTNIK_HIP_API int sputnik_hip_spmm_transposed_out_batched(int m, int k, int n, int nonzeros,
+                             int replicas, const float* values, int64_t values_stride,
+                             const int* value_permutation, const int* row_offsets,
+                             const int* column_indices, const float* dense,
+                             int64_t dense_stride, const float* bias, int relu,
+                             int block_rows, float* out, int64_t out_stride,
+                             sputnik_hip_stream_t stream);
+
+/*
  * softmax(scale * x) per CSR row: folds the 1/sqrt(d) of
  * modules/sparse_attention.py:72 into the softmax pass.
  */

@@ -190,6 +190,16 @@ def _permute_last_banded(values, dest_list, source_in_band):
     return out
 
 
+def _spmm_transposed_out(m, k, values, permutation, row_indices, row_offsets, column_indices,
+                         dense, block_rows, left, plan=None):
+    if permutation is not None:
+        values = values[..., permutation.long()].contiguous()
+    c = (_left_spmm if left else _spmm)(m, k, values, row_indices, row_offsets, column_indices,
+                                        dense)
+    n = c.shape[-1]
+    return c.reshape(-1, block_rows, n).transpose(1, 2).contiguous()
+
+
 def _sddmm_sum(m, n, row_indices, row_offsets, column_indices, lhs, rhs):
     out = _sddmm(m, n, row_indices, row_offsets, column_indices, lhs, rhs)
     return out.sum(dim=0) if out.dim() == 2 else out
@@ -233,6 +243,7 @@ def install():
     _lib.impl("sddmm_sum", _sddmm_sum, "CPU")
     _lib.impl("permute_last_banded", _permute_last_banded, "CPU")
     _lib.impl("spmm_permuted", _spmm_permuted, "CPU")
+    _lib.impl("spmm_transposed_out", _spmm_transposed_out, "CPU")
     _lib.impl("left_spmm_permuted", _left_spmm_permuted, "CPU")
     _lib.impl("sddmm_sum_planned", _sddmm_sum_planned, "CPU")
     _lib.impl("sparse_attention_planned", _sparse_attention_planned, "CPU")

@@ -512,6 +512,57 @@ def test_spmm_permuted_is_the_product_with_the_transpose(ts, dev, m, n, width, r
     assert rel_err(got.cpu().numpy(), two_step.reshape(replicas, n, width).cpu().numpy()) < TOL
 
 
+@pytest.mark.parametrize("m,k,n,replicas,block,left", [
+    (512, 512, 1024, 3, 64, True),     # projection with the head split (config 3 geometry)
+    (512, 512, 1024, 2, 128, True),    # head_dim 128
+    (1024, 1024, 64, 6, 1024, False),  # attention P.V stored as C^T: two panels, block = m
+    (320, 200, 72, 2, 64, True),       # m not a multiple of 256, partial column tile
+    (768, 96, 136, 2, 256, False),     # block = the workgroup's 256 rows; panel smaller than the tile
+    (512, 512, 256, 2, 512, True),     # block = 2 workgroups of rows
+    (192, 300, 20, 2, 64, True),       # n < 64: product + tiled transpose
+    (256, 5000, 64, 1, 64, False),     # k too large for the panel kernel: product + transpose
+    (128, 128, 64, 2, 32, True),       # block of 32 rows: product + transpose
+])
+def test_spmm_transposed_out(ts, dev, spmm_kernel, m, k, n, replicas, block, left):
+    """The product stored as the transposes of its row blocks equals the plain
+    product moved by a layout pass (bit for bit where both take the panel kernel:
+    same summation order) and the dense float64 definition."""
+    a, vals, ri, ro, ci = make_csr(m, k, 0.9, seed=m + n)
+    rng = np.random.default_rng(n)
+    v = rng.uniform(-1, 1, (len(ci),) if left else (replicas, len(ci))).astype(np.float32)
+    b = rng.uniform(-1, 1, (replicas, k, n)).astype(np.float32)
+    topo = [T(x, dev) for x in (ri, ro, ci)]
+    got = ts.spmm_transposed_out(m, k, T(v, dev), *topo, T(b, dev), block, left=left)
+    assert got.shape == (replicas * (m // block), n, block)
+    plain = (ts.left_spmm if left else ts.spmm)(m, k, T(v, dev), *topo, T(b, dev))
+    moved = plain.reshape(replicas * (m // block), block, n).transpose(1, 2)
+    assert rel_err(got.cpu().numpy(), moved.cpu().numpy()) < TOL
+    dense = np.zeros((replicas, m, k))
+    rows = np.repeat(np.arange(m), np.diff(ro))
+    dense[:, rows, ci] = v
+    want = np.einsum("rmk,rkn->rmn", dense, b.astype(np.float64))
+    want = want.reshape(replicas * (m // block), block, n).transpose(0, 2, 1)
+    assert rel_err(got.cpu().numpy(), np.ascontiguousarray(want).astype(np.float32)) < TOL
+
+
+def test_spmm_transposed_out_with_permuted_values(ts, dev):
+    """The input gradient of a projection, head split: transposed topology, values
+    gathered through the permutation, product stored in blocks."""
+    m, n, width, replicas, block = 512, 512, 1024, 2, 64
+    a, vals, ri, ro, ci = make_csr(m, n, 0.9, seed=3)
+    rng = np.random.default_rng(4)
+    v = rng.uniform(-1, 1, len(ci)).astype(np.float32)
+    x = rng.uniform(-1, 1, (replicas, m, width)).astype(np.float32)
+    _, ro_t, ci_t, perm = ts.csr_transpose_with_permutation(m, n, T(v, dev), T(ro, dev), T(ci, dev))
+    from torch_sputnik_amd.topology import diffsort
+    ri_t = diffsort(ro_t)
+    got = ts.spmm_transposed_out(n, m, T(v, dev), ri_t, ro_t, ci_t, T(x, dev), block,
+                                 permutation=perm, left=True)
+    plain = ts.spmm_permuted(n, m, T(v, dev), perm, ri_t, ro_t, ci_t, T(x, dev), left=True)
+    moved = plain.reshape(replicas * (n // block), block, width).transpose(1, 2)
+    assert torch.equal(got, moved.contiguous())
+
+
 @pytest.mark.parametrize("n,rows", [(104857, 64), (16384, 3), (16385, 2), (50001, 5), (100, 4), (40000, 1)])
 def test_permute_last_banded_equals_the_plain_gather(dev, n, rows):
     from torch_sputnik_amd import ops

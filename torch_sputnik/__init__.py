@@ -36,6 +36,7 @@ from torch_sputnik_amd.ops import (  # noqa: F401
     spmm_bias_relu,
     spmm_many_mask,
     spmm_permuted,
+    spmm_transposed_out,
     permute_last,
     spmm_plan,
     spmm_planned,
@@ -47,5 +48,5 @@ __all__ = ["spmm", "left_spmm", "left_replicated_spmm", "sddmm", "sparse_softmax
            "sparse_softmax_scaled", "sparse_softmax_backward", "spmm_many_mask",
            "sddmm_many_mask", "sparse_softmax_many_mask", "sparse_softmax_backward_many_mask",
            "csr_transpose_many_mask", "sparse_attention", "sparse_attention_with_lse", "spmm_plan", "spmm_planned",
-           "left_spmm_planned", "sddmm_plan", "sddmm_planned", "sddmm_sum", "sddmm_sum_plan", "spmm_permuted", "permute_last", "sddmm_sum_planned", "sparse_attention_plan",
+           "left_spmm_planned", "sddmm_plan", "sddmm_planned", "sddmm_sum", "sddmm_sum_plan", "spmm_permuted", "spmm_transposed_out", "permute_last", "sddmm_sum_planned", "sparse_attention_plan",
            "sparse_attention_planned"]

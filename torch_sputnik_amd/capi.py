@@ -48,6 +48,11 @@ SIGNATURES = {
     "sputnik_hip_spmm_permuted_batched": (_c_int, [_c_int] * 5 + [_c_ptr, _c_ptr, _c_i64, _c_ptr,
                                                                  _c_ptr, _c_ptr, _c_ptr, _c_i64,
                                                                  _c_ptr, _c_i64, _c_ptr]),
+    "sputnik_hip_spmm_transposed_out_supported": (_c_int, [_c_int] * 5),
+    "sputnik_hip_spmm_transposed_out_batched": (_c_int, [_c_int] * 5 + [_c_ptr, _c_i64, _c_ptr, _c_ptr,
+                                                                       _c_ptr, _c_ptr, _c_i64, _c_ptr,
+                                                                       _c_int, _c_int, _c_ptr, _c_i64,
+                                                                       _c_ptr]),
     "sputnik_hip_sddmm_sum_scratch_bytes": (_c_size, [_c_int] * 5),
     "sputnik_hip_sddmm_sum_workspace_bytes": (_c_size, [_c_int] * 4),
     "sputnik_hip_sddmm_sum_plan": (_c_int, [_c_int] * 4 + [_c_ptr] * 4 + [_c_size, _c_ptr]),

@@ -34,7 +34,7 @@ int spmm_panel_launch(int m, int k, int n, int nonzeros, int replicas, const int
                       const float* values, int64_t values_stride, const int* row_offsets,
                       const int* column_indices, const float* dense, int64_t dense_stride,
                       float* out, int64_t out_stride, hipStream_t stream, Epilogue epi,
-                      const int* value_permutation = nullptr);
+                      const int* value_permutation = nullptr, int block_rows = 0);
 
 namespace {
 
@@ -297,6 +297,41 @@ int sputnik_hip_spmm_permuted_batched(int m, int k, int n, int nonzeros, int rep
   return spmm_panel_launch(m, k, n, nonzeros, replicas, row_indices, values, values_stride,
                            row_offsets, column_indices, dense, dense_stride, out, out_stride,
                            stream, Epilogue{}, value_permutation);
+}
+
+namespace {
+// Row blocks the transposing store handles: a multiple of 64 that divides the
+// workgroup's 256 rows or is a multiple of them, and divides m.
+bool block_rows_ok(int m, int block_rows) {
+  return block_rows >= 64 && block_rows % 64 == 0 && m % block_rows == 0 &&
+         (256 % block_rows == 0 || block_rows % 256 == 0);
+}
+}  // namespace
+
+int sputnik_hip_spmm_transposed_out_supported(int m, int k, int n, int nonzeros, int block_rows) {
+  return m > 0 && nonzeros > 0 && k <= 1024 && block_rows_ok(m, block_rows) &&
+         spmm_panel_applicable(m, k, n, nonzeros, nullptr, 0, nullptr, 0) ? 1 : 0;
+}
+
+int sputnik_hip_spmm_transposed_out_batched(int m, int k, int n, int nonzeros, int replicas,
+                                            const float* values, int64_t values_stride,
+                                            const int* value_permutation, const int* row_offsets,
+                                            const int* column_indices, const float* dense,
+                                            int64_t dense_stride, const float* bias, int relu,
+                                            int block_rows, float* out, int64_t out_stride,
+                                            sputnik_hip_stream_t stream) {
+  if (m < 0 || k < 0 || n < 0 || nonzeros < 0 || replicas < 0 || block_rows <= 0)
+    return SPUTNIK_HIP_INVALID_ARGUMENT;
+  if (m == 0 || n == 0 || replicas == 0) return 0;
+  if (nonzeros == 0 || !block_rows_ok(m, block_rows) ||
+      !spmm_panel_applicable(m, k, n, nonzeros, dense, dense_stride, out, out_stride))
+    return SPUTNIK_HIP_UNSUPPORTED;
+  Epilogue epi;
+  epi.bias = bias;
+  epi.relu = relu != 0;
+  return spmm_panel_launch(m, k, n, nonzeros, replicas, /*row_indices=*/nullptr, values,
+                           values_stride, row_offsets, column_indices, dense, dense_stride, out,
+                           out_stride, stream, epi, value_permutation, block_rows);
 }
 
 int sputnik_hip_spmm(int m, int k, int n, int nonzeros, const int* row_indices,

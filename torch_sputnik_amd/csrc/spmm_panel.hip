@@ -18,6 +18,7 @@
 // number of steps (EXEC-masked).  Rows are dealt to workgroups interleaved
 // (dealt_index), neighbours in the caller's length-sorted row_indices share a
 // quad.  The last column tile may be partial (n a multiple of 4).
+#include <algorithm>
 #include <atomic>
 
 #include "options.h"
@@ -80,14 +81,14 @@ __device__ __forceinline__ void dpp_group4_pair(float (&acc_a)[4], float (&acc_b
 // row's whole stream again, working only on the groups of four entries that have
 // a column inside the resident panel (a row with ascending columns pays each
 // group once, plus the few that straddle a boundary; nothing has to be sorted).
-template <bool MULTI, bool PERM>
+template <bool MULTI, bool PERM, bool TOUT>
 __global__ __launch_bounds__(kPThreads) void spmm_panel64_kernel(
     int m, int k, int n, int nonzeros, int slots, int n_tiles,
     const int* __restrict__ row_indices, const float* __restrict__ values,
     int64_t values_stride, const int* __restrict__ row_offsets,
     const int* __restrict__ column_indices, const int* __restrict__ value_permutation,
     const float* __restrict__ dense, int64_t dense_stride, float* __restrict__ out,
-    int64_t out_stride, Epilogue epi) {
+    int64_t out_stride, Epilogue epi, int block_rows) {
   extern __shared__ float panel[];   // [min(k, 512)][64]
 
   const int lane = threadIdx.x % kWave;
@@ -107,9 +108,10 @@ __global__ __launch_bounds__(kPThreads) void spmm_panel64_kernel(
 #pragma unroll
   for (int t = 0; t < kPQuads; ++t) {
     const int slot = mblock * kPBM + wave * (kPQuads * 4) + 4 * t + g;
-    const int entry = dealt_index(slot, slots, kPBM);
+    // (TOUT: a workgroup owns the CONTIGUOUS rows mblock * 256 ..., see the store)
+    const int entry = TOUT ? slot : dealt_index(slot, slots, kPBM);
     const bool live = entry < m;
-    row[t] = row_indices[live ? entry : 0];
+    row[t] = TOUT ? (live ? entry : 0) : row_indices[live ? entry : 0];
     p0[t] = row_offsets[row[t]];
     cnt[t] = live ? row_offsets[row[t] + 1] - p0[t] : 0;
     if (!live) row[t] = -1;
@@ -216,11 +218,47 @@ __global__ __launch_bounds__(kPThreads) void spmm_panel64_kernel(
     }
     }
   }
+  if constexpr (!TOUT) {
 #pragma unroll
-  for (int t = 0; t < kPQuads; ++t)
-    if (row[t] >= 0 && n0 + i * 4 < n)
-      *reinterpret_cast<float4*>(out + static_cast<int64_t>(row[t]) * n + n0 + i * 4) =
-          apply_epilogue(make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]), epi, row[t]);
+    for (int t = 0; t < kPQuads; ++t)
+      if (row[t] >= 0 && n0 + i * 4 < n)
+        *reinterpret_cast<float4*>(out + static_cast<int64_t>(row[t]) * n + n0 + i * 4) =
+            apply_epilogue(make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]), epi, row[t]);
+  } else {
+    // Transposed store in row blocks of `block_rows` (hd):
+    //   out[(row / hd) * n * hd + col * hd + row % hd] = C[row][col]
+    // i.e. every block of hd rows of C is written as its transpose [n][hd] -- the
+    // head split of modules/sparse_attention.py:38-45,108-126 (hd = head_dim), or
+    // the whole C^T (hd = m).  The workgroup's 256 x 64 tile goes through LDS
+    // (the panel is no longer needed; row pitch 65 words: both the row-wise
+    // writes and the column-wise reads are conflict-free) and leaves as runs of
+    // 64 consecutive rows = 256 contiguous bytes per column.
+    constexpr int kPitch = kPBN + 1;
+    __syncthreads();   // every wave is done with the panel
+#pragma unroll
+    for (int t = 0; t < kPQuads; ++t) {
+      const float4 v = apply_epilogue(make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]),
+                                      epi, max(row[t], 0));
+      float* dst = panel + (wave * (kPQuads * 4) + 4 * t + g) * kPitch + i * 4;
+      dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    }
+    __syncthreads();
+    const int row0 = mblock * kPBM;
+#pragma unroll
+    for (int j = 0; j < (kPBM / 4) * kPBN / kPThreads; ++j) {
+      const int f = j * kPThreads + threadIdx.x;
+      const int rq = (f % 16) + 16 * (f / (16 * kPBN));   // row quad 0..63 of the tile
+      const int c = (f / 16) % kPBN;
+      const int r = row0 + 4 * rq;
+      if (r < m && n0 + c < n) {   // (m is a multiple of 4: a quad is inside or outside)
+        const float* src = panel + (4 * rq) * kPitch + c;
+        const float4 v = make_float4(src[0], src[kPitch], src[2 * kPitch], src[3 * kPitch]);
+        const int64_t at = (static_cast<int64_t>(r / block_rows) * n + (n0 + c)) * block_rows +
+                           r % block_rows;
+        *reinterpret_cast<float4*>(out + at) = v;
+      }
+    }
+  }
 }
 
 }  // namespace
@@ -238,12 +276,14 @@ int spmm_panel_launch(int m, int k, int n, int nonzeros, int replicas, const int
                       const float* values, int64_t values_stride, const int* row_offsets,
                       const int* column_indices, const float* dense, int64_t dense_stride,
                       float* out, int64_t out_stride, hipStream_t stream, Epilogue epi,
-                      const int* value_permutation) {
+                      const int* value_permutation, int block_rows) {
   const int slots = ceil_div(m, kPBM) * kPBM;
   const int n_tiles = ceil_div(n, kPBN);
   const int64_t blocks = static_cast<int64_t>(slots / kPBM) * n_tiles;
   if (blocks > 0x7fffffff) return SPUTNIK_HIP_INVALID_ARGUMENT;
-  const size_t lds = static_cast<size_t>(ceil_div(min(k, kPMaxK), 4) * 4) * kPBN * sizeof(float);
+  size_t lds = static_cast<size_t>(ceil_div(min(k, kPMaxK), 4) * 4) * kPBN * sizeof(float);
+  if (block_rows > 0)   // the transposing store's tile (256 rows, pitch 65 words)
+    lds = std::max(lds, static_cast<size_t>(kPBM) * (kPBN + 1) * sizeof(float));
   const bool multi = k > kPMaxK;
   // more than 64 KiB of dynamic LDS has to be asked for, once per device
   static std::atomic<uint64_t> asked{0};
@@ -251,10 +291,14 @@ int spmm_panel_launch(int m, int k, int n, int nonzeros, int replicas, const int
   if (hipGetDevice(&device) != hipSuccess) return launch_status();
   const uint64_t bit = uint64_t{1} << (device & 63);
   if (!(asked.load(std::memory_order_acquire) & bit)) {
-    for (const void* f : {reinterpret_cast<const void*>(spmm_panel64_kernel<false, false>),
-                          reinterpret_cast<const void*>(spmm_panel64_kernel<true, false>),
-                          reinterpret_cast<const void*>(spmm_panel64_kernel<false, true>),
-                          reinterpret_cast<const void*>(spmm_panel64_kernel<true, true>)}) {
+    for (const void* f : {reinterpret_cast<const void*>(spmm_panel64_kernel<false, false, false>),
+                          reinterpret_cast<const void*>(spmm_panel64_kernel<true, false, false>),
+                          reinterpret_cast<const void*>(spmm_panel64_kernel<false, true, false>),
+                          reinterpret_cast<const void*>(spmm_panel64_kernel<true, true, false>),
+                          reinterpret_cast<const void*>(spmm_panel64_kernel<false, false, true>),
+                          reinterpret_cast<const void*>(spmm_panel64_kernel<true, false, true>),
+                          reinterpret_cast<const void*>(spmm_panel64_kernel<false, true, true>),
+                          reinterpret_cast<const void*>(spmm_panel64_kernel<true, true, true>)}) {
       const hipError_t st = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                 kPMaxK * kPBN * sizeof(float));
       if (st != hipSuccess) return static_cast<int>(st);
@@ -263,14 +307,17 @@ int spmm_panel_launch(int m, int k, int n, int nonzeros, int replicas, const int
   }
   for (int r0 = 0; r0 < replicas; r0 += kMaxGridYZ) {
     const int ry = min(replicas - r0, kMaxGridYZ);
-    const auto kernel = value_permutation != nullptr
-                            ? (multi ? spmm_panel64_kernel<true, true> : spmm_panel64_kernel<false, true>)
-                            : (multi ? spmm_panel64_kernel<true, false> : spmm_panel64_kernel<false, false>);
+    const bool perm = value_permutation != nullptr, tout = block_rows > 0;
+    const auto kernel =
+        tout ? (perm ? (multi ? spmm_panel64_kernel<true, true, true> : spmm_panel64_kernel<false, true, true>)
+                     : (multi ? spmm_panel64_kernel<true, false, true> : spmm_panel64_kernel<false, false, true>))
+             : (perm ? (multi ? spmm_panel64_kernel<true, true, false> : spmm_panel64_kernel<false, true, false>)
+                     : (multi ? spmm_panel64_kernel<true, false, false> : spmm_panel64_kernel<false, false, false>));
     hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(blocks), ry), dim3(kPThreads), lds,
                        stream, m, k, n, nonzeros, slots, n_tiles, row_indices,
                        values + r0 * values_stride, values_stride, row_offsets, column_indices,
                        value_permutation, dense + r0 * dense_stride, dense_stride,
-                       out + r0 * out_stride, out_stride, epi);
+                       out + r0 * out_stride, out_stride, epi, block_rows);
     const int st = launch_status();
     if (st != 0) return st;
   }

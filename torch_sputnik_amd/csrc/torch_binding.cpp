@@ -104,13 +104,14 @@ void check_plan(const Tensor& plan, size_t bytes, const Tensor& like) {
 }
 
 Tensor permute_last(const Tensor& values_in, const Tensor& permutation);
+Tensor transpose_last2(const Tensor& x);
 
 // Shared by spmm (values [nnz] / [R,nnz]) and left_spmm (values [nnz], shared).
 Tensor spmm_impl(int64_t m64, int64_t k64, const Tensor& values_in, const Tensor& row_indices,
                  const Tensor& row_offsets, const Tensor& column_indices, const Tensor& dense_in,
                  bool left, const char* what, const c10::optional<Tensor>& bias_in = c10::nullopt,
                  bool relu = false, const c10::optional<Tensor>& plan = c10::nullopt,
-                 const c10::optional<Tensor>& permutation = c10::nullopt) {
+                 const c10::optional<Tensor>& permutation = c10::nullopt, int64_t block_rows = 0) {
   const int m = to_int(m64, "m"), k = to_int(k64, "k");
   Tensor values = as_float(values_in, "values");
   const Tensor dense = as_float(dense_in, "dense");
@@ -143,9 +144,50 @@ Tensor spmm_impl(int64_t m64, int64_t k64, const Tensor& values_in, const Tensor
   }
 
   const auto options = values.options();
+  const int64_t values_stride = (left || values.dim() == 1) ? 0 : topo.nonzeros;
+  if (block_rows > 0) {
+    // The product stored as the transposes of its blocks of `block_rows` rows,
+    // [replicas * m / block_rows, n, block_rows]: the head split behind a projection
+    // (modules/sparse_attention.py:38-45) or the whole C^T (block_rows = m), written
+    // by the panel kernel's store phase where it serves the shape; elsewhere the
+    // usual product followed by the tiled transpose kernel.
+    TORCH_CHECK(m % block_rows == 0, "block_rows (", block_rows, ") must divide m = ", m);
+    if (permutation.has_value())
+      TORCH_CHECK(permutation->scalar_type() == at::kInt && permutation->dim() == 1 &&
+                      permutation->is_contiguous() && permutation->device() == values.device() &&
+                      permutation->size(0) == topo.nonzeros,
+                  "permutation must be a contiguous int32 vector of ", topo.nonzeros,
+                  " entries on ", values.device());
+    const bool fused_perm = !permutation.has_value() ||
+                            sputnik_hip_spmm_permuted_supported(m, k, n, topo.nonzeros);
+    if (fused_perm && sputnik_hip_spmm_transposed_out_supported(m, k, n, topo.nonzeros,
+                                                                static_cast<int>(block_rows))) {
+      Tensor bias;
+      if (bias_in.has_value()) {
+        bias = as_float(*bias_in, "bias");
+        TORCH_CHECK(bias.device() == values.device() && bias.dim() == 1 && bias.size(0) == m,
+                    "bias should have m = ", m, " elements on ", values.device());
+      }
+      Tensor tout = at::empty({replicas * (m / block_rows), n, block_rows}, options);
+      const int st = sputnik_hip_spmm_transposed_out_batched(
+          m, k, n, topo.nonzeros, replicas, values.data_ptr<float>(), values_stride,
+          permutation.has_value() ? permutation->data_ptr<int>() : nullptr,
+          topo.row_offsets.data_ptr<int>(), topo.column_indices.data_ptr<int>(),
+          dense.data_ptr<float>(), static_cast<int64_t>(k) * n,
+          bias.defined() ? bias.data_ptr<float>() : nullptr, relu ? 1 : 0,
+          static_cast<int>(block_rows), tout.data_ptr<float>(), static_cast<int64_t>(m) * n,
+          current_stream(values));
+      if (st != SPUTNIK_HIP_UNSUPPORTED) {
+        check_status(st, what);
+        return tout;
+      }
+    }
+    const Tensor c = spmm_impl(m64, k64, values_in, row_indices, row_offsets, column_indices,
+                               dense_in, left, what, bias_in, relu, plan, permutation, 0);
+    return transpose_last2(c.reshape({replicas * (m / block_rows), block_rows, n}));
+  }
   Tensor out = (replicas == 1 && !left) ? at::empty({m, n}, options)
                                         : at::empty({replicas, m, n}, options);
-  const int64_t values_stride = (left || values.dim() == 1) ? 0 : topo.nonzeros;
   if (permutation.has_value()) {
     // values are those of ANOTHER ordering of the same entries (the topology here
     // is its transpose): entry p takes values[permutation[p]].  One kernel where
@@ -220,6 +262,19 @@ Tensor spmm_permuted(int64_t m, int64_t k, const Tensor& values, const Tensor& p
                      const c10::optional<Tensor>& plan) {
   return spmm_impl(m, k, values, row_indices, row_offsets, column_indices, dense, false,
                    "spmm_permuted", c10::nullopt, false, plan, permutation);
+}
+
+// spmm / left_spmm with the product stored as the transposes of its blocks of
+// `block_rows` rows -> [replicas * m / block_rows, n, block_rows]; `permutation`
+// as in spmm_permuted.
+Tensor spmm_transposed_out(int64_t m, int64_t k, const Tensor& values,
+                           const c10::optional<Tensor>& permutation, const Tensor& row_indices,
+                           const Tensor& row_offsets, const Tensor& column_indices,
+                           const Tensor& dense, int64_t block_rows, bool left,
+                           const c10::optional<Tensor>& plan) {
+  TORCH_CHECK(block_rows > 0, "block_rows must be positive, got ", block_rows);
+  return spmm_impl(m, k, values, row_indices, row_offsets, column_indices, dense, left,
+                   "spmm_transposed_out", c10::nullopt, false, plan, permutation, block_rows);
 }
 
 Tensor left_spmm_permuted(int64_t m, int64_t k, const Tensor& values, const Tensor& permutation,
@@ -1066,6 +1121,10 @@ TORCH_LIBRARY(torch_sputnik, m) {
       "spmm_permuted(int m, int k, Tensor values, Tensor permutation, Tensor row_indices, "
       "Tensor row_offsets, Tensor column_indices, Tensor dense_matrix, Tensor? plan) -> Tensor");
   m.def(
+      "spmm_transposed_out(int m, int k, Tensor values, Tensor? permutation, Tensor row_indices, "
+      "Tensor row_offsets, Tensor column_indices, Tensor dense_matrix, int block_rows, bool left, "
+      "Tensor? plan) -> Tensor");
+  m.def(
       "left_spmm_permuted(int m, int k, Tensor values, Tensor permutation, Tensor row_indices, "
       "Tensor row_offsets, Tensor column_indices, Tensor dense_matrix, Tensor? plan) -> Tensor");
   m.def("transpose_last2(Tensor x) -> Tensor");
@@ -1105,6 +1164,7 @@ TORCH_LIBRARY_IMPL(torch_sputnik, CUDA, m) {
   m.impl("permute_last", &permute_last);
   m.impl("permute_last_banded", &permute_last_banded);
   m.impl("spmm_permuted", &spmm_permuted);
+  m.impl("spmm_transposed_out", &spmm_transposed_out);
   m.impl("left_spmm_permuted", &left_spmm_permuted);
   m.impl("transpose_last2", &transpose_last2);
   m.impl("transpose_last2_as", &transpose_last2_as);

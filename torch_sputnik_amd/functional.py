@@ -225,6 +225,16 @@ def _spmm(m, k, values, row_indices, row_offsets, column_indices, dense, left=Fa
         m, k, values, row_indices, row_offsets, column_indices, dense, plan)
 
 
+def _linear(m, k, values, row_indices, row_offsets, column_indices, dense, split_rows=0):
+    """left_spmm, optionally with the head-split store (ops.spmm_transposed_out)."""
+    if not split_rows:
+        return _spmm(m, k, values, row_indices, row_offsets, column_indices, dense, left=True)
+    plan = None if _plans is None else _plans.spmm(m, k, dense.size(-1), row_indices,
+                                                   row_offsets, column_indices)
+    return ops.spmm_transposed_out(m, k, values, row_indices, row_offsets, column_indices, dense,
+                                   block_rows=split_rows, plan=plan, left=True)
+
+
 def _sddmm(m, n, row_indices, row_offsets, column_indices, lhs_matrix, rhs_matrix,
            sum_replicas=False):
     if _plans is None:
@@ -281,13 +291,22 @@ def _to_operand(x):
 
 class Spmm(torch.autograd.Function):
     """sparse(values, CSR topology) @ dense.  ``apply(m, k, values, row_indices,
-    row_offsets, column_indices, dense)``."""
+    row_offsets, column_indices, dense[, transposed_out])``; with ``transposed_out``
+    the product comes back transposed, [R, n, m] (written in that order by the
+    kernel's store phase, ops.spmm_transposed_out: SparseAttention's head merge)."""
 
     @staticmethod
-    def forward(ctx, m, k, values, row_indices, row_offsets, column_indices, dense):
+    def forward(ctx, m, k, values, row_indices, row_offsets, column_indices, dense,
+                transposed_out=False):
         ctx.shape = (m, k)
         ctx.topology = (row_indices, row_offsets, column_indices)
+        ctx.transposed_out = bool(transposed_out)
         ctx.save_for_backward(values, dense)
+        if transposed_out:
+            plan = None if _plans is None else _plans.spmm(m, k, dense.size(-1), row_indices,
+                                                           row_offsets, column_indices)
+            return ops.spmm_transposed_out(m, k, values, row_indices, row_offsets,
+                                           column_indices, dense, block_rows=m, plan=plan)
         return _spmm(m, k, values, row_indices, row_offsets, column_indices, dense)
 
     @staticmethod
@@ -296,6 +315,10 @@ class Spmm(torch.autograd.Function):
         row_indices, row_offsets, column_indices = ctx.topology
         values, dense = ctx.saved_tensors
         grad_output = _contiguous(grad_output)
+        if ctx.transposed_out:   # [R, n, m] -> the product's own layout
+            grad_output = ops.transpose_last2(grad_output)
+            if dense.dim() == 2:
+                grad_output = grad_output[0]
         grad_values = grad_dense = None
         if ctx.needs_input_grad[2]:
             # dL/dA sampled at the pattern: <dC[i,:], B[j,:]>
@@ -304,7 +327,7 @@ class Spmm(torch.autograd.Function):
         if ctx.needs_input_grad[6]:
             # dL/dB = A^T @ dC
             grad_dense = _spmm_transposed(m, k, values, row_offsets, column_indices, grad_output)
-        return None, None, grad_values, None, None, None, grad_dense
+        return None, None, grad_values, None, None, None, grad_dense, None
 
 
 class Sddmm(torch.autograd.Function):
@@ -338,15 +361,19 @@ class Sddmm(torch.autograd.Function):
 
 class SparseLinearFunction(torch.autograd.Function):
     """One sparse weight x a batch of dense matrices (left_spmm).  ``apply(m, k,
-    values, row_indices, row_offsets, column_indices, dense)`` with dense
-    [B,k,n] -> [B,m,n]."""
+    values, row_indices, row_offsets, column_indices, dense[, split_rows])`` with
+    dense [B,k,n] -> [B,m,n]; with ``split_rows = d`` the product comes back head
+    split, [B * m/d, n, d] (every block of d output rows transposed, written by
+    the kernel's store phase: modules/sparse_attention.py:38-45,108-126)."""
 
     @staticmethod
-    def forward(ctx, m, k, values, row_indices, row_offsets, column_indices, dense):
+    def forward(ctx, m, k, values, row_indices, row_offsets, column_indices, dense,
+                split_rows=0):
         ctx.shape = (m, k)
         ctx.topology = (row_indices, row_offsets, column_indices)
+        ctx.split_rows = int(split_rows)
         ctx.save_for_backward(values, dense)
-        return _spmm(m, k, values, row_indices, row_offsets, column_indices, dense, left=True)
+        return _linear(m, k, values, row_indices, row_offsets, column_indices, dense, split_rows)
 
     @staticmethod
     def backward(ctx, grad_output):
@@ -354,6 +381,9 @@ class SparseLinearFunction(torch.autograd.Function):
         row_indices, row_offsets, column_indices = ctx.topology
         values, dense = ctx.saved_tensors
         grad_output = _contiguous(grad_output)
+        if ctx.split_rows:   # [B * m/d, n, d] -> [B, m, n]
+            grad_output = ops.transpose_last2(grad_output).reshape(
+                -1, m, grad_output.size(-2))
         grad_values = grad_dense = None
         if ctx.needs_input_grad[2]:
             # the [B,nnz] products summed over B (what autograd makes of the
@@ -365,7 +395,7 @@ class SparseLinearFunction(torch.autograd.Function):
                                           grad_output, left=True)
             if dense.dim() == 2:
                 grad_dense = grad_dense[0]
-        return None, None, grad_values, None, None, None, grad_dense
+        return None, None, grad_values, None, None, None, grad_dense, None
 
 
 class SparseSoftmax(torch.autograd.Function):

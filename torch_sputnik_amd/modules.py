@@ -46,20 +46,22 @@ class SparseLinear(nn.Module):
         # kernel (same values, same layout)
         return self.project(functional._to_operand(x))
 
-    def project(self, dense):
+    def project(self, dense, split_rows=0):
         """``W @ dense`` for an operand that is already k-major: [B, in, S] ->
-        [B, out, S].  (SparseAttention chains its layout passes and calls this.)"""
+        [B, out, S].  (SparseAttention chains its layout passes and calls this.)
+        ``split_rows = d``: the product comes back head split, [B * out/d, S, d],
+        written in that order by the kernel (no layout pass of its own)."""
         needs_grad = torch.is_grad_enabled() and (dense.requires_grad or self.values.requires_grad)
         if not needs_grad:
             # forward only: no autograd node.  (The weight's pattern is static: its
             # topology pre-pass comes from the plan cache, functional.PlanCache,
             # which is keyed on the identity and version of the index tensors.)
-            return functional._spmm(self.output_features, self.input_features,
-                                    self.values.detach(), self.row_indices, self.row_offsets,
-                                    self.column_indices, dense, left=True)
+            return functional._linear(self.output_features, self.input_features,
+                                      self.values.detach(), self.row_indices, self.row_offsets,
+                                      self.column_indices, dense, split_rows)
         return SparseLinearFunction.apply(
             self.output_features, self.input_features, self.values, self.row_indices,
-            self.row_offsets, self.column_indices, dense)
+            self.row_offsets, self.column_indices, dense, split_rows)
 
 
 def get_clones(module, num_of_deep_copies):
@@ -107,16 +109,21 @@ class SparseAttention(nn.Module):
         return self._attention3d(self.four_d_to_three_d(query), self.four_d_to_three_d(key),
                                  self.four_d_to_three_d(value))
 
-    def _attention3d(self, q3d, k3d, v3d):
+    def _attention3d(self, q3d, k3d, v3d, merged=False):
+        """-> [B*H, S, D]; ``merged``: transposed, [B*H, D, S] (= [B, E, S], the k-major
+        operand of the output projection), written that way by the last kernel where
+        it can (the SpMM of the separate-operator path), else by a layout pass."""
         scale = 1.0 / math.sqrt(self.head_dim)
         needs_grad = torch.is_grad_enabled() and (
             q3d.requires_grad or k3d.requires_grad or v3d.requires_grad)
         if self.fused_inference and not needs_grad:
-            return functional._attention(q3d, k3d, v3d, self.row_indices, self.row_offsets,
-                                         self.column_indices, scale)
+            out = functional._attention(q3d, k3d, v3d, self.row_indices, self.row_offsets,
+                                        self.column_indices, scale)
+            return functional.transpose_last2(out) if merged else out
         if self.fused_training:
-            return SparseAttentionFunction.apply(q3d, k3d, v3d, self.row_indices,
-                                                 self.row_offsets, self.column_indices, scale)
+            out = SparseAttentionFunction.apply(q3d, k3d, v3d, self.row_indices,
+                                                self.row_offsets, self.column_indices, scale)
+            return functional.transpose_last2(out) if merged else out
 
         # [B*H, nnz]: scores only at the mask's nonzeros
         scores = self.sddmm(self.m, self.n, self.row_indices, self.row_offsets,
@@ -127,9 +134,13 @@ class SparseAttention(nn.Module):
                    else ops.sparse_softmax_scaled)
         attention_weights = softmax(scores, self.row_indices, self.row_offsets,
                                     self.column_indices, scale)
-        # [B*H, S, D]
-        return self.spmm(self.m, self.n, attention_weights, self.row_indices, self.row_offsets,
-                         self.column_indices, v3d)
+        # [B*H, S, D] ([B*H, D, S] when merged)
+        if merged and getattr(self.spmm, "__self__", None) is Spmm:
+            return Spmm.apply(self.m, self.n, attention_weights, self.row_indices,
+                              self.row_offsets, self.column_indices, v3d, True)
+        out = self.spmm(self.m, self.n, attention_weights, self.row_indices, self.row_offsets,
+                        self.column_indices, v3d)
+        return functional.transpose_last2(out) if merged else out
 
     @staticmethod
     def four_d_to_three_d(tensor):
@@ -163,7 +174,9 @@ class SparseAttention(nn.Module):
             return functional.transpose_last2(projected.reshape(batch_size * heads, dim, seq))
 
         if not (query.is_cuda and self.parallel_projections):
-            q3d, k3d, v3d = (head_split(net.project(d)) for net, d in zip(self.linears, operands))
+            # (the projection kernel stores its product head split: [B*H, S, D])
+            q3d, k3d, v3d = (net.project(d, split_rows=dim)
+                             for net, d in zip(self.linears, operands))
         else:
             # (under autograd the backward of each projection runs on the stream its
             # forward ran on, so the three weight / input gradients overlap as well)
@@ -180,8 +193,8 @@ class SparseAttention(nn.Module):
                 main.wait_stream(self._side_stream(i, query.device))
             q3d, k3d, v3d = results
 
-        context = self._attention3d(q3d, k3d, v3d)                      # [B*H, S, D]
-        merged = functional.transpose_last2(context).reshape(batch_size, heads * dim, seq)
+        context = self._attention3d(q3d, k3d, v3d, merged=True)         # [B*H, D, S]
+        merged = context.reshape(batch_size, heads * dim, seq)
         return self.linears[-1].project(merged).transpose(1, 2)
 
     def _side_stream(self, index, device):

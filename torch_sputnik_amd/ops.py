@@ -217,6 +217,18 @@ def spmm_permuted(m, k, values, permutation, row_indices, row_offsets, column_in
               dense_matrix, plan)
 
 
+def spmm_transposed_out(m, k, values, row_indices, row_offsets, column_indices, dense_matrix,
+                        block_rows, permutation=None, plan=None, left=False):
+    """spmm / left_spmm with the product stored as the transposes of its blocks of
+    ``block_rows`` rows -> [replicas * m / block_rows, n, block_rows]: the head
+    split behind a projection (block_rows = head_dim,
+    modules/sparse_attention.py:38-45) or C^T (block_rows = m), written by the
+    kernel's store phase where the panel kernel serves the shape."""
+    return _ops.spmm_transposed_out(int(m), int(k), values, permutation, row_indices,
+                                    row_offsets, column_indices, dense_matrix, int(block_rows),
+                                    bool(left), plan)
+
+
 def sddmm_sum(m, n, row_indices, row_offsets, column_indices, lhs_matrix, rhs_matrix):
     """sum over the replicas of sddmm(...) -> [nnz]: the gradient of sparse values
     shared by a batch (what autograd makes of the [R, nnz] result of
