@@ -135,3 +135,68 @@ def test_fuzz_sparse_attention(capi, dev):
         got = out.cpu().numpy()
         assert not np.isnan(got).any(), (it, m, n)
         assert rel_err(got, O.sparse_attention(q, k, v, ri, ro, ci, 0.125)) < TOL, (it, m, n, sparsity)
+
+
+def test_fuzz_round2_entry_points(dev):
+    """Random shapes for the entry points added in round 2, through the ops (so
+    that unsupported shapes exercise the fall-back compositions as well): the
+    product stored transposed in row blocks, with and without values gathered
+    through a permutation; the SDDMM summed over the replicas; the banded
+    permutation."""
+    import torch_sputnik as ts
+    from torch_sputnik_amd import ops
+    from torch_sputnik_amd.topology import diffsort
+    rng = np.random.default_rng(777 + SEED_SHIFT)
+    for it in range(30 * SCALE):
+        block = int(rng.choice([32, 64, 128, 256]))
+        m = block * int(rng.integers(1, 9))
+        k = max(4, _dims(rng, [32, 64, 200, 512, 600, 1100]))
+        n = int(rng.choice([8, 20, 64, 72, 128, 200, 256]))
+        sparsity = float(rng.choice([0.0, 0.5, 0.9, 0.97]))
+        replicas = int(rng.integers(1, 5))
+        left = bool(rng.random() < 0.5)
+        order = ORDERS[int(rng.integers(0, len(ORDERS)))]
+        _, vals, ri, ro, ci = make_csr(m, k, sparsity, seed=500 + it, round_to=1, order=order,
+                                       empty_rows=(int(rng.integers(0, m)),))
+        if len(ci) == 0:
+            continue
+        values = vals if left else rng.uniform(-1, 1, (replicas, len(ci))).astype(np.float32)
+        b = rng.uniform(-1, 1, (replicas, k, n)).astype(np.float32)
+        topo = [T(x, dev) for x in (ri, ro, ci)]
+        want = np.stack([O.spmm(m, k, values if left else values[r], ri, ro, ci, b[r])
+                         for r in range(replicas)])
+        want_t = np.ascontiguousarray(
+            want.reshape(replicas * (m // block), block, n).transpose(0, 2, 1))
+        got = ts.spmm_transposed_out(m, k, T(values, dev), *topo, T(b, dev), block, left=left)
+        assert rel_err(got.cpu().numpy(), want_t) < TOL, (it, m, k, n, block, left)
+
+        # the transposed product A^T @ X with the values kept in A's order, stored in blocks
+        if k % 64 == 0 and k >= 64:
+            x = rng.uniform(-1, 1, (replicas, m, n)).astype(np.float32)
+            v1 = values if left else values[0]
+            _, ro_t, ci_t, perm = ts.csr_transpose_with_permutation(m, k, T(v1, dev), topo[1], topo[2])
+            ri_t = diffsort(ro_t)
+            got_t = ts.spmm_transposed_out(k, m, T(v1, dev), ri_t, ro_t, ci_t, T(x, dev), 64,
+                                           permutation=perm, left=True)
+            dense = np.zeros((m, k))
+            dense[np.repeat(np.arange(m), np.diff(ro)), ci] = v1
+            want2 = np.einsum("mk,rmn->rkn", dense, x.astype(np.float64)).astype(np.float32)
+            want2 = np.ascontiguousarray(want2.reshape(replicas * (k // 64), 64, n).transpose(0, 2, 1))
+            assert rel_err(got_t.cpu().numpy(), want2) < TOL, (it, m, k, n, "permuted")
+
+        # SDDMM summed over the replicas (mask m x k2 with inner dimension n2)
+        n2 = int(rng.choice([20, 64, 128, 192, 512, 1024]))
+        lhs = rng.uniform(-1, 1, (replicas, m, n2)).astype(np.float32)
+        rhs = rng.uniform(-1, 1, (replicas, k, n2)).astype(np.float32)
+        total = ts.sddmm_sum(m, k, *topo, T(lhs, dev), T(rhs, dev))
+        want3 = O.sddmm(m, k, ri, ro, ci, lhs, rhs).astype(np.float64).reshape(replicas, -1).sum(0)
+        assert rel_err(total.cpu().numpy()[None, :], want3[None, :].astype(np.float32), ro) < TOL, \
+            (it, m, k, n2, replicas)
+
+    for it in range(10 * SCALE):
+        n = int(rng.integers(1, 70000))
+        rows = int(rng.integers(1, 5))
+        perm = torch.from_numpy(rng.permutation(n).astype(np.int32)).to(dev)
+        values = torch.from_numpy(rng.uniform(-1, 1, (rows, n)).astype(np.float32)).to(dev)
+        lists = ops.banded_lists(perm)
+        assert torch.equal(ops.permute_last_banded(values, *lists), values[:, perm.long()]), (n, rows)
