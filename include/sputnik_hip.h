@@ -307,6 +307,45 @@ SPUTNIK_HIP_API int sputnik_hip_spmm_transposed_out_batched(int m, int k, int n,
                              sputnik_hip_stream_t stream);
 
 /*
+ * A GROUP of up to four SpMMs of one shape (m, k, n; values shared by the
+ * replicas) in one launch: the projections of an attention block
+ * (modules/sparse_attention.py:108-126 runs them one after the other).
+ *   accumulate = 0: out_p[r] = A_p * dense_p[r] for every problem p.  Problems
+ *     that name the same `dense` share one copy of its panel in LDS (the q, k
+ *     and v projections of one input); with block_rows > 0 every product is
+ *     stored head split as in sputnik_hip_spmm_transposed_out_batched.
+ *   accumulate = 1: all problems name the SAME `out`, which receives
+ *     sum_p A_p * dense_p[r] (overwritten, not added to): the input gradient
+ *     sum_w W_w^T dY_w of those projections, accumulated in registers.
+ * value_permutation: NULL in all problems or set in all (as in
+ * sputnik_hip_spmm_permuted_batched).  row_indices: the processing order for
+ * accumulate = 0 and block_rows = 0; ignored (may be NULL) otherwise.
+ * Served: k <= 512, n a multiple of 4 and >= 64, m >= 16, 16-byte aligned
+ * operands, at most 4 problems, and one of the combinations
+ * (block_rows > 0, no permutation, accumulate = 0), (block_rows = 0, accumulate
+ * = 1), (block_rows = 0, no permutation, accumulate = 0); anything else returns
+ * SPUTNIK_HIP_UNSUPPORTED and the caller runs the products one by one.
+ */
+typedef struct sputnik_hip_spmm_problem {
+  const int* row_indices;
+  const int* row_offsets;
+  const int* column_indices;
+  const float* values;            /* [nonzeros] */
+  const int* value_permutation;   /* NULL, or [nonzeros] */
+  const float* dense;             /* [replicas][k][n], dense_stride apart */
+  float* out;                     /* [replicas][m][n] (or its blocked transpose) */
+  int nonzeros;
+} sputnik_hip_spmm_problem;
+
+SPUTNIK_HIP_API int sputnik_hip_spmm_group_supported(int m, int k, int n, int count,
+                                                     int block_rows, int accumulate);
+
+SPUTNIK_HIP_API int sputnik_hip_spmm_group_batched(int m, int k, int n, int replicas, int count,
+                             const sputnik_hip_spmm_problem* problems,
+                             int64_t dense_stride, int64_t out_stride, int block_rows,
+                             int accumulate, sputnik_hip_stream_t stream);
+
+/*
  * softmax(scale * x) per CSR row: folds the 1/sqrt(d) of
  * modules/sparse_attention.py:72 into the softmax pass.
  */

@@ -200,6 +200,28 @@ def _spmm_transposed_out(m, k, values, permutation, row_indices, row_offsets, co
     return c.reshape(-1, block_rows, n).transpose(1, 2).contiguous()
 
 
+def _left_spmm_group(m, k, values, row_indices, row_offsets, column_indices, dense, block_rows):
+    outs = []
+    for v, ri, ro, ci in zip(values, row_indices, row_offsets, column_indices):
+        if block_rows > 0:
+            outs.append(_spmm_transposed_out(m, k, v, None, ri, ro, ci, dense, block_rows, True))
+        else:
+            outs.append(_left_spmm(m, k, v, ri, ro, ci, dense))
+    return outs
+
+
+def _left_spmm_group_sum(m, k, values, permutations, row_indices, row_offsets, column_indices,
+                         dense):
+    total = None
+    for p, (v, ri, ro, ci, d) in enumerate(zip(values, row_indices, row_offsets, column_indices,
+                                               dense)):
+        if len(permutations):
+            v = v[permutations[p].long()].contiguous()
+        part = _left_spmm(m, k, v, ri, ro, ci, d)
+        total = part if total is None else total + part
+    return total
+
+
 def _sddmm_sum(m, n, row_indices, row_offsets, column_indices, lhs, rhs):
     out = _sddmm(m, n, row_indices, row_offsets, column_indices, lhs, rhs)
     return out.sum(dim=0) if out.dim() == 2 else out
@@ -244,6 +266,8 @@ def install():
     _lib.impl("permute_last_banded", _permute_last_banded, "CPU")
     _lib.impl("spmm_permuted", _spmm_permuted, "CPU")
     _lib.impl("spmm_transposed_out", _spmm_transposed_out, "CPU")
+    _lib.impl("left_spmm_group", _left_spmm_group, "CPU")
+    _lib.impl("left_spmm_group_sum", _left_spmm_group_sum, "CPU")
     _lib.impl("left_spmm_permuted", _left_spmm_permuted, "CPU")
     _lib.impl("sddmm_sum_planned", _sddmm_sum_planned, "CPU")
     _lib.impl("sparse_attention_planned", _sparse_attention_planned, "CPU")

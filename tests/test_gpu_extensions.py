@@ -563,6 +563,70 @@ def test_spmm_transposed_out_with_permuted_values(ts, dev):
     assert torch.equal(got, moved.contiguous())
 
 
+@pytest.mark.parametrize("m,k,n,replicas,count,block", [
+    (512, 512, 1024, 3, 3, 64),    # q, k, v projections of config 3, head split
+    (512, 512, 1024, 2, 4, 0),     # plain stores, rows dealt from row_indices
+    (320, 200, 72, 2, 2, 64),      # ragged m, partial column tile
+    (256, 96, 64, 1, 3, 256),      # panel smaller than a tile phase
+    (128, 600, 64, 2, 2, 64),      # k > 512: one by one
+    (192, 128, 20, 2, 3, 64),      # n < 64: one by one
+])
+def test_left_spmm_group_equals_the_single_products(ts, dev, m, k, n, replicas, count, block):
+    rng = np.random.default_rng(m + k + count)
+    mats = [make_csr(m, k, 0.9 if p else 0.7, seed=10 * m + p, order="descending")
+            for p in range(count)]
+    vals = [T(rng.uniform(-1, 1, len(mat[4])).astype(np.float32), dev) for mat in mats]
+    topo = [[T(x, dev) for x in mat[2:5]] for mat in mats]
+    b = T(rng.uniform(-1, 1, (replicas, k, n)).astype(np.float32), dev)
+    outs = ts.left_spmm_group(m, k, vals, [t[0] for t in topo], [t[1] for t in topo],
+                              [t[2] for t in topo], b, block)
+    assert len(outs) == count
+    for p in range(count):
+        if block:
+            want = ts.spmm_transposed_out(m, k, vals[p], *topo[p], b, block, left=True)
+        else:
+            want = ts.left_spmm(m, k, vals[p], *topo[p], b)
+        assert outs[p].shape == want.shape
+        assert rel_err(outs[p].cpu().numpy(), want.cpu().numpy()) < TOL, p
+    # against the dense definition as well (first matrix)
+    dense = np.zeros((m, k))
+    dense[np.repeat(np.arange(m), np.diff(mats[0][3])), mats[0][4]] = vals[0].cpu().numpy()
+    ref = np.einsum("mk,rkn->rmn", dense, b.cpu().numpy().astype(np.float64))
+    if block:
+        ref = ref.reshape(replicas * (m // block), block, n).transpose(0, 2, 1)
+    assert rel_err(outs[0].cpu().numpy(), np.ascontiguousarray(ref).astype(np.float32)) < TOL
+
+
+@pytest.mark.parametrize("m,k,n,replicas,count,permuted", [
+    (512, 512, 1024, 3, 3, True),    # input gradient of the q, k, v projections
+    (512, 512, 1024, 2, 2, False),
+    (320, 192, 72, 2, 4, True),
+    (128, 640, 64, 2, 2, True),      # transposed k = 640 > 512: one by one
+])
+def test_left_spmm_group_sum(ts, dev, m, k, n, replicas, count, permuted):
+    """sum_p A_p^T @ X_p (A_p given by its transposed topology + permutation) against
+    the float64 definition and the sum of the single products."""
+    from torch_sputnik_amd.topology import diffsort
+    rng = np.random.default_rng(k + count)
+    want = np.zeros((replicas, k, n))
+    vals, perms, ris, ros, cis, xs = [], [], [], [], [], []
+    for p in range(count):
+        _, _, ri, ro, ci = make_csr(m, k, 0.9, seed=7 * m + p)
+        v = rng.uniform(-1, 1, len(ci)).astype(np.float32)
+        x = rng.uniform(-1, 1, (replicas, m, n)).astype(np.float32)
+        dense = np.zeros((m, k))
+        dense[np.repeat(np.arange(m), np.diff(ro)), ci] = v
+        want += np.einsum("mk,rmn->rkn", dense, x.astype(np.float64))
+        vt, ro_t, ci_t, perm = ts.csr_transpose_with_permutation(m, k, T(v, dev), T(ro, dev), T(ci, dev))
+        vals.append(T(v, dev) if permuted else vt)
+        perms.append(perm)
+        ris.append(diffsort(ro_t)); ros.append(ro_t); cis.append(ci_t)
+        xs.append(T(x, dev))
+    got = ts.left_spmm_group_sum(k, m, vals, perms if permuted else [], ris, ros, cis, xs)
+    assert got.shape == (replicas, k, n)
+    assert rel_err(got.cpu().numpy(), want.astype(np.float32)) < TOL
+
+
 @pytest.mark.parametrize("n,rows", [(104857, 64), (16384, 3), (16385, 2), (50001, 5), (100, 4), (40000, 1)])
 def test_permute_last_banded_equals_the_plain_gather(dev, n, rows):
     from torch_sputnik_amd import ops
@@ -607,9 +671,9 @@ def test_planned_attention_and_modules(ts, dev):
     with torch.no_grad():
         from torch_sputnik_amd import functional
         functional.clear_caches()
-        first = layer(x, x, x)     # builds the plans (four projections + the attention mask)
-        plans = len(functional._plans._entries)
-        assert plans == 5
+        first = layer(x, x, x)     # builds the plans: output projection + attention mask
+        plans = len(functional._plans._entries)   # (the grouped q/k/v projections need none)
+        assert plans == 2
         second = layer(x, x, x)    # reuses them
         assert len(functional._plans._entries) == plans
     assert torch.equal(first, second)

@@ -15,6 +15,8 @@ from torch_sputnik_amd.ops import (  # noqa: F401
     csr_transpose_with_permutation,
     left_replicated_spmm,
     left_spmm,
+    left_spmm_group,
+    left_spmm_group_sum,
     sddmm,
     sddmm_many_mask,
     sddmm_plan,
@@ -48,5 +50,5 @@ __all__ = ["spmm", "left_spmm", "left_replicated_spmm", "sddmm", "sparse_softmax
            "sparse_softmax_scaled", "sparse_softmax_backward", "spmm_many_mask",
            "sddmm_many_mask", "sparse_softmax_many_mask", "sparse_softmax_backward_many_mask",
            "csr_transpose_many_mask", "sparse_attention", "sparse_attention_with_lse", "spmm_plan", "spmm_planned",
-           "left_spmm_planned", "sddmm_plan", "sddmm_planned", "sddmm_sum", "sddmm_sum_plan", "spmm_permuted", "spmm_transposed_out", "permute_last", "sddmm_sum_planned", "sparse_attention_plan",
+           "left_spmm_planned", "sddmm_plan", "sddmm_planned", "sddmm_sum", "sddmm_sum_plan", "spmm_permuted", "left_spmm_group", "left_spmm_group_sum", "spmm_transposed_out", "permute_last", "sddmm_sum_planned", "sparse_attention_plan",
            "sparse_attention_planned"]

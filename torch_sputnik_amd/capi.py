@@ -48,6 +48,9 @@ SIGNATURES = {
     "sputnik_hip_spmm_permuted_batched": (_c_int, [_c_int] * 5 + [_c_ptr, _c_ptr, _c_i64, _c_ptr,
                                                                  _c_ptr, _c_ptr, _c_ptr, _c_i64,
                                                                  _c_ptr, _c_i64, _c_ptr]),
+    "sputnik_hip_spmm_group_supported": (_c_int, [_c_int] * 6),
+    "sputnik_hip_spmm_group_batched": (_c_int, [_c_int] * 5 + [_c_ptr, _c_i64, _c_i64, _c_int, _c_int,
+                                                              _c_ptr]),
     "sputnik_hip_spmm_transposed_out_supported": (_c_int, [_c_int] * 5),
     "sputnik_hip_spmm_transposed_out_batched": (_c_int, [_c_int] * 5 + [_c_ptr, _c_i64, _c_ptr, _c_ptr,
                                                                        _c_ptr, _c_ptr, _c_i64, _c_ptr,
@@ -429,6 +432,36 @@ def spmm_permuted_batched(m, k, n, replicas, row_indices, values, values_stride,
         m * n, _stream(out))
     if st != -2:
         _check(st, "sputnik_hip_spmm_permuted_batched")
+    return st
+
+
+class SpmmProblem(ctypes.Structure):
+    """sputnik_hip_spmm_problem (include/sputnik_hip.h)."""
+    _fields_ = [("row_indices", ctypes.c_void_p), ("row_offsets", ctypes.c_void_p),
+                ("column_indices", ctypes.c_void_p), ("values", ctypes.c_void_p),
+                ("value_permutation", ctypes.c_void_p), ("dense", ctypes.c_void_p),
+                ("out", ctypes.c_void_p), ("nonzeros", ctypes.c_int)]
+
+
+def spmm_group_batched(m, k, n, replicas, problems, block_rows=0, accumulate=False):
+    """`problems`: list of dicts with row_indices (or None), row_offsets,
+    column_indices, values, permutation (or None), dense, out.  Returns the status
+    (SPUTNIK_HIP_UNSUPPORTED = -2 when the combination is not served)."""
+    array = (SpmmProblem * len(problems))()
+    for slot, p in zip(array, problems):
+        slot.row_indices = _ptr(p.get("row_indices"))
+        slot.row_offsets = _ptr(p["row_offsets"])
+        slot.column_indices = _ptr(p["column_indices"])
+        slot.values = _ptr(p["values"])
+        slot.value_permutation = _ptr(p.get("permutation"))
+        slot.dense = _ptr(p["dense"])
+        slot.out = _ptr(p["out"])
+        slot.nonzeros = p["column_indices"].numel()
+    st = lib().sputnik_hip_spmm_group_batched(
+        m, k, n, replicas, len(problems), ctypes.cast(array, ctypes.c_void_p), k * n, m * n,
+        block_rows, int(bool(accumulate)), _stream(problems[0]["out"]))
+    if st != -2:
+        _check(st, "sputnik_hip_spmm_group_batched")
     return st
 
 

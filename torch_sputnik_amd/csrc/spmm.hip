@@ -30,6 +30,22 @@ size_t spmm_tiled_workspace_bytes(int m, int k, int n, int nonzeros);
 int spmm_tiled_choice(int m, int k, int n, int nonzeros, int replicas);
 bool spmm_panel_applicable(int m, int k, int n, int nonzeros, const float* dense,
                            int64_t dense_stride, const float* out, int64_t out_stride);
+struct GroupProblemHost {
+  const int* row_indices;
+  const int* row_offsets;
+  const int* column_indices;
+  const float* values;
+  const int* value_permutation;
+  const float* dense;
+  float* out;
+  int nonzeros;
+};
+bool spmm_panel_group_supported(int m, int k, int n, int count, int block_rows, bool accumulate);
+int spmm_panel_group_launch(int m, int k, int n, int replicas, int count,
+                            const GroupProblemHost* problems, int64_t dense_stride,
+                            int64_t out_stride, int block_rows, bool accumulate,
+                            hipStream_t stream);
+
 int spmm_panel_launch(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
                       const float* values, int64_t values_stride, const int* row_offsets,
                       const int* column_indices, const float* dense, int64_t dense_stride,
@@ -332,6 +348,28 @@ int sputnik_hip_spmm_transposed_out_batched(int m, int k, int n, int nonzeros, i
   return spmm_panel_launch(m, k, n, nonzeros, replicas, /*row_indices=*/nullptr, values,
                            values_stride, row_offsets, column_indices, dense, dense_stride, out,
                            out_stride, stream, epi, value_permutation, block_rows);
+}
+
+int sputnik_hip_spmm_group_supported(int m, int k, int n, int count, int block_rows,
+                                     int accumulate) {
+  if (block_rows > 0 && !block_rows_ok(m, block_rows)) return 0;
+  return spmm_panel_group_supported(m, k, n, count, block_rows, accumulate != 0) ? 1 : 0;
+}
+
+static_assert(sizeof(sputnik_hip_spmm_problem) == sizeof(GroupProblemHost),
+              "the C struct and the launcher's view of it are one layout");
+
+int sputnik_hip_spmm_group_batched(int m, int k, int n, int replicas, int count,
+                                   const sputnik_hip_spmm_problem* problems,
+                                   int64_t dense_stride, int64_t out_stride, int block_rows,
+                                   int accumulate, sputnik_hip_stream_t stream) {
+  if (m < 0 || k < 0 || n < 0 || replicas < 0 || count < 1 || problems == nullptr || block_rows < 0)
+    return SPUTNIK_HIP_INVALID_ARGUMENT;
+  if (m == 0 || n == 0 || replicas == 0) return 0;
+  if (block_rows > 0 && !block_rows_ok(m, block_rows)) return SPUTNIK_HIP_UNSUPPORTED;
+  return spmm_panel_group_launch(m, k, n, replicas, count,
+                                 reinterpret_cast<const GroupProblemHost*>(problems),
+                                 dense_stride, out_stride, block_rows, accumulate != 0, stream);
 }
 
 int sputnik_hip_spmm(int m, int k, int n, int nonzeros, const int* row_indices,

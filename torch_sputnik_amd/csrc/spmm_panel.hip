@@ -37,10 +37,6 @@ constexpr int kPBM = kPWaves * kPQuads * 4;   // 256 rows per workgroup
 constexpr int kPThreads = kPWaves * kWave;
 constexpr int kPMaxK = 512;   // rows of B per panel: 512 x 256 B = 128 KiB of LDS
 constexpr int kPMaxPasses = 8;
-#ifndef SPUTNIK_HIP_PANEL_PAIR
-#define SPUTNIK_HIP_PANEL_PAIR 1
-#endif
-constexpr bool kPairQuads = SPUTNIK_HIP_PANEL_PAIR != 0;   // two row quads side by side (one panel only)
 
 // Two independent row quads side by side: eight B strips in flight before the
 // first FMA, so that one quad's LDS latency is covered by the other's arithmetic.
@@ -72,15 +68,230 @@ __device__ __forceinline__ void dpp_group4_pair(float (&acc_a)[4], float (&acc_b
   sb3.fma(acc_b, entry_val(b3));
 }
 
+// ---------------------------------------------------------------------------
+// Building blocks shared by the kernels below.
+// ---------------------------------------------------------------------------
+// The 16 rows of a wave (4 row quads x 4 groups): row id (-1: padding), first
+// stream position and length, as seen by the lanes of each 16-lane group.
+struct Rows {
+  int row[kPQuads], p0[kPQuads], cnt[kPQuads];
+};
+
+// IDENTITY: slot s is row s (a workgroup owns CONTIGUOUS rows: the transposing
+// store and the accumulating group kernel need that); otherwise rows are dealt
+// from the caller's length-sorted row_indices as in spmm_tiled.hip.
+template <bool IDENTITY>
+__device__ __forceinline__ void load_rows(Rows& r, int m, int slots, int mblock, int wave, int g,
+                                          const int* __restrict__ row_indices,
+                                          const int* __restrict__ row_offsets) {
+#pragma unroll
+  for (int t = 0; t < kPQuads; ++t) {
+    const int slot = mblock * kPBM + wave * (kPQuads * 4) + 4 * t + g;
+    const int entry = IDENTITY ? slot : dealt_index(slot, slots, kPBM);
+    const bool live = entry < m;
+    r.row[t] = IDENTITY ? (live ? entry : 0) : row_indices[live ? entry : 0];
+    r.p0[t] = row_offsets[r.row[t]];
+    r.cnt[t] = live ? row_offsets[r.row[t] + 1] - r.p0[t] : 0;
+    if (!live) r.row[t] = -1;
+  }
+}
+
+// Rows kbase .. kbase + 511 of B, columns col .. col + 3 per lane group -> panel.
+// One wave instruction copies rows 4j .. 4j+3 (4 x 256 B; lane l -> row l / 16,
+// bytes (l % 16) * 16).  Lanes past the end of a row of B (partial last column
+// tile) or past the last row re-read valid bytes that are never used.  Returns
+// with the wave's own copies landed; the caller joins the waves.
+__device__ __forceinline__ void copy_panel(float* panel, const float* __restrict__ dense, int k,
+                                           int n, int kbase, int col, int wave, int g) {
+  const int rows_here = min(k - kbase, kPMaxK);
+  for (int j = wave; j * 4 < rows_here; j += kPWaves) {
+    const int src_row = min(kbase + 4 * j + g, k - 1);
+    const unsigned off = static_cast<unsigned>(src_row) * static_cast<unsigned>(n) * 4u +
+                         static_cast<unsigned>(col) * 4u;
+    lds_dma_row(dense, off, panel + 4 * j * kPBN);
+  }
+  wait_vm<0>();
+}
+
+// First 16-entry window of every row quad, requested as soon as the rows' bounds
+// are known: with ~50 entries per row a quad has only four windows, and a window
+// fetched only when its quad starts costs a whole memory latency per quad pair.
+template <bool PERM>
+__device__ __forceinline__ void fetch_first_windows(const Rows& r, int (&ecol)[kPQuads],
+                                                    float (&eval)[kPQuads],
+                                                    const int* __restrict__ column_indices,
+                                                    const float* __restrict__ values,
+                                                    const int* __restrict__ value_permutation,
+                                                    int last, int i) {
+#pragma unroll
+  for (int t = 0; t < kPQuads; ++t) {
+    const int idx = max(min(r.p0[t] + i, last), 0);
+    ecol[t] = column_indices[idx];
+    eval[t] = values[PERM ? value_permutation[idx] : idx];
+  }
+}
+
+// The whole streams of a wave's rows against the resident panel (which holds all
+// of B's rows: k <= 512), two row quads side by side.  Window w0 = entries w0 ..
+// w0+15 of a group's row, the next one requested before the current one is
+// worked on.  PERM: entry p takes values[value_permutation[p]].
+template <bool PERM>
+__device__ __forceinline__ void stream_pairs(float (&acc)[kPQuads][4], const Rows& r,
+                                             const int (&first_col)[kPQuads],
+                                             const float (&first_val)[kPQuads],
+                                             const int* __restrict__ column_indices,
+                                             const float* __restrict__ values,
+                                             const int* __restrict__ value_permutation, int last,
+                                             int i, const char* __restrict__ lane_base) {
+#pragma unroll
+  for (int t = 0; t < kPQuads; t += 2) {
+    const int n_a = r.cnt[t], n_b = r.cnt[t + 1];
+    const int n_max = max(n_a, n_b);
+    const int longest =
+        max(max(__builtin_amdgcn_readlane(n_max, 0), __builtin_amdgcn_readlane(n_max, 16)),
+            max(__builtin_amdgcn_readlane(n_max, 32), __builtin_amdgcn_readlane(n_max, 48)));
+    int idx_a, idx_b;
+    int ecol_a = first_col[t], ecol_b = first_col[t + 1];
+    float eval_a = first_val[t], eval_b = first_val[t + 1];
+    for (int w0 = 0; w0 < longest; w0 += 16) {
+      const int col_a = ecol_a, col_b = ecol_b;
+      const float val_a = eval_a, val_b = eval_b;
+      if (w0 + 16 < longest) {
+        idx_a = min(r.p0[t] + w0 + 16 + i, last);
+        idx_b = min(r.p0[t + 1] + w0 + 16 + i, last);
+        ecol_a = column_indices[idx_a];
+        ecol_b = column_indices[idx_b];
+        eval_a = values[PERM ? value_permutation[idx_a] : idx_a];
+        eval_b = values[PERM ? value_permutation[idx_b] : idx_b];
+      }
+      const int left_a = n_a - w0, left_b = n_b - w0;
+      const int roff_a = i < left_a ? col_a * (kPBN * 4) : 0;
+      const int roff_b = i < left_b ? col_b * (kPBN * 4) : 0;
+      const float rval_a = i < left_a ? val_a : 0.f;
+      const float rval_b = i < left_b ? val_b : 0.f;
+      const int left = max(left_a, left_b);   // (entries past a row's end carry a zero value)
+      if (left > 0) dpp_group4_pair<0>(acc[t], acc[t + 1], roff_a, rval_a, roff_b, rval_b, lane_base);
+      if (left > 4) dpp_group4_pair<4>(acc[t], acc[t + 1], roff_a, rval_a, roff_b, rval_b, lane_base);
+      if (left > 8) dpp_group4_pair<8>(acc[t], acc[t + 1], roff_a, rval_a, roff_b, rval_b, lane_base);
+      if (left > 12) dpp_group4_pair<12>(acc[t], acc[t + 1], roff_a, rval_a, roff_b, rval_b, lane_base);
+    }
+  }
+}
+
+// One pass of the multi-panel form: the panel holds B's rows kbase .. kbase+511;
+// every row's whole stream is walked, and only the groups of four entries that
+// have a column inside the panel are worked on (bit u of in_panel = entry u).
+template <bool PERM>
+__device__ __forceinline__ void stream_masked(float (&acc)[kPQuads][4], const Rows& r, int kbase,
+                                              const int* __restrict__ column_indices,
+                                              const float* __restrict__ values,
+                                              const int* __restrict__ value_permutation, int last,
+                                              int g, int i, const char* __restrict__ lane_base) {
+#pragma unroll
+  for (int t = 0; t < kPQuads; ++t) {
+    const int n_here = r.cnt[t];
+    const int longest =
+        max(max(__builtin_amdgcn_readlane(n_here, 0), __builtin_amdgcn_readlane(n_here, 16)),
+            max(__builtin_amdgcn_readlane(n_here, 32), __builtin_amdgcn_readlane(n_here, 48)));
+    int idx = max(min(r.p0[t] + i, last), 0);
+    int ecol = column_indices[idx];
+    float eval = values[PERM ? value_permutation[idx] : idx];
+    for (int w0 = 0; w0 < longest; w0 += 16) {
+      const int cur_col = ecol - kbase;
+      const float cur_val = eval;
+      if (w0 + 16 < longest) {
+        idx = min(r.p0[t] + w0 + 16 + i, last);
+        ecol = column_indices[idx];
+        eval = values[PERM ? value_permutation[idx] : idx];
+      }
+      const int left = n_here - w0;   // entries of this group's row at or after the window start
+      const bool valid = i < left && static_cast<unsigned>(cur_col) < static_cast<unsigned>(kPMaxK);
+      const int roff = valid ? cur_col * (kPBN * 4) : 0;
+      const float rval = valid ? cur_val : 0.f;
+      const unsigned in_panel =
+          static_cast<unsigned>(__builtin_amdgcn_ballot_w64(valid) >> (g * 16)) & 0xffffu;
+      if (in_panel & 0x000fu) dpp_group4<0>(acc[t], roff, rval, lane_base);
+      if (in_panel & 0x00f0u) dpp_group4<4>(acc[t], roff, rval, lane_base);
+      if (in_panel & 0x0f00u) dpp_group4<8>(acc[t], roff, rval, lane_base);
+      if (in_panel & 0xf000u) dpp_group4<12>(acc[t], roff, rval, lane_base);
+    }
+  }
+}
+
+__device__ __forceinline__ void store_rows(const float (&acc)[kPQuads][4], const Rows& r,
+                                           float* __restrict__ out, int n, int n0, int i,
+                                           const Epilogue& epi) {
+#pragma unroll
+  for (int t = 0; t < kPQuads; ++t)
+    if (r.row[t] >= 0 && n0 + i * 4 < n)
+      *reinterpret_cast<float4*>(out + static_cast<int64_t>(r.row[t]) * n + n0 + i * 4) =
+          apply_epilogue(make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]), epi, r.row[t]);
+}
+
+// Transposed store in row blocks of `block_rows` (hd):
+//   out[(row / hd) * n * hd + col * hd + row % hd] = C[row][col]
+// i.e. every block of hd rows of C is written as its transpose [n][hd] -- the
+// head split of modules/sparse_attention.py:38-45,108-126 (hd = head_dim), or
+// the whole C^T (hd = m).  The workgroup's 256 x 64 tile goes through LDS in
+// PHASES of kPhaseRows rows (row pitch 65 words: both the row-wise writes and the
+// column-wise reads are conflict-free) and leaves as runs of consecutive rows,
+// 256 contiguous bytes per column and 64 rows.  `tile` holds kPhaseRows x 65
+// floats; rows are the workgroup's contiguous rows (load_rows<true>).  Contains
+// workgroup barriers; the first one also separates the tile from whatever the
+// LDS behind `tile` was used for before.
+template <int kPhaseRows>
+__device__ __forceinline__ void store_transposed(float* tile, const float (&acc)[kPQuads][4],
+                                                 const Rows& r, float* __restrict__ out, int m,
+                                                 int n, int n0, int mblock, int block_rows,
+                                                 int wave, int g, int i, const Epilogue& epi) {
+  constexpr int kPitch = kPBN + 1;
+  constexpr int kWavesPerPhase = kPhaseRows / (kPQuads * 4);
+  static_assert(kPBM % kPhaseRows == 0 && kPhaseRows % 64 == 0, "phases of whole 64-row runs");
+#pragma unroll 1
+  for (int phase = 0; phase < kPBM / kPhaseRows; ++phase) {
+    __syncthreads();   // the tile is free (first phase: the panel is no longer read)
+    if (wave / kWavesPerPhase == phase) {
+#pragma unroll
+      for (int t = 0; t < kPQuads; ++t) {
+        const float4 v = apply_epilogue(make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]),
+                                        epi, max(r.row[t], 0));
+        float* dst = tile + ((wave % kWavesPerPhase) * (kPQuads * 4) + 4 * t + g) * kPitch + i * 4;
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+      }
+    }
+    __syncthreads();
+    const int row0 = mblock * kPBM + phase * kPhaseRows;
+#pragma unroll
+    for (int j = 0; j < (kPhaseRows / 4) * kPBN / kPThreads; ++j) {
+      const int f = j * kPThreads + threadIdx.x;
+      const int rq = (f % 16) + 16 * (f / (16 * kPBN));   // row quad of the phase's rows
+      const int c = (f / 16) % kPBN;
+      const int row = row0 + 4 * rq;
+      if (row < m && n0 + c < n) {   // (m is a multiple of 4: a quad is inside or outside)
+        const float* src = tile + (4 * rq) * kPitch + c;
+        const float4 v = make_float4(src[0], src[kPitch], src[2 * kPitch], src[3 * kPitch]);
+        const int64_t at = (static_cast<int64_t>(row / block_rows) * n + (n0 + c)) * block_rows +
+                           row % block_rows;
+        *reinterpret_cast<float4*>(out + at) = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// One product per launch.
 // PERM: entry p of the stream takes its value from values[value_permutation[p]]
 // (a transposed topology over the values of the original one: the gather that
 // a separate pass would do, 4-byte reads across a row of values that L2 holds,
 // overlaps the arithmetic here).
-// PASSES > 1 (k > 512): the panel is replaced every 512 rows of B; the C
+// MULTI (k > 512): the panel is replaced every 512 rows of B; the C
 // accumulators of a wave's 16 rows stay in registers, and every pass walks each
 // row's whole stream again, working only on the groups of four entries that have
 // a column inside the resident panel (a row with ascending columns pays each
 // group once, plus the few that straddle a boundary; nothing has to be sorted).
+// TOUT: transposed store (store_transposed), the whole tile in one phase through
+// the LDS of the panel, which is no longer needed then.
+// ---------------------------------------------------------------------------
 template <bool MULTI, bool PERM, bool TOUT>
 __global__ __launch_bounds__(kPThreads) void spmm_panel64_kernel(
     int m, int k, int n, int nonzeros, int slots, int n_tiles,
@@ -104,18 +315,8 @@ __global__ __launch_bounds__(kPThreads) void spmm_panel64_kernel(
   const int last = nonzeros - 1;
 
   // the rows' bounds first: their latency overlaps the panel copy
-  int row[kPQuads], p0[kPQuads], cnt[kPQuads];
-#pragma unroll
-  for (int t = 0; t < kPQuads; ++t) {
-    const int slot = mblock * kPBM + wave * (kPQuads * 4) + 4 * t + g;
-    // (TOUT: a workgroup owns the CONTIGUOUS rows mblock * 256 ..., see the store)
-    const int entry = TOUT ? slot : dealt_index(slot, slots, kPBM);
-    const bool live = entry < m;
-    row[t] = TOUT ? (live ? entry : 0) : row_indices[live ? entry : 0];
-    p0[t] = row_offsets[row[t]];
-    cnt[t] = live ? row_offsets[row[t] + 1] - p0[t] : 0;
-    if (!live) row[t] = -1;
-  }
+  Rows rows;
+  load_rows<TOUT>(rows, m, slots, mblock, wave, g, row_indices, row_offsets);
 
   float acc[kPQuads][4];
 #pragma unroll
@@ -123,140 +324,111 @@ __global__ __launch_bounds__(kPThreads) void spmm_panel64_kernel(
   const int col = min(n0 + i * 4, n - 4);
   const char* __restrict__ lane_base = reinterpret_cast<const char*>(panel + i * 4);
 
-  for (int kbase = 0; kbase < k; kbase += kPMaxK) {
-    // panel: one wave instruction copies rows 4j .. 4j+3 (4 x 256 B; lane l -> row
-    // l / 16, bytes (l % 16) * 16).  Lanes past the end of a row of B (partial last
-    // column tile) or past the last row re-read valid bytes that are never used.
-    if (MULTI && kbase > 0) __syncthreads();   // every wave is done with the previous panel
-    const int rows_here = min(k - kbase, kPMaxK);
-    for (int j = wave; j * 4 < rows_here; j += kPWaves) {
-      const int src_row = min(kbase + 4 * j + g, k - 1);
-      const unsigned off = static_cast<unsigned>(src_row) * static_cast<unsigned>(n) * 4u +
-                           static_cast<unsigned>(col) * 4u;
-      lds_dma_row(dense, off, panel + 4 * j * kPBN);
-    }
-    wait_vm<0>();
-    __syncthreads();
+  int first_col[kPQuads];
+  float first_val[kPQuads];
+  if constexpr (!MULTI)   // (in flight while the panel is copied)
+    fetch_first_windows<PERM>(rows, first_col, first_val, column_indices, values,
+                              value_permutation, last, i);
 
-    if constexpr (!MULTI && kPairQuads) {
-#pragma unroll
-      for (int t = 0; t < kPQuads; t += 2) {
-        const int n_a = cnt[t], n_b = cnt[t + 1];
-        const int n_max = max(n_a, n_b);
-        const int longest =
-            max(max(__builtin_amdgcn_readlane(n_max, 0), __builtin_amdgcn_readlane(n_max, 16)),
-                max(__builtin_amdgcn_readlane(n_max, 32), __builtin_amdgcn_readlane(n_max, 48)));
-        int idx_a = max(min(p0[t] + i, last), 0), idx_b = max(min(p0[t + 1] + i, last), 0);
-        int ecol_a = column_indices[idx_a], ecol_b = column_indices[idx_b];
-        float eval_a = values[PERM ? value_permutation[idx_a] : idx_a];
-        float eval_b = values[PERM ? value_permutation[idx_b] : idx_b];
-        for (int w0 = 0; w0 < longest; w0 += 16) {
-          const int col_a = ecol_a, col_b = ecol_b;
-          const float val_a = eval_a, val_b = eval_b;
-          if (w0 + 16 < longest) {
-            idx_a = min(p0[t] + w0 + 16 + i, last);
-            idx_b = min(p0[t + 1] + w0 + 16 + i, last);
-            ecol_a = column_indices[idx_a];
-            ecol_b = column_indices[idx_b];
-            eval_a = values[PERM ? value_permutation[idx_a] : idx_a];
-            eval_b = values[PERM ? value_permutation[idx_b] : idx_b];
-          }
-          const int left_a = n_a - w0, left_b = n_b - w0;
-          const int roff_a = i < left_a ? col_a * (kPBN * 4) : 0;
-          const int roff_b = i < left_b ? col_b * (kPBN * 4) : 0;
-          const float rval_a = i < left_a ? val_a : 0.f;
-          const float rval_b = i < left_b ? val_b : 0.f;
-          const int left = max(left_a, left_b);   // (entries past a row's end carry a zero value)
-          if (left > 0) dpp_group4_pair<0>(acc[t], acc[t + 1], roff_a, rval_a, roff_b, rval_b, lane_base);
-          if (left > 4) dpp_group4_pair<4>(acc[t], acc[t + 1], roff_a, rval_a, roff_b, rval_b, lane_base);
-          if (left > 8) dpp_group4_pair<8>(acc[t], acc[t + 1], roff_a, rval_a, roff_b, rval_b, lane_base);
-          if (left > 12) dpp_group4_pair<12>(acc[t], acc[t + 1], roff_a, rval_a, roff_b, rval_b, lane_base);
-        }
-      }
-    } else {
-#pragma unroll
-    for (int t = 0; t < kPQuads; ++t) {
-      const int n_here = cnt[t];
-      const int longest =
-          max(max(__builtin_amdgcn_readlane(n_here, 0), __builtin_amdgcn_readlane(n_here, 16)),
-              max(__builtin_amdgcn_readlane(n_here, 32), __builtin_amdgcn_readlane(n_here, 48)));
-      // window w0: entries w0 .. w0+15 of this group's row, the next one requested
-      // before the current one is worked on
-      int idx = max(min(p0[t] + i, last), 0);
-      int ecol = column_indices[idx];
-      float eval = values[PERM ? value_permutation[idx] : idx];
-      for (int w0 = 0; w0 < longest; w0 += 16) {
-        const int cur_col = ecol - kbase;
-        const float cur_val = eval;
-        if (w0 + 16 < longest) {
-          idx = min(p0[t] + w0 + 16 + i, last);
-          ecol = column_indices[idx];
-          eval = values[PERM ? value_permutation[idx] : idx];
-        }
-        const int left = n_here - w0;   // entries of this group's row at or after the window start
-        if (!MULTI) {
-          const bool valid = i < left;
-          const int roff = valid ? cur_col * (kPBN * 4) : 0;
-          const float rval = valid ? cur_val : 0.f;
-          if (left > 0) dpp_group4<0>(acc[t], roff, rval, lane_base);
-          if (left > 4) dpp_group4<4>(acc[t], roff, rval, lane_base);
-          if (left > 8) dpp_group4<8>(acc[t], roff, rval, lane_base);
-          if (left > 12) dpp_group4<12>(acc[t], roff, rval, lane_base);
-        } else {
-          const bool valid = i < left && static_cast<unsigned>(cur_col) < static_cast<unsigned>(kPMaxK);
-          const int roff = valid ? cur_col * (kPBN * 4) : 0;
-          const float rval = valid ? cur_val : 0.f;
-          // which of this group's 16 entries are in the panel (bit u = entry u)
-          const unsigned in_panel =
-              static_cast<unsigned>(__builtin_amdgcn_ballot_w64(valid) >> (g * 16)) & 0xffffu;
-          if (in_panel & 0x000fu) dpp_group4<0>(acc[t], roff, rval, lane_base);
-          if (in_panel & 0x00f0u) dpp_group4<4>(acc[t], roff, rval, lane_base);
-          if (in_panel & 0x0f00u) dpp_group4<8>(acc[t], roff, rval, lane_base);
-          if (in_panel & 0xf000u) dpp_group4<12>(acc[t], roff, rval, lane_base);
-        }
-      }
-    }
-    }
-  }
-  if constexpr (!TOUT) {
-#pragma unroll
-    for (int t = 0; t < kPQuads; ++t)
-      if (row[t] >= 0 && n0 + i * 4 < n)
-        *reinterpret_cast<float4*>(out + static_cast<int64_t>(row[t]) * n + n0 + i * 4) =
-            apply_epilogue(make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]), epi, row[t]);
-  } else {
-    // Transposed store in row blocks of `block_rows` (hd):
-    //   out[(row / hd) * n * hd + col * hd + row % hd] = C[row][col]
-    // i.e. every block of hd rows of C is written as its transpose [n][hd] -- the
-    // head split of modules/sparse_attention.py:38-45,108-126 (hd = head_dim), or
-    // the whole C^T (hd = m).  The workgroup's 256 x 64 tile goes through LDS
-    // (the panel is no longer needed; row pitch 65 words: both the row-wise
-    // writes and the column-wise reads are conflict-free) and leaves as runs of
-    // 64 consecutive rows = 256 contiguous bytes per column.
-    constexpr int kPitch = kPBN + 1;
-    __syncthreads();   // every wave is done with the panel
-#pragma unroll
-    for (int t = 0; t < kPQuads; ++t) {
-      const float4 v = apply_epilogue(make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]),
-                                      epi, max(row[t], 0));
-      float* dst = panel + (wave * (kPQuads * 4) + 4 * t + g) * kPitch + i * 4;
-      dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-    }
+  for (int kbase = 0; kbase < k; kbase += kPMaxK) {
+    if (MULTI && kbase > 0) __syncthreads();   // every wave is done with the previous panel
+    copy_panel(panel, dense, k, n, kbase, col, wave, g);
     __syncthreads();
-    const int row0 = mblock * kPBM;
+    if constexpr (!MULTI)
+      stream_pairs<PERM>(acc, rows, first_col, first_val, column_indices, values,
+                         value_permutation, last, i, lane_base);
+    else
+      stream_masked<PERM>(acc, rows, kbase, column_indices, values, value_permutation, last, g, i,
+                          lane_base);
+  }
+  if constexpr (!TOUT)
+    store_rows(acc, rows, out, n, n0, i, epi);
+  else
+    store_transposed<kPBM>(panel, acc, rows, out, m, n, n0, mblock, block_rows, wave, g, i, epi);
+}
+
+// ---------------------------------------------------------------------------
+// A GROUP of up to four products of one shape in one launch (k <= 512, values
+// shared by the replicas): the projections of an attention block.
+//   * same dense operand, separate outputs (ACCUM = false): the panel is copied
+//     ONCE and the rows of every matrix run against it -- the q, k and v
+//     projections of one input, each stored head split (TOUT);
+//   * separate dense operands, ONE output that receives the sum (ACCUM = true):
+//     the accumulators stay in registers while panel after panel is copied --
+//     the input gradient  sum_w W_w^T dY_w  of those projections (PERM: the
+//     transposed topologies over the weights' own value order), with no partial
+//     results written and no additions afterwards.
+// A workgroup owns contiguous rows whenever the stores are transposed or summed.
+// The transposing store goes through a 64-row tile BEHIND the panel (the panel
+// may still be needed by the next product): 128 + 16.25 KiB of LDS.
+// ---------------------------------------------------------------------------
+constexpr int kPMaxGroup = 4;
+struct PanelProblem {
+  const int* row_indices;
+  const int* row_offsets;
+  const int* column_indices;
+  const float* values;
+  const int* value_permutation;
+  const float* dense;
+  float* out;
+  int nonzeros;
+};
+struct PanelGroup {
+  PanelProblem p[kPMaxGroup];
+  int count;
+};
+constexpr int kGroupPhaseRows = 64;
+constexpr size_t kGroupTileBytes = kGroupPhaseRows * (kPBN + 1) * sizeof(float);
+
+template <bool PERM, bool TOUT, bool ACCUM>
+__global__ __launch_bounds__(kPThreads) void spmm_panel64_group_kernel(
+    int m, int k, int n, int slots, int n_tiles, PanelGroup group, int64_t dense_stride,
+    int64_t out_stride, int block_rows, int panel_floats) {
+  extern __shared__ float panel[];   // [k][64], then the store's tile
+  float* tile = panel + panel_floats;
+
+  const int lane = threadIdx.x % kWave;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int g = lane >> 4, i = lane & 15;
+  const int ntile = blockIdx.x % n_tiles;
+  const int mblock = blockIdx.x / n_tiles;
+  const int replica = blockIdx.y;
+  const int n0 = ntile * kPBN;
+  const int col = min(n0 + i * 4, n - 4);
+  const char* __restrict__ lane_base = reinterpret_cast<const char*>(panel + i * 4);
+  const Epilogue none;
+
+  float acc[kPQuads][4];
+  const float* resident = nullptr;   // the dense operand the panel holds
+#pragma unroll 1
+  for (int pi = 0; pi < group.count; ++pi) {
+    const PanelProblem& prob = group.p[pi];
+    Rows rows;
+    load_rows<(TOUT || ACCUM)>(rows, m, slots, mblock, wave, g, prob.row_indices, prob.row_offsets);
+    int first_col[kPQuads];
+    float first_val[kPQuads];
+    fetch_first_windows<PERM>(rows, first_col, first_val, prob.column_indices, prob.values,
+                              prob.value_permutation, prob.nonzeros - 1, i);
+    const float* dense = prob.dense + replica * dense_stride;
+    if (dense != resident) {   // (workgroup-uniform)
+      if (pi > 0) __syncthreads();   // every wave is done with the previous panel
+      copy_panel(panel, dense, k, n, 0, col, wave, g);
+      __syncthreads();
+      resident = dense;
+    }
+    if (pi == 0 || !ACCUM) {
 #pragma unroll
-    for (int j = 0; j < (kPBM / 4) * kPBN / kPThreads; ++j) {
-      const int f = j * kPThreads + threadIdx.x;
-      const int rq = (f % 16) + 16 * (f / (16 * kPBN));   // row quad 0..63 of the tile
-      const int c = (f / 16) % kPBN;
-      const int r = row0 + 4 * rq;
-      if (r < m && n0 + c < n) {   // (m is a multiple of 4: a quad is inside or outside)
-        const float* src = panel + (4 * rq) * kPitch + c;
-        const float4 v = make_float4(src[0], src[kPitch], src[2 * kPitch], src[3 * kPitch]);
-        const int64_t at = (static_cast<int64_t>(r / block_rows) * n + (n0 + c)) * block_rows +
-                           r % block_rows;
-        *reinterpret_cast<float4*>(out + at) = v;
-      }
+      for (int t = 0; t < kPQuads; ++t) acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0.f;
+    }
+    stream_pairs<PERM>(acc, rows, first_col, first_val, prob.column_indices, prob.values,
+                       prob.value_permutation, prob.nonzeros - 1, i, lane_base);
+    if (!ACCUM || pi == group.count - 1) {
+      float* out = prob.out + replica * out_stride;
+      if constexpr (TOUT)
+        store_transposed<kGroupPhaseRows>(tile, acc, rows, out, m, n, n0, mblock, block_rows,
+                                          wave, g, i, none);
+      else
+        store_rows(acc, rows, out, n, n0, i, none);
     }
   }
 }
@@ -318,6 +490,98 @@ int spmm_panel_launch(int m, int k, int n, int nonzeros, int replicas, const int
                        values + r0 * values_stride, values_stride, row_offsets, column_indices,
                        value_permutation, dense + r0 * dense_stride, dense_stride,
                        out + r0 * out_stride, out_stride, epi, block_rows);
+    const int st = launch_status();
+    if (st != 0) return st;
+  }
+  return 0;
+}
+
+// Host side of the group kernel.  `problems`: host array of `count` entries.
+// Returns SPUTNIK_HIP_UNSUPPORTED for shapes / combinations the kernel does not
+// serve (the caller then runs the products one by one).
+struct GroupProblemHost {   // = sputnik_hip_spmm_problem (include/sputnik_hip.h)
+  const int* row_indices;
+  const int* row_offsets;
+  const int* column_indices;
+  const float* values;
+  const int* value_permutation;
+  const float* dense;
+  float* out;
+  int nonzeros;
+};
+
+bool spmm_panel_group_supported(int m, int k, int n, int count, int block_rows, bool accumulate) {
+  return count >= 1 && count <= kPMaxGroup && k >= 1 && k <= kPMaxK && n % 4 == 0 && n >= kPBN &&
+         m >= 16 && static_cast<int64_t>(k) * n * 4 < (int64_t{1} << 32) &&
+         !(accumulate && block_rows > 0);
+}
+
+int spmm_panel_group_launch(int m, int k, int n, int replicas, int count,
+                            const GroupProblemHost* problems, int64_t dense_stride,
+                            int64_t out_stride, int block_rows, bool accumulate,
+                            hipStream_t stream) {
+  if (!spmm_panel_group_supported(m, k, n, count, block_rows, accumulate) ||
+      dense_stride % 4 != 0 || out_stride % 4 != 0)
+    return SPUTNIK_HIP_UNSUPPORTED;
+  PanelGroup group{};
+  group.count = count;
+  bool all_perm = true, any_perm = false;
+  for (int p = 0; p < count; ++p) {
+    const GroupProblemHost& h = problems[p];
+    if (h.nonzeros <= 0 || !aligned_to(h.dense, 16) || !aligned_to(h.out, 16))
+      return SPUTNIK_HIP_UNSUPPORTED;
+    if (accumulate && h.out != problems[0].out) return SPUTNIK_HIP_INVALID_ARGUMENT;
+    all_perm = all_perm && h.value_permutation != nullptr;
+    any_perm = any_perm || h.value_permutation != nullptr;
+    group.p[p] = PanelProblem{h.row_indices, h.row_offsets, h.column_indices, h.values,
+                              h.value_permutation, h.dense, h.out, h.nonzeros};
+  }
+  if (any_perm && !all_perm) return SPUTNIK_HIP_UNSUPPORTED;
+  const bool tout = block_rows > 0;
+  using Kernel = void (*)(int, int, int, int, int, PanelGroup, int64_t, int64_t, int, int);
+  Kernel kernel = nullptr;
+  if (!any_perm && tout && !accumulate) kernel = spmm_panel64_group_kernel<false, true, false>;
+  else if (any_perm && !tout && accumulate) kernel = spmm_panel64_group_kernel<true, false, true>;
+  else if (!any_perm && !tout && accumulate) kernel = spmm_panel64_group_kernel<false, false, true>;
+  else if (!any_perm && !tout && !accumulate) kernel = spmm_panel64_group_kernel<false, false, false>;
+  else return SPUTNIK_HIP_UNSUPPORTED;
+  if (!tout && !accumulate)
+    for (int p = 0; p < count; ++p)
+      if (problems[p].row_indices == nullptr) return SPUTNIK_HIP_INVALID_ARGUMENT;
+
+  const int slots = ceil_div(m, kPBM) * kPBM;
+  const int n_tiles = ceil_div(n, kPBN);
+  const int64_t blocks = static_cast<int64_t>(slots / kPBM) * n_tiles;
+  if (blocks > 0x7fffffff) return SPUTNIK_HIP_INVALID_ARGUMENT;
+  const int panel_floats = ceil_div(k, 4) * 4 * kPBN;
+  const size_t lds = panel_floats * sizeof(float) + (tout ? kGroupTileBytes : 0);
+  static std::atomic<uint64_t> asked{0};
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) return launch_status();
+  const uint64_t bit = uint64_t{1} << (device & 63);
+  if (!(asked.load(std::memory_order_acquire) & bit)) {
+    for (Kernel f : {static_cast<Kernel>(spmm_panel64_group_kernel<false, true, false>),
+                     static_cast<Kernel>(spmm_panel64_group_kernel<true, false, true>),
+                     static_cast<Kernel>(spmm_panel64_group_kernel<false, false, true>),
+                     static_cast<Kernel>(spmm_panel64_group_kernel<false, false, false>)}) {
+      const hipError_t st =
+          hipFuncSetAttribute(reinterpret_cast<const void*>(f),
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              kPMaxK * kPBN * sizeof(float) + kGroupTileBytes);
+      if (st != hipSuccess) return static_cast<int>(st);
+    }
+    asked.fetch_or(bit, std::memory_order_release);
+  }
+  for (int r0 = 0; r0 < replicas; r0 += kMaxGridYZ) {
+    const int ry = min(replicas - r0, kMaxGridYZ);
+    PanelGroup shifted = group;
+    for (int p = 0; p < count; ++p) {
+      shifted.p[p].dense += r0 * dense_stride;
+      shifted.p[p].out += r0 * out_stride;
+    }
+    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(blocks), ry), dim3(kPThreads), lds,
+                       stream, m, k, n, slots, n_tiles, shifted, dense_stride, out_stride,
+                       block_rows, panel_floats);
     const int st = launch_status();
     if (st != 0) return st;
   }

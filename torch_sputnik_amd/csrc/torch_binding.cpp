@@ -277,6 +277,150 @@ Tensor spmm_transposed_out(int64_t m, int64_t k, const Tensor& values,
                    "spmm_transposed_out", c10::nullopt, false, plan, permutation, block_rows);
 }
 
+// ---------------------------------------------------------------------------
+// Groups of projections in one launch (sputnik_hip.h: sputnik_hip_spmm_group_batched).
+// ---------------------------------------------------------------------------
+struct GroupArgs {
+  std::vector<Tensor> values, permutations, dense;
+  std::vector<Topology> topo;
+  int m, k, n, replicas;
+};
+
+GroupArgs check_group(int64_t m64, int64_t k64, at::TensorList values, at::TensorList permutations,
+                      at::TensorList row_indices, at::TensorList row_offsets,
+                      at::TensorList column_indices, at::TensorList dense, const char* what) {
+  const size_t count = values.size();
+  TORCH_CHECK(count >= 1, what, ": expected at least one matrix");
+  TORCH_CHECK(row_indices.size() == count && row_offsets.size() == count &&
+                  column_indices.size() == count && (dense.size() == count || dense.size() == 1) &&
+                  (permutations.empty() || permutations.size() == count),
+              what, ": the lists must have one entry per matrix");
+  GroupArgs a;
+  a.m = to_int(m64, "m");
+  a.k = to_int(k64, "k");
+  for (size_t p = 0; p < dense.size(); ++p) {
+    Tensor d = as_float(dense[p], "dense");
+    TORCH_CHECK(d.dim() == 3 && d.size(1) == a.k, what, ": dense should be [B, k = ", a.k,
+                ", n], got ", d.sizes());
+    if (p == 0) {
+      a.replicas = to_int(d.size(0), "replicas");
+      a.n = to_int(d.size(2), "n");
+    }
+    TORCH_CHECK(d.size(0) == a.replicas && d.size(2) == a.n && d.device() == dense[0].device(),
+                what, ": all dense operands must have one shape and device");
+    a.dense.push_back(d);
+  }
+  for (size_t p = 0; p < count; ++p) {
+    Tensor v = as_float(values[p], "values");
+    TORCH_CHECK(v.dim() == 1 && v.device() == a.dense[0].device(), what,
+                ": values should have 1 dimension (shared by the batch) on ", a.dense[0].device());
+    Topology t = check_topology(a.m, row_indices[p], row_offsets[p], column_indices[p], v);
+    TORCH_CHECK(v.size(0) == t.nonzeros, "number of values (", v.size(0),
+                ") must equal the number of column_indices (", t.nonzeros, ")");
+    if (!permutations.empty()) {
+      const Tensor& perm = permutations[p];
+      TORCH_CHECK(perm.scalar_type() == at::kInt && perm.dim() == 1 && perm.is_contiguous() &&
+                      perm.device() == v.device() && perm.size(0) == t.nonzeros,
+                  "permutation must be a contiguous int32 vector of ", t.nonzeros, " entries");
+      a.permutations.push_back(perm);
+    }
+    a.values.push_back(v);
+    a.topo.push_back(t);
+  }
+  return a;
+}
+
+// One input, several sparse weights, every product stored head split
+// ([B * m / block_rows, n, block_rows] each; block_rows = 0: plain [B, m, n]).
+std::vector<Tensor> left_spmm_group(int64_t m64, int64_t k64, at::TensorList values,
+                                    at::TensorList row_indices, at::TensorList row_offsets,
+                                    at::TensorList column_indices, const Tensor& dense,
+                                    int64_t block_rows) {
+  const GroupArgs a = check_group(m64, k64, values, {}, row_indices, row_offsets, column_indices,
+                                  {dense}, "left_spmm_group");
+  const c10::DeviceGuard guard(a.dense[0].device());
+  const size_t count = a.values.size();
+  std::vector<Tensor> outs;
+  if (sputnik_hip_spmm_group_supported(a.m, a.k, a.n, static_cast<int>(count),
+                                       static_cast<int>(block_rows), 0)) {
+    std::vector<sputnik_hip_spmm_problem> problems(count);
+    bool all_nonempty = true;
+    for (size_t p = 0; p < count; ++p) {
+      outs.push_back(block_rows > 0
+                         ? at::empty({a.replicas * (a.m / block_rows), a.n, block_rows},
+                                     a.values[p].options())
+                         : at::empty({a.replicas, a.m, a.n}, a.values[p].options()));
+      all_nonempty = all_nonempty && a.topo[p].nonzeros > 0;
+      problems[p] = {a.topo[p].row_indices.data_ptr<int>(), a.topo[p].row_offsets.data_ptr<int>(),
+                     a.topo[p].column_indices.data_ptr<int>(), a.values[p].data_ptr<float>(),
+                     nullptr, a.dense[0].data_ptr<float>(), outs[p].data_ptr<float>(),
+                     a.topo[p].nonzeros};
+    }
+    const int st = !all_nonempty ? SPUTNIK_HIP_UNSUPPORTED
+                                 : sputnik_hip_spmm_group_batched(
+                                       a.m, a.k, a.n, a.replicas, static_cast<int>(count),
+                                       problems.data(), static_cast<int64_t>(a.k) * a.n,
+                                       static_cast<int64_t>(a.m) * a.n,
+                                       static_cast<int>(block_rows), 0,
+                                       current_stream(a.dense[0]));
+    if (st != SPUTNIK_HIP_UNSUPPORTED) {
+      check_status(st, "left_spmm_group");
+      return outs;
+    }
+    outs.clear();
+  }
+  for (size_t p = 0; p < count; ++p)   // one by one
+    outs.push_back(spmm_impl(m64, k64, values[p], row_indices[p], row_offsets[p],
+                             column_indices[p], dense, true, "left_spmm_group", c10::nullopt,
+                             false, c10::nullopt, c10::nullopt, block_rows));
+  return outs;
+}
+
+// sum over the matrices of  A_p @ dense_p  (values gathered through
+// `permutations` when given): the input gradient of a group of projections.
+Tensor left_spmm_group_sum(int64_t m64, int64_t k64, at::TensorList values,
+                           at::TensorList permutations, at::TensorList row_indices,
+                           at::TensorList row_offsets, at::TensorList column_indices,
+                           at::TensorList dense) {
+  const GroupArgs a = check_group(m64, k64, values, permutations, row_indices, row_offsets,
+                                  column_indices, dense, "left_spmm_group_sum");
+  TORCH_CHECK(a.dense.size() == a.values.size(),
+              "left_spmm_group_sum: one dense operand per matrix");
+  const c10::DeviceGuard guard(a.dense[0].device());
+  const size_t count = a.values.size();
+  if (sputnik_hip_spmm_group_supported(a.m, a.k, a.n, static_cast<int>(count), 0, 1)) {
+    Tensor out = at::empty({a.replicas, a.m, a.n}, a.values[0].options());
+    std::vector<sputnik_hip_spmm_problem> problems(count);
+    bool all_nonempty = true;
+    for (size_t p = 0; p < count; ++p) {
+      all_nonempty = all_nonempty && a.topo[p].nonzeros > 0;
+      problems[p] = {a.topo[p].row_indices.data_ptr<int>(), a.topo[p].row_offsets.data_ptr<int>(),
+                     a.topo[p].column_indices.data_ptr<int>(), a.values[p].data_ptr<float>(),
+                     a.permutations.empty() ? nullptr : a.permutations[p].data_ptr<int>(),
+                     a.dense[p].data_ptr<float>(), out.data_ptr<float>(), a.topo[p].nonzeros};
+    }
+    const int st = !all_nonempty ? SPUTNIK_HIP_UNSUPPORTED
+                                 : sputnik_hip_spmm_group_batched(
+                                       a.m, a.k, a.n, a.replicas, static_cast<int>(count),
+                                       problems.data(), static_cast<int64_t>(a.k) * a.n,
+                                       static_cast<int64_t>(a.m) * a.n, 0, 1,
+                                       current_stream(a.dense[0]));
+    if (st != SPUTNIK_HIP_UNSUPPORTED) {
+      check_status(st, "left_spmm_group_sum");
+      return out;
+    }
+  }
+  Tensor total;
+  for (size_t p = 0; p < count; ++p) {   // one by one
+    const Tensor part = spmm_impl(
+        m64, k64, values[p], row_indices[p], row_offsets[p], column_indices[p], dense[p], true,
+        "left_spmm_group_sum", c10::nullopt, false, c10::nullopt,
+        permutations.empty() ? c10::optional<Tensor>() : c10::optional<Tensor>(permutations[p]));
+    total = p == 0 ? part : total + part;
+  }
+  return total;
+}
+
 Tensor left_spmm_permuted(int64_t m, int64_t k, const Tensor& values, const Tensor& permutation,
                           const Tensor& row_indices, const Tensor& row_offsets,
                           const Tensor& column_indices, const Tensor& dense,
@@ -1125,6 +1269,13 @@ TORCH_LIBRARY(torch_sputnik, m) {
       "Tensor row_offsets, Tensor column_indices, Tensor dense_matrix, int block_rows, bool left, "
       "Tensor? plan) -> Tensor");
   m.def(
+      "left_spmm_group(int m, int k, Tensor[] values, Tensor[] row_indices, Tensor[] row_offsets, "
+      "Tensor[] column_indices, Tensor dense_matrix, int block_rows) -> Tensor[]");
+  m.def(
+      "left_spmm_group_sum(int m, int k, Tensor[] values, Tensor[] permutations, "
+      "Tensor[] row_indices, Tensor[] row_offsets, Tensor[] column_indices, "
+      "Tensor[] dense_matrices) -> Tensor");
+  m.def(
       "left_spmm_permuted(int m, int k, Tensor values, Tensor permutation, Tensor row_indices, "
       "Tensor row_offsets, Tensor column_indices, Tensor dense_matrix, Tensor? plan) -> Tensor");
   m.def("transpose_last2(Tensor x) -> Tensor");
@@ -1165,6 +1316,8 @@ TORCH_LIBRARY_IMPL(torch_sputnik, CUDA, m) {
   m.impl("permute_last_banded", &permute_last_banded);
   m.impl("spmm_permuted", &spmm_permuted);
   m.impl("spmm_transposed_out", &spmm_transposed_out);
+  m.impl("left_spmm_group", &left_spmm_group);
+  m.impl("left_spmm_group_sum", &left_spmm_group_sum);
   m.impl("left_spmm_permuted", &left_spmm_permuted);
   m.impl("transpose_last2", &transpose_last2);
   m.impl("transpose_last2_as", &transpose_last2_as);

@@ -398,6 +398,65 @@ class SparseLinearFunction(torch.autograd.Function):
         return None, None, grad_values, None, None, None, grad_dense, None
 
 
+class GroupProjectionFunction(torch.autograd.Function):
+    """Several SparseLinear weights of one shape applied to ONE input in one launch
+    (ops.left_spmm_group): the q, k and v projections of a self-attention block,
+    which the reference runs one after the other (modules/sparse_attention.py:108-110).
+    ``apply(m, k, split_rows, dense, values_0, row_indices_0, row_offsets_0,
+    column_indices_0, values_1, ...)`` -> one product per weight ([B, m, n], or head
+    split [B * m/d, n, d] with ``split_rows = d``).  The backward runs one summed
+    SDDMM per weight and ONE launch for the input gradient  sum_w W_w^T dY_w
+    (ops.left_spmm_group_sum: accumulated in registers, no partial results)."""
+
+    @staticmethod
+    def forward(ctx, m, k, split_rows, dense, *flat):
+        values, ris, ros, cis = flat[0::4], flat[1::4], flat[2::4], flat[3::4]
+        ctx.shape = (m, k, int(split_rows))
+        ctx.topologies = list(zip(ris, ros, cis))
+        ctx.save_for_backward(dense, *values)
+        return tuple(ops.left_spmm_group(m, k, values, ris, ros, cis, dense, split_rows))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        m, k, split_rows = ctx.shape
+        dense, *values = ctx.saved_tensors
+        n = dense.size(-1)
+        live, grad_ys = [], []
+        for w, g in enumerate(grads):
+            if g is None:
+                continue
+            g = _contiguous(g)
+            if split_rows:   # [B * m/d, n, d] -> [B, m, n]
+                g = ops.transpose_last2(g).reshape(-1, m, n)
+            live.append(w)
+            grad_ys.append(g)
+        grad_values = [None] * len(values)
+        for w, g in zip(live, grad_ys):
+            if ctx.needs_input_grad[4 + 4 * w]:
+                ri, ro, ci = ctx.topologies[w]
+                grad_values[w] = _sddmm(m, k, ri, ro, ci, g, dense, sum_replicas=True)
+        grad_dense = None
+        if ctx.needs_input_grad[3] and live:
+            if _cache is not None:
+                vals, perms, ris_t, ros_t, cis_t = [], [], [], [], []
+                for w in live:
+                    _, ro, ci = ctx.topologies[w]
+                    ri_t, ro_t, ci_t, perm = _cache.lookup(m, k, ro, ci, values[w])
+                    vals.append(values[w]); perms.append(perm)
+                    ris_t.append(ri_t); ros_t.append(ro_t); cis_t.append(ci_t)
+                grad_dense = ops.left_spmm_group_sum(k, m, vals, perms, ris_t, ros_t, cis_t,
+                                                     grad_ys)
+            else:
+                for w, g in zip(live, grad_ys):
+                    _, ro, ci = ctx.topologies[w]
+                    part = _spmm_transposed(m, k, values[w], ro, ci, g, left=True)
+                    grad_dense = part if grad_dense is None else grad_dense + part
+        flat = []
+        for gv in grad_values:
+            flat += [gv, None, None, None]
+        return (None, None, None, grad_dense, *flat)
+
+
 class SparseSoftmax(torch.autograd.Function):
     """sparse_softmax with a gradient: dX = scale * Y * (dY - rowsum(dY * Y)), the
     row sums taken over the stored entries (extension).

@@ -19,7 +19,8 @@ import torch
 import torch.nn as nn
 
 from . import functional, ops
-from .functional import SparseAttentionFunction, Sddmm, SparseLinearFunction, SparseSoftmax, Spmm
+from .functional import (GroupProjectionFunction, SparseAttentionFunction, Sddmm,
+                         SparseLinearFunction, SparseSoftmax, Spmm)
 from .topology import dense_to_sparse, generate_mask
 
 
@@ -173,7 +174,11 @@ class SparseAttention(nn.Module):
         def head_split(projected):   # [B, H*D, S] -> [B*H, S, D]
             return functional.transpose_last2(projected.reshape(batch_size * heads, dim, seq))
 
-        if not (query.is_cuda and self.parallel_projections):
+        if query is key and key is value and not self.parallel_projections:
+            # self-attention: the three projections of the one input in ONE launch
+            # (one copy of the input's panel per workgroup), each stored head split
+            q3d, k3d, v3d = self._project_group(self.linears[:3], operands[0], dim)
+        elif not (query.is_cuda and self.parallel_projections):
             # (the projection kernel stores its product head split: [B*H, S, D])
             q3d, k3d, v3d = (net.project(d, split_rows=dim)
                              for net, d in zip(self.linears, operands))
@@ -196,6 +201,22 @@ class SparseAttention(nn.Module):
         context = self._attention3d(q3d, k3d, v3d, merged=True)         # [B*H, D, S]
         merged = context.reshape(batch_size, heads * dim, seq)
         return self.linears[-1].project(merged).transpose(1, 2)
+
+    @staticmethod
+    def _project_group(nets, dense, split_rows):
+        first = nets[0]
+        m, k = first.output_features, first.input_features
+        needs_grad = torch.is_grad_enabled() and (
+            dense.requires_grad or any(net.values.requires_grad for net in nets))
+        if not needs_grad:
+            return ops.left_spmm_group(m, k, [net.values.detach() for net in nets],
+                                       [net.row_indices for net in nets],
+                                       [net.row_offsets for net in nets],
+                                       [net.column_indices for net in nets], dense, split_rows)
+        flat = []
+        for net in nets:
+            flat += [net.values, net.row_indices, net.row_offsets, net.column_indices]
+        return GroupProjectionFunction.apply(m, k, split_rows, dense, *flat)
 
     def _side_stream(self, index, device):
         streams = self.__dict__.setdefault("_streams", {})

@@ -229,6 +229,27 @@ def spmm_transposed_out(m, k, values, row_indices, row_offsets, column_indices, 
                                     bool(left), plan)
 
 
+def left_spmm_group(m, k, values, row_indices, row_offsets, column_indices, dense_matrix,
+                    block_rows=0):
+    """Several sparse weights of one shape times ONE batch of dense matrices in one
+    launch (lists with one entry per weight) -> list of products, each head split
+    as in spmm_transposed_out when ``block_rows`` > 0: the q, k and v projections of
+    a self-attention block (modules/sparse_attention.py:108-110)."""
+    return _ops.left_spmm_group(int(m), int(k), list(values), list(row_indices),
+                                list(row_offsets), list(column_indices), dense_matrix,
+                                int(block_rows))
+
+
+def left_spmm_group_sum(m, k, values, permutations, row_indices, row_offsets, column_indices,
+                        dense_matrices):
+    """sum_p A_p @ dense_p in one launch, accumulated in registers (values gathered
+    through ``permutations`` when the list is not empty): the input gradient of a
+    group of projections."""
+    return _ops.left_spmm_group_sum(int(m), int(k), list(values), list(permutations),
+                                    list(row_indices), list(row_offsets), list(column_indices),
+                                    list(dense_matrices))
+
+
 def sddmm_sum(m, n, row_indices, row_offsets, column_indices, lhs_matrix, rhs_matrix):
     """sum over the replicas of sddmm(...) -> [nnz]: the gradient of sparse values
     shared by a batch (what autograd makes of the [R, nnz] result of
