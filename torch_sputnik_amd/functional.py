@@ -163,6 +163,17 @@ def _contiguous(x):
     return x.contiguous()
 
 
+def _as_transposed(x):
+    """``x.transpose(-1, -2)`` as a contiguous tensor.  Free when `x` is itself the
+    transposed view of a contiguous tensor -- how the Functions below hand each
+    other gradients that a kernel's store phase already wrote in the layout the
+    receiver needs (`transposed_grads`) -- and one tiled-transpose launch otherwise."""
+    view = x.transpose(-1, -2)
+    if view.is_contiguous():
+        return view
+    return ops.transpose_last2(_contiguous(x))
+
+
 # From this many values on (several rows of them) a cached permutation goes
 # through the LDS-banded kernel; its two index lists are made once per cached
 # permutation and kept on the permutation tensor (the cache entry owns it).
@@ -193,26 +204,35 @@ def _transpose(m, n, values, row_offsets, column_indices):
     return values_t, diffsort(row_offsets_t), row_offsets_t, column_indices_t
 
 
-def _spmm_transposed(m, n, values, row_offsets, column_indices, dense, left=False):
+def _spmm_transposed(m, n, values, row_offsets, column_indices, dense, left=False,
+                     block_rows=0):
     """(A^T) @ dense for the m x n CSR matrix A: with the transposed-topology cache
     the values stay in A's order and the kernel gathers them through the cached
     permutation (ops.spmm_permuted); without it the reference's per-call
-    csr_transpose (modules/spmm.py:59-62)."""
+    csr_transpose (modules/spmm.py:59-62).  ``block_rows``: the product comes
+    back as ops.spmm_transposed_out stores it, [R * n / block_rows, width, block_rows]."""
     if _cache is None:
         values_t, row_indices_t, row_offsets_t, column_indices_t = _transpose(
             m, n, values, row_offsets, column_indices)
-        return _spmm(n, m, values_t, row_indices_t, row_offsets_t, column_indices_t, dense,
-                     left=left)
-    values = values.contiguous()
-    row_indices_t, row_offsets_t, column_indices_t, perm = _cache.lookup(
-        m, n, row_offsets, column_indices, values)
-    if ops.spmm_permuted_fused(n, m, dense.size(-1), perm.numel()):
-        plan = None if _plans is None else _plans.spmm(n, m, dense.size(-1), row_indices_t,
-                                                       row_offsets_t, column_indices_t)
-        return ops.spmm_permuted(n, m, values, perm, row_indices_t, row_offsets_t,
+        perm = None
+    else:
+        values = values.contiguous()
+        row_indices_t, row_offsets_t, column_indices_t, perm = _cache.lookup(
+            m, n, row_offsets, column_indices, values)
+        if ops.spmm_permuted_fused(n, m, dense.size(-1), perm.numel()):
+            values_t = values          # gathered through `perm` inside the kernel
+        else:
+            values_t, perm = _permute_cached(values, perm), None
+    plan = None if _plans is None else _plans.spmm(n, m, dense.size(-1), row_indices_t,
+                                                   row_offsets_t, column_indices_t)
+    if block_rows:
+        return ops.spmm_transposed_out(n, m, values_t, row_indices_t, row_offsets_t,
+                                       column_indices_t, dense, block_rows, permutation=perm,
+                                       plan=plan, left=left)
+    if perm is not None:
+        return ops.spmm_permuted(n, m, values_t, perm, row_indices_t, row_offsets_t,
                                  column_indices_t, dense, plan, left=left)
-    return _spmm(n, m, _permute_cached(values, perm), row_indices_t, row_offsets_t,
-                 column_indices_t, dense, left=left)
+    return _spmm(n, m, values_t, row_indices_t, row_offsets_t, column_indices_t, dense, left=left)
 
 
 def _spmm(m, k, values, row_indices, row_offsets, column_indices, dense, left=False):
@@ -291,16 +311,20 @@ def _to_operand(x):
 
 class Spmm(torch.autograd.Function):
     """sparse(values, CSR topology) @ dense.  ``apply(m, k, values, row_indices,
-    row_offsets, column_indices, dense[, transposed_out])``; with ``transposed_out``
-    the product comes back transposed, [R, n, m] (written in that order by the
-    kernel's store phase, ops.spmm_transposed_out: SparseAttention's head merge)."""
+    row_offsets, column_indices, dense[, transposed_out[, transposed_grads]])``; with
+    ``transposed_out`` the product comes back transposed, [R, n, m] (written in that
+    order by the kernel's store phase, ops.spmm_transposed_out: SparseAttention's
+    head merge).  ``transposed_grads``: the gradient of `dense` is handed back as
+    the transposed VIEW of a buffer the kernel wrote transposed (same shape and
+    values; free for a receiver that wants that layout, see `_as_transposed`)."""
 
     @staticmethod
     def forward(ctx, m, k, values, row_indices, row_offsets, column_indices, dense,
-                transposed_out=False):
+                transposed_out=False, transposed_grads=False):
         ctx.shape = (m, k)
         ctx.topology = (row_indices, row_offsets, column_indices)
         ctx.transposed_out = bool(transposed_out)
+        ctx.transposed_grads = bool(transposed_grads)
         ctx.save_for_backward(values, dense)
         if transposed_out:
             plan = None if _plans is None else _plans.spmm(m, k, dense.size(-1), row_indices,
@@ -314,11 +338,12 @@ class Spmm(torch.autograd.Function):
         m, k = ctx.shape
         row_indices, row_offsets, column_indices = ctx.topology
         values, dense = ctx.saved_tensors
-        grad_output = _contiguous(grad_output)
         if ctx.transposed_out:   # [R, n, m] -> the product's own layout
-            grad_output = ops.transpose_last2(grad_output)
+            grad_output = _as_transposed(grad_output)
             if dense.dim() == 2:
                 grad_output = grad_output[0]
+        else:
+            grad_output = _contiguous(grad_output)
         grad_values = grad_dense = None
         if ctx.needs_input_grad[2]:
             # dL/dA sampled at the pattern: <dC[i,:], B[j,:]>
@@ -326,18 +351,26 @@ class Spmm(torch.autograd.Function):
                                  dense.contiguous())
         if ctx.needs_input_grad[6]:
             # dL/dB = A^T @ dC
-            grad_dense = _spmm_transposed(m, k, values, row_offsets, column_indices, grad_output)
-        return None, None, grad_values, None, None, None, grad_dense, None
+            if ctx.transposed_grads and dense.dim() == 3:
+                grad_dense = _spmm_transposed(m, k, values, row_offsets, column_indices,
+                                              grad_output, block_rows=k).transpose(1, 2)
+            else:
+                grad_dense = _spmm_transposed(m, k, values, row_offsets, column_indices,
+                                              grad_output)
+        return None, None, grad_values, None, None, None, grad_dense, None, None
 
 
 class Sddmm(torch.autograd.Function):
     """(lhs @ rhs^T) sampled at a CSR mask.  ``apply(m, n, row_indices,
-    row_offsets, column_indices, lhs_matrix, rhs_matrix)``."""
+    row_offsets, column_indices, lhs_matrix, rhs_matrix[, transposed_grads])``;
+    ``transposed_grads`` as in `Spmm` (both gradients, 3-D operands)."""
 
     @staticmethod
-    def forward(ctx, m, n, row_indices, row_offsets, column_indices, lhs_matrix, rhs_matrix):
+    def forward(ctx, m, n, row_indices, row_offsets, column_indices, lhs_matrix, rhs_matrix,
+                transposed_grads=False):
         ctx.shape = (m, n)
         ctx.topology = (row_indices, row_offsets, column_indices)
+        ctx.transposed_grads = bool(transposed_grads) and lhs_matrix.dim() == 3
         ctx.save_for_backward(lhs_matrix, rhs_matrix)
         return _sddmm(m, n, row_indices, row_offsets, column_indices, lhs_matrix, rhs_matrix)
 
@@ -350,28 +383,46 @@ class Sddmm(torch.autograd.Function):
         grad_lhs = grad_rhs = None
         if ctx.needs_input_grad[5]:
             # dL/dlhs = dS @ rhs, dS sparse with the mask's pattern
-            grad_lhs = _spmm(m, n, grad_output, row_indices, row_offsets, column_indices,
-                             rhs_matrix.contiguous())
+            rhs = rhs_matrix.contiguous()
+            if ctx.transposed_grads:
+                plan = None if _plans is None else _plans.spmm(m, n, rhs.size(-1), row_indices,
+                                                               row_offsets, column_indices)
+                grad_lhs = ops.spmm_transposed_out(m, n, grad_output, row_indices, row_offsets,
+                                                   column_indices, rhs, block_rows=m,
+                                                   plan=plan).transpose(1, 2)
+            else:
+                grad_lhs = _spmm(m, n, grad_output, row_indices, row_offsets, column_indices, rhs)
         if ctx.needs_input_grad[6]:
             # dL/drhs = dS^T @ lhs
-            grad_rhs = _spmm_transposed(m, n, grad_output, row_offsets, column_indices,
-                                        lhs_matrix.contiguous())
-        return None, None, None, None, None, grad_lhs, grad_rhs
+            if ctx.transposed_grads:
+                grad_rhs = _spmm_transposed(m, n, grad_output, row_offsets, column_indices,
+                                            lhs_matrix.contiguous(), block_rows=n).transpose(1, 2)
+            else:
+                grad_rhs = _spmm_transposed(m, n, grad_output, row_offsets, column_indices,
+                                            lhs_matrix.contiguous())
+        return None, None, None, None, None, grad_lhs, grad_rhs, None
 
 
 class SparseLinearFunction(torch.autograd.Function):
     """One sparse weight x a batch of dense matrices (left_spmm).  ``apply(m, k,
-    values, row_indices, row_offsets, column_indices, dense[, split_rows])`` with
-    dense [B,k,n] -> [B,m,n]; with ``split_rows = d`` the product comes back head
-    split, [B * m/d, n, d] (every block of d output rows transposed, written by
-    the kernel's store phase: modules/sparse_attention.py:38-45,108-126)."""
+    values, row_indices, row_offsets, column_indices, dense[, split_rows[,
+    dense_blocks]])`` with dense [B,k,n] -> [B,m,n]; with ``split_rows = d`` the
+    product comes back head split, [B * m/d, n, d] (every block of d output rows
+    transposed, written by the kernel's store phase:
+    modules/sparse_attention.py:38-45,108-126).  ``dense_blocks = d``: `dense` is
+    given as [B * k/d, d, n] (the same memory: merged heads) and its gradient is
+    handed back in that shape as the transposed view of a head-split buffer the
+    kernel wrote (see `Spmm`, ``transposed_grads``)."""
 
     @staticmethod
     def forward(ctx, m, k, values, row_indices, row_offsets, column_indices, dense,
-                split_rows=0):
+                split_rows=0, dense_blocks=0):
         ctx.shape = (m, k)
         ctx.topology = (row_indices, row_offsets, column_indices)
         ctx.split_rows = int(split_rows)
+        ctx.dense_blocks = int(dense_blocks)
+        if dense_blocks:
+            dense = dense.reshape(-1, k, dense.size(-1))
         ctx.save_for_backward(values, dense)
         return _linear(m, k, values, row_indices, row_offsets, column_indices, dense, split_rows)
 
@@ -380,10 +431,10 @@ class SparseLinearFunction(torch.autograd.Function):
         m, k = ctx.shape
         row_indices, row_offsets, column_indices = ctx.topology
         values, dense = ctx.saved_tensors
-        grad_output = _contiguous(grad_output)
         if ctx.split_rows:   # [B * m/d, n, d] -> [B, m, n]
-            grad_output = ops.transpose_last2(grad_output).reshape(
-                -1, m, grad_output.size(-2))
+            grad_output = _as_transposed(grad_output).reshape(-1, m, grad_output.size(-2))
+        else:
+            grad_output = _contiguous(grad_output)
         grad_values = grad_dense = None
         if ctx.needs_input_grad[2]:
             # the [B,nnz] products summed over B (what autograd makes of the
@@ -391,11 +442,16 @@ class SparseLinearFunction(torch.autograd.Function):
             grad_values = _sddmm(m, k, row_indices, row_offsets, column_indices, grad_output,
                                  dense.contiguous(), sum_replicas=True)
         if ctx.needs_input_grad[6]:
-            grad_dense = _spmm_transposed(m, k, values, row_offsets, column_indices,
-                                          grad_output, left=True)
-            if dense.dim() == 2:
-                grad_dense = grad_dense[0]
-        return None, None, grad_values, None, None, None, grad_dense, None
+            if ctx.dense_blocks:
+                grad_dense = _spmm_transposed(m, k, values, row_offsets, column_indices,
+                                              grad_output, left=True,
+                                              block_rows=ctx.dense_blocks).transpose(1, 2)
+            else:
+                grad_dense = _spmm_transposed(m, k, values, row_offsets, column_indices,
+                                              grad_output, left=True)
+                if dense.dim() == 2:
+                    grad_dense = grad_dense[0]
+        return None, None, grad_values, None, None, None, grad_dense, None, None
 
 
 class GroupProjectionFunction(torch.autograd.Function):
@@ -425,9 +481,10 @@ class GroupProjectionFunction(torch.autograd.Function):
         for w, g in enumerate(grads):
             if g is None:
                 continue
-            g = _contiguous(g)
             if split_rows:   # [B * m/d, n, d] -> [B, m, n]
-                g = ops.transpose_last2(g).reshape(-1, m, n)
+                g = _as_transposed(g).reshape(-1, m, n)
+            else:
+                g = _contiguous(g)
             live.append(w)
             grad_ys.append(g)
         grad_values = [None] * len(values)

@@ -47,22 +47,26 @@ class SparseLinear(nn.Module):
         # kernel (same values, same layout)
         return self.project(functional._to_operand(x))
 
-    def project(self, dense, split_rows=0):
+    def project(self, dense, split_rows=0, dense_blocks=0):
         """``W @ dense`` for an operand that is already k-major: [B, in, S] ->
         [B, out, S].  (SparseAttention chains its layout passes and calls this.)
         ``split_rows = d``: the product comes back head split, [B * out/d, S, d],
-        written in that order by the kernel (no layout pass of its own)."""
+        written in that order by the kernel (no layout pass of its own).
+        ``dense_blocks = d``: `dense` is given as [B * in/d, d, S] (merged heads, the
+        same memory); see functional.SparseLinearFunction."""
         needs_grad = torch.is_grad_enabled() and (dense.requires_grad or self.values.requires_grad)
         if not needs_grad:
             # forward only: no autograd node.  (The weight's pattern is static: its
             # topology pre-pass comes from the plan cache, functional.PlanCache,
             # which is keyed on the identity and version of the index tensors.)
+            if dense_blocks:
+                dense = dense.reshape(-1, self.input_features, dense.size(-1))
             return functional._linear(self.output_features, self.input_features,
                                       self.values.detach(), self.row_indices, self.row_offsets,
                                       self.column_indices, dense, split_rows)
         return SparseLinearFunction.apply(
             self.output_features, self.input_features, self.values, self.row_indices,
-            self.row_offsets, self.column_indices, dense, split_rows)
+            self.row_offsets, self.column_indices, dense, split_rows, dense_blocks)
 
 
 def get_clones(module, num_of_deep_copies):
@@ -127,8 +131,14 @@ class SparseAttention(nn.Module):
             return functional.transpose_last2(out) if merged else out
 
         # [B*H, nnz]: scores only at the mask's nonzeros
-        scores = self.sddmm(self.m, self.n, self.row_indices, self.row_offsets,
-                            self.column_indices, q3d, k3d)
+        ours = getattr(self.sddmm, "__self__", None) is Sddmm and \
+            getattr(self.spmm, "__self__", None) is Spmm
+        if ours:   # gradients of q, k, v leave the kernels in the projections' layout
+            scores = Sddmm.apply(self.m, self.n, self.row_indices, self.row_offsets,
+                                 self.column_indices, q3d, k3d, merged)
+        else:
+            scores = self.sddmm(self.m, self.n, self.row_indices, self.row_offsets,
+                                self.column_indices, q3d, k3d)
         # the reference divides the scores in a pass of its own
         # (modules/sparse_attention.py:72); here the softmax kernel applies it
         softmax = (SparseSoftmax.apply if self.differentiable_softmax
@@ -136,9 +146,9 @@ class SparseAttention(nn.Module):
         attention_weights = softmax(scores, self.row_indices, self.row_offsets,
                                     self.column_indices, scale)
         # [B*H, S, D] ([B*H, D, S] when merged)
-        if merged and getattr(self.spmm, "__self__", None) is Spmm:
+        if merged and ours:
             return Spmm.apply(self.m, self.n, attention_weights, self.row_indices,
-                              self.row_offsets, self.column_indices, v3d, True)
+                              self.row_offsets, self.column_indices, v3d, True, True)
         out = self.spmm(self.m, self.n, attention_weights, self.row_indices, self.row_offsets,
                         self.column_indices, v3d)
         return functional.transpose_last2(out) if merged else out
@@ -199,8 +209,10 @@ class SparseAttention(nn.Module):
             q3d, k3d, v3d = results
 
         context = self._attention3d(q3d, k3d, v3d, merged=True)         # [B*H, D, S]
-        merged = context.reshape(batch_size, heads * dim, seq)
-        return self.linears[-1].project(merged).transpose(1, 2)
+        # = [B, E, S], the k-major operand of the output projection (handed over in the
+        # per-head shape so that its gradient can come back in the layout the
+        # attention's backward wants, without a pass of its own)
+        return self.linears[-1].project(context, dense_blocks=dim).transpose(1, 2)
 
     @staticmethod
     def _project_group(nets, dense, split_rows):
