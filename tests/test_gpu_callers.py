@@ -227,8 +227,9 @@ def test_sparse_attention_module_forward_vs_dense(tsa, dev, heads, embed, seq, b
     assert rel_err_torch(composed, want) < TOL
 
 
+@pytest.mark.parametrize("shared_input", [False, True])
 @pytest.mark.parametrize("fused_training", [False, True])
-def test_sparse_attention_module_backward_vs_dense(tsa, dev, fused_training):
+def test_sparse_attention_module_backward_vs_dense(tsa, dev, fused_training, shared_input):
     """Gradients of the whole module w.r.t. the inputs and every projection's
     values, against dense float64 autograd.  (The reference's module calls the
     raw softmax op and so cuts the gradient to Q/K, modules/sparse_attention.py:76;
@@ -239,6 +240,8 @@ def test_sparse_attention_module_backward_vs_dense(tsa, dev, fused_training):
     rng = np.random.default_rng(8)
     q, k, v = (T(rng.uniform(-1, 1, (batch, seq, embed)).astype(np.float32), dev).requires_grad_(True)
                for _ in range(3))
+    if shared_input:   # self-attention: the three projections run as one group launch
+        k = v = q
     go = T(rng.uniform(-1, 1, (batch, seq, embed)).astype(np.float32), dev)
     out = module(q, k, v)
     out.backward(go)
@@ -250,6 +253,8 @@ def test_sparse_attention_module_backward_vs_dense(tsa, dev, fused_training):
                                 layer.column_indices, layer.values.detach())
         leaves.append((w.requires_grad_(True), rows, layer))
     qd, kd, vd = (x.detach().double().requires_grad_(True) for x in (q, k, v))
+    if shared_input:
+        kd = vd = qd
 
     def project(x, w):
         return torch.matmul(x, w.t()).view(batch, seq, heads, embed // heads).transpose(1, 2)
@@ -263,7 +268,7 @@ def test_sparse_attention_module_backward_vs_dense(tsa, dev, fused_training):
 
     assert rel_err_torch(out.detach(), want.detach()) < TOL
     # gradients pass through three to five chained fp32 kernels: 5e-4
-    for got, ref in ((q, qd), (k, kd), (v, vd)):
+    for got, ref in (((q, qd),) if shared_input else ((q, qd), (k, kd), (v, vd))):
         assert rel_err_torch(got.grad, ref.grad) < 5 * TOL
     for w, rows, layer in leaves:
         want_grad = w.grad[rows, layer.column_indices.long()]
