@@ -84,8 +84,9 @@ def test_spmm_null_bias_is_plain_spmm(capi, dev):
     assert torch.equal(a, c)
 
 
-def test_spmm_bias_unsorted_columns_take_the_fallback_epilogue(capi, dev, spmm_kernel):
-    m, k, n = 256, 512, 256
+@pytest.mark.parametrize("k", [512, 1600])   # 1600: four panels of the panel kernel
+def test_spmm_bias_unsorted_columns_take_the_fallback_epilogue(capi, dev, spmm_kernel, k):
+    m, n = 256, 256
     _, vals, ri, ro, ci = make_csr(m, k, 0.7, seed=21)
     rng = np.random.default_rng(3)
     ci = ci.copy()

@@ -179,10 +179,15 @@ __device__ __forceinline__ void stream_pairs(float (&acc)[kPQuads][4], const Row
 }
 
 // One pass of the multi-panel form: the panel holds B's rows kbase .. kbase+511;
-// every row's whole stream is walked, and only the groups of four entries that
-// have a column inside the panel are worked on (bit u of in_panel = entry u).
+// every row's stream is walked, and only the groups of four entries that have a
+// column inside the panel are worked on (bit u of in_panel = entry u).  The walk
+// of quad t starts at window start[t] and reports, in start[t], the first window
+// in which any of the wave's four rows held an entry of a LATER panel: the
+// windows before it are done for good, whatever the order of the columns (rows
+// with ascending columns thus walk each window about once over all passes).
 template <bool PERM>
 __device__ __forceinline__ void stream_masked(float (&acc)[kPQuads][4], const Rows& r, int kbase,
+                                              int (&start)[kPQuads],
                                               const int* __restrict__ column_indices,
                                               const float* __restrict__ values,
                                               const int* __restrict__ value_permutation, int last,
@@ -193,10 +198,13 @@ __device__ __forceinline__ void stream_masked(float (&acc)[kPQuads][4], const Ro
     const int longest =
         max(max(__builtin_amdgcn_readlane(n_here, 0), __builtin_amdgcn_readlane(n_here, 16)),
             max(__builtin_amdgcn_readlane(n_here, 32), __builtin_amdgcn_readlane(n_here, 48)));
-    int idx = max(min(r.p0[t] + i, last), 0);
+    const int begin = start[t];        // wave-uniform, a multiple of 16
+    int first_later = longest;         // (rounded up below: "nothing left")
+    bool seen_later = false;
+    int idx = max(min(r.p0[t] + begin + i, last), 0);
     int ecol = column_indices[idx];
     float eval = values[PERM ? value_permutation[idx] : idx];
-    for (int w0 = 0; w0 < longest; w0 += 16) {
+    for (int w0 = begin; w0 < longest; w0 += 16) {
       const int cur_col = ecol - kbase;
       const float cur_val = eval;
       if (w0 + 16 < longest) {
@@ -205,7 +213,12 @@ __device__ __forceinline__ void stream_masked(float (&acc)[kPQuads][4], const Ro
         eval = values[PERM ? value_permutation[idx] : idx];
       }
       const int left = n_here - w0;   // entries of this group's row at or after the window start
-      const bool valid = i < left && static_cast<unsigned>(cur_col) < static_cast<unsigned>(kPMaxK);
+      const bool in_row = i < left;
+      const bool valid = in_row && static_cast<unsigned>(cur_col) < static_cast<unsigned>(kPMaxK);
+      if (!seen_later && __builtin_amdgcn_ballot_w64(in_row && cur_col >= kPMaxK) != 0) {
+        seen_later = true;             // (wave-uniform branch)
+        first_later = w0;
+      }
       const int roff = valid ? cur_col * (kPBN * 4) : 0;
       const float rval = valid ? cur_val : 0.f;
       const unsigned in_panel =
@@ -215,6 +228,7 @@ __device__ __forceinline__ void stream_masked(float (&acc)[kPQuads][4], const Ro
       if (in_panel & 0x0f00u) dpp_group4<8>(acc[t], roff, rval, lane_base);
       if (in_panel & 0xf000u) dpp_group4<12>(acc[t], roff, rval, lane_base);
     }
+    start[t] = seen_later ? first_later : ((longest + 15) & ~15);
   }
 }
 
@@ -326,6 +340,7 @@ __global__ __launch_bounds__(kPThreads) void spmm_panel64_kernel(
 
   int first_col[kPQuads];
   float first_val[kPQuads];
+  int start[kPQuads] = {};   // MULTI: first window a pass still has to look at
   if constexpr (!MULTI)   // (in flight while the panel is copied)
     fetch_first_windows<PERM>(rows, first_col, first_val, column_indices, values,
                               value_permutation, last, i);
@@ -338,8 +353,8 @@ __global__ __launch_bounds__(kPThreads) void spmm_panel64_kernel(
       stream_pairs<PERM>(acc, rows, first_col, first_val, column_indices, values,
                          value_permutation, last, i, lane_base);
     else
-      stream_masked<PERM>(acc, rows, kbase, column_indices, values, value_permutation, last, g, i,
-                          lane_base);
+      stream_masked<PERM>(acc, rows, kbase, start, column_indices, values, value_permutation,
+                          last, g, i, lane_base);
   }
   if constexpr (!TOUT)
     store_rows(acc, rows, out, n, n0, i, epi);
