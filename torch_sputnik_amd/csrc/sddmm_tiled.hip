@@ -34,6 +34,7 @@ namespace sputnik_hip {
 namespace {
 
 using namespace tiled;
+using v2f = float __attribute__((ext_vector_type(2)));
 
 constexpr int kSWaves = 8;
 constexpr int kSThreads = kSWaves * kWave;
@@ -153,16 +154,17 @@ void sddmm_stationary_kernel(
 #pragma unroll
       for (int v = 0; v < KV; ++v) b[v] = *reinterpret_cast<const float4*>(p + 256 * v);
     };
+    // (two interleaved partial sums: the even and the odd elements, so that every
+    // pair of multiply-adds is ONE v_pk_fma_f32 -- a single chain leaves the
+    // compiler nothing to pack: 4 v_fma_f32 per ds_read_b128 before, 2 packed now)
     auto dot = [&](const float4 (&b)[KV]) {
-      float acc = 0.f;
+      v2f acc = {0.f, 0.f};
 #pragma unroll
       for (int v = 0; v < KV; ++v) {
-        acc = fmaf(cur_lf[v].x, b[v].x, acc);
-        acc = fmaf(cur_lf[v].y, b[v].y, acc);
-        acc = fmaf(cur_lf[v].z, b[v].z, acc);
-        acc = fmaf(cur_lf[v].w, b[v].w, acc);
+        acc = __builtin_elementwise_fma(v2f{cur_lf[v].x, cur_lf[v].y}, v2f{b[v].x, b[v].y}, acc);
+        acc = __builtin_elementwise_fma(v2f{cur_lf[v].z, cur_lf[v].w}, v2f{b[v].z, b[v].w}, acc);
       }
-      return acc;
+      return acc.x + acc.y;
     };
     // Four entries.  k = 64: all reads in flight at once.  Longer
     // ones: two register sets, the reads of entry e+1 issued before the FMAs of
