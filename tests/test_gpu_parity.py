@@ -406,9 +406,10 @@ SDDMM_SUM_SHAPES = [
     (100, 40, 60, 0.5, 5),      # row-wave kernel ([R, nnz] partials)
     (64, 64, 64, 0.0, 1),       # nothing to sum
     (33, 100, 47, 0.6, 4),      # odd sizes: scalar reduction
-    (512, 512, 512, 0.9, 8),    # sparse mask: the summed form cuts k into 128-wide panels
-    (300, 2048, 260, 0.95, 2),  # k = 2048 sparse: 256-wide panels, 8 per replica
-    (256, 4096, 256, 0.95, 2),  # k = 4096: 16 panels of 256 would be too many, stays at 512
+    (512, 512, 512, 0.9, 8),    # the summed form cuts k into 256-wide panels (16-wave workgroups)
+    (300, 2048, 260, 0.95, 2),  # k = 2048: 8 panels per replica
+    (256, 4096, 256, 0.95, 2),  # k = 4096: 16 panels per replica in one launch
+    (128, 384, 200, 0.8, 3),    # k = 384: 128-wide panels (8-wave workgroups)
 ]
 
 

@@ -37,7 +37,6 @@ using namespace tiled;
 using v2f = float __attribute__((ext_vector_type(2)));
 
 constexpr int kSWaves = 8;
-constexpr int kSThreads = kSWaves * kWave;
 constexpr int kSGroups = kSWaves * 4;  // 16-lane row groups per workgroup
 constexpr int kSRows = 8;              // mask rows per group: a workgroup owns 256 rows
 constexpr int kWin = 2;                // 16-entry column windows fetched ahead per row
@@ -49,6 +48,16 @@ struct Slab {
   static constexpr int kRows = kBytes / (kdim * 4);
   // lhs fragments in flight (KV float4 each): fetched 2 rows / 1 row ahead
   static constexpr int kRing = KV <= 2 ? 3 : 2;
+  // Waves per workgroup.  A 128 KiB slab admits one workgroup per CU; with 8
+  // waves that is two per SIMD, each issuing VALU work in 23 % of its cycles
+  // (rocprofv3 SQ counters: the SIMD idles half the time).  Panel width 256 needs
+  // few enough registers (<= 128) for four waves per SIMD, so its workgroup has
+  // 16 waves that share the slab, each group walking 4 mask rows instead of 8
+  // (the workgroup still owns 256 rows: plans and tables are unchanged).
+  static constexpr int kWaves = KV == 4 ? 2 * kSWaves : kSWaves;
+  static constexpr int kThreads = kWaves * kWave;
+  static constexpr int kGroups = kWaves * 4;            // 16-lane row groups per workgroup
+  static constexpr int kGroupRows = kSGroups * kSRows / kGroups;   // mask rows per group
   static_assert(kRows >= 16, "a slab holds at least one full column window");
 };
 
@@ -56,7 +65,8 @@ struct Slab {
 // 128 KiB (2 waves per SIMD); telling the compiler stops it from spilling to
 // keep a wave count the LDS footprint rules out anyway.
 template <int KV>
-__global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(2, (KV <= 2 ? 4 : 2))))
+__global__ __launch_bounds__(Slab<KV>::kThreads)
+__attribute__((amdgpu_waves_per_eu(2, (KV <= 2 || KV == 4 ? 4 : 2))))
 void sddmm_stationary_kernel(
     int m, int n, int nonzeros, int slots, const int* __restrict__ row_indices,
     const int* __restrict__ row_offsets, const int* __restrict__ column_indices,
@@ -89,8 +99,8 @@ void sddmm_stationary_kernel(
   if (!(debug & 2)) {  // stage the slab in 1 KiB pieces (64 lanes x 16 B, lane-linear in LDS)
     constexpr int kPieces = S::kBytes / 1024;
 #pragma unroll
-    for (int j = 0; j < kPieces / kSWaves; ++j) {
-      const int piece = wave + j * kSWaves;
+    for (int j = 0; j < kPieces / S::kWaves; ++j) {
+      const int piece = wave + j * S::kWaves;
       const unsigned b = static_cast<unsigned>(piece) * 1024u + lane * 16u;  // byte in the slab
       const int src_row = min(jc + static_cast<int>(b / kRowBytes), n - 1);  // past the end: last row
       const unsigned off =
@@ -109,10 +119,11 @@ void sddmm_stationary_kernel(
   const int* __restrict__ tab0 = table + static_cast<int64_t>(slab) * slots;
   const int* __restrict__ tab1 = tab0 + slots;
 
-  int row[kSRows], ps[kSRows], cnt[kSRows];
+  constexpr int kRowsHere = S::kGroupRows;
+  int row[kRowsHere], ps[kRowsHere], cnt[kRowsHere];
 #pragma unroll
-  for (int r = 0; r < kSRows; ++r) {
-    const int sl = slot_begin + r * kSGroups + gid;  // < slots: table and status are padded
+  for (int r = 0; r < kRowsHere; ++r) {
+    const int sl = slot_begin + r * S::kGroups + gid;  // < slots: table and status are padded
     const int entry = dealt_index(sl, slots, kSGroups * kSRows);
     const bool live = entry < m;
     row[r] = row_indices[live ? entry : 0];
@@ -143,9 +154,9 @@ void sddmm_stationary_kernel(
   __syncthreads();
 
   const char* __restrict__ lane_base = reinterpret_cast<const char*>(&tile[0] + i * 4);
-  static_for<kSRows>([&](auto R) {
+  static_for<kRowsHere>([&](auto R) {
     constexpr int r = decltype(R)::value;
-    if constexpr (r + kRing - 1 < kSRows) fetch(r + kRing - 1, (r + kRing - 1) % kRing);
+    if constexpr (r + kRing - 1 < kRowsHere) fetch(r + kRing - 1, (r + kRing - 1) % kRing);
     const float4 (&cur_lf)[KV] = lf[r % kRing];
     const int cur_ps = ps[r];
 
@@ -273,22 +284,25 @@ inline int panel_width(int k) {
 }
 inline int slab_rows_of_width(int w) { return (w <= 128 ? 64 * 1024 : 128 * 1024) / (w * 4); }
 // Panel width of the SUMMED product (sddmm_tiled_launch_partials), whose panels
-// run side by side, so a narrower panel costs no extra launch.  What it buys: a
-// narrower panel means a taller slab, hence more entries of a mask row per slab
-// visit; below about ten the 16-entry windows run mostly empty.  Measured
+// run side by side, so a narrower panel costs no extra launch.  256 wherever it
+// divides k: that width runs 16 waves per workgroup (Slab<4>: four per SIMD instead
+// of two) and has the taller slab -- more entries of a mask row per slab visit;
+// below about ten the 16-entry windows run mostly empty.  Measured
 // (tools/sddmm_panel_bench.py, 8 replicas, widths 512 / 256 / 128):
-//   512^2   x k 1024, density 0.1 (6.4 per visit at 512):   39 / 32 / 36 us
-//   4096^2  x k 512,  density 0.1:                          809 / 665 / 636 us
-//   4096^2  x k 512,  density 0.05:                         668 / 578 / 527 us
-//   2048^2  x k 512,  density 0.2 (12.8):                   252 / 259 / 242 us
-//   1024^2  x k 1024, density 0.3 (19):                     173 / 180 / 175 us
+//   512^2   x k 1024, density 0.1 (6.4 per visit at 512):   37 / 29 / 36 us
+//   4096^2  x k 512,  density 0.05:                         647 / 449 / 528 us
+//   2048^2  x k 512,  density 0.2 (12.8):                   246 / 229 / 250 us
+//   1024^2  x k 1024, density 0.3 (19):                     168 / 160 / 180 us
+//   512^2   x k 1024, density 0.5:                          66 / 66 / 79 us
+// (with 8 waves per workgroup 256 was 5-10 % behind 512 at 12 and more entries
+// per visit).  Up to 16 panels: the (replica, panel) pairs are one grid dimension.
 inline int sum_panel_width(int m, int k, int n, int nonzeros) {
   const int w = panel_width(k);
   if (options().sddmm_panel > 0 || w <= 128 || m <= 0 || n <= 0) return w;
+  if (k % 256 == 0 && k / 256 <= 16) return 256;
   const double per_visit = static_cast<double>(nonzeros) / m * slab_rows_of_width(w) / n;
   if (per_visit >= 10.0) return w;
-  const int narrow = (k >= 1024 && k % 256 == 0) ? 256 : 128;
-  return (narrow < w && k / narrow <= 8) ? narrow : w;
+  return k / 128 <= 16 ? 128 : w;
 }
 inline int width_for(int m, int k, int n, int nonzeros, bool summed) {
   return summed ? sum_panel_width(m, k, n, nonzeros) : panel_width(k);
@@ -321,7 +335,7 @@ int launch(int m, int k, int n, int nonzeros, int replicas, int slots, const int
     for (int r0 = 0; r0 < replicas; r0 += kMaxGridYZ) {
       const int rz = min(replicas - r0, kMaxGridYZ);
       hipLaunchKernelGGL(sddmm_stationary_kernel<KV>, dim3(slabs, row_blocks, rz),
-                         dim3(kSThreads), 0, stream, m, n, nonzeros, slots, row_indices,
+                         dim3(S::kThreads), 0, stream, m, n, nonzeros, slots, row_indices,
                          row_offsets, column_indices, table, row_ok, lhs + r0 * lhs_stride + k0,
                          lhs_stride, rhs + r0 * rhs_stride + k0, rhs_stride, k, k0 != 0,
                          out + r0 * out_stride, out_stride, 1, debug);
@@ -349,7 +363,7 @@ int launch_partials(int m, int k, int n, int nonzeros, int replicas, int slots,
   if (row_blocks > kMaxGridYZ || static_cast<int64_t>(replicas) * panels > kMaxGridYZ)
     return SPUTNIK_HIP_INVALID_ARGUMENT;
   hipLaunchKernelGGL(sddmm_stationary_kernel<KV>, dim3(slabs, row_blocks, replicas * panels),
-                     dim3(kSThreads), 0, stream, m, n, nonzeros, slots, row_indices, row_offsets,
+                     dim3(S::kThreads), 0, stream, m, n, nonzeros, slots, row_indices, row_offsets,
                      column_indices, table, row_ok, lhs, lhs_stride, rhs, rhs_stride, k, 0,
                      partials, static_cast<int64_t>(nonzeros), panels, debug);
   return launch_status();
