@@ -598,6 +598,39 @@ def test_left_spmm_group_equals_the_single_products(ts, dev, m, k, n, replicas, 
     assert rel_err(outs[0].cpu().numpy(), np.ascontiguousarray(ref).astype(np.float32)) < TOL
 
 
+def test_spmm_group_capi_struct_array(capi, dev):
+    """sputnik_hip_spmm_group_batched through ctypes (array of sputnik_hip_spmm_problem):
+    two weights, one input, plain stores -- against the single C-ABI products -- and
+    the refusals the header promises."""
+    m, k, n, replicas = 256, 320, 128, 2
+    rng = np.random.default_rng(12)
+    b = T(rng.uniform(-1, 1, (replicas, k, n)).astype(np.float32), dev)
+    problems, wants = [], []
+    for p in range(2):
+        _, _, ri, ro, ci = make_csr(m, k, 0.85, seed=40 + p)
+        v = T(rng.uniform(-1, 1, len(ci)).astype(np.float32), dev)
+        topo = [T(x, dev) for x in (ri, ro, ci)]
+        out = torch.full((replicas, m, n), float("nan"), device=dev)
+        problems.append({"row_indices": topo[0], "row_offsets": topo[1], "column_indices": topo[2],
+                         "values": v, "dense": b, "out": out})
+        ws = torch.empty(capi.spmm_workspace_bytes(m, k, n, len(ci)) + 16, dtype=torch.uint8, device=dev)
+        wants.append(capi.spmm_batched(m, k, n, replicas, topo[0], v, 0, topo[1], topo[2], b,
+                                       torch.empty(replicas, m, n, device=dev), ws))
+    assert capi.spmm_group_batched(m, k, n, replicas, problems) == 0
+    for p in range(2):
+        assert rel_err(problems[p]["out"].cpu().numpy(), wants[p].cpu().numpy()) < TOL
+    # summed into one output
+    total = torch.full((replicas, m, n), float("nan"), device=dev)
+    for p in problems:
+        p["out"] = total
+    assert capi.spmm_group_batched(m, k, n, replicas, problems, accumulate=True) == 0
+    assert rel_err(total.cpu().numpy(), (wants[0] + wants[1]).cpu().numpy()) < TOL
+    # not served: transposed stores together with accumulation; k beyond one panel
+    assert capi.spmm_group_batched(m, k, n, replicas, problems, block_rows=64, accumulate=True) == -2
+    assert capi.lib().sputnik_hip_spmm_group_supported(m, 600, n, 2, 0, 0) == 0
+    assert capi.lib().sputnik_hip_spmm_group_supported(m, k, n, 5, 0, 0) == 0
+
+
 @pytest.mark.parametrize("m,k,n,replicas,count,permuted", [
     (512, 512, 1024, 3, 3, True),    # input gradient of the q, k, v projections
     (512, 512, 1024, 2, 2, False),
