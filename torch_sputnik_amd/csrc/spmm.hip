@@ -211,10 +211,10 @@ bool takes_panel(int m, int k, int n, int nonzeros, int replicas, const float* d
       !spmm_panel_applicable(m, k, n, nonzeros, dense, dense_stride, out, out_stride))
     return false;
   if (forced == 3) return true;
-  // More than one panel (k > 512): every pass walks the rows' whole streams, which
-  // pays for two panels of short rows only (1024^2 x 64 x 64 replicas: density 0.1
-  // 43 vs 48 us, 0.3 96 vs 89 us; four panels, 2048^2: 100 vs 60 us).
-  if (k > 1024 || (k > 512 && nonzeros > 128 * static_cast<int64_t>(m))) return false;
+  // More than one panel (k > 512): every pass walks (part of) the rows' streams
+  // again, which pays for two panels (1024^2 x 64 x 64 replicas: density 0.1 36 vs
+  // 47 us, 0.3 84 vs 90 us; four panels, 2048^2: 83 vs 60 us).
+  if (k > 1024 || (k > 512 && nonzeros > 320 * static_cast<int64_t>(m))) return false;
   // (two panels on a grid that does not fill the chip: 2048 x 1024 x 1024, one
   // replica, 128 workgroups: 33.0 vs 30.9 us for the chunked kernel)
   if (k > 512 && static_cast<int64_t>((m + 255) / 256) * ((n + 63) / 64) * replicas < 192)

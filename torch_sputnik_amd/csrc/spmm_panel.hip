@@ -71,6 +71,27 @@ __device__ __forceinline__ void dpp_group4_pair(float (&acc_a)[4], float (&acc_b
 // ---------------------------------------------------------------------------
 // Building blocks shared by the kernels below.
 // ---------------------------------------------------------------------------
+// Which (row block, column tile, replica) a workgroup works on.  Workgroups are
+// dealt to the 8 XCDs round-robin in launch order, and each XCD has its own L2:
+// the row blocks that copy the SAME panel of B (same replica and column tile)
+// are therefore given launch positions that are congruent modulo 8, so that one
+// L2 fetches the panel from memory and serves the others (attention shapes: four
+// row blocks per panel, which in plain order sit on four different XCDs).
+struct Place {
+  int mblock, ntile, replica;
+};
+__device__ __forceinline__ Place place_of_workgroup(int n_tiles) {
+  const int total = gridDim.x * gridDim.y;
+  const int launch = blockIdx.y * gridDim.x + blockIdx.x;
+  const int v = total % 8 == 0 ? (launch % 8) * (total / 8) + launch / 8 : launch;
+  const int mblocks = gridDim.x / n_tiles;
+  Place p;
+  p.mblock = v % mblocks;
+  p.ntile = (v / mblocks) % n_tiles;
+  p.replica = v / (mblocks * n_tiles);
+  return p;
+}
+
 // The 16 rows of a wave (4 row quads x 4 groups): row id (-1: padding), first
 // stream position and length, as seen by the lanes of each 16-lane group.
 struct Rows {
@@ -319,9 +340,8 @@ __global__ __launch_bounds__(kPThreads) void spmm_panel64_kernel(
   const int lane = threadIdx.x % kWave;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int g = lane >> 4, i = lane & 15;
-  const int ntile = blockIdx.x % n_tiles;
-  const int mblock = blockIdx.x / n_tiles;
-  const int replica = blockIdx.y;
+  const Place place = place_of_workgroup(n_tiles);
+  const int ntile = place.ntile, mblock = place.mblock, replica = place.replica;
   values += replica * values_stride;
   dense += replica * dense_stride;
   out += replica * out_stride;
@@ -405,9 +425,8 @@ __global__ __launch_bounds__(kPThreads) void spmm_panel64_group_kernel(
   const int lane = threadIdx.x % kWave;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int g = lane >> 4, i = lane & 15;
-  const int ntile = blockIdx.x % n_tiles;
-  const int mblock = blockIdx.x / n_tiles;
-  const int replica = blockIdx.y;
+  const Place place = place_of_workgroup(n_tiles);
+  const int ntile = place.ntile, mblock = place.mblock, replica = place.replica;
   const int n0 = ntile * kPBN;
   const int col = min(n0 + i * 4, n - 4);
   const char* __restrict__ lane_base = reinterpret_cast<const char*>(panel + i * 4);
