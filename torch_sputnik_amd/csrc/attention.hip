@@ -94,8 +94,10 @@ __global__ __launch_bounds__(kThreads) void sparse_attention_kernel(
   const int lane = threadIdx.x % kWave;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int g = lane >> 4, i = lane & 15;
-  const int mblock = blockIdx.x;
-  const int replica = blockIdx.y;
+  // (the row blocks of a replica read the same K and V: one XCD, see xcd_local_index)
+  const int work = xcd_local_index();
+  const int mblock = work % gridDim.x;
+  const int replica = work / gridDim.x;
   q += replica * q_stride;
   k += replica * k_stride;
   v += replica * v_stride;

@@ -83,11 +83,16 @@ void sddmm_stationary_kernel(
   const int lane = threadIdx.x % kWave;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int g = lane >> 4, i = lane & 15;
-  const int slab = blockIdx.x;
+  // (slab fastest, then row block, then replica / panel: the workgroups that share
+  // an lhs row block or an rhs slab sit behind one XCD's L2, see xcd_local_index)
+  const int work = xcd_local_index();
+  const int slab = work % gridDim.x;
+  const int row_block = (work / gridDim.x) % gridDim.y;
+  const int grid_z = work / (gridDim.x * gridDim.y);
   // grid z = replica * panels + panel (panels == 1: the launch is one panel of
   // every replica; > 1: all panels at once, each into its own output, see
   // sddmm_tiled_launch_partials)
-  const int z = blockIdx.z;
+  const int z = grid_z;
   const int replica = panels > 1 ? z / panels : z;
   const int panel = z - replica * panels;
   lhs += replica * lhs_stride + panel * kdim;
@@ -114,7 +119,7 @@ void sddmm_stationary_kernel(
   // flight; a row's column windows and lhs fragment are fetched kRing-1 rows
   // ahead.  Everything is statically indexed (the row loop is fully
   // unrolled), so no register is ever copied while its load is outstanding.
-  const int slot_begin = blockIdx.y * (kSGroups * kSRows);
+  const int slot_begin = row_block * (kSGroups * kSRows);
   const int gid = wave * 4 + g;
   const int* __restrict__ tab0 = table + static_cast<int64_t>(slab) * slots;
   const int* __restrict__ tab1 = tab0 + slots;

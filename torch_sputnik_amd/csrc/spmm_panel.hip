@@ -81,9 +81,7 @@ struct Place {
   int mblock, ntile, replica;
 };
 __device__ __forceinline__ Place place_of_workgroup(int n_tiles) {
-  const int total = gridDim.x * gridDim.y;
-  const int launch = blockIdx.y * gridDim.x + blockIdx.x;
-  const int v = total % 8 == 0 ? (launch % 8) * (total / 8) + launch / 8 : launch;
+  const int v = xcd_local_index();
   const int mblocks = gridDim.x / n_tiles;
   Place p;
   p.mblock = v % mblocks;

@@ -331,11 +331,19 @@ __global__ __launch_bounds__(Cfg::kThreads) void spmm_tiled_kernel(
     const int xcd = bid % 8, i = bid / 8;
     ntile = xcd * per_xcd + i % per_xcd;
     mblock = i / per_xcd;
-  } else {
-    ntile = bid % n_tiles;
-    mblock = bid / n_tiles;
   }
-  const int replica = blockIdx.y;
+  int replica = blockIdx.y;
+  if (n_tiles % 8 != 0) {
+    // fewer (or an odd number of) column tiles: the row blocks that stage the
+    // same B tile (same replica, same column tile) get consecutive work indices,
+    // i.e. one XCD (xcd_local_index) -- with one 512-column tile and 8 replicas
+    // every XCD would otherwise fetch every replica's B for itself
+    const int work = xcd_local_index();
+    const int mblocks = gridDim.x / n_tiles;
+    mblock = work % mblocks;
+    ntile = (work / mblocks) % n_tiles;
+    replica = work / (mblocks * n_tiles);
+  }
   values += replica * values_stride;
   dense += replica * dense_stride;
   out += replica * out_stride;

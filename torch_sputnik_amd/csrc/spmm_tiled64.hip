@@ -77,9 +77,13 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled64_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int g = lane >> 4, i = lane & 15;
 
-  const int ntile = blockIdx.x % n_tiles;
-  const int mblock = blockIdx.x / n_tiles;
-  const int replica = blockIdx.y;
+  // (row blocks that stage the same B tile -- same replica and column tile -- run
+  // on one XCD: consecutive work indices, see xcd_local_index)
+  const int work = xcd_local_index();
+  const int mblocks = gridDim.x / n_tiles;
+  const int mblock = work % mblocks;
+  const int ntile = (work / mblocks) % n_tiles;
+  const int replica = work / (mblocks * n_tiles);
   values += replica * values_stride;
   dense += replica * dense_stride;
   out += replica * out_stride;

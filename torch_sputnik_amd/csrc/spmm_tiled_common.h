@@ -32,6 +32,18 @@ inline size_t row_ok_bytes(int slots) { return (sizeof(int) * static_cast<size_t
 // first workgroup the longest rows and the last one the shortest (+-10 % of
 // work at 4096^2, density 0.1), and with about one workgroup per CU the launch
 // lasts as long as the slowest (measured 427 -> 408 us).  Entries >= m are padding.
+// Launch position -> work index such that CONSECUTIVE work indices run on the
+// same XCD.  Workgroups are dealt to the 8 XCDs round-robin in launch order
+// (x fastest, then y, then z), and each XCD has its own L2: a kernel that
+// decodes its (tile, block, replica) from this index with the operand-sharing
+// dimension fastest has all workgroups that read the same bytes behind ONE L2
+// (otherwise every XCD fetches them from memory for itself).
+__device__ __forceinline__ int xcd_local_index() {
+  const int total = gridDim.x * gridDim.y * gridDim.z;
+  const int launch = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  return total % 8 == 0 ? (launch % 8) * (total / 8) + launch / 8 : launch;
+}
+
 __device__ __forceinline__ int dealt_index(int slot, int slots, int per) {
   return (slot % per) * (slots / per) + slot / per;
 }
