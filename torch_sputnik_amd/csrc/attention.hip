@@ -95,9 +95,9 @@ __global__ __launch_bounds__(kThreads) void sparse_attention_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int g = lane >> 4, i = lane & 15;
   // (the row blocks of a replica read the same K and V: one XCD, see xcd_local_index)
-  const int work = xcd_local_index();
-  const int mblock = work % gridDim.x;
-  const int replica = work / gridDim.x;
+  const unsigned long long work = xcd_local_index();
+  const int mblock = static_cast<int>(work % gridDim.x);
+  const int replica = static_cast<int>(work / gridDim.x);
   q += replica * q_stride;
   k += replica * k_stride;
   v += replica * v_stride;

@@ -85,10 +85,10 @@ void sddmm_stationary_kernel(
   const int g = lane >> 4, i = lane & 15;
   // (slab fastest, then row block, then replica / panel: the workgroups that share
   // an lhs row block or an rhs slab sit behind one XCD's L2, see xcd_local_index)
-  const int work = xcd_local_index();
-  const int slab = work % gridDim.x;
-  const int row_block = (work / gridDim.x) % gridDim.y;
-  const int grid_z = work / (gridDim.x * gridDim.y);
+  const unsigned long long work = xcd_local_index();
+  const int slab = static_cast<int>(work % gridDim.x);
+  const int row_block = static_cast<int>((work / gridDim.x) % gridDim.y);
+  const int grid_z = static_cast<int>(work / (static_cast<unsigned long long>(gridDim.x) * gridDim.y));
   // grid z = replica * panels + panel (panels == 1: the launch is one panel of
   // every replica; > 1: all panels at once, each into its own output, see
   // sddmm_tiled_launch_partials)

@@ -81,12 +81,12 @@ struct Place {
   int mblock, ntile, replica;
 };
 __device__ __forceinline__ Place place_of_workgroup(int n_tiles) {
-  const int v = xcd_local_index();
-  const int mblocks = gridDim.x / n_tiles;
+  const unsigned long long v = xcd_local_index();
+  const unsigned mblocks = gridDim.x / n_tiles;
   Place p;
-  p.mblock = v % mblocks;
-  p.ntile = (v / mblocks) % n_tiles;
-  p.replica = v / (mblocks * n_tiles);
+  p.mblock = static_cast<int>(v % mblocks);
+  p.ntile = static_cast<int>((v / mblocks) % n_tiles);
+  p.replica = static_cast<int>(v / (static_cast<unsigned long long>(mblocks) * n_tiles));
   return p;
 }
 

@@ -338,7 +338,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void spmm_tiled_kernel(
     // same B tile (same replica, same column tile) get consecutive work indices,
     // i.e. one XCD (xcd_local_index) -- with one 512-column tile and 8 replicas
     // every XCD would otherwise fetch every replica's B for itself
-    const int work = xcd_local_index();
+    const int work = xcd_local_index32();
     const int mblocks = gridDim.x / n_tiles;
     mblock = work % mblocks;
     ntile = (work / mblocks) % n_tiles;

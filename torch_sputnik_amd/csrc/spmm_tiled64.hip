@@ -79,11 +79,11 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled64_kernel(
 
   // (row blocks that stage the same B tile -- same replica and column tile -- run
   // on one XCD: consecutive work indices, see xcd_local_index)
-  const int work = xcd_local_index();
-  const int mblocks = gridDim.x / n_tiles;
-  const int mblock = work % mblocks;
-  const int ntile = (work / mblocks) % n_tiles;
-  const int replica = work / (mblocks * n_tiles);
+  const unsigned long long work = xcd_local_index();
+  const unsigned mblocks = gridDim.x / n_tiles;
+  const int mblock = static_cast<int>(work % mblocks);
+  const int ntile = static_cast<int>((work / mblocks) % n_tiles);
+  const int replica = static_cast<int>(work / (static_cast<unsigned long long>(mblocks) * n_tiles));
   values += replica * values_stride;
   dense += replica * dense_stride;
   out += replica * out_stride;

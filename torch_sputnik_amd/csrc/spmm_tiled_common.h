@@ -38,7 +38,19 @@ inline size_t row_ok_bytes(int slots) { return (sizeof(int) * static_cast<size_t
 // decodes its (tile, block, replica) from this index with the operand-sharing
 // dimension fastest has all workgroups that read the same bytes behind ONE L2
 // (otherwise every XCD fetches them from memory for itself).
-__device__ __forceinline__ int xcd_local_index() {
+// (64-bit: grid.x * grid.y * grid.z may exceed 2^31 for a huge batch)
+__device__ __forceinline__ unsigned long long xcd_local_index() {
+  using u64 = unsigned long long;
+  const u64 total = static_cast<u64>(gridDim.x) * gridDim.y * gridDim.z;
+  const u64 launch = (static_cast<u64>(blockIdx.z) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  return total % 8 == 0 ? (launch % 8) * (total / 8) + launch / 8 : launch;
+}
+
+// 32-bit form for the dense-output kernels, whose workgroup count is bounded by
+// memory: every workgroup owns at least 64 x 64 output elements (16 KiB), so 2^31
+// workgroups would be 32 TiB of output.  (Keeps 64-bit division out of the
+// register-tight 128 x 512 kernel.)
+__device__ __forceinline__ int xcd_local_index32() {
   const int total = gridDim.x * gridDim.y * gridDim.z;
   const int launch = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
   return total % 8 == 0 ? (launch % 8) * (total / 8) + launch / 8 : launch;
