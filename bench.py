@@ -787,6 +787,20 @@ def main():
             result["other_ops"]["spmm_c2_d010_via_torch_op"] = {
                 "ms": ms_op, "gflops": problem.flops / ms_op / 1e6,
                 "note": "allocates C and the workspace per call (caching allocator)"}
+            # the same product with the rows in the order the reference's modules
+            # produce (`diffsort`: ASCENDING length, modules/spmm.py:4-6) instead of
+            # tests/sparse_matrix.py:22's descending order -- results and speed must not
+            # depend on the permutation (rows are dealt to workgroups)
+            try:
+                from torch_sputnik_amd.topology import diffsort
+                ri_up = diffsort(problem.ro)
+                ms_up = event_time_ms(lambda: problem.capi.spmm_batched(
+                    M, K, N, 1, ri_up, problem.values, 0, problem.ro, problem.ci, problem.dense,
+                    problem.out, problem.ws), 20)
+                result["other_ops"]["spmm_c2_d010_rows_in_diffsort_order"] = {
+                    "ms": ms_up, "gflops": problem.flops / ms_up / 1e6}
+            except Exception as e:  # noqa: BLE001 - extra metric, best effort
+                result["other_ops"]["spmm_c2_d010_rows_in_diffsort_order"] = {"error": str(e)[:200]}
             # What one GPU does in the N > 1 runs (config 4's share: 16 replicas in one
             # launch), so that weak-scaling efficiency can be taken against the SAME
             # per-GPU workload rather than against the single product above.
