@@ -66,7 +66,7 @@ def _reload_library_options():
     capi.reload_options()
 
 
-@pytest.fixture(params=["auto", "wide", "wide512", "narrow", "gather", "panel"])
+@pytest.fixture(params=["auto", "wide", "wide512", "flat", "narrow", "gather", "panel"])
 def spmm_kernel(request, monkeypatch):
     """Small inputs take the single-launch row-gather kernel on their own; the
     library's test knob steers them onto each tiled kernel in turn (a kernel

@@ -42,6 +42,8 @@
 // columns ascend.  A workgroup that finds a non-ascending row in its block
 // takes an order-independent path (B gathered from L2) inside the same launch:
 // no host synchronisation, no second kernel.
+#include <algorithm>
+
 #include "options.h"
 #include "spmm_tiled_common.h"
 
@@ -56,6 +58,17 @@ int spmm_tiled64_exec(int m, int k, int n, int nonzeros, int replicas, const int
                       const int* column_indices, const float* dense, int64_t dense_stride,
                       float* out, int64_t out_stride, const void* workspace,
                       hipStream_t stream, Epilogue epi);
+
+// Flat-stream form of the 128 x 512 tile (spmm_flat.hip).
+bool spmm_flat_applicable(int m, int k, int n, int nonzeros);
+size_t spmm_flat_workspace_bytes(int m, int k, int n, int nonzeros);
+int spmm_flat_plan(int m, int k, int n, int nonzeros, const int* row_indices,
+                   const int* row_offsets, const int* column_indices, void* workspace,
+                   hipStream_t stream);
+int spmm_flat_exec(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
+                   const float* values, int64_t values_stride, const int* row_offsets,
+                   const int* column_indices, const float* dense, int64_t dense_stride, float* out,
+                   int64_t out_stride, const void* workspace, hipStream_t stream, Epilogue epi);
 
 namespace {
 
@@ -445,7 +458,9 @@ using CfgWide512Half = TileConfig<512, 16, 4, 32>;
 // Developer / test knob SPUTNIK_HIP_SPMM_KERNEL (options.h: read once): "wide" =
 // 256-column kernel whenever it applies, "wide512" = 512-column kernel whenever
 // it applies (else as "wide"), "narrow" = 64-column kernel whenever it applies,
-// "gather" = row-gather kernel; anything else = the automatic choice.
+// "gather" = row-gather kernel, "flat" = as "wide512" with the flat-stream form
+// of that tile (spmm_flat.hip) whenever it applies; anything else = the
+// automatic choice.
 // (The parity tests use it to reach every kernel with small inputs.)
 inline int forced_kernel() { return options().spmm_kernel == 3 ? 0 : options().spmm_kernel; }
 
@@ -484,6 +499,14 @@ inline int64_t tiles512(int m, int n) {
   return static_cast<int64_t>(ceil_div(m, CfgWide512::kBM)) * ceil_div(n, CfgWide512::kBN);
 }
 constexpr int64_t kTiles512From = 192;
+// The flat-stream kernel serves the 128 x 512 tile when ONE replica gives about a
+// workgroup per CU (its plan then does not depend on the replica count); the knob
+// "flat" takes it for any shape it can serve, "wide512" keeps the visit-per-row form.
+inline bool use_flat(int m, int k, int n, int nonzeros) {
+  const int forced = forced_kernel();
+  return (forced == -3 || (forced == 0 && tiles512(m, n) >= kTiles512From)) &&
+         spmm_flat_applicable(m, k, n, nonzeros);
+}
 // A row has more than about two entries per 32-row chunk (below that the 64-row
 // chunks of the 256-column kernel win by 2 %: 4096^3 at density 0.05).
 inline bool long_enough_for_512(int m, int k, int nonzeros) {
@@ -497,9 +520,14 @@ inline bool wide512_possible(int m, int k, int n, int nonzeros) {
          long_enough_for_512(m, k, nonzeros) && 2 * tiles512(m, n) < kTiles512From;
 }
 
-inline size_t wide512_workspace_bytes(int m, int k, int n) {
+inline size_t wide512_workspace_bytes(int m, int k, int n, int nonzeros) {
   const Plan plan = make_plan<CfgWide512>(m, k, n);
-  return (row_ok_bytes(plan.slots) + plan.table_bytes + 15) / 16 * 16;
+  const size_t visit_form = (row_ok_bytes(plan.slots) + plan.table_bytes + 15) / 16 * 16;
+  // (the larger of the two forms whenever the flat one is possible at all, so that a
+  // workspace serves whichever the knob selects)
+  return spmm_flat_applicable(m, k, n, nonzeros)
+             ? std::max(visit_form, spmm_flat_workspace_bytes(m, k, n, nonzeros))
+             : visit_form;
 }
 
 inline size_t wide_workspace_bytes(int m, int k, int n) {
@@ -531,7 +559,8 @@ inline Kernel choose_kernel(int m, int k, int n, int nonzeros, int replicas /* <
   if (tiled512_applicable(m, k, n, nonzeros)) {
     // (with its 64-row variant the count that matters is that of 64-row tiles)
     const int64_t tiles = 2 * tiles512(m, n) * (replicas > 0 ? replicas : 1);
-    if (forced == -2 || (forced == 0 && tiles >= kTiles512From && long_enough_for_512(m, k, nonzeros)))
+    if (forced == -2 || forced == -3 ||
+        (forced == 0 && tiles >= kTiles512From && long_enough_for_512(m, k, nonzeros)))
       return Kernel::kWide512;
   }
   const bool wide = tiled_applicable(m, k, n, nonzeros);
@@ -553,7 +582,7 @@ namespace {
 size_t base_workspace_bytes(int m, int k, int n, int nonzeros) {
   switch (choose_kernel(m, k, n, nonzeros, -1)) {
     case Kernel::kWide: return wide_workspace_bytes(m, k, n);
-    case Kernel::kWide512: return wide512_workspace_bytes(m, k, n);
+    case Kernel::kWide512: return wide512_workspace_bytes(m, k, n, nonzeros);
     case Kernel::kNarrow: return spmm_tiled64_workspace_bytes(m, k);
     case Kernel::kEither: return wide_workspace_bytes(m, k, n) + spmm_tiled64_workspace_bytes(m, k);
     default: return 0;
@@ -575,7 +604,7 @@ int spmm_tiled_choice(int m, int k, int n, int nonzeros, int replicas) {
 
 size_t spmm_tiled_workspace_bytes(int m, int k, int n, int nonzeros) {
   return wide512_possible(m, k, n, nonzeros)
-             ? wide512_offset(m, k, n, nonzeros) + wide512_workspace_bytes(m, k, n)
+             ? wide512_offset(m, k, n, nonzeros) + wide512_workspace_bytes(m, k, n, nonzeros)
              : base_workspace_bytes(m, k, n, nonzeros);
 }
 
@@ -612,7 +641,12 @@ int spmm_tiled_plan(int m, int k, int n, int nonzeros, int replicas, const int* 
     const int st = launch_status();
     if (st != 0) return st;
   }
-  if (which == Kernel::kWide512 || also512) {
+  if ((which == Kernel::kWide512 || also512) && use_flat(m, k, n, nonzeros)) {
+    const int st = spmm_flat_plan(m, k, n, nonzeros, row_indices, row_offsets, column_indices,
+                                  static_cast<char*>(workspace) + wide512_offset(m, k, n, nonzeros),
+                                  stream);
+    if (st != 0) return st;
+  } else if (which == Kernel::kWide512 || also512) {
     const Plan plan = make_plan<CfgWide512>(m, k, n);
     char* base = static_cast<char*>(workspace) + wide512_offset(m, k, n, nonzeros);
     int* row_ok = reinterpret_cast<int*>(base);
@@ -652,6 +686,13 @@ int spmm_tiled_exec(int m, int k, int n, int nonzeros, int replicas, const int* 
   }
   using Cfg = CfgLarge;
   const bool w512 = which == Kernel::kWide512;
+  if (w512 && use_flat(m, k, n, nonzeros)) {
+    *handled = true;
+    return spmm_flat_exec(m, k, n, nonzeros, replicas, row_indices, values, values_stride,
+                          row_offsets, column_indices, dense, dense_stride, out, out_stride,
+                          static_cast<const char*>(workspace) + wide512_offset(m, k, n, nonzeros),
+                          stream, epi);
+  }
   const Plan plan = w512 ? make_plan<CfgWide512>(m, k, n) : make_plan<Cfg>(m, k, n);
   const char* ws_base =
       static_cast<const char*>(workspace) + (w512 ? wide512_offset(m, k, n, nonzeros) : 0);
