@@ -62,6 +62,9 @@ def main():
     ap.add_argument("--densities", default="0.1")
     ap.add_argument("--kernels", default="flat,wide512")
     ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--loops", default="", help="flat kernel only: comma list of 2,3,4 = entry / group straight / "
+                    "group diagonal loop (SPUTNIK_HIP_SPMM_SPARSE); empty = the dispatcher's choice")
+    ap.add_argument("--patterns", default="random,balanced")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     m = k = n = args.size
@@ -69,11 +72,16 @@ def main():
     b = torch.rand(k, n, device=dev)
     out = torch.empty(m, n, device=dev)
     for d in [float(x) for x in args.densities.split(",")]:
-        for pattern in ("random", "balanced"):
+        for pattern in args.patterns.split(","):
             ri, ro, ci, nnz = (random_csr if pattern == "random" else balanced_csr)(m, k, d, dev)
             vals = torch.rand(nnz, device=dev)
-            for kern in args.kernels.split(","):
+            for kern, loop in [(kk, ll) for kk in args.kernels.split(",")
+                               for ll in (args.loops.split(",") if kk == "flat" and args.loops else [""])]:
                 os.environ["SPUTNIK_HIP_SPMM_KERNEL"] = kern
+                if loop:
+                    os.environ["SPUTNIK_HIP_SPMM_SPARSE"] = loop
+                else:
+                    os.environ.pop("SPUTNIK_HIP_SPMM_SPARSE", None)
                 capi.reload_options()
                 ws = torch.empty(capi.spmm_workspace_bytes(m, k, n, nnz) + 16, dtype=torch.uint8,
                                  device=dev)
@@ -82,7 +90,7 @@ def main():
                 capi.spmm_plan(m, k, n, ri, ro, ci, ws)
                 kernel = timeit(lambda: capi.spmm_batched_planned(m, k, n, 1, ri, vals, 0, ro, ci, b,
                                                                   out, ws))
-                print(json.dumps(dict(density=d, pattern=pattern, kernel=kern, nnz=nnz,
+                print(json.dumps(dict(density=d, pattern=pattern, kernel=kern + (":" + loop if loop else ""), nnz=nnz,
                                       call_ms=round(call, 4), plan_ms=round(plan, 4),
                                       kernel_ms=round(kernel, 4),
                                       kernel_tflops=round(2.0 * nnz * n / kernel / 1e9, 2))), flush=True)

@@ -10,6 +10,8 @@
 //   hipcc --offload-arch=gfx950 -O2 tools/gpridx_bench.hip -o /tmp/gpridx && /tmp/gpridx
 #include <hip/hip_runtime.h>
 
+#include "gpridx_v2_body.inc"
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -227,10 +229,20 @@ DEF_STEP(k_pipe_idx_salu,
          "s_waitcnt lgkmcnt(4)\ns_set_gpr_idx_idx s43\n" PK8("36:37", "56:57", "58:59", "60:61", "62:63")
          "s_set_gpr_idx_off\ns_cmp_eq_u32 s20, 0\ns_cbranch_scc1 2f\n2:\n")
 
+// d) column-grouped loop: the B strip of a column is read ONCE for all the rows of the wave
+//    that hold the column (entries sorted by column); per entry only a 32-bit value broadcast
+//    and the four FMAs.  Body = one 16-entry window with 9 column groups (density 0.1, 8 rows
+//    per wave) / 4 groups (density 0.5).  DEF_STEP repeats the body 4 times per iteration.
+DEF_STEP(k_colgroup_d10, V2_BODY_D10)
+DEF_STEP(k_colgroup_d50, V2_BODY_D50)
+// (the value broadcast of the NEXT entry issued in front of the FMAs of this one)
+DEF_STEP(k_colgroup_d10_ahead, V2_BODY_D10_AHEAD)
+DEF_STEP(k_colgroup_d50_ahead, V2_BODY_D50_AHEAD)
+
 typedef void (*kern_t)(unsigned long long*, int, int);
 
-static void run(const char* name, kern_t k, int rnd) {
-  const int iters = 40000;
+static void run(const char* name, kern_t k, int rnd, int per_iter = 16) {
+  const int iters = 20000;
   for (int waves : {4, 8, 16}) {
     unsigned long long* d;
     CHECK(hipMalloc(&d, sizeof(unsigned long long) * 256 * 16));
@@ -245,8 +257,8 @@ static void run(const char* name, kern_t k, int rnd) {
     CHECK(hipDeviceSynchronize());
     float ms;
     CHECK(hipEventElapsedTime(&ms, e0, e1));
-    // 16 entries per loop iteration (4 bodies of 4)
-    const double entries_per_simd = double(iters) * 16 * (waves / 4.0);
+    // entries per loop iteration: 4 bodies of 4, or 4 windows of 16
+    const double entries_per_simd = double(iters) * per_iter * (waves / 4.0);
     printf("%-18s rnd=%d waves/SIMD=%d  wall=%.3f ms  ns/entry/SIMD=%.2f\n", name, rnd, waves / 4, ms,
            ms * 1e6 / entries_per_simd);
     CHECK(hipFree(d));
@@ -276,6 +288,10 @@ int main() {
     run("pipe_plain", k_pipe_plain, rnd);
     run("pipe_idx", k_pipe_idx, rnd);
     run("pipe_idx_salu", k_pipe_idx_salu, rnd);
+    run("colgroup_d10", k_colgroup_d10, rnd, 64);
+    run("colgroup_d50", k_colgroup_d50, rnd, 64);
+    run("colgroup_d10_ahead", k_colgroup_d10_ahead, rnd, 64);
+    run("colgroup_d50_ahead", k_colgroup_d50_ahead, rnd, 64);
   }
   return 0;
 }

@@ -1,35 +1,55 @@
 #!/usr/bin/env python3
-"""Generates spmm_flat_body.inc: the main loop of the flat-stream SpMM kernel
-(spmm_flat.hip) as one gfx950 inline-asm text.
+"""Generates the main loop of the flat-stream SpMM kernel (spmm_flat.hip) as
+gfx950 inline-asm text: spmm_flat_body_<variant>.inc.
 
-Why generated assembly.  The loop keeps the accumulators of a wave's rows in
+Why generated assembly.  The loop keeps the accumulators of a wave's 8 rows in
 FIXED vector registers and picks the row of every nonzero with the VGPR index
 mode (s_set_gpr_idx_on: destination and src2 of the FMAs become M0-relative).
 That makes the instruction stream independent of the row a nonzero belongs to:
-a wave walks ONE flat stream of entries per K chunk -- all of its rows' entries
-back to back -- in a software pipeline (LDS reads of entry j+3 in flight while
-entry j is multiplied), with no per-(row, chunk) bookkeeping at all.  hipcc has
-no notion of an M0-relative register, hence the fixed register map below and a
-generator instead of C++.
+a wave walks ONE flat stream of entries -- all of its rows' entries of a K
+chunk back to back, sorted by (column, row) -- with no per-(row, chunk)
+bookkeeping at all.  hipcc has no notion of an M0-relative register, hence the
+fixed register map below and a generator instead of C++.
 
-Structure (see spmm_flat.hip for the data the loop reads):
+Two loops over the same stream (--mode):
 
-  window   16 consecutive stream entries, one per lane of every 16-lane row:
-           (LDS byte offset of the B row, value) as a register pair plus the
-           packed row bytes; three window register sets rotate (current /
-           value gather in flight / plan load in flight), so the slot code
-           exists three times, once per register set
-  slot s   entry s of the current window: chunk-boundary test, DPP broadcast of
-           the pair, address add, two ds_read_b128 into strip set s % 4, then
-           the four v_pk_fma_f32 of the entry issued three slots earlier
-  boundary a subroutine (s_swappc_b64): the wave has issued all entries of K
-           chunk c -> LDS reads drained, next B tile landed, workgroup barrier,
-           next tile's LDS-DMA copies issued
+  entry   every entry reads its B strip (two ds_read_b128) three entries ahead
+          of its four v_pk_fma_f32, in a ring of four strip sets; no taken branch
+          in the steady state.  One B dword from LDS per FMA: bound by the LDS
+          (17 ns per entry and SIMD on random data, tools/gpridx_bench.hip).
+  group   the entries of one column of B that several of the wave's rows hold
+          follow each other in the stream (a "column group"), and the strip is
+          read ONCE per group, three groups ahead: 0.57 reads per entry at density
+          0.1, 0.25 at 0.5; per entry one 32-bit value broadcast and the FMAs
+          (13.6 / 11.6 ns).  Which strip is current is a state of the program
+          counter (four copies of the slot code), and a group start costs taken
+          branches, tens of cycles each: the dense half of the benchmark's sweep
+          gains (density 0.25 +10 %, 0.5 +17 %), the sparse half loses, so the
+          dispatcher picks the loop by density (spmm_flat.hip).
+          --layout: which path falls through.  With p = the share of entries that
+          start a group, "straight" (a group start jumps out and back into the
+          next copy) takes 2 p branches per entry, "diagonal" (the path "every
+          entry starts a group" falls through; an entry that stays in its group
+          jumps) 1 - p.
+
+Common structure (see spmm_flat.hip for the data the loop reads):
+
+  window   16 consecutive stream entries, one per lane of every 16-lane row: a
+           packed word (byte 0: tile row of the entry's own column, byte 1: tile
+           row of the column group three ahead, meaningful in the first entry of
+           a group), the value, and the packed row bytes (bit 7: first entry of a
+           column group, bits 0-6: accumulator index 8 * row).  "current" plus
+           two prefetch stages (value gather in flight / plan load in flight)
+           that are copied down at a window switch.
+  boundary a subroutine (s_swappc_b64) reached when the chunk's entries / groups
+           are used up: LDS reads drained, next B tile landed, workgroup barrier,
+           the copies of the tile after it (all four pieces at once: spreading
+           them over the chunk's entries was measured twice, 5-10 % slower).
   vmcnt    window loads and B copies share the counter and their interleaving
            depends on the data, so the two waits pick their immediate from what
-           was issued since (s_sb: B batches since the last window switch,
+           was issued since (s_sb: copy batches since the last window switch,
            s_nsw: window switches since the last boundary); both choices are
-           conservative when clamped
+           conservative when clamped.
 
 Register map (everything is pinned; the kernel passes its inputs in exactly
 these registers):
@@ -37,33 +57,55 @@ these registers):
   v0        lane * 16 + LDS address of the tile       (input)
   v1        byte offset of the lane's 16 bytes inside a B row, for the copies (input)
   v2, v3    byte offsets of the lane's plan words inside the stream (input, advanced here)
-  v[4:6] v[8:10] v[12:14]   the three windows: offset, value (first: value's byte offset), row bytes
-  v[16:23]  four broadcast pairs (LDS address, value)
+  v[4:5]    current window: LDS offset (own column / group ahead), value
+  v[6:7] v8        next window: packed word, value (gather in flight), row bytes
+  v[10:11] v12     the window after it: packed word, value's byte offset, row bytes (load in flight)
+  v[16:23]  entry mode: four (LDS address, value) pairs; group mode: v[16:17] v[18:19]
+            value broadcasts, v20 LDS address of a group
   v[32:63]  four strips of 8 floats
   v[64:127] accumulators, row r at v[64 + 8 r ...]   (outputs)
-  s[36:37] stream  s[38:39] values  s[40:41] ends  s[42:43] dense
+  s[36:37] stream  s[38:39] values  s[40:41] chunk info  s[42:43] dense
   s44 row pitch of B in bytes  s45 k - 1  s46 chunks  s47 first B row of the
-  wave inside a chunk  s48 LDS address of the wave's first piece, buffer 0   (inputs)
+  wave inside a chunk  s48 LDS address of the wave's first piece, buffer 0
+  s49 timing-experiment bits   (inputs)
   s50.. scratch (see names below)
 """
-import sys
+import argparse
 
-BK = 32          # rows of B per chunk
-WIN_BYTES = 144  # 16 x (offset, value offset) + 16 row bytes
-NSTRIP = 4       # software pipeline depth (strip sets)
+_ap = argparse.ArgumentParser()
+_ap.add_argument("--mode", default="entry", choices=["entry", "group"])
+_ap.add_argument("--layout", default="straight", choices=["straight", "diagonal"])
+_ap.add_argument("out", nargs="?")
+ARGS = _ap.parse_args()
+GROUP = ARGS.mode == "group"
+
+BK = 32            # rows of B per chunk: a stage is 64 KiB
+BK_SHIFT = 5
+ROW_BYTES = 2048   # bytes of a tile row (512 columns)
+ROW_SHIFT = 11
+WIN_BYTES = 144    # 16 x (packed word, value offset) + 16 row bytes
+NSTRIP = 4         # strips in the ring (reads are issued NSTRIP - 1 entries / groups ahead)
+NPIECES = 4        # 1 KiB pieces of a B tile that a wave copies (32 rows x 2 pieces / 16 waves)
+ROWSTEP = 8        # B rows between a wave's pieces
 
 V_LANE, V_STAGE, V_PLAN, V_ROWS = "v0", "v1", "v2", "v3"
-WIN = [4, 8, 12]                    # first register of each window set
-PAIR = [16, 18, 20, 22]
+CUR_OFF, CUR_VAL = 4, 5
+NXT_OFF, NXT_VAL, NXT_ROWS = 6, 7, 8
+NN_OFF, NN_VAL, NN_ROWS = 10, 11, 12
+PAIR = [16, 18, 20, 22]     # entry mode
+VALT = [16, 18]             # group mode
+V_ADDR = 20                 # group mode
 STRIP = [32, 40, 48, 56]
 ACC = 64
 
-S_STREAM, S_VALUES, S_ENDS, S_DENSE = "s[36:37]", "s[38:39]", "s[40:41]", "s[42:43]"
+S_STREAM, S_VALUES, S_CINFO, S_DENSE = "s[36:37]", "s[38:39]", "s[40:41]", "s[42:43]"
 S_PITCH, S_KMAX, S_NCHUNKS, S_ROW0, S_LDS0, S_DEBUG = "s44", "s45", "s46", "s47", "s48", "s49"
-S_REM, S_C, S_ENDCUR, S_ENDNEXT, S_SB, S_NSW, S_ENDOFF = "s50", "s51", "s52", "s53", "s54", "s55", "s56"
+S_REM, S_C, S_CIOFF, S_MINE, S_SB, S_NSW = "s50", "s51", "s56", "s57", "s76", "s77"
+S_CI = ["s52", "s53", "s54", "s55"]   # the NEXT chunk's info: groups, first group rows, unused, entries
 S_RET, S_BND = "s[58:59]", "s[60:61]"
 S_ROWS = [62, 63, 64, 65]
-S_IDX = [66, 67, 68, 69]
+S_IDX = [66, 67, 68, 69]   # entry mode: ring of accumulator indices; group mode: the first one
+S_COLS = "s78"             # group mode: the new chunk's first three group rows while their reads are issued
 S_T = ["s70", "s71", "s72", "s73", "s74", "s75"]
 
 out = []
@@ -77,86 +119,151 @@ def label(name):
     return f"L_{name}_%="
 
 
-def fma_stage(ring, lgkm):
-    p, s = PAIR[ring], STRIP[ring]
+def strip_reads(ring, addr):
+    s = STRIP[ring]
+    emit(f"ds_read_b128 v[{s}:{s + 3}], v{addr}")
+    emit(f"ds_read_b128 v[{s + 4}:{s + 7}], v{addr} offset:1024")
+
+
+def fmas(src_pair, op_sel, ring):
+    s = STRIP[ring]
+    for q in range(4):
+        emit(f"v_pk_fma_f32 v[{ACC + 2 * q}:{ACC + 2 * q + 1}], v[{src_pair}:{src_pair + 1}], "
+             f"v[{s + 2 * q}:{s + 2 * q + 1}], v[{ACC + 2 * q}:{ACC + 2 * q + 1}] {op_sel}")
+
+
+# ---- entry mode -----------------------------------------------------------
+def entry_fma_stage(ring, lgkm):
+    """The FMAs of the entry whose pair and strip are in ring position `ring`
+    (value = HIGH half of the pair)."""
     emit(f"s_waitcnt lgkmcnt({lgkm})")
     emit(f"s_set_gpr_idx_on s{S_IDX[ring]}, 0xc")
-    for q in range(4):
-        emit(f"v_pk_fma_f32 v[{ACC + 2 * q}:{ACC + 2 * q + 1}], v[{p}:{p + 1}], "
-             f"v[{s + 2 * q}:{s + 2 * q + 1}], v[{ACC + 2 * q}:{ACC + 2 * q + 1}] "
-             f"op_sel:[1,0,0] op_sel_hi:[1,1,1]")
+    fmas(PAIR[ring], "op_sel:[1,0,0] op_sel_hi:[1,1,1]", ring)
     emit("s_set_gpr_idx_off")
 
 
-def issue_stage(win, slot):
+def entry_slot(slot):
     ring = slot % NSTRIP
-    w, p, s = WIN[win], PAIR[ring], STRIP[ring]
-    emit(f"v_mov_b64_dpp v[{p}:{p + 1}], v[{w}:{w + 1}] row_newbcast:{slot} row_mask:0xf bank_mask:0xf")
-    emit(f"s_bfe_u32 s{S_IDX[ring]}, s{S_ROWS[slot // 4]}, {hex(8 * (slot % 4) | (8 << 16))}")
+    p = PAIR[ring]
+    emit(f"{label(f'E_{slot}')}:")
+    emit(f"s_sub_u32 {S_REM}, {S_REM}, 1")
+    emit(f"s_cbranch_scc1 {label(f'bnd_{slot}')}")
+    emit(f"v_mov_b64_dpp v[{p}:{p + 1}], v[{CUR_OFF}:{CUR_VAL}] row_newbcast:{slot} row_mask:0xf bank_mask:0xf")
+    emit(f"s_bfe_u32 s{S_IDX[ring]}, s{S_ROWS[slot // 4]}, {hex(8 * (slot % 4) | (7 << 16))}")
     emit(f"v_add_u32 v{p}, v{p}, {V_LANE}")
-    emit(f"ds_read_b128 v[{s}:{s + 3}], v{p}")
-    emit(f"ds_read_b128 v[{s + 4}:{s + 7}], v{p} offset:1024")
+    strip_reads(ring, p)
+    entry_fma_stage((ring + 1) % NSTRIP, 2 * (NSTRIP - 1))
 
 
+# ---- group mode -----------------------------------------------------------
+def group_entry_body(ring, slot):
+    t = VALT[slot % 2]
+    emit(f"v_mov_b32_dpp v{t}, v{CUR_VAL} row_newbcast:{slot} row_mask:0xf bank_mask:0xf")
+    emit(f"s_bfe_u32 s{S_IDX[0]}, s{S_ROWS[slot // 4]}, {hex(8 * (slot % 4) | (7 << 16))}")
+    emit(f"s_set_gpr_idx_on s{S_IDX[0]}, 0xc")
+    fmas(t, "op_sel:[0,0,0] op_sel_hi:[0,1,1]", ring)
+    emit("s_set_gpr_idx_off")
+
+
+def group_start(ring, slot):
+    """First entry of a column group while strip `ring` is current: the chunk's
+    groups may be used up (-> boundary); else the reads of the group NSTRIP - 1
+    ahead go into strip `ring`, whose group is finished, and strip ring + 1,
+    waited for here, becomes current."""
+    emit(f"{label(f'N_{ring}_{slot}')}:")
+    emit(f"s_sub_u32 {S_REM}, {S_REM}, 1")
+    emit(f"s_cbranch_scc1 {label(f'bnd_{slot}')}")
+    emit(f"v_mov_b32_dpp v{V_ADDR}, v{CUR_OFF} row_newbcast:{slot} row_mask:0xf bank_mask:0xf")
+    emit(f"v_add_u32 v{V_ADDR}, v{V_ADDR}, {V_LANE}")
+    strip_reads(ring, V_ADDR)
+    emit(f"s_waitcnt lgkmcnt({2 * (NSTRIP - 1)})")
+
+
+def first_groups():
+    """Reads of the first three column groups of the chunk whose tile rows (a
+    byte each) are in S_COLS, into strips 0..2."""
+    for i in range(NSTRIP - 1):
+        emit(f"s_bfe_u32 {S_T[0]}, {S_COLS}, {hex(8 * i | (8 << 16))}")
+        emit(f"s_lshl_b32 {S_T[0]}, {S_T[0]}, {ROW_SHIFT}")
+        emit(f"v_add_u32 v{V_ADDR}, {S_T[0]}, {V_LANE}")
+        strip_reads(i, V_ADDR)
+
+
+# ---- common ---------------------------------------------------------------
 def stage_chunk(chunk_sgpr):
-    """LDS-DMA copies of this wave's four pieces of chunk `chunk_sgpr` (< chunks)."""
+    """LDS-DMA copies of this wave's pieces of chunk `chunk_sgpr` (< chunks):
+    B rows chunk * 32 + row0 + 8 i, clamped to the last row of B in the last
+    (possibly partial) chunk -- no nonzero refers to the rows past it."""
     t_row, t_lds, t_r, t_lo, t_hi = S_T[1], S_T[2], S_T[3], S_T[4], S_T[5]
-    emit(f"s_lshl_b32 {t_row}, {chunk_sgpr}, 5")
+    emit(f"s_lshl_b32 {t_row}, {chunk_sgpr}, {BK_SHIFT}")
     emit(f"s_add_u32 {t_row}, {t_row}, {S_ROW0}")
     emit(f"s_and_b32 {t_lds}, {chunk_sgpr}, 1")
     emit(f"s_lshl_b32 {t_lds}, {t_lds}, 16")
     emit(f"s_add_u32 {t_lds}, {t_lds}, {S_LDS0}")
-    for i in range(4):
-        emit(f"s_add_u32 {t_r}, {t_row}, {8 * i}")
+    for i in range(NPIECES):
+        emit(f"s_add_u32 {t_r}, {t_row}, {ROWSTEP * i}")
         emit(f"s_min_u32 {t_r}, {t_r}, {S_KMAX}")
         emit(f"s_mul_hi_u32 {t_hi}, {t_r}, {S_PITCH}")
         emit(f"s_mul_i32 {t_lo}, {t_r}, {S_PITCH}")
         emit(f"s_add_u32 {t_lo}, {t_lo}, s42")
         emit(f"s_addc_u32 {t_hi}, {t_hi}, s43")
-        emit(f"s_add_u32 m0, {t_lds}, {hex(8 * i * 2048)}")
+        emit(f"s_add_u32 m0, {t_lds}, {hex(ROWSTEP * i * ROW_BYTES)}")
         emit("s_nop 0")
         emit(f"global_load_lds_dwordx4 {V_STAGE}, s[{t_lo[1:]}:{t_hi[1:]}]")
 
 
-def plan_load(win):
-    w = WIN[win]
-    emit(f"global_load_dwordx2 v[{w}:{w + 1}], {V_PLAN}, {S_STREAM}")
-    emit(f"global_load_dword v{w + 2}, {V_ROWS}, {S_STREAM}")
+def plan_load(off, rows):
+    emit(f"global_load_dwordx2 v[{off}:{off + 1}], {V_PLAN}, {S_STREAM}")
+    emit(f"global_load_dword v{rows}, {V_ROWS}, {S_STREAM}")
     emit(f"v_add_u32 {V_PLAN}, {hex(WIN_BYTES)}, {V_PLAN}")
     emit(f"v_add_u32 {V_ROWS}, {hex(WIN_BYTES)}, {V_ROWS}")
 
 
-def gather(win):
-    w = WIN[win]
-    emit(f"global_load_dword v{w + 1}, v{w + 1}, {S_VALUES}")
+def gather(val):
+    emit(f"global_load_dword v{val}, v{val}, {S_VALUES}")
 
 
-def switch_to(win, tag):
-    """Window set `win` becomes current: its value gather and the plan load of
-    the set after it must have landed; start that set's gather and the plan
-    load into the set that was current until now."""
-    nxt, old = (win + 1) % 3, (win + 2) % 3
+def switch_window(tag):
+    """The next window becomes current: its value gather and the plan load of the
+    window after it must have landed (the newest operations are the copies of a B
+    tile, if a boundary came since the last switch)."""
     emit(f"s_cmp_lg_u32 {S_SB}, 0")
-    emit(f"s_cbranch_scc1 {label('sw4_' + tag)}")
+    emit(f"s_cbranch_scc1 {label('swc_' + tag)}")
     emit("s_waitcnt vmcnt(0)")
     emit(f"s_branch {label('swd_' + tag)}")
-    emit(f"{label('sw4_' + tag)}:")
-    emit("s_waitcnt vmcnt(4)")
+    emit(f"{label('swc_' + tag)}:")
+    emit(f"s_waitcnt vmcnt({NPIECES})")
     emit(f"{label('swd_' + tag)}:")
     emit(f"s_mov_b32 {S_SB}, 0")
     emit(f"s_add_u32 {S_NSW}, {S_NSW}, 1")
     for i in range(4):
-        emit(f"v_readlane_b32 s{S_ROWS[i]}, v{WIN[win] + 2}, {i}")
+        emit(f"v_readlane_b32 s{S_ROWS[i]}, v{NXT_ROWS}, {i}")
+    # LDS offset of the column the loop reads for an entry: its own (entry mode,
+    # byte 0 of the packed word) or the group three ahead (group mode, byte 1)
+    emit(f"v_bfe_u32 v{CUR_OFF}, v{NXT_OFF}, {8 if GROUP else 0}, 8")
+    emit(f"v_mov_b32 v{CUR_VAL}, v{NXT_VAL}")
+    emit(f"v_lshlrev_b32 v{CUR_OFF}, {ROW_SHIFT}, v{CUR_OFF}")
+    emit(f"v_mov_b64 v[{NXT_OFF}:{NXT_VAL}], v[{NN_OFF}:{NN_VAL}]")
+    emit(f"v_mov_b32 v{NXT_ROWS}, v{NN_ROWS}")
     emit(f"s_bitcmp1_b32 {S_DEBUG}, 3")        # timing experiment: no window loads
     emit(f"s_cbranch_scc1 {label('swskip_' + tag)}")
-    gather(nxt)
-    plan_load(old)
+    gather(NXT_VAL)
+    plan_load(NN_OFF, NN_ROWS)
     emit(f"{label('swskip_' + tag)}:")
+    emit("s_nop 1")                            # VALU write of the window -> DPP read: 2 wait states
+
+
+def take_chunk_info():
+    """The chunk that starts: its count into S_REM (entries or groups), its first
+    group rows into S_COLS."""
+    emit(f"s_mov_b32 {S_REM}, {S_CI[0] if GROUP else S_CI[3]}")
+    if GROUP:
+        emit(f"s_mov_b32 {S_COLS}, {S_CI[1]}")
 
 
 def generate():
     emit("; ---- prologue ----")
-    for r in list(range(ACC, ACC + 64)) + list(range(STRIP[0], STRIP[0] + 32)) + list(range(PAIR[0], PAIR[0] + 8)):
+    for r in list(range(ACC, ACC + 64)) + list(range(STRIP[0], STRIP[0] + 32)) + list(range(16, 24)):
         emit(f"v_mov_b32 v{r}, 0")
     for r in S_IDX:
         emit(f"s_mov_b32 s{r}, 0")
@@ -164,52 +271,84 @@ def generate():
     emit(f"{label('pc')}:")
     emit(f"s_add_u32 s60, s60, {label('boundary')}-{label('pc')}")
     emit("s_addc_u32 s61, s61, 0")
-    plan_load(0)
-    plan_load(1)
-    emit("s_waitcnt vmcnt(2)")       # plan of window 0 landed
-    gather(0)
+    # windows: the plan of window 0 into "next", of window 1 into the stage behind it
+    plan_load(NXT_OFF, NXT_ROWS)
+    plan_load(NN_OFF, NN_ROWS)
+    emit("s_waitcnt vmcnt(2)")
+    gather(NXT_VAL)
     emit(f"s_mov_b32 {S_T[0]}, 0")
     stage_chunk(S_T[0])
-    emit("s_waitcnt vmcnt(0)")
+    emit(f"s_load_dwordx4 s[52:55], {S_CINFO}, 0x0")   # chunk 0
+    emit("s_waitcnt vmcnt(0) lgkmcnt(0)")
     emit("s_barrier")
+    take_chunk_info()
+    emit(f"s_load_dwordx4 s[52:55], {S_CINFO}, 0x10")  # chunk 1 (waited for at the first boundary)
+    emit(f"s_mov_b32 {S_CIOFF}, 32")
     emit(f"s_mov_b32 {S_C}, 0")
-    emit(f"s_mov_b32 {S_SB}, 0")
     emit(f"s_mov_b32 {S_NSW}, 0")
+    emit(f"s_mov_b32 {S_SB}, 0")
+    emit(f"s_mov_b32 {S_MINE}, 0")
+    if GROUP:
+        first_groups()
     emit(f"s_cmp_lt_u32 {S_NCHUNKS}, 2")
     emit(f"s_cbranch_scc1 {label('pro_nostage')}")
     emit(f"s_mov_b32 {S_T[0]}, 1")
     stage_chunk(S_T[0])
     emit(f"s_mov_b32 {S_SB}, 1")
+    emit(f"s_mov_b32 {S_MINE}, 1")
     emit(f"{label('pro_nostage')}:")
-    emit(f"s_load_dwordx2 s[52:53], {S_ENDS}, 0x0")
-    emit(f"s_mov_b32 {S_ENDOFF}, 8")
-    emit("s_waitcnt lgkmcnt(0)")
-    emit(f"s_mov_b32 {S_REM}, {S_ENDCUR}")
-    # window 0 becomes current (its gather and window 1's plan landed: the copies
-    # of chunk 1, if any, are the newest operations)
-    # (s_nsw stays 1: this switch's three loads are newer than the copies of chunk 1)
-    switch_to(0, "pro")
+    # window 0 becomes current (its gather and window 1's plan landed before the
+    # barrier; the copies of chunk 1, if any, are the newest operations)
+    switch_window("pro")
 
     emit("; ---- main loop ----")
-    for win in range(3):
+    if not GROUP:
         for slot in range(16):
-            ring = slot % NSTRIP
-            emit(f"{label(f'slot_{win}_{slot}')}:")
-            emit(f"s_sub_u32 {S_REM}, {S_REM}, 1")
-            emit(f"s_cbranch_scc1 {label(f'bnd_{win}_{slot}')}")
-            issue_stage(win, slot)
-            fma_stage((ring + 1) % NSTRIP, 2 * (NSTRIP - 1))
-        switch_to((win + 1) % 3, f"w{win}")
-        if win == 2:
-            emit(f"s_branch {label('slot_0_0')}")
+            entry_slot(slot)
+        switch_window("w")
+        emit(f"s_branch {label('E_0')}")
+    elif ARGS.layout == "straight":
+        emit(f"s_branch {label(f'E_{NSTRIP - 1}_0')}")
+        for ring in range(NSTRIP):
+            for slot in range(16):
+                emit(f"{label(f'E_{ring}_{slot}')}:")
+                emit(f"s_bitcmp1_b32 s{S_ROWS[slot // 4]}, {8 * (slot % 4) + 7}")
+                emit(f"s_cbranch_scc1 {label(f'N_{ring}_{slot}')}")
+                emit(f"{label(f'B_{ring}_{slot}')}:")
+                group_entry_body(ring, slot)
+            switch_window(f"r{ring}")
+            emit(f"s_branch {label(f'E_{ring}_0')}")
+        emit("; ---- first entry of a column group ----")
+        for ring in range(NSTRIP):
+            for slot in range(16):
+                group_start(ring, slot)
+                emit(f"s_branch {label(f'B_{(ring + 1) % NSTRIP}_{slot}')}")
+    else:
+        emit(f"s_branch {label(f'E_{NSTRIP - 1}_0')}")
+        for diag in range(NSTRIP):
+            for slot in range(16):
+                ring = (diag + slot) % NSTRIP
+                emit(f"{label(f'E_{ring}_{slot}')}:")
+                emit(f"s_bitcmp1_b32 s{S_ROWS[slot // 4]}, {8 * (slot % 4) + 7}")
+                emit(f"s_cbranch_scc0 {label(f'B_{ring}_{slot}')}")
+                group_start(ring, slot)
+                emit(f"{label(f'B_{(ring + 1) % NSTRIP}_{slot}')}:")
+                group_entry_body((ring + 1) % NSTRIP, slot)
+            ring = (diag + 16) % NSTRIP       # current behind slot 15
+            switch_window(f"r{diag}")
+            emit(f"s_branch {label(f'E_{ring}_0')}")
 
     emit("; ---- boundary stubs ----")
-    for win in range(3):
-        for slot in range(16):
-            emit(f"{label(f'bnd_{win}_{slot}')}:")
-            emit(f"s_swappc_b64 {S_RET}, {S_BND}")
+    for slot in range(16):
+        emit(f"{label(f'bnd_{slot}')}:")
+        emit(f"s_swappc_b64 {S_RET}, {S_BND}")
+        if GROUP:
+            emit(f"s_cbranch_scc1 {label('end')}")
+            # strips 0..2 hold the new chunk's first groups: "strip 3 was current"
+            emit(f"s_branch {label(f'N_{NSTRIP - 1}_{slot}')}")
+        else:
             emit(f"s_cbranch_scc1 {label(f'drain_{slot % NSTRIP}')}")
-            emit(f"s_branch {label(f'slot_{win}_{slot}')}")
+            emit(f"s_branch {label(f'E_{slot}')}")
 
     emit("; ---- boundary subroutine ----")
     emit(f"{label('boundary')}:")
@@ -217,6 +356,8 @@ def generate():
     emit(f"s_cbranch_scc1 {label('bnodrain')}")
     emit("s_waitcnt lgkmcnt(0)")
     emit(f"{label('bnodrain')}:")
+    emit(f"s_cmp_eq_u32 {S_MINE}, 0")          # no copies of the next chunk pending
+    emit(f"s_cbranch_scc1 {label('bvd')}")
     for n in range(3):
         emit(f"s_cmp_eq_u32 {S_NSW}, {n}")
         emit(f"s_cbranch_scc1 {label(f'bv{n}')}")
@@ -235,11 +376,13 @@ def generate():
     emit(f"s_add_u32 {S_C}, {S_C}, 1")
     emit(f"s_cmp_eq_u32 {S_C}, {S_NCHUNKS}")
     emit(f"s_cbranch_scc1 {label('bret')}")
-    emit(f"s_sub_u32 {S_REM}, {S_ENDNEXT}, {S_ENDCUR}")
-    emit(f"s_mov_b32 {S_ENDCUR}, {S_ENDNEXT}")
-    emit(f"s_load_dword {S_ENDNEXT}, {S_ENDS}, {S_ENDOFF}")
-    emit(f"s_add_u32 {S_ENDOFF}, {S_ENDOFF}, 4")
+    take_chunk_info()
+    emit(f"s_load_dwordx4 s[52:55], {S_CINFO}, {S_CIOFF}")   # the chunk after this one
+    emit(f"s_add_u32 {S_CIOFF}, {S_CIOFF}, 16")
+    if GROUP:
+        first_groups()
     emit(f"s_mov_b32 {S_NSW}, 0")
+    emit(f"s_mov_b32 {S_MINE}, 0")
     emit(f"s_add_u32 {S_T[0]}, {S_C}, 1")
     emit(f"s_cmp_ge_u32 {S_T[0]}, {S_NCHUNKS}")
     emit(f"s_cbranch_scc1 {label('bnostage')}")
@@ -247,32 +390,33 @@ def generate():
     emit(f"s_cbranch_scc1 {label('bnostage')}")
     stage_chunk(S_T[0])
     emit(f"s_add_u32 {S_SB}, {S_SB}, 1")
+    emit(f"s_mov_b32 {S_MINE}, 1")
     emit(f"{label('bnostage')}:")
     emit(f"s_cmp_eq_u32 {S_C}, {S_NCHUNKS}")   # SCC = 0: not finished
     emit(f"{label('bret')}:")
     emit(f"s_setpc_b64 {S_RET}")
 
-    emit("; ---- drain: the three entries still in the pipeline ----")
-    for ring in range(NSTRIP):
-        emit(f"{label(f'drain_{ring}')}:")
-        for j in range(1, NSTRIP):
-            fma_stage((ring + j) % NSTRIP, 2 * (NSTRIP - 1 - j))
-        if ring < NSTRIP - 1:
-            emit(f"s_branch {label('end')}")
+    if not GROUP:
+        emit("; ---- drain: the three entries still in the pipeline ----")
+        for ring in range(NSTRIP):
+            emit(f"{label(f'drain_{ring}')}:")
+            for j in range(1, NSTRIP):
+                entry_fma_stage((ring + j) % NSTRIP, 2 * (NSTRIP - 1 - j))
+            if ring < NSTRIP - 1:
+                emit(f"s_branch {label('end')}")
     emit(f"{label('end')}:")
     emit("s_waitcnt vmcnt(0) lgkmcnt(0)")
 
 
 def main():
     generate()
-    path = sys.argv[1] if len(sys.argv) > 1 else None
     text = "// GENERATED by gen_spmm_flat.py -- do not edit.\n" + "".join(
         f'"{line}\\n"\n' for line in out)
-    if path:
-        with open(path, "w") as f:
+    if ARGS.out:
+        with open(ARGS.out, "w") as f:
             f.write(text)
     else:
-        sys.stdout.write(text)
+        print(text, end="")
 
 
 if __name__ == "__main__":

@@ -10,25 +10,36 @@
 //
 // Here the accumulator row of a nonzero is selected at run time with the VGPR
 // index mode (s_set_gpr_idx_on: destination and src2 of the four v_pk_fma_f32
-// become M0-relative), so ONE instruction stream serves every row, and a wave
-// consumes a FLAT stream per K chunk: the entries of all of its rows back to
-// back, in a software pipeline (the LDS reads of entry j+3 are in flight while
-// entry j is multiplied; tools/gpridx_bench.hip: 16 ns per entry and SIMD, what
-// the static-register step costs).  Per chunk a wave pays one boundary
-// (rendezvous + the copies of the next B tile), whatever the number of rows.
+// become M0-relative), so ONE instruction stream serves every row and a wave
+// consumes a FLAT stream: the entries of all of its 8 rows, K chunk after K
+// chunk, sorted by (column, row).  Two loops read it (gen_spmm_flat.py):
+//   * "entry": every entry reads its B strip from LDS three entries ahead of
+//     its FMAs, in a software pipeline without a taken branch -- the loop of
+//     spmm_tiled.hip minus everything per (row, chunk); bound by the LDS (one B
+//     dword per FMA);
+//   * "group": entries of the same column of B follow each other in the stream
+//     (a "column group") and the column's strip is read once per group, three
+//     groups ahead -- 0.57 reads per entry at density 0.1, 0.25 at 0.5 -- which
+//     takes the loop off the LDS roof at the price of branches at group starts.
+// The dispatcher picks the loop by density (flat_mode below).  Per K chunk a wave
+// pays one boundary (rendezvous + the copies of the next B tile), whatever the
+// number of rows.
 //
 // The stream is made by the pre-pass from the topology alone (the plan is valid
-// for any values and any number of replicas): per group of RPW rows (one
-// wave's), the entries sorted by (K chunk, row, column) in blocks ("windows") of
-// 16 -- per entry the LDS byte offset of its B row, the byte offset of its value
-// in `values` (gathered by the kernel one window ahead), and the accumulator
-// index of its row.  Per output element the summation order is the CSR order,
-// as in every other kernel of this library (bitwise the same results).
+// for any values, any number of replicas and both loops): per group of 8 row
+// slots (one wave's) blocks ("windows") of 16 entries -- per entry the byte
+// offset of its value in `values` (gathered by the kernel one window ahead), the
+// tile row of its column, the accumulator index of its row, a flag on the first
+// entry of a column group and, there, the tile row of the group three ahead.
+// Per output element the summation order is the ascending-column order, i.e. the
+// CSR order, as in every other kernel of this library (bitwise the same results).
 //
 // The main loop is generated assembly (gen_spmm_flat.py -> spmm_flat_body.inc);
 // this file holds the pre-pass, the prologue / epilogue around the loop and the
 // host side.  Replaces sputnik::CudaSpmm at /root/reference/src/spmm_cuda.cu:49-56
 // for the shapes spmm_flat_applicable() names.
+#include <algorithm>
+
 #include "options.h"
 #include "spmm_tiled_common.h"
 
@@ -41,32 +52,58 @@ using namespace tiled;
 constexpr int kBN = 512;       // columns of C per workgroup
 constexpr int kBK = 32;        // rows of B per chunk (two 64 KiB stages)
 constexpr int kWaves = 16;     // waves per workgroup
+constexpr int kRPW = 8;        // rows per wave (the generated loop's accumulator map)
+constexpr int kBM = kWaves * kRPW;
+constexpr int kAhead = 3;      // column groups read ahead (strip ring of 4)
 constexpr int kDealPer = 256;  // as spmm_tiled.hip: row slots are dealt in runs of 256
 constexpr int kWindow = 16;    // entries per window
-constexpr int kWindowBytes = 144;  // 16 x (offset, value offset) + 16 row bytes
-constexpr int kTailWindows = 4;    // zero windows behind the last group (prefetch runs ahead)
-constexpr int kMaxFlat = 8192;     // chunks x rows per wave that the fill kernel scans in LDS
+constexpr int kWindowBytes = 144;  // 16 x (tile rows, value offset) + 16 row bytes
+constexpr int kTailWindows = 4;    // empty windows behind the last group (prefetch runs ahead)
+constexpr int kMaxColumns = 65536; // the pre-pass keeps a row mask (one byte) per column in LDS
+constexpr unsigned kNewGroup = 0x80;  // row byte: first entry of a column group
+
+// (A 256 x 256 shape of the same loops -- 16 rows per wave, 64-row chunks, half
+// the B copies per FMA, a quarter of the boundaries -- was built and measured:
+// 0.42 ms against 0.33 at density 0.1.  Per entry it has half the FMAs for the
+// same scalar instructions and branches.)
+
+// Per group of row slots and K chunk: the number of column groups and of entries
+// of the chunk, and the tile rows (column modulo 2 BK, a byte each) of the first
+// three groups, whose LDS reads the group loop issues right behind the rendezvous.
+struct ChunkInfo {
+  int groups;
+  unsigned first_rows;
+  unsigned unused;
+  int entries;
+};
 
 // ---------------------------------------------------------------------------
-// Pre-pass, second half (the first is spmm_chunk_table_kernel<32>): one
-// workgroup per group of RPW row slots, one wave per row.
-//   ends[g][c]  stream position (in entries) of the group behind K chunk c
-//   gwin[g]     first window of the group's stream
-//   stream      the windows
+// Pre-pass: one workgroup per group of 8 row slots, one wave per row.
+//   row_ok[slot]  the row's columns ascend and are in range (else its workgroup
+//                 takes the order-independent path, as in spmm_tiled.hip)
+//   cinfo[g][c]   ChunkInfo
+//   gwin[g]       first window of the group's stream
+//   stream        the windows
+// The (column, row) order comes from one byte per column in LDS: bit r = row r
+// of the group holds the column.  The position of an entry is the number of set
+// bits in front of it, the first set bit of a byte starts a column group.
 // ---------------------------------------------------------------------------
-template <int RPW>
-__global__ __launch_bounds__(RPW * 64) void spmm_flat_fill_kernel(
-    int m, int slots, int nchunks, const int* __restrict__ row_indices,
+__global__ __launch_bounds__(kRPW * 64) void spmm_flat_fill_kernel(
+    int m, int k, int slots, int nchunks, const int* __restrict__ row_indices,
     const int* __restrict__ row_offsets, const int* __restrict__ column_indices,
-    const int* __restrict__ table, const int* __restrict__ row_ok, int* __restrict__ ends,
-    int* __restrict__ gwin, unsigned char* __restrict__ stream) {
-  extern __shared__ int lds[];  // [nchunks * RPW] position deltas, then scratch
-  constexpr int NT = RPW * 64;
+    int* __restrict__ row_ok, ChunkInfo* __restrict__ cinfo, int* __restrict__ gwin,
+    unsigned char* __restrict__ stream) {
+  extern __shared__ unsigned lds[];
+  constexpr int RPW = kRPW, BK = kBK, NT = RPW * 64;
+  constexpr int CPW = 32 / RPW;           // columns per mask word (RPW bits each)
+  constexpr int WPC = BK / CPW;           // mask words per chunk
+  constexpr unsigned kRowBits = (1u << RPW) - 1u;
   const int g = blockIdx.x, tid = threadIdx.x, lane = tid % 64, wave = tid / 64;
   const int groups = gridDim.x;
-  const int flat = nchunks * RPW;
-  int* delta = lds;
-  int* scratch = lds + flat;  // NT + 2 words
+  unsigned* maskw = lds;                                        // [nchunks * WPC]
+  int* ebase = reinterpret_cast<int*>(lds + nchunks * WPC);     // [nchunks]: entries before the chunk
+  int* scratch = ebase + nchunks;                               // [NT + 2]
+  auto col_mask = [&](int c, int j) { return (maskw[c * WPC + j / CPW] >> (RPW * (j % CPW))) & kRowBits; };
 
   auto slot_len = [&](int slot) {
     const int entry = dealt_index(slot, slots, kDealPer);
@@ -75,7 +112,8 @@ __global__ __launch_bounds__(RPW * 64) void spmm_flat_fill_kernel(
     return row_offsets[row + 1] - row_offsets[row];
   };
 
-  // (1) windows of all groups before this one; this group's entry count and state
+  for (int i = tid; i < nchunks * WPC; i += NT) maskw[i] = 0;
+  // (1) windows of all groups before this one; this group's entry count
   int before = 0;
   for (int gp = tid; gp < g; gp += NT) {
     int len = 0;
@@ -84,13 +122,10 @@ __global__ __launch_bounds__(RPW * 64) void spmm_flat_fill_kernel(
   }
   scratch[tid] = before;
   if (tid == 0) {
-    int len = 0, ok = 1;
-    for (int r = 0; r < RPW; ++r) {
-      len += slot_len(g * RPW + r);
-      ok &= row_ok[g * RPW + r];
-    }
+    int len = 0;
+    for (int r = 0; r < RPW; ++r) len += slot_len(g * RPW + r);
     scratch[NT] = len;
-    scratch[NT + 1] = ok;
+    scratch[NT + 1] = 1;
   }
   __syncthreads();
   for (int s = NT / 2; s > 0; s /= 2) {
@@ -99,82 +134,123 @@ __global__ __launch_bounds__(RPW * 64) void spmm_flat_fill_kernel(
   }
   const int wbase = scratch[0];
   const int total = scratch[NT];
-  const bool group_ok = scratch[NT + 1] != 0;
   __syncthreads();
   if (tid == 0) gwin[g] = wbase;
   unsigned char* my_stream = stream + static_cast<int64_t>(wbase) * kWindowBytes;
   const int windows = (total + kWindow - 1) / kWindow;
 
-  if (!group_ok) {
+  // (2) the rows: order check, column masks
+  const int slot = g * RPW + wave;
+  const int entry = dealt_index(slot, slots, kDealPer);
+  int p0 = 0, p1 = 0;
+  if (entry < m) {
+    const int row = row_indices[entry];
+    p0 = row_offsets[row];
+    p1 = row_offsets[row + 1];
+  }
+  bool ok = true;
+  for (int p = p0 + lane; p < p1; p += 64) {
+    const int cur = column_indices[p];
+    const int prev = p > p0 ? column_indices[p - 1] : -1;
+    if (cur <= prev || cur >= k) ok = false;
+    else atomicOr(&maskw[cur / CPW], (1u << wave) << (RPW * (cur % CPW)));
+  }
+  const bool wave_ok = __builtin_amdgcn_ballot_w64(!ok) == 0;
+  if (lane == 0) {
+    row_ok[slot] = wave_ok ? 1 : 0;
+    if (!wave_ok) scratch[NT + 1] = 0;
+  }
+  __syncthreads();
+  ChunkInfo* my_info = cinfo + static_cast<int64_t>(g) * (nchunks + 1);
+  if (scratch[NT + 1] == 0) {
     // A row whose columns do not ascend: its workgroup takes the order-independent
     // path and never reads this stream -- but the prefetch of the group before
-    // runs into it, so it must hold valid value offsets: all zero.
-    int* w = reinterpret_cast<int*>(my_stream);
-    const int words = (windows + (g == groups - 1 ? kTailWindows : 0)) * (kWindowBytes / 4);
-    for (int i = tid; i < words; i += NT) w[i] = 0;
-    for (int c = tid; c <= nchunks; c += NT) ends[static_cast<int64_t>(g) * (nchunks + 1) + c] = 0;
+    // runs into it, so it must hold valid value offsets (zero) and group flags.
+    unsigned* w = reinterpret_cast<unsigned*>(my_stream);
+    const int nwin = windows + (g == groups - 1 ? kTailWindows : 0);
+    for (int i = tid; i < nwin * (kWindowBytes / 4); i += NT)
+      w[i] = i % (kWindowBytes / 4) >= 32 ? 0x80808080u : 0u;
+    for (int c = tid; c <= nchunks; c += NT) my_info[c] = ChunkInfo{0, 0u, 0u, 0};
     return;
   }
 
-  // (2) exclusive scan of the (chunk, row) counts in chunk-major order
-  const int per = (flat + NT - 1) / NT;
-  const int f0 = tid * per, f1 = min(f0 + per, flat);
-  int sum = 0;
-  for (int f = f0; f < f1; ++f) {
-    const int c = f / RPW, slot = g * RPW + f % RPW;
-    sum += table[static_cast<int64_t>(c + 1) * slots + slot] - table[static_cast<int64_t>(c) * slots + slot];
+  // (3) per chunk: entries, column groups, the tile rows of the first groups
+  for (int c = tid; c < nchunks; c += NT) {
+    int entries = 0, cgroups = 0;
+    unsigned first = 0u;
+    for (int j = 0; j < BK; ++j) {
+      const unsigned rows = col_mask(c, j);
+      if (rows) {
+        entries += __popc(rows);
+        if (cgroups < kAhead) first |= static_cast<unsigned>((c & 1) * BK + j) << (8 * cgroups);
+        ++cgroups;
+      }
+    }
+    ebase[c] = entries;
+    my_info[c] = ChunkInfo{cgroups, first, 0u, entries};
   }
-  scratch[tid] = sum;
+  if (tid == 0) my_info[nchunks] = ChunkInfo{0, 0u, 0u, 0};   // (read one chunk ahead)
   __syncthreads();
-  for (int off = 1; off < NT; off *= 2) {   // inclusive scan of the per-thread sums
-    const int v = tid >= off ? scratch[tid - off] : 0;
+  {  // exclusive scan of the entry counts over the chunks
+    const int per = (nchunks + NT - 1) / NT;
+    const int c0 = min(tid * per, nchunks), c1 = min(c0 + per, nchunks);
+    int sum = 0;
+    for (int c = c0; c < c1; ++c) sum += ebase[c];
+    scratch[tid] = sum;
     __syncthreads();
-    scratch[tid] += v;
-    __syncthreads();
-  }
-  int run = scratch[tid] - sum;
-  int* my_ends = ends + static_cast<int64_t>(g) * (nchunks + 1);
-  for (int f = f0; f < f1; ++f) {
-    const int c = f / RPW, r = f % RPW, slot = g * RPW + r;
-    const int first = table[static_cast<int64_t>(c) * slots + slot];
-    const int cnt = table[static_cast<int64_t>(c + 1) * slots + slot] - first;
-    delta[f] = run - first;   // stream position of the row's entry p in chunk c = delta + p
-    run += cnt;
-    if (r == RPW - 1) {
-      my_ends[c] = run;
-      if (c == nchunks - 1) my_ends[nchunks] = run;  // (read one chunk ahead)
+    for (int off = 1; off < NT; off *= 2) {
+      const int v = tid >= off ? scratch[tid - off] : 0;
+      __syncthreads();
+      scratch[tid] += v;
+      __syncthreads();
+    }
+    int run = scratch[tid] - sum;
+    for (int c = c0; c < c1; ++c) {
+      const int e = ebase[c];
+      ebase[c] = run;
+      run += e;
     }
   }
   __syncthreads();
 
-  // (3) the entries: wave = row
-  {
-    const int slot = g * RPW + wave;
-    const int entry = dealt_index(slot, slots, kDealPer);
-    if (entry < m) {
-      const int row = row_indices[entry];
-      const int p1 = row_offsets[row + 1];
-      for (int p = row_offsets[row] + lane; p < p1; p += 64) {
-        const int col = column_indices[p];
-        const int pos = delta[(col / kBK) * RPW + wave] + p;
-        unsigned char* block = my_stream + static_cast<int64_t>(pos / kWindow) * kWindowBytes;
-        const int e = pos % kWindow;
-        // LDS byte offset of the B row: chunk parity picks the stage, 2 KiB per row
-        *reinterpret_cast<uint2*>(block + 8 * e) =
-            make_uint2(static_cast<unsigned>(col % (2 * kBK)) * (kBN * 4), static_cast<unsigned>(p) * 4u);
-        block[128 + e] = static_cast<unsigned char>(wave * 8);
-      }
+  // (4) the entries
+  for (int p = p0 + lane; p < p1; p += 64) {
+    const int col = column_indices[p];
+    const int c = col / BK, j = col % BK;
+    int prefix = 0;
+    for (int i = 0; i < j / CPW; ++i) prefix += __popc(maskw[c * WPC + i]);
+    prefix += __popc(maskw[c * WPC + j / CPW] & ((1u << (RPW * (j % CPW))) - 1u));
+    const int own = __popc(col_mask(c, j) & ((1u << wave) - 1u));
+    const int pos = ebase[c] + prefix + own;
+    // tile rows (stage parity * BK + column in chunk): byte 0 the entry's own
+    // column, byte 1 the column group kAhead groups further on, if the chunk has one
+    unsigned rowbyte = wave * 8, tile_rows = static_cast<unsigned>((c & 1) * BK + j);
+    if (own == 0) {
+      rowbyte |= kNewGroup;
+      int seen = 0;
+      for (int jj = j + 1; jj < BK; ++jj)
+        if (col_mask(c, jj))
+          if (++seen == kAhead) {
+            tile_rows |= static_cast<unsigned>((c & 1) * BK + jj) << 8;
+            break;
+          }
     }
+    unsigned char* block = my_stream + static_cast<int64_t>(pos / kWindow) * kWindowBytes;
+    const int e = pos % kWindow;
+    *reinterpret_cast<uint2*>(block + 8 * e) = make_uint2(tile_rows, static_cast<unsigned>(p) * 4u);
+    block[128 + e] = static_cast<unsigned char>(rowbyte);
   }
-  // (4) unused entries of the last window, and the zero windows behind the last group
+  // (5) unused entries of the last window, and the empty windows behind the last group:
+  // flagged as group starts, so that the loop meets its end-of-chunk test there
   for (int pos = total + tid; pos < windows * kWindow; pos += NT) {
     unsigned char* block = my_stream + static_cast<int64_t>(pos / kWindow) * kWindowBytes;
     *reinterpret_cast<uint2*>(block + 8 * (pos % kWindow)) = make_uint2(0u, 0u);
-    block[128 + pos % kWindow] = 0;
+    block[128 + pos % kWindow] = static_cast<unsigned char>(kNewGroup);
   }
   if (g == groups - 1) {
-    int* w = reinterpret_cast<int*>(my_stream + static_cast<int64_t>(windows) * kWindowBytes);
-    for (int i = tid; i < kTailWindows * (kWindowBytes / 4); i += NT) w[i] = 0;
+    unsigned* w = reinterpret_cast<unsigned*>(my_stream + static_cast<int64_t>(windows) * kWindowBytes);
+    for (int i = tid; i < kTailWindows * (kWindowBytes / 4); i += NT)
+      w[i] = i % (kWindowBytes / 4) >= 32 ? 0x80808080u : 0u;
   }
 }
 
@@ -183,17 +259,33 @@ __global__ __launch_bounds__(RPW * 64) void spmm_flat_fill_kernel(
 // ---------------------------------------------------------------------------
 using v8f = float __attribute__((ext_vector_type(8)));
 
-template <int RPW>
+#define SPUTNIK_HIP_FLAT_ASM_OPERANDS                                                              \
+      : "={v[64:71]}"(a0), "={v[72:79]}"(a1), "={v[80:87]}"(a2), "={v[88:95]}"(a3),                \
+        "={v[96:103]}"(a4), "={v[104:111]}"(a5), "={v[112:119]}"(a6), "={v[120:127]}"(a7)          \
+      : "{v0}"(lane_base), "{v1}"(stage_off), "{v2}"(plan_off), "{v3}"(rows_off),                  \
+        "{s[36:37]}"(my_stream), "{s[38:39]}"(values), "{s[40:41]}"(my_info), "{s[42:43]}"(dense), \
+        "{s44}"(pitch), "{s45}"(kmax), "{s46}"(nchunks), "{s47}"(row0), "{s48}"(lds0),             \
+        "{s49}"(debug)                                                                             \
+      : "memory", "m0", "scc", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13",     \
+        "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v32", "v33", "v34", \
+        "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", \
+        "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", \
+        "v61", "v62", "v63", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", \
+        "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", \
+        "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80"
+
+// LOOP: 0 = entry loop, 1 = group loop, straight layout, 2 = group loop, diagonal layout
+template <int LOOP>
 __global__ __launch_bounds__(kWaves * 64) void spmm_flat_kernel(
     int m, int k, int n, int slots, int nchunks, int n_tiles, const int* __restrict__ row_indices,
-    const float* __restrict__ values, int64_t values_stride, const int* __restrict__ ends,
+    const float* __restrict__ values, int64_t values_stride, const ChunkInfo* __restrict__ cinfo,
     const int* __restrict__ gwin, const unsigned char* __restrict__ stream,
     const float* __restrict__ dense, int64_t dense_stride, float* __restrict__ out,
     int64_t out_stride, const int* __restrict__ row_ok, const int* __restrict__ row_offsets,
     const int* __restrict__ column_indices, int debug, Epilogue epi) {
-  static_assert(RPW == 8, "accumulator map of the generated loop");
-  constexpr int BM = kWaves * RPW;
-  __shared__ float tile[2][kBK * kBN];
+  constexpr int RPW = kRPW, BM = kBM, BN = kBN, BK = kBK, VEC = 8;
+  constexpr int PPR = VEC / 4;   // 1 KiB pieces per B row
+  __shared__ float tile[2][BK * BN];
 
   const int lane = threadIdx.x % kWave;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -220,7 +312,7 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_flat_kernel(
   dense += replica * dense_stride;
   out += replica * out_stride;
 
-  const int n0 = ntile * kBN;
+  const int n0 = ntile * BN;
   const int slot0 = mblock * BM + wave * RPW;
 
   if (!block_rows_ok_wave(row_ok, mblock * BM, BM)) {
@@ -229,7 +321,7 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_flat_kernel(
       if (entry >= m) continue;
       const int row = row_indices[entry];
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      for (int h = 0; h < PPR; ++h) {
         const int col = n0 + h * 256 + lane * 4;
         if (col >= n) continue;
         const float4 acc4 = gather_row_strip(values, column_indices, row_offsets[row],
@@ -244,31 +336,32 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_flat_kernel(
   const int group = slot0 / RPW;
   const unsigned char* my_stream =
       stream + static_cast<int64_t>(__builtin_amdgcn_readfirstlane(gwin[group])) * kWindowBytes;
-  const int* my_ends = ends + static_cast<int64_t>(group) * (nchunks + 1);
+  const ChunkInfo* my_info = cinfo + static_cast<int64_t>(group) * (nchunks + 1);
   const unsigned tile_lds = static_cast<unsigned>(reinterpret_cast<uintptr_t>(AS_LDS(&tile[0][0])));
   const unsigned lane_base = tile_lds + lane * 16;
-  // this wave copies piece (wave % 2) of rows wave / 2 + 8 i of every chunk
-  const unsigned stage_off = static_cast<unsigned>(min(n0 + (wave & 1) * 256 + lane * 4, n - 4)) * 4u;
+  // this wave copies piece (wave % PPR) of rows wave / PPR + (16 / PPR) i, i < 4, of every chunk
+  const unsigned stage_off =
+      static_cast<unsigned>(min(n0 + (wave % PPR) * 256 + lane * 4, n - 4)) * 4u;
   const unsigned plan_off = (lane & 15) * 8, rows_off = 128 + (lane & 3) * 4;
-  const int pitch = n * 4, kmax = k - 1, row0 = wave / 2;
-  const int lds0 = static_cast<int>(tile_lds) + (wave / 2) * (kBN * 4) + (wave & 1) * 1024;
+  const int pitch = n * 4, kmax = k - 1, row0 = wave / PPR;
+  const int lds0 = static_cast<int>(tile_lds) + (wave / PPR) * (BN * 4) + (wave % PPR) * 1024;
 
   v8f a0, a1, a2, a3, a4, a5, a6, a7;
-  asm volatile(
-#include "spmm_flat_body.inc"
-      : "={v[64:71]}"(a0), "={v[72:79]}"(a1), "={v[80:87]}"(a2), "={v[88:95]}"(a3),
-        "={v[96:103]}"(a4), "={v[104:111]}"(a5), "={v[112:119]}"(a6), "={v[120:127]}"(a7)
-      : "{v0}"(lane_base), "{v1}"(stage_off), "{v2}"(plan_off), "{v3}"(rows_off),
-        "{s[36:37]}"(my_stream), "{s[38:39]}"(values), "{s[40:41]}"(my_ends), "{s[42:43]}"(dense),
-        "{s44}"(pitch), "{s45}"(kmax), "{s46}"(nchunks), "{s47}"(row0), "{s48}"(lds0), "{s49}"(debug)
-      : "memory", "m0", "scc", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13",
-        "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v32", "v33", "v34",
-        "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47",
-        "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60",
-        "v61", "v62", "v63", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59",
-        "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72",
-        "s73", "s74", "s75");
+  if constexpr (LOOP == 0) {
+    asm volatile(
+#include "spmm_flat_body_entry.inc"
+        SPUTNIK_HIP_FLAT_ASM_OPERANDS);
+  } else if constexpr (LOOP == 1) {
+    asm volatile(
+#include "spmm_flat_body_group_s.inc"
+        SPUTNIK_HIP_FLAT_ASM_OPERANDS);
+  } else {
+    asm volatile(
+#include "spmm_flat_body_group_d.inc"
+        SPUTNIK_HIP_FLAT_ASM_OPERANDS);
+  }
 
+  // accumulator registers: row r of the wave at 64 + VEC * r
   const v8f acc[8] = {a0, a1, a2, a3, a4, a5, a6, a7};
 #pragma unroll
   for (int r = 0; r < RPW; ++r) {
@@ -276,52 +369,82 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_flat_kernel(
     if (entry < m) {
       const int row = row_indices[entry];
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
-        if (n0 + h * 256 + lane * 4 < n)
+      for (int h = 0; h < PPR; ++h)
+        if (n0 + h * 256 + lane * 4 < n) {
+          const int f = r * VEC + 4 * h;   // first of the four registers
           *reinterpret_cast<float4*>(out + static_cast<int64_t>(row) * n + n0 + h * 256 + lane * 4) =
-              apply_epilogue(make_float4(acc[r][4 * h], acc[r][4 * h + 1], acc[r][4 * h + 2],
-                                         acc[r][4 * h + 3]),
+              apply_epilogue(make_float4(acc[f / 8][f % 8], acc[f / 8][f % 8 + 1],
+                                         acc[f / 8][f % 8 + 2], acc[f / 8][f % 8 + 3]),
                              epi, row);
+        }
     }
   }
 }
 
 struct FlatPlan {
   int slots, nchunks, n_tiles, groups;
-  size_t row_ok_off, table_off, ends_off, gwin_off, stream_off, bytes;
+  size_t row_ok_off, cinfo_off, gwin_off, stream_off, bytes;
 };
 
 FlatPlan make_flat_plan(int m, int k, int n, int nonzeros) {
-  constexpr int RPW = 8;
   FlatPlan p;
   p.slots = ceil_div(m, kDealPer) * kDealPer;
   p.nchunks = ceil_div(k, kBK);
   p.n_tiles = ceil_div(n, kBN);
-  p.groups = p.slots / RPW;
+  p.groups = p.slots / kRPW;
   auto up = [](size_t v) { return (v + 255) / 256 * 256; };
   p.row_ok_off = 0;
-  p.table_off = row_ok_bytes(p.slots);
-  p.ends_off = up(p.table_off + sizeof(int) * static_cast<size_t>(p.nchunks + 1) * p.slots);
-  p.gwin_off = up(p.ends_off + sizeof(int) * static_cast<size_t>(p.nchunks + 1) * p.groups);
+  p.cinfo_off = row_ok_bytes(p.slots);
+  p.gwin_off = up(p.cinfo_off + sizeof(ChunkInfo) * static_cast<size_t>(p.nchunks + 1) * p.groups);
   p.stream_off = up(p.gwin_off + sizeof(int) * static_cast<size_t>(p.groups));
   const size_t windows = static_cast<size_t>(nonzeros) / kWindow + p.groups + kTailWindows;
   p.bytes = up(p.stream_off + windows * kWindowBytes);
   return p;
 }
 
+size_t fill_lds_bytes(int nchunks) {
+  // masks (a byte per column) + entries per chunk + scratch
+  return sizeof(int) * (static_cast<size_t>(nchunks) * (kBK / 4 + 1) + kRPW * 64 + 2);
+}
+
+// Which loop reads the stream.  p = share of the entries that start a column
+// group = (1 - (1 - d)^8) / (8 d) for density d and 8 rows per wave; the group
+// loop reads p strips per entry instead of one but takes branches at group
+// starts (gen_spmm_flat.py).  Measured at 4096^3 on one GPU (tools/flat_bench.py
+// --loops 2,3,4; ms of the kernel alone, entry / group straight / group diagonal;
+// last column the visit-per-row kernel of spmm_tiled.hip):
+//   density 0.05   0.205  0.234  0.217   0.256
+//           0.10   0.329  0.349  0.326   0.351
+//           0.15   0.439  0.450  0.431   0.456
+//           0.20   0.554  0.546  0.525   0.565
+//           0.25   0.674  0.639  0.623   0.675
+//           0.50   1.259  1.055  1.069   1.277
+// Knob SPUTNIK_HIP_SPMM_SPARSE: 2 / 3 / 4 force entry / group straight / group
+// diagonal.
+int flat_mode(int m, int k, int nonzeros) {
+  const int forced = options().spmm_sparse;
+  if (forced >= 2 && forced <= 4) return forced - 2;
+  const double d = static_cast<double>(nonzeros) / (static_cast<double>(m) * k);
+  return d < 0.12 ? 0 : d < 0.36 ? 2 : 1;
+}
+
 }  // namespace
 
-// The shapes the flat kernel takes: those of the 128 x 512 tile of
-// spmm_tiled.hip when one replica alone gives about one workgroup per CU (the
-// plan then does not depend on the replica count), within the fill kernel's LDS
-// scan and its per-group prefix sum.
+// The shapes the flat kernel can serve: any n that is a multiple of 4 whose column
+// tiles are at most a quarter padding, within the pre-pass's LDS (a row mask per
+// column) and its per-group prefix sum over the groups before.  (Whether it is
+// TAKEN is the dispatcher's matter: spmm_tiled.hip, use_flat.)
 bool spmm_flat_applicable(int m, int k, int n, int nonzeros) {
   if (n % 4 != 0 || k < kBK || m < 64 || nonzeros < 16 * static_cast<int64_t>(m) ||
       nonzeros >= (1 << 29))
     return false;
-  const int64_t tiles = static_cast<int64_t>(ceil_div(m, kWaves * 8)) * ceil_div(n, kBN);
   if (static_cast<int64_t>(ceil_div(n, kBN)) * kBN * 3 > static_cast<int64_t>(n) * 4) return false;
-  return tiles >= 192 && ceil_div(k, kBK) * 8 <= kMaxFlat && m <= 16384;
+  return k <= kMaxColumns && m <= 16384;
+}
+
+// Workgroups of one replica (the dispatcher takes the kernel when they fill the chip).
+int64_t spmm_flat_tiles(int m, int n) {
+  return static_cast<int64_t>(ceil_div(m, kBM)) * ceil_div(n, kBN);
 }
 
 size_t spmm_flat_workspace_bytes(int m, int k, int n, int nonzeros) {
@@ -331,20 +454,18 @@ size_t spmm_flat_workspace_bytes(int m, int k, int n, int nonzeros) {
 int spmm_flat_plan(int m, int k, int n, int nonzeros, const int* row_indices,
                    const int* row_offsets, const int* column_indices, void* workspace,
                    hipStream_t stream) {
-  constexpr int RPW = 8;
   const FlatPlan p = make_flat_plan(m, k, n, nonzeros);
   char* base = static_cast<char*>(workspace);
-  int* row_ok = reinterpret_cast<int*>(base + p.row_ok_off);
-  int* table = reinterpret_cast<int*>(base + p.table_off);
-  hipLaunchKernelGGL((spmm_chunk_table_kernel<kBK>), dim3(ceil_div(p.slots, 4)), dim3(256), 0,
-                     stream, m, k, p.slots, kDealPer, p.nchunks, row_indices, row_offsets,
-                     column_indices, table, row_ok);
-  int st = launch_status();
-  if (st != 0) return st;
-  const size_t lds = sizeof(int) * (static_cast<size_t>(p.nchunks) * RPW + RPW * 64 + 2);
-  hipLaunchKernelGGL((spmm_flat_fill_kernel<RPW>), dim3(p.groups), dim3(RPW * 64), lds, stream, m,
-                     p.slots, p.nchunks, row_indices, row_offsets, column_indices, table, row_ok,
-                     reinterpret_cast<int*>(base + p.ends_off),
+  static const bool lds_ok = [] {   // more than the default 64 KiB for large k
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_flat_fill_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                               static_cast<int>(fill_lds_bytes(kMaxColumns / kBK))) == hipSuccess;
+  }();
+  if (!lds_ok && fill_lds_bytes(p.nchunks) > 64 * 1024) return SPUTNIK_HIP_UNSUPPORTED;
+  hipLaunchKernelGGL(spmm_flat_fill_kernel, dim3(p.groups), dim3(kRPW * 64),
+                     fill_lds_bytes(p.nchunks), stream, m, k, p.slots, p.nchunks, row_indices,
+                     row_offsets, column_indices, reinterpret_cast<int*>(base + p.row_ok_off),
+                     reinterpret_cast<ChunkInfo*>(base + p.cinfo_off),
                      reinterpret_cast<int*>(base + p.gwin_off),
                      reinterpret_cast<unsigned char*>(base + p.stream_off));
   return launch_status();
@@ -354,17 +475,24 @@ int spmm_flat_exec(int m, int k, int n, int nonzeros, int replicas, const int* r
                    const float* values, int64_t values_stride, const int* row_offsets,
                    const int* column_indices, const float* dense, int64_t dense_stride, float* out,
                    int64_t out_stride, const void* workspace, hipStream_t stream, Epilogue epi) {
-  constexpr int RPW = 8;
   const FlatPlan p = make_flat_plan(m, k, n, nonzeros);
   const char* base = static_cast<const char*>(workspace);
-  hipLaunchKernelGGL((spmm_flat_kernel<RPW>), dim3((p.slots / (kWaves * RPW)) * p.n_tiles, replicas),
-                     dim3(kWaves * 64), 0, stream, m, k, n, p.slots, p.nchunks, p.n_tiles,
-                     row_indices, values, values_stride,
-                     reinterpret_cast<const int*>(base + p.ends_off),
-                     reinterpret_cast<const int*>(base + p.gwin_off),
-                     reinterpret_cast<const unsigned char*>(base + p.stream_off), dense,
-                     dense_stride, out, out_stride, reinterpret_cast<const int*>(base + p.row_ok_off),
-                     row_offsets, column_indices, options().spmm_debug, epi);
+#define SPUTNIK_HIP_LAUNCH_FLAT(LOOP)                                                              \
+  hipLaunchKernelGGL((spmm_flat_kernel<LOOP>), dim3((p.slots / kBM) * p.n_tiles, replicas),        \
+                     dim3(kWaves * 64), 0, stream, m, k, n, p.slots, p.nchunks, p.n_tiles,         \
+                     row_indices, values, values_stride,                                           \
+                     reinterpret_cast<const ChunkInfo*>(base + p.cinfo_off),                       \
+                     reinterpret_cast<const int*>(base + p.gwin_off),                              \
+                     reinterpret_cast<const unsigned char*>(base + p.stream_off), dense,           \
+                     dense_stride, out, out_stride,                                                \
+                     reinterpret_cast<const int*>(base + p.row_ok_off), row_offsets,               \
+                     column_indices, options().spmm_debug, epi)
+  switch (flat_mode(m, k, nonzeros)) {
+    case 0: SPUTNIK_HIP_LAUNCH_FLAT(0); break;
+    case 1: SPUTNIK_HIP_LAUNCH_FLAT(1); break;
+    default: SPUTNIK_HIP_LAUNCH_FLAT(2); break;
+  }
+#undef SPUTNIK_HIP_LAUNCH_FLAT
   return launch_status();
 }
 

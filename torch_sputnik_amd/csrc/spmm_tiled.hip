@@ -61,6 +61,7 @@ int spmm_tiled64_exec(int m, int k, int n, int nonzeros, int replicas, const int
 
 // Flat-stream form of the 128 x 512 tile (spmm_flat.hip).
 bool spmm_flat_applicable(int m, int k, int n, int nonzeros);
+int64_t spmm_flat_tiles(int m, int n);
 size_t spmm_flat_workspace_bytes(int m, int k, int n, int nonzeros);
 int spmm_flat_plan(int m, int k, int n, int nonzeros, const int* row_indices,
                    const int* row_offsets, const int* column_indices, void* workspace,
@@ -488,7 +489,7 @@ inline bool tiled_applicable(int m, int k, int n, int nonzeros) {
 // 15.2 TFLOP/s, with 16 replicas 28.5 vs 23.2).  The choice needs the replica
 // count, which a plan made ahead of time does not know: then both tables are
 // built (side by side in the workspace) and the call decides.
-enum class Kernel { kNone, kWide, kNarrow, kEither, kWide512 };
+enum class Kernel { kNone, kWide, kNarrow, kEither, kWide512, kFlat };
 
 inline bool tiled512_applicable(int m, int k, int n, int nonzeros) {
   return forced_kernel() <= 0 && fits_tiles(n, CfgWide512::kBN) && k >= CfgWide512::kBK && m >= 64 &&
@@ -499,12 +500,13 @@ inline int64_t tiles512(int m, int n) {
   return static_cast<int64_t>(ceil_div(m, CfgWide512::kBM)) * ceil_div(n, CfgWide512::kBN);
 }
 constexpr int64_t kTiles512From = 192;
-// The flat-stream kernel serves the 128 x 512 tile when ONE replica gives about a
+// The flat-stream kernel (spmm_flat.hip) is taken when ONE replica gives about a
 // workgroup per CU (its plan then does not depend on the replica count); the knob
-// "flat" takes it for any shape it can serve, "wide512" keeps the visit-per-row form.
+// "flat" takes it for any shape it can serve, "wide512" / "wide" keep the
+// visit-per-row kernels of this file.
 inline bool use_flat(int m, int k, int n, int nonzeros) {
   const int forced = forced_kernel();
-  return (forced == -3 || (forced == 0 && tiles512(m, n) >= kTiles512From)) &&
+  return (forced == -3 || (forced == 0 && spmm_flat_tiles(m, n) >= kTiles512From)) &&
          spmm_flat_applicable(m, k, n, nonzeros);
 }
 // A row has more than about two entries per 32-row chunk (below that the 64-row
@@ -516,18 +518,14 @@ inline bool long_enough_for_512(int m, int k, int nonzeros) {
 // call, but the shape alone does not select it: a workspace that has to serve
 // any replica count carries its table BEHIND those of the other kernels.
 inline bool wide512_possible(int m, int k, int n, int nonzeros) {
-  return forced_kernel() == 0 && tiled512_applicable(m, k, n, nonzeros) &&
+  return forced_kernel() == 0 && !use_flat(m, k, n, nonzeros) && tiled512_applicable(m, k, n, nonzeros) &&
          long_enough_for_512(m, k, nonzeros) && 2 * tiles512(m, n) < kTiles512From;
 }
 
 inline size_t wide512_workspace_bytes(int m, int k, int n, int nonzeros) {
   const Plan plan = make_plan<CfgWide512>(m, k, n);
-  const size_t visit_form = (row_ok_bytes(plan.slots) + plan.table_bytes + 15) / 16 * 16;
-  // (the larger of the two forms whenever the flat one is possible at all, so that a
-  // workspace serves whichever the knob selects)
-  return spmm_flat_applicable(m, k, n, nonzeros)
-             ? std::max(visit_form, spmm_flat_workspace_bytes(m, k, n, nonzeros))
-             : visit_form;
+  (void)nonzeros;
+  return (row_ok_bytes(plan.slots) + plan.table_bytes + 15) / 16 * 16;
 }
 
 inline size_t wide_workspace_bytes(int m, int k, int n) {
@@ -552,6 +550,7 @@ inline Kernel choose_kernel(int m, int k, int n, int nonzeros, int replicas /* <
     if (work < (int64_t{1} << 27) || (replicas < 8 && work < (int64_t{1} << 29)))
       return Kernel::kNone;
   }
+  if (use_flat(m, k, n, nonzeros)) return Kernel::kFlat;
   // The 512-column kernel has one tile size: taken when the tiles of all replicas
   // give about one workgroup per CU.  (A plan made ahead of the call does not
   // know the replica count: when the shape alone does not decide, it builds this
@@ -559,8 +558,7 @@ inline Kernel choose_kernel(int m, int k, int n, int nonzeros, int replicas /* <
   if (tiled512_applicable(m, k, n, nonzeros)) {
     // (with its 64-row variant the count that matters is that of 64-row tiles)
     const int64_t tiles = 2 * tiles512(m, n) * (replicas > 0 ? replicas : 1);
-    if (forced == -2 || forced == -3 ||
-        (forced == 0 && tiles >= kTiles512From && long_enough_for_512(m, k, nonzeros)))
+    if (forced == -2 || (forced == 0 && tiles >= kTiles512From && long_enough_for_512(m, k, nonzeros)))
       return Kernel::kWide512;
   }
   const bool wide = tiled_applicable(m, k, n, nonzeros);
@@ -583,6 +581,7 @@ size_t base_workspace_bytes(int m, int k, int n, int nonzeros) {
   switch (choose_kernel(m, k, n, nonzeros, -1)) {
     case Kernel::kWide: return wide_workspace_bytes(m, k, n);
     case Kernel::kWide512: return wide512_workspace_bytes(m, k, n, nonzeros);
+    case Kernel::kFlat: return spmm_flat_workspace_bytes(m, k, n, nonzeros);
     case Kernel::kNarrow: return spmm_tiled64_workspace_bytes(m, k);
     case Kernel::kEither: return wide_workspace_bytes(m, k, n) + spmm_tiled64_workspace_bytes(m, k);
     default: return 0;
@@ -597,7 +596,7 @@ size_t wide512_offset(int m, int k, int n, int nonzeros) {
 }
 }  // namespace
 
-// 0 = row gather, 1 = 256-column, 2 = 64-column, 3 = either (by replica count), 4 = 512-column
+// 0 = row gather, 1 = 256-column, 2 = 64-column, 3 = either (by replica count), 4 = 512-column, 5 = flat stream
 int spmm_tiled_choice(int m, int k, int n, int nonzeros, int replicas) {
   return static_cast<int>(choose_kernel(m, k, n, nonzeros, replicas));
 }
@@ -641,12 +640,12 @@ int spmm_tiled_plan(int m, int k, int n, int nonzeros, int replicas, const int* 
     const int st = launch_status();
     if (st != 0) return st;
   }
-  if ((which == Kernel::kWide512 || also512) && use_flat(m, k, n, nonzeros)) {
+  if (which == Kernel::kFlat) {
     const int st = spmm_flat_plan(m, k, n, nonzeros, row_indices, row_offsets, column_indices,
-                                  static_cast<char*>(workspace) + wide512_offset(m, k, n, nonzeros),
-                                  stream);
+                                  workspace, stream);
     if (st != 0) return st;
-  } else if (which == Kernel::kWide512 || also512) {
+  }
+  if (which == Kernel::kWide512 || also512) {
     const Plan plan = make_plan<CfgWide512>(m, k, n);
     char* base = static_cast<char*>(workspace) + wide512_offset(m, k, n, nonzeros);
     int* row_ok = reinterpret_cast<int*>(base);
@@ -686,12 +685,11 @@ int spmm_tiled_exec(int m, int k, int n, int nonzeros, int replicas, const int* 
   }
   using Cfg = CfgLarge;
   const bool w512 = which == Kernel::kWide512;
-  if (w512 && use_flat(m, k, n, nonzeros)) {
+  if (which == Kernel::kFlat) {
     *handled = true;
     return spmm_flat_exec(m, k, n, nonzeros, replicas, row_indices, values, values_stride,
                           row_offsets, column_indices, dense, dense_stride, out, out_stride,
-                          static_cast<const char*>(workspace) + wide512_offset(m, k, n, nonzeros),
-                          stream, epi);
+                          workspace, stream, epi);
   }
   const Plan plan = w512 ? make_plan<CfgWide512>(m, k, n) : make_plan<Cfg>(m, k, n);
   const char* ws_base =
