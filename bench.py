@@ -538,16 +538,21 @@ def other_ops(dev):
     return res
 
 
-def load_pmc_traffic():
+def load_pmc_traffic(build_id, kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3
-    PMC passes (profiles/*.json, collected as MI355X_MICROARCH.md prescribes);
-    None when no such file exists for this build."""
+    PMC passes (profiles/spmm_c2_d010_traffic.json, collected as
+    MI355X_MICROARCH.md prescribes by tools/collect_profiles.sh).  The file
+    records the build it was collected on and the kernel it describes: a figure
+    from another build or for another kernel is not quoted (None)."""
     path = os.path.join(REPO, "profiles", "spmm_c2_d010_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get("traffic_bytes_per_launch")
+            rec = json.load(f)
     except (OSError, ValueError):
         return None
+    if rec.get("build_id") != build_id or not kernel.startswith(rec.get("dominant_kernel", "?")):
+        return None
+    return rec.get("traffic_bytes_per_launch")
 
 
 def main():
@@ -651,6 +656,9 @@ def main():
     problem.step()
     kernel_ms = event_time_ms(problem.kernel_only, max(10, args.steps))
     achieved_gbs = problem.bytes / (kernel_ms * 1e-3) / 1e9
+    from torch_sputnik_amd import capi as _capi
+    build_id = _capi.build_id()
+    dominant_kernel = _capi.spmm_kernel_name(M, K, N, problem.nnz, replicas)
 
     def core_result(headline, ms_per_step, multi):
         value = problem.flops * n_gpus / (ms_per_step * 1e-3) / 1e9
@@ -677,8 +685,8 @@ def main():
                 "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS,
                 # the PMC passes were taken at one replica per launch
-                "traffic": load_pmc_traffic() if replicas == 1 else None,
-                "kernel": "spmm_tiled_kernel", "kernel_ms": kernel_ms,
+                "traffic": load_pmc_traffic(build_id, dominant_kernel) if replicas == 1 else None,
+                "kernel": dominant_kernel, "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_launch": problem.bytes,
                 "note": "fp32 SpMM at this size is above the HBM ridge (93 flop/B vs 19.7): see roofline_valu",
             },
@@ -688,6 +696,7 @@ def main():
                 "frac": problem.flops / (kernel_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
                 "lds_operand_bound_tflops": 78.6,
             },
+            "library": {"version": _capi.version(), "build_id": build_id},
             "a100_reference_sputnik_gflops": 3416.0,  # README.md:54 of the reference (other hardware)
         }
         if multi is not None:

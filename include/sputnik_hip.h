@@ -53,6 +53,18 @@ typedef struct ihipStream_t* sputnik_hip_stream_t;
 /* Library / build identification: "sputnik_hip <version> gfx950". */
 SPUTNIK_HIP_API const char* sputnik_hip_version(void);
 
+/* Hash of the kernel sources this library was built from (12 hex digits).  The
+ * profiles under profiles/ record it, and bench.py quotes a PMC traffic figure
+ * only when it was collected on the build that is running. */
+SPUTNIK_HIP_API const char* sputnik_hip_build_id(void);
+
+/* Name of the device kernel that serves an SpMM call of this shape (the
+ * dispatcher's choice: spmm.hip, spmm_tiled.hip), e.g. "spmm_flat_kernel<0>"; for
+ * benchmarks and profiles, which report the dominant kernel by name.  The
+ * pointer is to a static string. */
+SPUTNIK_HIP_API const char* sputnik_hip_spmm_kernel_name(int m, int k, int n, int nonzeros,
+                                                         int replicas);
+
 /* ------------------------------------------------------------------------
  * SpMM   C[m,n] = A_csr[m,k] * B[k,n]
  * replaces sputnik::CudaSpmm(m,k,n,nnz,row_indices,values,row_offsets,

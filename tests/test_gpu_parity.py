@@ -328,6 +328,93 @@ def test_spmm_unsorted_columns(capi, dev, spmm_kernel, m, k, n):
     assert rel_err(out.cpu().numpy(), want) < TOL
 
 
+@pytest.fixture
+def flat_loop(monkeypatch):
+    """Forces the flat-stream SpMM kernel (csrc/spmm_flat.hip) and one of its
+    three loops over the plan's stream: 2 entry, 3 group straight, 4 group diagonal."""
+    from torch_sputnik_amd import capi as _capi
+
+    def select(loop):
+        monkeypatch.setenv("SPUTNIK_HIP_SPMM_KERNEL", "flat")
+        monkeypatch.setenv("SPUTNIK_HIP_SPMM_SPARSE", str(loop))
+        _capi.reload_options()
+    yield select
+    monkeypatch.delenv("SPUTNIK_HIP_SPMM_KERNEL", raising=False)
+    monkeypatch.delenv("SPUTNIK_HIP_SPMM_SPARSE", raising=False)
+    _capi.reload_options()
+
+
+FLAT_SHAPES = [
+    # m, k, n, sparsity, replicas, empty rows
+    (128, 32, 512, 0.0, 1, ()),              # one chunk, every entry shares its column with 7 rows
+    (200, 41, 1024, 0.4, 1, (0, 199)),       # partial last chunk (9 rows), padded row slots
+    (300, 1000, 1000, 0.9, 2, (17,)),        # partial last column tile, two replicas
+    (1000, 33, 1536, 0.5, 1, ()),            # three column tiles (not a multiple of 8), k % 32 = 1
+    (384, 4096, 512, 0.97, 3, (1, 2, 3)),    # 128 chunks, most of them empty for a wave
+    (2048, 2048, 512, 0.8, 1, ()),           # 16 row blocks
+    (136, 70000, 512, 0.9995, 1, ()),        # k beyond the pre-pass's column limit: other kernels take it
+]
+
+
+@pytest.mark.parametrize("m,k,n,sparsity,replicas,empty", FLAT_SHAPES)
+def test_spmm_flat_loops_vs_oracle(capi, dev, flat_loop, m, k, n, sparsity, replicas, empty):
+    """Every loop of the flat-stream kernel against the oracle on one plan; the
+    three sum every output element in the same (CSR) order, so they must also
+    agree with each other bit for bit.  The plan is made once, then used with
+    fresh values (it depends on the topology alone)."""
+    _, vals, ri, ro, ci = make_csr(m, k, sparsity, seed=5 * m + k, round_to=1, empty_rows=empty,
+                                   order="random")
+    rng = np.random.default_rng(m + n)
+    b = rng.uniform(-1, 1, size=(replicas, k, n)).astype(np.float32)
+    v = rng.uniform(-1, 1, size=(replicas, len(vals))).astype(np.float32)
+    want = c_oracle.spmm(m, k, v, ro, ci, b)
+    tri, tro, tci, tb, tv = T(ri, dev), T(ro, dev), T(ci, dev), T(b, dev), T(v, dev)
+    outs = []
+    for loop in (2, 3, 4):
+        flat_loop(loop)
+        ws = torch.empty(capi.spmm_workspace_bytes(m, k, n, len(ci)) + 16, dtype=torch.uint8, device=dev)
+        capi.spmm_plan(m, k, n, tri, tro, tci, ws)
+        out = torch.full((replicas, m, n), float("nan"), device=dev)
+        capi.spmm_batched_planned(m, k, n, replicas, tri, tv, len(vals), tro, tci, tb, out, ws)
+        got = out.cpu().numpy()
+        assert not np.isnan(got).any(), "some output elements were never written"
+        assert rel_err(got, want) < TOL
+        for r in empty:
+            assert np.all(got[:, r] == 0)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_spmm_flat_mixed_sorted_and_unsorted_rows(capi, dev, flat_loop):
+    """Row blocks with a row whose columns do not ascend take the order-independent
+    path inside the same launch; their part of the stream is never read, but the
+    prefetch of the block before runs into it (it must hold valid offsets)."""
+    m, k, n = 512, 256, 512
+    _, vals, ri, ro, ci = make_csr(m, k, 0.7, seed=77, order="identity")
+    rng = np.random.default_rng(78)
+    vals, ci = vals.copy(), ci.copy()
+    for r in (130, 131, 400):            # rows of the second and fourth 128-row block
+        p = rng.permutation(ro[r + 1] - ro[r]) + ro[r]
+        vals[ro[r]:ro[r + 1]], ci[ro[r]:ro[r + 1]] = vals[p], ci[p]
+    b = rng.uniform(-1, 1, size=(k, n)).astype(np.float32)
+    want = c_oracle.spmm(m, k, vals, ro, ci, b)
+    for loop in (2, 3, 4):
+        flat_loop(loop)
+        out = torch.full((m, n), float("nan"), device=dev)
+        ws = torch.empty(capi.spmm_workspace_bytes(m, k, n, len(ci)) + 16, dtype=torch.uint8, device=dev)
+        capi.spmm_batched(m, k, n, 1, T(ri, dev), T(vals, dev), 0, T(ro, dev), T(ci, dev), T(b, dev),
+                          out, ws)
+        got = out.cpu().numpy()
+        assert not np.isnan(got).any()
+        assert rel_err(got, want) < TOL
+
+
+def test_spmm_kernel_name_reports_the_dispatch(capi):
+    assert capi.spmm_kernel_name(4096, 4096, 4096, 1677724, 1).startswith("spmm_flat_kernel")
+    assert capi.spmm_kernel_name(64, 64, 64, 2048, 1) == "spmm_rowgather_kernel"
+    assert len(capi.build_id()) == 12
+
+
 @pytest.mark.parametrize("name", ["spmm_c1_64_d050", "spmm_2d_72x64x72", "spmm_3d_r8_72x64x72"])
 def test_spmm_op_golden(ts, dev, golden, name):
     g = golden(name)

@@ -59,3 +59,33 @@ def test_lint_catches_scratch_and_miscounted_iterations():
     assert lint.lint_kernel(name, _loop(body)) == []
     extra = body + [("global_load_dword", "v40, v1, s[2:3]", None)]
     assert any("per iteration" in e for e in lint.lint_kernel(name, _loop(extra)))
+
+
+def test_lint_checks_the_index_mode_regions_of_the_flat_kernel():
+    lint = _lint()
+    name = "_ZN11sputnik_hip12_GLOBAL__N_116spmm_flat_kernelILi0EEEvi"
+
+    def stream(body):
+        return [(4 * i, mn, ops, t) for i, (mn, ops, t) in enumerate(body)]
+
+    fma = ("v_pk_fma_f32", "v[64:65], v[16:17], v[32:33], v[64:65] op_sel:[1,0,0]", None)
+    good = stream([("s_set_gpr_idx_on", "s66, gpr_idx(SRC2,DST)", None), fma, fma,
+                   ("s_set_gpr_idx_off", "", None), ("s_endpgm", "", None)])
+    assert lint.lint_kernel(name, good) == []
+    # any other vector instruction inside a region would have its destination shifted by M0
+    bad = stream([("s_set_gpr_idx_on", "s66, gpr_idx(SRC2,DST)", None), fma,
+                  ("v_add_u32_e32", "v16, v16, v0", None),
+                  ("s_set_gpr_idx_off", "", None), ("s_endpgm", "", None)])
+    assert any("inside an index-mode region" in e for e in lint.lint_kernel(name, bad))
+    # the index mode overwrites M0: not between an M0 write and its LDS-DMA copy
+    m0 = stream([("s_add_u32", "m0, s72, 0x4000", None),
+                 ("s_set_gpr_idx_on", "s66, gpr_idx(SRC2,DST)", None), fma,
+                 ("s_set_gpr_idx_off", "", None),
+                 ("global_load_lds_dwordx4", "v1, s[74:75]", None), ("s_endpgm", "", None)])
+    assert any("between an M0 write" in e for e in lint.lint_kernel(name, m0))
+    # VALU write -> DPP read needs two wait states
+    dpp = stream([("v_mov_b32_e32", "v5, v7", None),
+                  ("v_mov_b32_dpp", "v16, v5 row_newbcast:0 row_mask:0xf bank_mask:0xf", None),
+                  ("s_set_gpr_idx_on", "s66, gpr_idx(SRC2,DST)", None), fma,
+                  ("s_set_gpr_idx_off", "", None), ("s_endpgm", "", None)])
+    assert any("DPP reads" in e for e in lint.lint_kernel(name, dpp))

@@ -2,6 +2,8 @@
 # Run ON THE GPU BOX (through gpurun): rocprofv3 passes of `bench.py --no-extras`.
 #   kernel-trace/stats and each PMC counter in its own run (TCC slots: FETCH_SIZE 3, WRITE_SIZE 2).
 # usage: tools/collect_profiles.sh <tag>      -> gpurun_out/prof_<tag>_{stats,fetch,write}
+# then HERE: python tools/summarize_profile.py --stats gpurun_out/prof_<tag>_stats --fetch ... --write ...
+#            --bench-log gpurun_out/prof_<tag>_stats.log --tag <tag> --traffic-name spmm_c2_d010_traffic.json
 set -u
 TAG=${1:-run}
 R=${GRAFT_REPO_ROOT:-/root/repo}

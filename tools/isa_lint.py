@@ -189,11 +189,70 @@ class Cfg:
         return best
 
 
+def lint_flat_kernel(instrs):
+    """spmm_flat_kernel (generated loop, gen_spmm_flat.py): the VGPR index mode
+    makes destination and src2 of EVERY vector ALU instruction M0-relative, and
+    it shares M0 with the LDS-DMA copies.  Checked on the linear instruction
+    stream (the loop calls its boundary through s_swappc_b64, which no CFG follows):
+      * between s_set_gpr_idx_on and s_set_gpr_idx_off: only v_pk_fma_f32 into the
+        accumulators v[64:127]; no branch, no branch target, every region closed;
+      * an M0 write for an LDS-DMA copy is followed by that copy before the next
+        s_set_gpr_idx_on (which overwrites M0), with an instruction in between;
+      * a DPP move does not read a register that one of the two instructions in
+        front of it wrote (VALU write -> DPP read: 2 wait states)."""
+    errors = []
+    targets = {t for _o, mn, _ops, t in instrs if t is not None}
+    in_mode, m0_pending, m0_gap = False, False, 0
+    recent = []   # (mnemonic, destination registers) of the last two instructions
+    for off, mn, ops, _t in instrs:
+        first = ops.split(",")[0] if ops else ""
+        dest = vregs(first) if mn.startswith(("v_", "ds_read", "global_load", "buffer_load")) and \
+            not mn.startswith(("v_cmp", "v_readlane", "v_readfirstlane")) else set()
+        if mn == "s_set_gpr_idx_on":
+            if in_mode:
+                errors.append(f"+0x{off:x}: s_set_gpr_idx_on inside an open index-mode region")
+            if m0_pending:
+                errors.append(f"+0x{off:x}: index mode switched on between an M0 write and its LDS-DMA copy")
+            in_mode = True
+        elif mn == "s_set_gpr_idx_off":
+            in_mode = False
+        elif in_mode:
+            if off in targets:
+                errors.append(f"+0x{off:x}: branch target inside an index-mode region")
+            if mn.startswith("v_pk_fma_f32"):
+                if not dest or min(dest) < 64 or max(dest) > 127:
+                    errors.append(f"+0x{off:x} {mn} {ops}: index-mode FMA outside the accumulators")
+            elif mn != "s_set_gpr_idx_idx":
+                errors.append(f"+0x{off:x} {mn}: instruction inside an index-mode region")
+        if "m0" in first and mn.startswith("s_"):
+            m0_pending, m0_gap = True, 0
+        elif mn == "global_load_lds_dwordx4":
+            if m0_pending and m0_gap < 1:
+                errors.append(f"+0x{off:x}: LDS-DMA copy directly behind its M0 write (1 wait state)")
+            m0_pending = False
+        elif m0_pending:
+            m0_gap += 1
+        if "_dpp" in mn:
+            src = vregs(",".join(ops.split(",")[1:2]))
+            for pmn, pdest in recent:
+                if pmn.startswith("v_") and src & pdest:
+                    errors.append(f"+0x{off:x} {mn} {ops}: DPP reads v{sorted(src & pdest)} written by "
+                                  f"{pmn} within two instructions")
+        recent = (recent + [(mn, dest)])[-2:]
+    if in_mode:
+        errors.append("index-mode region left open at the end of the kernel")
+    if not any(mn == "s_set_gpr_idx_on" for _o, mn, _ops, _t in instrs):
+        errors.append("no index-mode region found (wrong kernel?)")
+    return errors
+
+
 def lint_kernel(name, instrs):
     errors = []
     for off, mn, ops, _t in instrs:
         if mn.startswith(("scratch_", "flat_")):
             errors.append(f"{mn} at +0x{off:x}: scratch / flat access in a hand-counted kernel")
+    if "spmm_flat_kernel" in name:
+        return errors + lint_flat_kernel(instrs)
     if "spmm_panel" in name:
         # its one hand-written wait is the vmcnt(0) behind the panel copy, which
         # drains everything; all other loads are the compiler's, with its waits

@@ -38,7 +38,10 @@ def main():
     ap.add_argument("--fetch")
     ap.add_argument("--write")
     ap.add_argument("--tag", required=True)
-    ap.add_argument("--kernel", default="spmm_tiled_kernel")
+    ap.add_argument("--kernel", default="spmm_flat_kernel")
+    ap.add_argument("--bench-log", default=None,
+                    help="stdout of the profiled bench.py run: its JSON line names the build "
+                         "(library.build_id) the counters were collected on")
     ap.add_argument("--algorithmic-bytes", type=float, default=None)
     ap.add_argument("--traffic-name", default=None,
                     help="also write profiles/<name> (the file bench.py reads)")
@@ -60,6 +63,13 @@ def main():
 
     traffic = {"units": "FETCH_SIZE / WRITE_SIZE are KiB per launch (rocprofv3); bytes = KiB * 1024",
                "kernels": {}}
+    if args.bench_log:
+        for line in open(args.bench_log):
+            if line.startswith("{"):
+                try:
+                    traffic["build_id"] = json.loads(line)["library"]["build_id"]
+                except (ValueError, KeyError):
+                    pass
     for label, d in (("FETCH_SIZE", args.fetch), ("WRITE_SIZE", args.write)):
         if not d:
             continue

@@ -22,6 +22,8 @@ _c_float = ctypes.c_float
 # name -> (restype, argtypes); must list every symbol include/sputnik_hip.h declares.
 SIGNATURES = {
     "sputnik_hip_version": (ctypes.c_char_p, []),
+    "sputnik_hip_build_id": (ctypes.c_char_p, []),
+    "sputnik_hip_spmm_kernel_name": (ctypes.c_char_p, [_c_int] * 5),
     "sputnik_hip_reload_options": (None, []),
     "sputnik_hip_spmm": (_c_int, [_c_int] * 4 + [_c_ptr] * 7),
     "sputnik_hip_spmm_workspace_bytes": (_c_size, [_c_int] * 4),
@@ -126,6 +128,16 @@ def lib():
 
 def version():
     return lib().sputnik_hip_version().decode()
+
+
+def build_id():
+    """Hash of the kernel sources the loaded library was built from."""
+    return lib().sputnik_hip_build_id().decode()
+
+
+def spmm_kernel_name(m, k, n, nonzeros, replicas=1):
+    """Device kernel the dispatcher picks for an SpMM call of this shape."""
+    return lib().sputnik_hip_spmm_kernel_name(m, k, n, nonzeros, replicas).decode()
 
 
 def reload_options():

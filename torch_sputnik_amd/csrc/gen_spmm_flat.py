@@ -116,7 +116,7 @@ def emit(line):
 
 
 def label(name):
-    return f"L_{name}_%="
+    return f".L_{name}_%="
 
 
 def strip_reads(ring, addr):

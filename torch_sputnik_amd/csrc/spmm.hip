@@ -28,6 +28,7 @@ int spmm_tiled_exec(int m, int k, int n, int nonzeros, int replicas, const int* 
                     size_t workspace_bytes, hipStream_t stream, Epilogue epi, bool* handled);
 size_t spmm_tiled_workspace_bytes(int m, int k, int n, int nonzeros);
 int spmm_tiled_choice(int m, int k, int n, int nonzeros, int replicas);
+const char* spmm_tiled_kernel_name(int m, int k, int n, int nonzeros, int replicas);
 bool spmm_panel_applicable(int m, int k, int n, int nonzeros, const float* dense,
                            int64_t dense_stride, const float* out, int64_t out_stride);
 struct GroupProblemHost {
@@ -294,6 +295,12 @@ int sputnik_hip_spmm_bias_batched(int m, int k, int n, int nonzeros, int replica
   return spmm_exec(m, k, n, nonzeros, replicas, row_indices, values, values_stride, row_offsets,
                    column_indices, dense, dense_stride, out, out_stride, workspace,
                    workspace_bytes, stream, epi);
+}
+
+const char* sputnik_hip_spmm_kernel_name(int m, int k, int n, int nonzeros, int replicas) {
+  if (m <= 0 || n <= 0 || replicas <= 0) return "none";
+  if (takes_panel(m, k, n, nonzeros, replicas, nullptr, 0, nullptr, 0)) return "spmm_panel64_kernel";
+  return spmm_tiled_kernel_name(m, k, n, nonzeros, replicas);
 }
 
 int sputnik_hip_spmm_permuted_supported(int m, int k, int n, int nonzeros) {

@@ -88,6 +88,20 @@ struct ChunkInfo {
 // of the group holds the column.  The position of an entry is the number of set
 // bits in front of it, the first set bit of a byte starts a column group.
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ int wave_inclusive_scan(int v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(v, o);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
 __global__ __launch_bounds__(kRPW * 64) void spmm_flat_fill_kernel(
     int m, int k, int slots, int nchunks, const int* __restrict__ row_indices,
     const int* __restrict__ row_offsets, const int* __restrict__ column_indices,
@@ -95,15 +109,15 @@ __global__ __launch_bounds__(kRPW * 64) void spmm_flat_fill_kernel(
     unsigned char* __restrict__ stream) {
   extern __shared__ unsigned lds[];
   constexpr int RPW = kRPW, BK = kBK, NT = RPW * 64;
-  constexpr int CPW = 32 / RPW;           // columns per mask word (RPW bits each)
-  constexpr int WPC = BK / CPW;           // mask words per chunk
-  constexpr unsigned kRowBits = (1u << RPW) - 1u;
+  constexpr int WPC = BK / 4;             // mask words per chunk (a byte per column)
+  constexpr int UN = 4;                   // row entries a lane handles per round (loads in flight)
   const int g = blockIdx.x, tid = threadIdx.x, lane = tid % 64, wave = tid / 64;
   const int groups = gridDim.x;
   unsigned* maskw = lds;                                        // [nchunks * WPC]
   int* ebase = reinterpret_cast<int*>(lds + nchunks * WPC);     // [nchunks]: entries before the chunk
-  int* scratch = ebase + nchunks;                               // [NT + 2]
-  auto col_mask = [&](int c, int j) { return (maskw[c * WPC + j / CPW] >> (RPW * (j % CPW))) & kRowBits; };
+  unsigned* nzmask = reinterpret_cast<unsigned*>(ebase + nchunks);   // [nchunks]: bit j = column j is held
+  unsigned* wprefix = nzmask + nchunks;                         // [nchunks * 2]: entries before word i, a byte each
+  int* scratch = reinterpret_cast<int*>(wprefix + 2 * nchunks); // [2 * RPW + 2]
 
   auto slot_len = [&](int slot) {
     const int entry = dealt_index(slot, slots, kDealPer);
@@ -113,33 +127,7 @@ __global__ __launch_bounds__(kRPW * 64) void spmm_flat_fill_kernel(
   };
 
   for (int i = tid; i < nchunks * WPC; i += NT) maskw[i] = 0;
-  // (1) windows of all groups before this one; this group's entry count
-  int before = 0;
-  for (int gp = tid; gp < g; gp += NT) {
-    int len = 0;
-    for (int r = 0; r < RPW; ++r) len += slot_len(gp * RPW + r);
-    before += (len + kWindow - 1) / kWindow;
-  }
-  scratch[tid] = before;
-  if (tid == 0) {
-    int len = 0;
-    for (int r = 0; r < RPW; ++r) len += slot_len(g * RPW + r);
-    scratch[NT] = len;
-    scratch[NT + 1] = 1;
-  }
-  __syncthreads();
-  for (int s = NT / 2; s > 0; s /= 2) {
-    if (tid < s) scratch[tid] += scratch[tid + s];
-    __syncthreads();
-  }
-  const int wbase = scratch[0];
-  const int total = scratch[NT];
-  __syncthreads();
-  if (tid == 0) gwin[g] = wbase;
-  unsigned char* my_stream = stream + static_cast<int64_t>(wbase) * kWindowBytes;
-  const int windows = (total + kWindow - 1) / kWindow;
-
-  // (2) the rows: order check, column masks
+  // (1) this wave's row; windows of all groups before this one
   const int slot = g * RPW + wave;
   const int entry = dealt_index(slot, slots, kDealPer);
   int p0 = 0, p1 = 0;
@@ -148,21 +136,55 @@ __global__ __launch_bounds__(kRPW * 64) void spmm_flat_fill_kernel(
     p0 = row_offsets[row];
     p1 = row_offsets[row + 1];
   }
+  int before = 0;
+  for (int gp = tid; gp < g; gp += NT) {
+    int len = 0;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) len += slot_len(gp * RPW + r);
+    before += (len + kWindow - 1) / kWindow;
+  }
+  before = wave_sum(before);
+  if (lane == 0) {
+    scratch[wave] = before;
+    scratch[RPW + wave] = p1 - p0;
+  }
+  if (tid == 0) scratch[2 * RPW] = 1;
+  __syncthreads();
+  int wbase = 0, total = 0;
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    wbase += scratch[r];
+    total += scratch[RPW + r];
+  }
+  if (tid == 0) gwin[g] = wbase;
+  unsigned char* my_stream = stream + static_cast<int64_t>(wbase) * kWindowBytes;
+  const int windows = (total + kWindow - 1) / kWindow;
+
+  // (2) the rows: order check, column masks (UN independent loads per lane and round)
   bool ok = true;
-  for (int p = p0 + lane; p < p1; p += 64) {
-    const int cur = column_indices[p];
-    const int prev = p > p0 ? column_indices[p - 1] : -1;
-    if (cur <= prev || cur >= k) ok = false;
-    else atomicOr(&maskw[cur / CPW], (1u << wave) << (RPW * (cur % CPW)));
+  for (int base = p0; base < p1; base += 64 * UN) {
+    int cur[UN], prev[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int p = base + u * 64 + lane;
+      cur[u] = p < p1 ? column_indices[p] : -2;
+      prev[u] = (p < p1 && p > p0) ? column_indices[p - 1] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      if (cur[u] == -2) continue;
+      if (cur[u] <= prev[u] || cur[u] >= k) ok = false;
+      else atomicOr(&maskw[cur[u] >> 2], (1u << wave) << (8 * (cur[u] & 3)));
+    }
   }
   const bool wave_ok = __builtin_amdgcn_ballot_w64(!ok) == 0;
   if (lane == 0) {
     row_ok[slot] = wave_ok ? 1 : 0;
-    if (!wave_ok) scratch[NT + 1] = 0;
+    if (!wave_ok) scratch[2 * RPW] = 0;
   }
   __syncthreads();
   ChunkInfo* my_info = cinfo + static_cast<int64_t>(g) * (nchunks + 1);
-  if (scratch[NT + 1] == 0) {
+  if (scratch[2 * RPW] == 0) {
     // A row whose columns do not ascend: its workgroup takes the order-independent
     // path and never reads this stream -- but the prefetch of the group before
     // runs into it, so it must hold valid value offsets (zero) and group flags.
@@ -174,71 +196,79 @@ __global__ __launch_bounds__(kRPW * 64) void spmm_flat_fill_kernel(
     return;
   }
 
-  // (3) per chunk: entries, column groups, the tile rows of the first groups
+  // (3) per chunk: entries, column groups, the tile rows of the first groups, and what
+  // the entries' positions are computed from (held-column mask, entries before each word)
   for (int c = tid; c < nchunks; c += NT) {
     int entries = 0, cgroups = 0;
-    unsigned first = 0u;
-    for (int j = 0; j < BK; ++j) {
-      const unsigned rows = col_mask(c, j);
-      if (rows) {
-        entries += __popc(rows);
-        if (cgroups < kAhead) first |= static_cast<unsigned>((c & 1) * BK + j) << (8 * cgroups);
-        ++cgroups;
-      }
+    unsigned first = 0u, nz = 0u, pre[2] = {0u, 0u};
+#pragma unroll
+    for (int i = 0; i < WPC; ++i) {
+      const unsigned w = maskw[c * WPC + i];
+      pre[i / 4] |= static_cast<unsigned>(entries) << (8 * (i % 4));
+      entries += __popc(w);
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        if ((w >> (8 * b)) & 0xffu) {
+          nz |= 1u << (4 * i + b);
+          if (cgroups < kAhead) first |= static_cast<unsigned>((c & 1) * BK + 4 * i + b) << (8 * cgroups);
+          ++cgroups;
+        }
     }
     ebase[c] = entries;
+    nzmask[c] = nz;
+    wprefix[2 * c] = pre[0];
+    wprefix[2 * c + 1] = pre[1];
     my_info[c] = ChunkInfo{cgroups, first, 0u, entries};
   }
   if (tid == 0) my_info[nchunks] = ChunkInfo{0, 0u, 0u, 0};   // (read one chunk ahead)
   __syncthreads();
-  {  // exclusive scan of the entry counts over the chunks
-    const int per = (nchunks + NT - 1) / NT;
-    const int c0 = min(tid * per, nchunks), c1 = min(c0 + per, nchunks);
-    int sum = 0;
-    for (int c = c0; c < c1; ++c) sum += ebase[c];
-    scratch[tid] = sum;
-    __syncthreads();
-    for (int off = 1; off < NT; off *= 2) {
-      const int v = tid >= off ? scratch[tid - off] : 0;
-      __syncthreads();
-      scratch[tid] += v;
-      __syncthreads();
-    }
-    int run = scratch[tid] - sum;
-    for (int c = c0; c < c1; ++c) {
-      const int e = ebase[c];
-      ebase[c] = run;
-      run += e;
+  if (wave == 0) {  // exclusive scan of the entry counts over the chunks
+    int carry = 0;
+    for (int c0 = 0; c0 < nchunks; c0 += 64) {
+      const int c = c0 + lane;
+      const int e = c < nchunks ? ebase[c] : 0;
+      const int incl = wave_inclusive_scan(e, lane);
+      if (c < nchunks) ebase[c] = carry + incl - e;
+      carry += __shfl(incl, 63);
     }
   }
   __syncthreads();
 
   // (4) the entries
-  for (int p = p0 + lane; p < p1; p += 64) {
-    const int col = column_indices[p];
-    const int c = col / BK, j = col % BK;
-    int prefix = 0;
-    for (int i = 0; i < j / CPW; ++i) prefix += __popc(maskw[c * WPC + i]);
-    prefix += __popc(maskw[c * WPC + j / CPW] & ((1u << (RPW * (j % CPW))) - 1u));
-    const int own = __popc(col_mask(c, j) & ((1u << wave) - 1u));
-    const int pos = ebase[c] + prefix + own;
-    // tile rows (stage parity * BK + column in chunk): byte 0 the entry's own
-    // column, byte 1 the column group kAhead groups further on, if the chunk has one
-    unsigned rowbyte = wave * 8, tile_rows = static_cast<unsigned>((c & 1) * BK + j);
-    if (own == 0) {
-      rowbyte |= kNewGroup;
-      int seen = 0;
-      for (int jj = j + 1; jj < BK; ++jj)
-        if (col_mask(c, jj))
-          if (++seen == kAhead) {
-            tile_rows |= static_cast<unsigned>((c & 1) * BK + jj) << 8;
-            break;
-          }
+  static_assert(WPC == 8, "two prefix words per chunk");
+  for (int base = p0; base < p1; base += 64 * UN) {
+    int cols[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int p = base + u * 64 + lane;
+      cols[u] = p < p1 ? column_indices[p] : -1;
     }
-    unsigned char* block = my_stream + static_cast<int64_t>(pos / kWindow) * kWindowBytes;
-    const int e = pos % kWindow;
-    *reinterpret_cast<uint2*>(block + 8 * e) = make_uint2(tile_rows, static_cast<unsigned>(p) * 4u);
-    block[128 + e] = static_cast<unsigned char>(rowbyte);
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      if (cols[u] < 0) continue;
+      const int p = base + u * 64 + lane;
+      const int col = cols[u], c = col / BK, j = col % BK;
+      const unsigned w = maskw[c * WPC + j / 4];
+      const int prefix = static_cast<int>((wprefix[2 * c + j / 16] >> (8 * ((j / 4) % 4))) & 0xffu) +
+                         __popc(w & ((1u << (8 * (j & 3))) - 1u));
+      const unsigned byte = (w >> (8 * (j & 3))) & 0xffu;
+      const int own = __popc(byte & ((1u << wave) - 1u));
+      const int pos = ebase[c] + prefix + own;
+      // tile rows (stage parity * BK + column in chunk): byte 0 the entry's own
+      // column, byte 1 the column group kAhead groups further on, if the chunk has one
+      unsigned rowbyte = wave * 8, tile_rows = static_cast<unsigned>((c & 1) * BK + j);
+      if (own == 0) {
+        rowbyte |= kNewGroup;
+        unsigned ahead = j == BK - 1 ? 0u : nzmask[c] >> (j + 1);   // held columns behind j
+        ahead &= ahead - 1u;   // (kAhead = 3: drop the next two)
+        ahead &= ahead - 1u;
+        if (ahead) tile_rows |= static_cast<unsigned>((c & 1) * BK + j + __ffs(ahead)) << 8;
+      }
+      unsigned char* block = my_stream + static_cast<int64_t>(pos / kWindow) * kWindowBytes;
+      const int e = pos % kWindow;
+      *reinterpret_cast<uint2*>(block + 8 * e) = make_uint2(tile_rows, static_cast<unsigned>(p) * 4u);
+      block[128 + e] = static_cast<unsigned char>(rowbyte);
+    }
   }
   // (5) unused entries of the last window, and the empty windows behind the last group:
   // flagged as group starts, so that the loop meets its end-of-chunk test there
@@ -403,8 +433,8 @@ FlatPlan make_flat_plan(int m, int k, int n, int nonzeros) {
 }
 
 size_t fill_lds_bytes(int nchunks) {
-  // masks (a byte per column) + entries per chunk + scratch
-  return sizeof(int) * (static_cast<size_t>(nchunks) * (kBK / 4 + 1) + kRPW * 64 + 2);
+  // masks (a byte per column) + per chunk: entries before, held columns, word prefixes; scratch
+  return sizeof(int) * (static_cast<size_t>(nchunks) * (kBK / 4 + 4) + 2 * kRPW + 2);
 }
 
 // Which loop reads the stream.  p = share of the entries that start a column
@@ -440,6 +470,11 @@ bool spmm_flat_applicable(int m, int k, int n, int nonzeros) {
     return false;
   if (static_cast<int64_t>(ceil_div(n, kBN)) * kBN * 3 > static_cast<int64_t>(n) * 4) return false;
   return k <= kMaxColumns && m <= 16384;
+}
+
+const char* spmm_flat_kernel_name(int m, int k, int nonzeros) {
+  static const char* const names[] = {"spmm_flat_kernel<0>", "spmm_flat_kernel<1>", "spmm_flat_kernel<2>"};
+  return names[flat_mode(m, k, nonzeros)];
 }
 
 // Workgroups of one replica (the dispatcher takes the kernel when they fill the chip).

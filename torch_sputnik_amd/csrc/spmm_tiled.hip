@@ -62,6 +62,7 @@ int spmm_tiled64_exec(int m, int k, int n, int nonzeros, int replicas, const int
 // Flat-stream form of the 128 x 512 tile (spmm_flat.hip).
 bool spmm_flat_applicable(int m, int k, int n, int nonzeros);
 int64_t spmm_flat_tiles(int m, int n);
+const char* spmm_flat_kernel_name(int m, int k, int nonzeros);
 size_t spmm_flat_workspace_bytes(int m, int k, int n, int nonzeros);
 int spmm_flat_plan(int m, int k, int n, int nonzeros, const int* row_indices,
                    const int* row_offsets, const int* column_indices, void* workspace,
@@ -599,6 +600,17 @@ size_t wide512_offset(int m, int k, int n, int nonzeros) {
 // 0 = row gather, 1 = 256-column, 2 = 64-column, 3 = either (by replica count), 4 = 512-column, 5 = flat stream
 int spmm_tiled_choice(int m, int k, int n, int nonzeros, int replicas) {
   return static_cast<int>(choose_kernel(m, k, n, nonzeros, replicas));
+}
+
+const char* spmm_tiled_kernel_name(int m, int k, int n, int nonzeros, int replicas) {
+  switch (choose_kernel(m, k, n, nonzeros, replicas)) {
+    case Kernel::kFlat: return spmm_flat_kernel_name(m, k, nonzeros);
+    case Kernel::kWide512: return "spmm_tiled_kernel<TileConfig<512";
+    case Kernel::kWide: return "spmm_tiled_kernel<TileConfig<256";
+    case Kernel::kNarrow: return "spmm_tiled64_kernel";
+    case Kernel::kEither: return "spmm_tiled_kernel";
+    default: return "spmm_rowgather_kernel";
+  }
 }
 
 size_t spmm_tiled_workspace_bytes(int m, int k, int n, int nonzeros) {

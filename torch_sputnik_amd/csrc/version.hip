@@ -51,7 +51,12 @@ const Options& options() {
 
 }  // namespace sputnik_hip
 
-extern "C" const char* sputnik_hip_version(void) { return "sputnik_hip 0.2.0 gfx950"; }
+extern "C" const char* sputnik_hip_version(void) { return "sputnik_hip 0.3.0 gfx950"; }
+
+#ifndef SPUTNIK_HIP_BUILD_ID
+#define SPUTNIK_HIP_BUILD_ID "unknown"
+#endif
+extern "C" const char* sputnik_hip_build_id(void) { return SPUTNIK_HIP_BUILD_ID; }
 
 // Not for use while launches are being issued from other threads.
 extern "C" void sputnik_hip_reload_options(void) {
