@@ -242,10 +242,17 @@ class Exchange:
         }
 
 
+WATCHDOG_EXIT_CODE = 3
+
+
 class Watchdog:
     """arm(make_line, fd): unless disarm() comes within `seconds`, the process writes
-    make_line() (bytes or None) to fd and exits -- from a daemon thread, because the
-    main thread of a hung run sits inside a blocking runtime call."""
+    make_line() (bytes or None) to fd and exits with WATCHDOG_EXIT_CODE -- from a
+    daemon thread, because the main thread of a hung run sits inside a blocking
+    runtime call.  A hung schedule is a FAILED run on every rank: the partial line
+    (it carries a "watchdog" key and only the schedules that finished) is there for
+    diagnosis, the exit code says that the headline is not to be trusted.  Nothing is
+    restarted or re-executed from a process that has touched the GPU."""
 
     def __init__(self, seconds, printer=True):
         import threading
@@ -278,9 +285,7 @@ class Watchdog:
                     if line:
                         os.write(fd, line)
                 finally:
-                    # (the other ranks leave quietly: a non-zero exit would make the
-                    # launcher report the whole run as failed although the line is out)
-                    os._exit(0 if (line or not self.printer) else 3)
+                    os._exit(WATCHDOG_EXIT_CODE)
 
 
 def cpu_baseline(problem):

@@ -226,13 +226,26 @@ SPUTNIK_HIP_API int sputnik_hip_sparse_softmax_batched(int m, int n, int nonzero
  * of the source nonzero, so a caller can reuse a static topology's transpose.
  * Preconditions (as for cusparseCsr2cscEx2 on valid CSR): column indices in
  * [0, n), a row stores a column at most once (order inside a row is free).
- * Workspace: 4 * (2 * ceil(m / 32) * n + n) bytes -- it depends on the SHAPE,
- * not on the number of nonzeros (2 MiB at 2048 x 2048, 33 MiB at 16384^2,
- * 1 GiB at 65536^2): very sparse very large matrices are outside what this
- * path is built for (the reference's callers transpose weight matrices and
- * attention masks of a few thousand rows).
+ * A violation is DETECTED on the device: the status word (the last 16 bytes of
+ * the workspace) is non-zero afterwards, and the outputs are unspecified.
+ * sputnik_hip_csr_transpose is asynchronous and leaves the word to the caller;
+ * sputnik_hip_csr_transpose_checked (same arguments) waits for the stream and
+ * returns SPUTNIK_HIP_INVALID_ARGUMENT.
+ * Workspace: the smaller of about 4 * (2 * ceil(m / 32) * n + n) bytes (mask / count
+ * tables: 2 MiB at 2048 x 2048) and, where those would exceed eight table entries
+ * per nonzero, 4 * (2 n + 3 nnz) bytes (histogram path, O(n + nnz) like the
+ * buffer cusparseCsr2cscEx2_bufferSize asks for: 5.4 MiB at 65536^2, density
+ * 1e-4, where the tables would be 1 GiB); + 16.
  * ---------------------------------------------------------------------- */
 SPUTNIK_HIP_API size_t sputnik_hip_csr_transpose_workspace_bytes(int m, int n, int nonzeros);
+
+SPUTNIK_HIP_API int sputnik_hip_csr_transpose_checked(int m, int n, int nonzeros, int replicas,
+                              const float* values, int64_t values_stride,
+                              const int* row_offsets, const int* column_indices,
+                              float* out_values, int64_t out_values_stride,
+                              int* out_row_offsets, int* out_column_indices,
+                              int* out_permutation, void* workspace, size_t workspace_bytes,
+                              sputnik_hip_stream_t stream);
 
 SPUTNIK_HIP_API int sputnik_hip_csr_transpose(int m, int n, int nonzeros, int replicas,
                               const float* values, int64_t values_stride,

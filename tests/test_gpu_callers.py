@@ -208,6 +208,7 @@ def build_attention(tsa, dev, heads, embed, seq, seed, **flags):
 
 
 @pytest.mark.parametrize("heads,embed,seq,batch", [
+    (8, 512, 1024, 8),     # config 3 at FULL size: 64 replicas (scores 512 MB in float64)
     (8, 512, 1024, 2),     # config 3's geometry (head_dim 64), batch reduced
     (4, 256, 256, 3),      # head_dim 64, small
     (2, 64, 128, 2),       # head_dim 32: composed from the three operators
@@ -227,14 +228,16 @@ def test_sparse_attention_module_forward_vs_dense(tsa, dev, heads, embed, seq, b
     assert rel_err_torch(composed, want) < TOL
 
 
+@pytest.mark.parametrize("geometry", [(4, 256, 256, 2), (8, 512, 1024, 2)],
+                         ids=["h4_e256_s256_b2", "c3_geometry_b2"])
 @pytest.mark.parametrize("shared_input", [False, True])
 @pytest.mark.parametrize("fused_training", [False, True])
-def test_sparse_attention_module_backward_vs_dense(tsa, dev, fused_training, shared_input):
+def test_sparse_attention_module_backward_vs_dense(tsa, dev, fused_training, shared_input, geometry):
     """Gradients of the whole module w.r.t. the inputs and every projection's
     values, against dense float64 autograd.  (The reference's module calls the
     raw softmax op and so cuts the gradient to Q/K, modules/sparse_attention.py:76;
     `differentiable_softmax` / `fused_training` give the true gradient.)"""
-    heads, embed, seq, batch = 4, 256, 256, 2
+    heads, embed, seq, batch = geometry   # (config 3's geometry: S 1024, 8 heads of 64, batch 2)
     module = build_attention(tsa, dev, heads, embed, seq, seed=11, differentiable_softmax=True,
                              fused_training=fused_training)
     rng = np.random.default_rng(8)

@@ -7,7 +7,7 @@ import torch
 
 from oracle import c_oracle
 from oracle import sputnik_oracle as O
-from helpers import make_csr, rel_err
+from helpers import make_csr, rel_err, rel_err_torch
 
 pytestmark = pytest.mark.gpu
 
@@ -339,6 +339,36 @@ def test_sparse_attention_capi_vs_oracle(capi, dev, m, n, sparsity, replicas, em
     finite = np.isfinite(want_lse)
     assert np.array_equal(np.isneginf(got_lse), ~finite)
     assert np.max(np.abs(got_lse[finite] - want_lse[finite])) < 1e-4 * (1 + np.abs(want_lse[finite]).max())
+
+
+def test_sparse_attention_capi_c3_full_size(capi, dev):
+    """BASELINE config 3 at FULL size through the C ABI: 64 replicas (batch 8 x 8
+    heads), S = 1024, head_dim 64, mask density 0.1 -- every output element and
+    every log-sum-exp against the dense float64 definition (scores [64, 1024, 1024]
+    in float64 on the device, 512 MB).  The kernel's grid decode (XCD-local 64-bit
+    work index) is only exercised at this replica count."""
+    m = n = 1024
+    d, replicas = 64, 64
+    _, _, ri, ro, ci = make_csr(m, n, 0.9, seed=31, order="ascending")
+    g = torch.Generator(device="cpu").manual_seed(32)
+    q, k, v = (torch.empty(replicas, m, d).uniform_(-2, 2, generator=g).to(dev) for _ in range(3))
+    scale = 1.0 / np.sqrt(d)
+    ws = torch.empty(capi.sparse_attention_workspace_bytes(m, n, d, len(ci)), dtype=torch.uint8,
+                     device=dev)
+    out = torch.full((replicas, m, d), float("nan"), device=dev)
+    lse = torch.full((replicas, m), float("nan"), device=dev)
+    capi.sparse_attention_forward(m, n, d, replicas, T(ri, dev), T(ro, dev), T(ci, dev), q, k, v,
+                                  scale, out, lse, ws)
+    mask = torch.zeros(m, n, dtype=torch.bool, device=dev)
+    rows = torch.repeat_interleave(torch.arange(m, device=dev), T(np.diff(ro).astype(np.int64), dev))
+    mask[rows, T(ci.astype(np.int64), dev)] = True
+    scores = torch.matmul(q.double(), k.double().transpose(1, 2)) * scale
+    scores = scores.masked_fill(~mask, float("-inf"))
+    want = torch.matmul(torch.nan_to_num(torch.softmax(scores, dim=-1)), v.double())
+    assert not torch.isnan(out).any()
+    assert rel_err_torch(out, want) < TOL
+    want_lse = torch.logsumexp(scores, dim=-1)
+    assert torch.max(torch.abs(lse.double() - want_lse)) < 1e-4 * (1 + want_lse.abs().max())
 
 
 def test_sparse_attention_unsorted_columns(capi, dev):

@@ -94,7 +94,8 @@ def test_bench_line_carries_the_three_multi_gpu_figures():
 
 def test_bench_watchdog_prints_what_was_measured():
     """A schedule that never returns: rank 0 still prints the line, with the
-    schedules measured before it and a note."""
+    schedules measured before it and a note -- and the run FAILS (non-zero exit on
+    every rank): a hung transport must not be reported as a success."""
     env = dict(os.environ, BENCH_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
                MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
                HSA_ENABLE_IPC_MODE_LEGACY="0", BENCH_TEST_HANG="allgather_p2p")
@@ -102,7 +103,7 @@ def test_bench_watchdog_prints_what_was_measured():
                            "--replicas-per-gpu", "2", "--device-warmup-s", "0.05",
                            "--schedule-timeout-s", "5"],
                           env=env, capture_output=True, text=True, timeout=600)
-    assert proc.returncode == 0, proc.stderr[-2000:]
+    assert proc.returncode == 3, (proc.returncode, proc.stderr[-2000:])
     line = json.loads([ln for ln in proc.stdout.splitlines() if ln.strip()][-1])
     assert "allgather_p2p did not finish" in line["watchdog"]
     assert line["headline_schedule"].startswith("allgather") and line["value"] > 0

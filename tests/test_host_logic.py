@@ -121,6 +121,55 @@ def test_transpose_cache_gives_same_gradients(cpu_ops):
         assert torch.equal(got[0], base[0]) and torch.equal(got[1], base[1])
 
 
+def test_default_caches_serve_registered_topologies_only(cpu_ops):
+    """by default nothing is remembered about arbitrary index tensors
+    (the reference's per-call behaviour, modules/spmm.py:59-64); a pattern that
+    its owner registered as static is cached, and its entries die with it."""
+    import gc
+    from torch_sputnik_amd import functional
+    dense_a, vals, ri, ro, ci = make_csr(15, 11, 0.7, seed=4)
+    b = np.random.default_rng(5).uniform(-1, 1, (11, 8)).astype(np.float32)
+
+    def grads(topo):
+        v = T(vals).requires_grad_(True)
+        d = T(b).requires_grad_(True)
+        cpu_ops.Spmm.apply(15, 11, v, *topo, d).square().sum().backward()
+        return v.grad.clone(), d.grad.clone()
+
+    functional.enable_transpose_cache(functional.TRANSPOSE_CACHE_DEFAULT)
+    functional.enable_plan_cache(functional.PLAN_CACHE_DEFAULT)
+    cache = functional._cache
+    assert cache.scope == "static"
+    topo = (T(ri), T(ro), T(ci))
+    base = grads(topo)
+    assert len(cache) == 0, "an unregistered pattern was cached"
+    functional.register_static_topology(*topo)
+    first, second = grads(topo), grads(topo)
+    assert len(cache) == 1
+    for got in (first, second):
+        assert torch.equal(got[0], base[0]) and torch.equal(got[1], base[1])
+    # an in-place write changes the key (version counter): a new entry, not a stale hit
+    topo[2].add_(0)
+    grads(topo)
+    assert len(cache) == 2
+    # the owner drops the pattern: registration and entries go with it
+    del topo
+    gc.collect()
+    assert len(cache) == 0 and not functional._static
+
+
+def test_cache_is_bounded_by_bytes():
+    from torch_sputnik_amd import functional
+    lru = functional._Lru(capacity=100, max_bytes=4096)
+    for i in range(10):
+        lru.put(i, (torch.zeros(256, dtype=torch.float32),))   # 1 KiB each
+    assert len(lru) == 4 and lru.bytes == 4096
+    assert lru.get(0) is None and lru.get(9) is not None
+    lru.forget("nothing")
+    lru.clear()
+    assert lru.bytes == 0
+
+
 def test_sparse_softmax_backward(cpu_ops):
     mask, vals, ri, ro, ci = make_csr(10, 14, 0.6, seed=6, round_to=1, empty_rows=(3,))
     x = T((vals * 4 - 2).astype(np.float32)).requires_grad_(True)

@@ -75,6 +75,9 @@ SIGNATURES = {
     "sputnik_hip_csr_transpose": (_c_int, [_c_int] * 4 + [_c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr,
                                                          _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
                                                          _c_size, _c_ptr]),
+    "sputnik_hip_csr_transpose_checked": (_c_int, [_c_int] * 4 + [_c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr,
+                                                         _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
+                                                         _c_size, _c_ptr]),
     # extensions
     "sputnik_hip_spmm_bias_batched": (_c_int, [_c_int] * 5 + [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr,
                                                              _c_ptr, _c_i64, _c_ptr, _c_int, _c_ptr,
@@ -254,7 +257,9 @@ def csr_transpose_workspace_bytes(m, n, nonzeros):
 
 
 def csr_transpose(m, n, replicas, values, row_offsets, column_indices, out_values,
-                  out_row_offsets, out_column_indices, out_permutation, workspace):
+                  out_row_offsets, out_column_indices, out_permutation, workspace, checked=False):
+    """``checked``: the synchronising entry, which raises for a pattern the transpose
+    is not defined for (a row storing a column twice, a column out of range)."""
     nonzeros = column_indices.numel()
     for t, d, nm in ((values, torch.float32, "values"), (row_offsets, torch.int32, "row_offsets"),
                      (column_indices, torch.int32, "column_indices"),
@@ -263,7 +268,8 @@ def csr_transpose(m, n, replicas, values, row_offsets, column_indices, out_value
                      (out_column_indices, torch.int32, "out_column_indices")):
         _require(t, d, nm)
     ws_bytes = 0 if workspace is None else workspace.numel() * workspace.element_size()
-    _check(lib().sputnik_hip_csr_transpose(
+    entry = lib().sputnik_hip_csr_transpose_checked if checked else lib().sputnik_hip_csr_transpose
+    _check(entry(
         m, n, nonzeros, replicas, _ptr(values), nonzeros, _ptr(row_offsets), _ptr(column_indices),
         _ptr(out_values), nonzeros, _ptr(out_row_offsets), _ptr(out_column_indices),
         _ptr(out_permutation), _ptr(workspace), ws_bytes, _stream(out_values)),

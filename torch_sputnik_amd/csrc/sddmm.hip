@@ -276,8 +276,13 @@ int sddmm_sum_exec(int m, int k, int n, int nonzeros, int replicas, const int* r
     const hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * static_cast<size_t>(nonzeros), stream);
     return static_cast<int>(e);
   }
-  const bool tiled = takes_tiled(m, k, n, nonzeros, replicas, lhs, lhs_stride, rhs, rhs_stride,
-                                 workspace, workspace_bytes, /*summed=*/true);
+  bool tiled = takes_tiled(m, k, n, nonzeros, replicas, lhs, lhs_stride, rhs, rhs_stride,
+                           workspace, workspace_bytes, /*summed=*/true);
+  // (the tiled form puts every (replica, panel) pair on grid z: beyond 65535 of them --
+  // a SparseLinear weight gradient over a very large batch -- the row-wave kernel, which
+  // walks z in chunks, writes the per-replica partial products instead)
+  if (tiled && static_cast<int64_t>(replicas) * sddmm_tiled_panels(m, k, n, nonzeros) > kMaxGridYZ)
+    tiled = false;
   const int panels = tiled ? sddmm_tiled_panels(m, k, n, nonzeros) : 1;
   const int64_t parts = static_cast<int64_t>(replicas) * panels;
   if (parts == 1)   // (one panel: the summed form's plan is the plain one)
@@ -288,7 +293,6 @@ int sddmm_sum_exec(int m, int k, int n, int nonzeros, int replicas, const int* r
       scratch_bytes < sizeof(float) * static_cast<size_t>(parts) * nonzeros)
     return SPUTNIK_HIP_INVALID_ARGUMENT;
   float* partials = static_cast<float*>(scratch);
-  if (tiled && parts > kMaxGridYZ) return SPUTNIK_HIP_INVALID_ARGUMENT;
   int st;
   if (tiled) {
     if (!planned) {

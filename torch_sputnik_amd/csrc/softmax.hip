@@ -264,9 +264,12 @@ int launch_rows(int m, int nonzeros, int replicas, const float* a, int64_t a_str
   const int depth = options().softmax_depth;                                       // developer knob
   const int gx = ceil_div(ceil_div(m, rows_per_group), groups_per_block);
   // The fast path needs the inputs and the output of every replica aligned alike
-  // (the common case: fresh allocations, equal strides) and 32-bit byte offsets.
-  const bool strides_alike = (a_stride - out_stride) % 4 == 0 &&
-                             (!BACKWARD || (a_stride - b_stride) % 4 == 0);
+  // and 32-bit byte offsets.  Its window of clamped 16-byte pieces is derived from
+  // ONE stride and applied to every operand, so the strides must be EQUAL (fresh
+  // allocations: the common case), not merely congruent: with a broadcast gradient
+  // (stride 0) or a padded input the unconditional loads of the other operand would
+  // reach up to a window outside its buffer.
+  const bool strides_alike = a_stride == out_stride && (!BACKWARD || a_stride == b_stride);
   for (int r0 = 0; r0 < replicas; r0 += kMaxGridYZ) {
     const int ry = min(replicas - r0, kMaxGridYZ);
     const float* a_r = a + r0 * a_stride;

@@ -469,8 +469,28 @@ __global__ __launch_bounds__(kPThreads) void spmm_panel64_group_kernel(
 
 // Shapes the panel kernel serves.  (Column indices must lie in [0, k): as for
 // every kernel of the library, an out-of-range index is the caller's error.)
+// LDS a workgroup of the current device may allocate (queried once per device): the
+// panel kernels need 128 KiB, the group kernel 144.25 KiB; a device or partition
+// that offers less takes the chunked kernels instead.
+static size_t device_lds_bytes() {
+  static std::atomic<int> cached[64];
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) return 0;
+  std::atomic<int>& slot = cached[device & 63];
+  int v = slot.load(std::memory_order_acquire);
+  if (v == 0) {
+    int bytes = 0;
+    if (hipDeviceGetAttribute(&bytes, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess)
+      bytes = 64 * 1024;
+    v = bytes > 0 ? bytes : 64 * 1024;
+    slot.store(v, std::memory_order_release);
+  }
+  return static_cast<size_t>(v);
+}
+
 bool spmm_panel_applicable(int m, int k, int n, int nonzeros, const float* dense,
                            int64_t dense_stride, const float* out, int64_t out_stride) {
+  if (device_lds_bytes() < kPMaxK * kPBN * sizeof(float)) return false;
   return k >= 1 && k <= kPMaxK * kPMaxPasses && n % 4 == 0 && n >= kPBN && m >= 16 &&
          static_cast<int64_t>(k) * n * 4 < (int64_t{1} << 32) && aligned_to(dense, 16) &&
          aligned_to(out, 16) && dense_stride % 4 == 0 && out_stride % 4 == 0 && nonzeros >= 0;
@@ -543,6 +563,7 @@ struct GroupProblemHost {   // = sputnik_hip_spmm_problem (include/sputnik_hip.h
 };
 
 bool spmm_panel_group_supported(int m, int k, int n, int count, int block_rows, bool accumulate) {
+  if (device_lds_bytes() < kPMaxK * kPBN * sizeof(float) + kGroupTileBytes) return false;
   return count >= 1 && count <= kPMaxGroup && k >= 1 && k <= kPMaxK && n % 4 == 0 && n >= kPBN &&
          m >= 16 && static_cast<int64_t>(k) * n * 4 < (int64_t{1} << 32) &&
          !(accumulate && block_rows > 0);

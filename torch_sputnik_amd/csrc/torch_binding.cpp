@@ -707,15 +707,24 @@ std::vector<Tensor> csr_transpose_impl(int64_t m64, int64_t n64, const Tensor& v
   const size_t ws_bytes = sputnik_hip_csr_transpose_workspace_bytes(m, n, nonzeros);
   Tensor workspace =
       at::empty({static_cast<int64_t>(ws_bytes)}, values.options().dtype(at::kByte));
-  check_status(
-      sputnik_hip_csr_transpose(m, n, nonzeros, replicas, values.data_ptr<float>(), nonzeros,
-                                row_offsets.data_ptr<int>(), column_indices.data_ptr<int>(),
-                                out_values.data_ptr<float>(), nonzeros,
-                                out_row_offsets.data_ptr<int>(),
-                                out_column_indices.data_ptr<int>(),
-                                want_permutation ? permutation.data_ptr<int>() : nullptr,
-                                workspace.data_ptr(), ws_bytes, current_stream(values)),
-      "csr_transpose");
+  // csr_transpose itself is asynchronous like the reference's (src/transpose_cuda.cu:90-99:
+  // no host round trip).  The form that also returns the permutation is what a cache calls
+  // ONCE per static topology: it takes the checked entry, which waits for the stream and
+  // reports a pattern the transpose is not defined for (a row storing a column twice, a
+  // column out of range) instead of handing out a silently wrong permutation.
+  const auto entry = want_permutation ? sputnik_hip_csr_transpose_checked : sputnik_hip_csr_transpose;
+  const int status =
+      entry(m, n, nonzeros, replicas, values.data_ptr<float>(), nonzeros,
+            row_offsets.data_ptr<int>(), column_indices.data_ptr<int>(),
+            out_values.data_ptr<float>(), nonzeros, out_row_offsets.data_ptr<int>(),
+            out_column_indices.data_ptr<int>(),
+            want_permutation ? permutation.data_ptr<int>() : nullptr, workspace.data_ptr(),
+            ws_bytes, current_stream(values));
+  TORCH_CHECK(!(want_permutation && status == SPUTNIK_HIP_INVALID_ARGUMENT),
+              "torch_sputnik::csr_transpose_with_permutation: the pattern is not a valid CSR "
+              "matrix for a transpose (a row stores a column twice, or a column index is out of "
+              "range)");
+  check_status(status, "csr_transpose");
   std::vector<Tensor> out{out_values, out_row_offsets, out_column_indices};
   if (want_permutation) out.push_back(permutation);
   return out;

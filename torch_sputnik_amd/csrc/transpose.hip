@@ -34,8 +34,20 @@
 // Three launches (four above 8192 columns).  HBM traffic: 16 B per nonzero
 // (values and indices read and written once) + the mask / count tables (8 B
 // per chunk and column).
-// Workspace: two int tables of [ceil(m / 32)][n] + [n] totals -- independent of
-// the number of nonzeros (include/sputnik_hip.h states the bound).
+// Workspace: two int tables of [ceil(m / 32)][n] + [n] totals.
+//
+// VERY SPARSE, VERY LARGE matrices (the tables would dwarf the nonzeros: 1 GiB at
+// 65536^2 whatever nnz is) take a second path with O(n + nnz) work and workspace,
+// as cusparseCsr2cscEx2 has (src/transpose_cuda.cu:22-31): column histogram
+// (integer atomics) -> scan -> unordered scatter of (source row, source index)
+// through per-column cursors -> every output row RANKS its few entries by source
+// row (the stable order, whatever order the atomics came in: deterministic).
+//
+// Both paths DETECT a row that stores a column twice (the mask kernel: the set
+// bits of a chunk's masks must number the chunk's entries; the ranking kernel: two
+// equal source rows in one output row) and set a status word at the end of the
+// workspace; sputnik_hip_csr_transpose_checked waits for it and returns
+// SPUTNIK_HIP_INVALID_ARGUMENT, the asynchronous entry leaves it for the caller.
 #include "common.h"
 #include "wave_utils.h"
 
@@ -69,8 +81,11 @@ constexpr int kMaskBlock = 1024;
 constexpr int kRowsPerWave = kRowsPerChunk / (kMaskBlock / kWave);  // 2
 __global__ __launch_bounds__(kMaskBlock) void transpose_mask_kernel(
     int m, int n, const int* __restrict__ row_offsets, const int* __restrict__ column_indices,
-    mask_t* __restrict__ gmask) {
+    mask_t* __restrict__ gmask, int* __restrict__ balances) {
   extern __shared__ mask_t masks[];
+  __shared__ int balance;   // entries put into the masks minus bits found set: 0 unless a row repeats a column
+  if (threadIdx.x == 0) balance = 0;
+  int entries = 0;
   const int chunk = blockIdx.x;
   const int c0 = blockIdx.y * kColsPerRange, c1 = min(n, c0 + kColsPerRange);
   const int row0 = chunk * kRowsPerChunk;
@@ -98,7 +113,10 @@ __global__ __launch_bounds__(kMaskBlock) void transpose_mask_kernel(
     const mask_t bit = mask_t{1} << (wave + j * (kMaskBlock / kWave));
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u)
-      if (c[j][u] >= c0 && c[j][u] < c1) atomicOr(&masks[c[j][u] - c0], bit);
+      if (c[j][u] >= c0 && c[j][u] < c1) {
+        atomicOr(&masks[c[j][u] - c0], bit);
+        ++entries;
+      }
     // rows longer than kUnroll x 64 entries: the rest, one batch at a time
     for (int first = p0[j] + lane + kUnroll * kWave; first < p1[j]; first += kUnroll * kWave) {
       int more[kUnroll];
@@ -109,20 +127,136 @@ __global__ __launch_bounds__(kMaskBlock) void transpose_mask_kernel(
       }
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u)
-        if (more[u] >= c0 && more[u] < c1) atomicOr(&masks[more[u] - c0], bit);
+        if (more[u] >= c0 && more[u] < c1) {
+          atomicOr(&masks[more[u] - c0], bit);
+          ++entries;
+        }
     }
   }
   __syncthreads();
   mask_t* __restrict__ mine = gmask + static_cast<int64_t>(chunk) * n + c0;
-  for (int i = threadIdx.x; i < c1 - c0; i += kMaskBlock) mine[i] = masks[i];
+  int bits = 0;
+  for (int i = threadIdx.x; i < c1 - c0; i += kMaskBlock) {
+    mine[i] = masks[i];
+    bits += __popc(masks[i]);
+  }
+  int diff = entries - bits;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) diff += __shfl_xor(diff, o);
+  if (lane == 0 && diff != 0) atomicAdd(&balance, diff);
+  __syncthreads();
+  // (every workgroup writes its own slot: the table needs no initialisation; the scan
+  // kernel's first workgroup folds the slots into the status word)
+  if (threadIdx.x == 0) balances[blockIdx.y * gridDim.x + blockIdx.x] = balance;
+}
+
+// ---------------------------------------------------------------------------
+// O(n + nnz) path (see the file header).
+// ---------------------------------------------------------------------------
+// one wave per row: counts[c] += 1 for each of its entries (unordered = false), or
+// (unordered = true) the entry takes the next slot of its column's cursor
+template <bool SCATTER>
+__global__ __launch_bounds__(kBlock) void transpose_sparse_rows_kernel(
+    int m, int n, const int* __restrict__ row_offsets, const int* __restrict__ column_indices,
+    int* __restrict__ counts_or_cursor, int* __restrict__ tmp_row, int* __restrict__ tmp_src,
+    int* __restrict__ status) {
+  const int lane = threadIdx.x % kWave;
+  const int row = blockIdx.x * kWaves + threadIdx.x / kWave;
+  if (row >= m) return;
+  const int p1 = row_offsets[row + 1];
+  for (int p = row_offsets[row] + lane; p < p1; p += kWave) {
+    const int c = column_indices[p];
+    if (c < 0 || c >= n) {
+      atomicOr(status, 2);   // column out of range
+      continue;
+    }
+    if constexpr (SCATTER) {
+      const int slot = atomicAdd(&counts_or_cursor[c], 1);
+      tmp_row[slot] = row;
+      tmp_src[slot] = p;
+    } else {
+      atomicAdd(&counts_or_cursor[c], 1);
+    }
+  }
+}
+
+// out_row_offsets = exclusive scan of counts (n + 1 values); cursor = the same
+__global__ __launch_bounds__(1024) void transpose_sparse_scan_kernel(
+    int n, const int* __restrict__ counts, int* __restrict__ out_row_offsets,
+    int* __restrict__ cursor) {
+  __shared__ int partial[1024];
+  const int t = threadIdx.x;
+  const int per = (n + 1023) / 1024;
+  const int i0 = min(t * per, n), i1 = min(i0 + per, n);
+  int sum = 0;
+  for (int i = i0; i < i1; ++i) sum += counts[i];
+  partial[t] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off *= 2) {
+    const int v = t >= off ? partial[t - off] : 0;
+    __syncthreads();
+    partial[t] += v;
+    __syncthreads();
+  }
+  int run = partial[t] - sum;
+  for (int i = i0; i < i1; ++i) {
+    out_row_offsets[i] = run;
+    cursor[i] = run;
+    run += counts[i];
+  }
+  if (t == 1023) out_row_offsets[n] = partial[1023];
+}
+
+// one wave per output row: every entry of the row's (unordered) segment finds its
+// rank = number of entries with a smaller source row, and goes there
+__global__ __launch_bounds__(kBlock) void transpose_sparse_rank_kernel(
+    int n, const int* __restrict__ out_row_offsets, const int* __restrict__ tmp_row,
+    const int* __restrict__ tmp_src, int* __restrict__ out_column_indices,
+    int* __restrict__ permutation, int* __restrict__ status) {
+  const int lane = threadIdx.x % kWave;
+  const int c = blockIdx.x * kWaves + threadIdx.x / kWave;
+  if (c >= n) return;
+  const int o0 = out_row_offsets[c], o1 = out_row_offsets[c + 1];
+  for (int i = o0 + lane; i < o1; i += kWave) {
+    const int mine = tmp_row[i];
+    int rank = 0, same = 0;
+    for (int j = o0; j < o1; ++j) {
+      const int other = tmp_row[j];
+      rank += other < mine;
+      same += other == mine;
+    }
+    if (same != 1) {
+      atomicOr(status, 1);   // a row holds this column twice: no stable order exists
+      continue;
+    }
+    out_column_indices[o0 + rank] = mine;
+    permutation[o0 + rank] = tmp_src[i];
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void transpose_sparse_values_kernel(
+    int nonzeros, int replicas, const float* __restrict__ values, int64_t values_stride,
+    const int* __restrict__ permutation, float* __restrict__ out_values,
+    int64_t out_values_stride) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= nonzeros) return;
+  const int p = permutation[i];
+  for (int r = 0; r < replicas; ++r) out_values[r * out_values_stride + i] = values[r * values_stride + p];
 }
 
 // table[chunk][c] = sum of popc(gmask[chunk'][c]) over chunk' < chunk;
 // totals[c] = column count.  Block = 64 columns x kScanGroups chunk groups.
 __global__ __launch_bounds__(kWave* kScanGroups) void transpose_scan_table_kernel(
     int n, int chunks, const mask_t* __restrict__ gmask, int* __restrict__ table,
-    int* __restrict__ totals) {
+    int* __restrict__ totals, const int* __restrict__ balances, int nbalances,
+    int* __restrict__ status) {
   __shared__ int group_sum[kScanGroups][kWave];
+  if (blockIdx.x == 0) {   // status word: a non-zero balance = a row holds a column twice
+    int bad = 0;
+    for (int i = threadIdx.x; i < nbalances; i += kWave * kScanGroups) bad |= balances[i] != 0;
+    const int any = __syncthreads_or(bad);
+    if (threadIdx.x == 0) *status = any ? 1 : 0;
+  }
   const int lane = threadIdx.x % kWave;
   const int group = threadIdx.x / kWave;
   const int c = blockIdx.x * kWave + lane;
@@ -417,6 +551,24 @@ __global__ __launch_bounds__(kGroupBlock) void transpose_scatter_grouped_kernel(
 
 inline int chunks_of(int m) { return ceil_div(m, kRowsPerChunk); }
 
+// The table path costs 2 * chunks * n table entries of work and workspace whatever
+// nnz is; beyond eight per nonzero the O(n + nnz) path takes over (2048^2 at density
+// 0.2 and 4096^2 at 0.1 stay on the tables; 65536^2 at 1e-4 does not).
+inline bool sparse_path(int m, int n, int nonzeros) {
+  return static_cast<int64_t>(chunks_of(m)) * n > 8 * static_cast<int64_t>(nonzeros);
+}
+inline size_t table_bytes(int m, int n) {   // masks, counts, totals, one balance per mask workgroup
+  return sizeof(int) * (2 * static_cast<size_t>(chunks_of(m)) * n + n +
+                        static_cast<size_t>(chunks_of(m)) * ceil_div(n, kColsPerRange));
+}
+inline size_t sparse_bytes(int n, int nonzeros) {   // counts + cursor + (row, source, permutation) per nonzero
+  return sizeof(int) * (2 * static_cast<size_t>(n) + 3 * static_cast<size_t>(nonzeros));
+}
+inline size_t status_offset(int m, int n, int nonzeros) {
+  const size_t body = sparse_path(m, n, nonzeros) ? sparse_bytes(n, nonzeros) : table_bytes(m, n);
+  return (body + 15) / 16 * 16;
+}
+
 }  // namespace
 }  // namespace sputnik_hip
 
@@ -425,10 +577,10 @@ using namespace sputnik_hip;
 extern "C" {
 
 size_t sputnik_hip_csr_transpose_workspace_bytes(int m, int n, int nonzeros) {
-  (void)nonzeros;
   if (m <= 0 || n <= 0) return 0;
-  // masks [chunks][n] + counts [chunks][n] + totals [n]
-  return sizeof(int) * (2 * static_cast<size_t>(chunks_of(m)) * n + n);
+  // tables: masks [chunks][n] + counts [chunks][n] + totals [n]; or the O(n + nnz)
+  // path's arrays; + the status word (16 bytes)
+  return status_offset(m, n, max(nonzeros, 0)) + 16;
 }
 
 int sputnik_hip_csr_transpose(int m, int n, int nonzeros, int replicas, const float* values,
@@ -449,23 +601,51 @@ int sputnik_hip_csr_transpose(int m, int n, int nonzeros, int replicas, const fl
       workspace_bytes < sputnik_hip_csr_transpose_workspace_bytes(m, n, nonzeros))
     return SPUTNIK_HIP_INVALID_ARGUMENT;
 
+  int* status = reinterpret_cast<int*>(static_cast<char*>(workspace) + status_offset(m, n, nonzeros));
+  if (sparse_path(m, n, nonzeros)) {
+    int* counts = static_cast<int*>(workspace);
+    int* cursor = counts + n;
+    int* tmp_row = cursor + n;
+    int* tmp_src = tmp_row + nonzeros;
+    int* perm = out_permutation != nullptr ? out_permutation : tmp_src + nonzeros;
+    // counts and the status word in one memset (the status word sits behind the arrays)
+    hipError_t e = hipMemsetAsync(counts, 0, sizeof(int) * static_cast<size_t>(n), stream);
+    if (e == hipSuccess) e = hipMemsetAsync(status, 0, sizeof(int), stream);
+    if (e != hipSuccess) return static_cast<int>(e);
+    const int row_blocks = ceil_div(m, kWaves);
+    hipLaunchKernelGGL(transpose_sparse_rows_kernel<false>, dim3(row_blocks), dim3(kBlock), 0,
+                       stream, m, n, row_offsets, column_indices, counts, nullptr, nullptr, status);
+    hipLaunchKernelGGL(transpose_sparse_scan_kernel, dim3(1), dim3(1024), 0, stream, n, counts,
+                       out_row_offsets, cursor);
+    hipLaunchKernelGGL(transpose_sparse_rows_kernel<true>, dim3(row_blocks), dim3(kBlock), 0,
+                       stream, m, n, row_offsets, column_indices, cursor, tmp_row, tmp_src, status);
+    hipLaunchKernelGGL(transpose_sparse_rank_kernel, dim3(ceil_div(n, kWaves)), dim3(kBlock), 0,
+                       stream, n, out_row_offsets, tmp_row, tmp_src, out_column_indices, perm,
+                       status);
+    hipLaunchKernelGGL(transpose_sparse_values_kernel, dim3(ceil_div(nonzeros, kBlock)),
+                       dim3(kBlock), 0, stream, nonzeros, replicas, values, values_stride, perm,
+                       out_values, out_values_stride);
+    return launch_status();
+  }
   const int chunks = chunks_of(m);
   const int ranges = ceil_div(n, kColsPerRange);
   if (ranges > kMaxGridYZ) return SPUTNIK_HIP_INVALID_ARGUMENT;
   mask_t* gmask = static_cast<mask_t*>(workspace);
   int* table = reinterpret_cast<int*>(gmask + static_cast<size_t>(chunks) * n);
   int* totals = table + static_cast<size_t>(chunks) * n;
+  int* balances = totals + n;
   const size_t range_cols = static_cast<size_t>(min(n, kColsPerRange));
   const size_t lds_bytes = sizeof(mask_t) * range_cols;
   const int groups = column_groups(n);
   const bool grouped = ranges == 1 && chunks <= 0x7fffffff / groups;
 
   hipLaunchKernelGGL(transpose_mask_kernel, dim3(chunks, ranges), dim3(kMaskBlock), lds_bytes,
-                     stream, m, n, row_offsets, column_indices, gmask);
+                     stream, m, n, row_offsets, column_indices, gmask, balances);
   int st = launch_status();
   if (st != 0) return st;
   hipLaunchKernelGGL(transpose_scan_table_kernel, dim3(ceil_div(n, kWave)),
-                     dim3(kWave * kScanGroups), 0, stream, n, chunks, gmask, table, totals);
+                     dim3(kWave * kScanGroups), 0, stream, n, chunks, gmask, table, totals, balances,
+                     chunks * ranges, status);
   st = launch_status();
   if (st != 0) return st;
   if (grouped) {
@@ -490,6 +670,27 @@ int sputnik_hip_csr_transpose(int m, int n, int nonzeros, int replicas, const fl
                      column_indices, gmask, table, out_row_offsets, out_values, out_values_stride,
                      out_column_indices, out_permutation);
   return launch_status();
+}
+
+int sputnik_hip_csr_transpose_checked(int m, int n, int nonzeros, int replicas,
+                                      const float* values, int64_t values_stride,
+                                      const int* row_offsets, const int* column_indices,
+                                      float* out_values, int64_t out_values_stride,
+                                      int* out_row_offsets, int* out_column_indices,
+                                      int* out_permutation, void* workspace,
+                                      size_t workspace_bytes, sputnik_hip_stream_t stream) {
+  const int st = sputnik_hip_csr_transpose(m, n, nonzeros, replicas, values, values_stride,
+                                           row_offsets, column_indices, out_values,
+                                           out_values_stride, out_row_offsets, out_column_indices,
+                                           out_permutation, workspace, workspace_bytes, stream);
+  if (st != 0 || m <= 0 || n <= 0 || nonzeros <= 0) return st;
+  int status = 0;
+  const int* device_status =
+      reinterpret_cast<const int*>(static_cast<const char*>(workspace) + status_offset(m, n, nonzeros));
+  hipError_t e = hipMemcpyAsync(&status, device_status, sizeof(int), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  if (e != hipSuccess) return static_cast<int>(e);
+  return status != 0 ? SPUTNIK_HIP_INVALID_ARGUMENT : 0;
 }
 
 }  // extern "C"

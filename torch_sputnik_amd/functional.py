@@ -21,30 +21,143 @@ from .topology import diffsort
 
 def _identity(*tensors):
     """Key part naming these tensors' storage and contents: address, version
-    counter (bumped by every in-place write), size, device.  The caches below
-    keep a reference to the keyed tensors, so an address cannot be recycled
-    while its entry is alive."""
+    counter (bumped by every in-place write through autograd-visible ops), size,
+    dtype, device."""
     return tuple((t.data_ptr(), t._version, t.numel(), t.dtype, str(t.device)) for t in tensors)
 
 
-class _Lru:
-    """Small bounded map (static topologies are few: a model's layers and masks)."""
+def _storage_key(t):
+    return (t.data_ptr(), t.numel(), t.dtype, str(t.device))
 
-    def __init__(self, capacity):
+
+def _tensor_bytes(obj):
+    if isinstance(obj, torch.Tensor):
+        return obj.numel() * obj.element_size()
+    if isinstance(obj, (tuple, list)):
+        return sum(_tensor_bytes(o) for o in obj)
+    return 0
+
+
+# ---------------------------------------------------------------------------
+# Static topologies.
+#
+# The caches below serve, by default, only index tensors that their OWNER has
+# declared static (`register_static_topology`: SparseLinear.setup_sparse_tensors
+# and SparseAttention do, for the patterns they create and never write to).  An
+# arbitrary tensor handed to Spmm / Sddmm gets the reference's per-call behaviour
+# (modules/spmm.py:59-64): nothing is remembered about it.
+#
+# A registration lives as long as the registered tensor object (weakref): when
+# the owner drops it, the registration and every cache entry made for it go too,
+# so a recycled address can never hit an old entry and no topology is pinned in
+# memory by the cache alone.
+#
+# What the key cannot see: writes that bypass the version counter --
+# `index.data.copy_(...)`, `set_`, a kernel or C-ABI call writing through the raw
+# pointer.  Whoever does that to a registered topology calls
+# `unregister_static_topology` / `clear_caches()` (or simply builds new tensors).
+# ---------------------------------------------------------------------------
+_static = {}        # storage key -> number of live registrations
+_listeners = []     # caches to tell when a registration dies
+
+
+def _drop_registration(key):
+    left = _static.get(key, 0) - 1
+    if left > 0:
+        _static[key] = left
+        return
+    _static.pop(key, None)
+    for cache in list(_listeners):
+        cache.forget(key)
+
+
+def register_static_topology(*tensors):
+    """Declares index tensors (row_indices / row_offsets / column_indices) as
+    static: transposed topologies and kernel plans derived from them are cached
+    until the tensors are written to (in place) or die."""
+    import weakref
+    for t in tensors:
+        key = _storage_key(t)
+        _static[key] = _static.get(key, 0) + 1
+        weakref.finalize(t, _drop_registration, key)
+    return tensors
+
+
+def unregister_static_topology(*tensors):
+    for t in tensors:
+        key = _storage_key(t)
+        _static.pop(key, None)
+        for cache in list(_listeners):
+            cache.forget(key)
+
+
+def _is_static(*tensors):
+    return all(_storage_key(t) in _static for t in tensors)
+
+
+class _Lru:
+    """Bounded map: at most `capacity` entries and `max_bytes` of device memory
+    (static topologies are few -- a model's layers and masks -- but a 4096^2
+    pattern at density 0.1 comes to 27 MB of transposed indices and plan)."""
+
+    def __init__(self, capacity, max_bytes=1 << 30):
         self.capacity = capacity
-        self._entries = collections.OrderedDict()
+        self.max_bytes = max_bytes
+        self.bytes = 0
+        self._entries = collections.OrderedDict()   # key -> (entry, bytes, storage keys it was made for)
 
     def get(self, key):
-        entry = self._entries.get(key)
-        if entry is not None:
-            self._entries.move_to_end(key)
+        slot = self._entries.get(key)
+        if slot is None:
+            return None
+        self._entries.move_to_end(key)
+        return slot[0]
+
+    def put(self, key, entry, made_for=()):
+        size = _tensor_bytes(entry)
+        old = self._entries.pop(key, None)
+        if old is not None:
+            self.bytes -= old[1]
+        self._entries[key] = (entry, size, tuple(made_for))
+        self.bytes += size
+        while len(self._entries) > 1 and (len(self._entries) > self.capacity or self.bytes > self.max_bytes):
+            _, (_, dropped, _) = self._entries.popitem(last=False)
+            self.bytes -= dropped
         return entry
 
-    def put(self, key, entry):
-        self._entries[key] = entry
-        while len(self._entries) > self.capacity:
-            self._entries.popitem(last=False)
-        return entry
+    def forget(self, storage_key):
+        for key in [k for k, (_, _, made_for) in self._entries.items() if storage_key in made_for]:
+            self.bytes -= self._entries.pop(key)[1]
+
+    def clear(self):
+        self._entries.clear()
+        self.bytes = 0
+
+    def __len__(self):
+        return len(self._entries)
+
+
+class _TopologyCache:
+    """Common part of the two caches: whom they serve.  scope "static": index
+    tensors registered with `register_static_topology` only (entries hold no
+    reference to them: they die with their owner); scope "all": any tensor --
+    the caller's promise that the index tensors it passes are not written to
+    behind the version counter; entries then keep the tensors alive so that an
+    address cannot be recycled under a live entry."""
+
+    def __init__(self, capacity, scope):
+        self.scope = scope
+        self._entries = _Lru(capacity)
+        _listeners.append(self)
+
+    def serves(self, *tensors):
+        return self.scope == "all" or _is_static(*tensors)
+
+    def _keep(self, *tensors):
+        return tensors if self.scope == "all" else ()
+
+    def forget(self, storage_key):
+        self._entries.forget(storage_key)
 
     def clear(self):
         self._entries.clear()
@@ -53,93 +166,107 @@ class _Lru:
         return len(self._entries)
 
 
-class TransposeCache:
+class TransposeCache(_TopologyCache):
     """Memoises the transposed topology (and the value permutation) of static
-    CSR patterns, keyed by the identity and version of the index tensors.  The
-    reference re-runs csr_transpose + diffsort in every backward although the
-    topology never changes (modules/spmm.py:59-64, modules/sddmm.py:60-65,
-    modules/sparse_linear.py:52-57); with the cache a backward is one gather of
-    the values through the stored permutation."""
+    CSR patterns.  The reference re-runs csr_transpose + diffsort in every
+    backward although the topology never changes (modules/spmm.py:59-64,
+    modules/sddmm.py:60-65, modules/sparse_linear.py:52-57); with the cache a
+    backward is one gather of the values through the stored permutation."""
 
-    def __init__(self, capacity=128):
-        self._entries = _Lru(capacity)
+    def __init__(self, capacity=128, scope="static"):
+        super().__init__(capacity, scope)
 
     def lookup(self, m, n, row_offsets, column_indices, probe_values):
+        """(row_indices_t, row_offsets_t, column_indices_t, permutation), cached
+        when this cache serves the pattern, computed for this call otherwise."""
+        cached = self.serves(row_offsets, column_indices)
         key = (m, n) + _identity(row_offsets, column_indices)
-        entry = self._entries.get(key)
+        entry = self._entries.get(key) if cached else None
         if entry is None:
             _, row_offsets_t, column_indices_t, permutation = ops.csr_transpose_with_permutation(
                 m, n, probe_values.detach().reshape(-1, probe_values.shape[-1])[0].contiguous(),
                 row_offsets, column_indices)
-            entry = self._entries.put(key, (diffsort(row_offsets_t), row_offsets_t,
-                                            column_indices_t, permutation.contiguous(),
-                                            row_offsets, column_indices))
+            entry = (diffsort(row_offsets_t), row_offsets_t, column_indices_t,
+                     permutation.contiguous()) + self._keep(row_offsets, column_indices)
+            if cached:
+                # the derived pattern is as static as the one it was made from: plans
+                # for it (the transposed products of every backward) are cached too,
+                # for as long as this entry holds its tensors
+                register_static_topology(*entry[:3])
+                self._entries.put(key, entry, (_storage_key(row_offsets), _storage_key(column_indices)))
         return entry[:4]
 
-    def clear(self):
-        self._entries.clear()
 
-
-class PlanCache:
+class PlanCache(_TopologyCache):
     """Memoises the topology-only pre-pass of the LDS-tiled kernels
     (ops.spmm_plan / ops.sddmm_plan) per static topology and operand width, so
-    that training steps launch kernels only.  Keyed like TransposeCache."""
+    that training steps launch kernels only.  Every method returns None for a
+    pattern this cache does not serve (the caller then takes the per-call op)."""
 
-    def __init__(self, capacity=256):
-        self._entries = _Lru(capacity)
+    def __init__(self, capacity=256, scope="static"):
+        super().__init__(capacity, scope)
+
+    def _plan(self, kind, shape, make, *index):
+        if not self.serves(*index):
+            return None
+        key = (kind,) + shape + _identity(*index)
+        entry = self._entries.get(key)
+        if entry is None:
+            entry = self._entries.put(key, (make(),) + self._keep(*index),
+                                      tuple(_storage_key(t) for t in index))
+        return entry[0]
 
     def spmm(self, m, k, n, row_indices, row_offsets, column_indices):
-        key = ("spmm", m, k, n) + _identity(row_indices, row_offsets, column_indices)
-        entry = self._entries.get(key)
-        if entry is None:
-            plan = ops.spmm_plan(m, k, n, row_indices, row_offsets, column_indices)
-            entry = self._entries.put(key, (plan, row_indices, row_offsets, column_indices))
-        return entry[0]
+        return self._plan("spmm", (m, k, n),
+                          lambda: ops.spmm_plan(m, k, n, row_indices, row_offsets, column_indices),
+                          row_indices, row_offsets, column_indices)
 
     def sddmm(self, m, n, k, row_indices, row_offsets, column_indices, summed=False):
-        key = ("sddmm_sum" if summed else "sddmm", m, n, k) + _identity(
-            row_indices, row_offsets, column_indices)
-        entry = self._entries.get(key)
-        if entry is None:
-            plan = (ops.sddmm_sum_plan if summed else ops.sddmm_plan)(
-                m, n, k, row_indices, row_offsets, column_indices)
-            entry = self._entries.put(key, (plan, row_indices, row_offsets, column_indices))
-        return entry[0]
+        return self._plan("sddmm_sum" if summed else "sddmm", (m, n, k),
+                          lambda: (ops.sddmm_sum_plan if summed else ops.sddmm_plan)(
+                              m, n, k, row_indices, row_offsets, column_indices),
+                          row_indices, row_offsets, column_indices)
 
     def attention(self, m, n, d, row_indices, row_offsets, column_indices):
-        key = ("attention", m, n, d) + _identity(row_indices, row_offsets, column_indices)
-        entry = self._entries.get(key)
-        if entry is None:
-            plan = ops.sparse_attention_plan(m, n, d, row_indices, row_offsets, column_indices)
-            entry = self._entries.put(key, (plan, row_indices, row_offsets, column_indices))
-        return entry[0]
-
-    def clear(self):
-        self._entries.clear()
+        return self._plan("attention", (m, n, d),
+                          lambda: ops.sparse_attention_plan(m, n, d, row_indices, row_offsets,
+                                                            column_indices),
+                          row_indices, row_offsets, column_indices)
 
 
-# Both caches are ON by default: the topologies of a sparse model are static,
-# and the keys (address + version counter + size of every index tensor, with the
-# tensors kept alive by the entry) change whenever a topology is replaced or
-# written to.  `enable_transpose_cache(False)` / `enable_plan_cache(False)` give
-# the reference's per-call behaviour.
-TRANSPOSE_CACHE_DEFAULT = True
-PLAN_CACHE_DEFAULT = True
-_cache = TransposeCache() if TRANSPOSE_CACHE_DEFAULT else None
-_plans = PlanCache() if PLAN_CACHE_DEFAULT else None
+# Both caches exist by default with scope "static": they serve the patterns that
+# modules register (see above) and nothing else.  `enable_*_cache(True)` widens
+# a cache to every tensor (scope "all": the caller vouches for the tensors),
+# `enable_*_cache(False)` gives the reference's per-call behaviour everywhere.
+TRANSPOSE_CACHE_DEFAULT = "static"
+PLAN_CACHE_DEFAULT = "static"
+
+
+def _make_cache(cls, enabled):
+    if not enabled:
+        return None
+    return cls(scope="all" if enabled is True or enabled == "all" else "static")
+
+
+_cache = _make_cache(TransposeCache, TRANSPOSE_CACHE_DEFAULT)
+_plans = _make_cache(PlanCache, PLAN_CACHE_DEFAULT)
 
 
 def enable_transpose_cache(enabled=True):
-    """Cache transposed topologies across backward calls (default: on)."""
+    """False: off; "static" (the default): registered topologies only; True: all tensors."""
     global _cache
-    _cache = TransposeCache() if enabled else None
+    if _cache is not None and _cache in _listeners:
+        _listeners.remove(_cache)
+    _cache = _make_cache(TransposeCache, enabled)
     return _cache
 
 
 def enable_plan_cache(enabled=True):
-    """Cache the kernels' topology pre-pass across calls (default: on)."""
+    """False: off; "static" (the default): registered topologies only; True: all tensors."""
     global _plans
-    _plans = PlanCache() if enabled else None
+    if _plans is not None and _plans in _listeners:
+        _listeners.remove(_plans)
+    _plans = _make_cache(PlanCache, enabled)
     return _plans
 
 
@@ -237,10 +364,11 @@ def _spmm_transposed(m, n, values, row_offsets, column_indices, dense, left=Fals
 
 def _spmm(m, k, values, row_indices, row_offsets, column_indices, dense, left=False):
     """spmm / left_spmm, through the cached plan of the topology when enabled."""
-    if _plans is None:
+    plan = None if _plans is None else _plans.spmm(m, k, dense.size(-1), row_indices, row_offsets,
+                                                   column_indices)
+    if plan is None:
         return (ops.left_spmm if left else ops.spmm)(m, k, values, row_indices, row_offsets,
                                                      column_indices, dense)
-    plan = _plans.spmm(m, k, dense.size(-1), row_indices, row_offsets, column_indices)
     return (ops.left_spmm_planned if left else ops.spmm_planned)(
         m, k, values, row_indices, row_offsets, column_indices, dense, plan)
 
@@ -257,22 +385,22 @@ def _linear(m, k, values, row_indices, row_offsets, column_indices, dense, split
 
 def _sddmm(m, n, row_indices, row_offsets, column_indices, lhs_matrix, rhs_matrix,
            sum_replicas=False):
-    if _plans is None:
+    plan = None if _plans is None else _plans.sddmm(m, n, lhs_matrix.size(-1), row_indices,
+                                                    row_offsets, column_indices, summed=sum_replicas)
+    if plan is None:
         return (ops.sddmm_sum if sum_replicas else ops.sddmm)(
             m, n, row_indices, row_offsets, column_indices, lhs_matrix, rhs_matrix)
-    plan = _plans.sddmm(m, n, lhs_matrix.size(-1), row_indices, row_offsets, column_indices,
-                        summed=sum_replicas)
     return (ops.sddmm_sum_planned if sum_replicas else ops.sddmm_planned)(
         m, n, row_indices, row_offsets, column_indices, lhs_matrix, rhs_matrix, plan)
 
 
 def _attention(query, key, value, row_indices, row_offsets, column_indices, scale):
     """Fused attention forward, through the cached plan of the mask when enabled."""
-    if _plans is None:
+    plan = None if _plans is None else _plans.attention(query.size(-2), key.size(-2), query.size(-1),
+                                                        row_indices, row_offsets, column_indices)
+    if plan is None:
         return ops.sparse_attention(query, key, value, row_indices, row_offsets, column_indices,
                                     scale)
-    plan = _plans.attention(query.size(-2), key.size(-2), query.size(-1), row_indices,
-                            row_offsets, column_indices)
     return ops.sparse_attention_planned(query, key, value, row_indices, row_offsets,
                                         column_indices, scale, plan)
 

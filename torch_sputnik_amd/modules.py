@@ -40,6 +40,11 @@ class SparseLinear(nn.Module):
         self.row_indices = row_indices
         self.row_offsets = row_offsets
         self.column_indices = column_indices
+        # The module owns this pattern and never writes to it: transposed topology
+        # and kernel plans are cached for as long as these tensors live.  (Replace
+        # the pattern by calling setup_sparse_tensors() again -- do not write into
+        # the index tensors through .data or a raw pointer: functional.py.)
+        functional.register_static_topology(row_indices, row_offsets, column_indices)
 
     def forward(self, x):
         # [B, S, in] -> the k-major operand [B, in, S] of left_spmm: the reference's
@@ -94,6 +99,7 @@ class SparseAttention(nn.Module):
         self.mask2d = generate_mask(self.m, self.n, device, sparsity=sparsity,
                                     generator=mask_generator)
         _, self.row_indices, self.row_offsets, self.column_indices = dense_to_sparse(self.mask2d)
+        functional.register_static_topology(self.row_indices, self.row_offsets, self.column_indices)
 
         self.sddmm = Sddmm.apply
         self.spmm = Spmm.apply
