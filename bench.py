@@ -129,6 +129,16 @@ class Exchange:
         self.local = problem.out.reshape(r, m, n)
         self.flat = torch.empty(world * r * m * n, device=dev)
         self.rank_major = self.flat.view(world, r, m, n)          # = global replica order
+        self.set_chunks(chunks)
+        # (tests/test_bench_exchange.py drives this class on CPU tensors over gloo)
+        self.side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self.bytes_per_peer = r * m * n * 4.0
+
+    def set_chunks(self, chunks):
+        """The overlapped schedules exchange the local block in `chunks` pieces (at
+        most one replica each): chunk i travels while chunk i + 1 is computed."""
+        r, m, n, world = self.problem.replicas, self.m, self.n, self.world
+        chunks = max(1, min(chunks, r))
         per = (r + chunks - 1) // chunks
         self.bounds = [(a, min(a + per, r)) for a in range(0, r, per)]
         # collective chunks land chunk-major ([chunk][rank][replicas of the chunk]):
@@ -138,9 +148,7 @@ class Exchange:
             size = world * (b - a) * m * n
             self.chunk_major.append(self.flat[off:off + size].view(world * (b - a), m, n))
             off += size
-        # (tests/test_bench_exchange.py drives this class on CPU tensors over gloo)
-        self.side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
-        self.bytes_per_peer = r * m * n * 4.0
+        return len(self.bounds)
 
     def collective(self):
         self.dist.all_gather_into_tensor(self.rank_major.view(-1, self.m, self.n), self.local)
@@ -204,7 +212,7 @@ class Exchange:
         mine = self.local[:, 0, :].contiguous()                       # [r, n]
         prints = torch.empty((self.world, r, n), device=self.dev)
         self.dist.all_gather_into_tensor(prints.view(-1, n), mine)
-        if schedule == "allgather_overlapped_collective":
+        if schedule.startswith("allgather_overlapped_collective"):
             for c, (a, b) in enumerate(self.bounds):
                 got = self.chunk_major[c].view(self.world, b - a, m, n)[:, :, 0, :]
                 assert torch.equal(got, prints[:, a:b]), f"{schedule}: gathered chunk {c} is wrong"
@@ -225,20 +233,50 @@ class Exchange:
             return {"ms": ms, "gbs_per_link_per_direction": self.bytes_per_peer / ms / 1e6,
                     "gbs_received_per_gpu": self.bytes_per_peer * max(1, self.world - 1) / ms / 1e6}
 
+        # the overlapped schedules were timed for several chunk counts
+        # ("allgather_overlapped_<transport>_c<chunks>"): the best per transport is the
+        # figure, all of them are listed
+        by_chunks, best = {}, {}
+        for transport in ("collective", "p2p"):
+            prefix = f"allgather_overlapped_{transport}_c"
+            for name, ms in timings.items():
+                if name.startswith(prefix) and ms:
+                    c = int(name[len(prefix):])
+                    by_chunks.setdefault(str(c), {})[transport] = line(name)
+                    if transport not in best or ms < timings[best[transport]]:
+                        best[transport] = name
+        compute_ms = timings.get("compute_only") or 0.0
+        # what the links allow (xGMI full mesh, ~153 GB/s per link and direction; a direct
+        # exchange sends one block over each of the 7 links at once)
+        floor_ms = self.bytes_per_peer / 153.0e6 if self.world > 1 else 0.0
+        chunk_counts = sorted(int(c) for c in by_chunks) or [len(self.bounds)]
+        model = {
+            "links_per_gpu": 7, "gbs_per_link": 153.0,
+            "direct_exchange_floor_ms": floor_ms,
+            "allgather_floor_ms": compute_ms + floor_ms,
+            # chunks of equal size: the longer of the two streams, plus one chunk of the
+            # other (the first chunk's compute / the last chunk's exchange is exposed)
+            "allgather_overlapped_floor_ms": {
+                str(c): max(compute_ms, floor_ms) + min(compute_ms, floor_ms) / c for c in chunk_counts},
+            "ring_collective_floor_ms": floor_ms * max(1, self.world - 1),
+        }
         return {
             "compute_only": line("compute_only"),
+            "per_gpu_share": {"replicas": self.problem.replicas, "ms": compute_ms or None,
+                              "gflops_per_gpu": (self.problem.flops / compute_ms / 1e6) if compute_ms else None,
+                              "note": "what ONE GPU does per step in this run; the one-GPU line's "
+                                      "per_gpu_share_of_multi_gpu_runs measures the same workload"},
             "allgather": {"collective": line("allgather_collective"), "p2p": line("allgather_p2p")},
-            "allgather_overlapped": {"collective": line("allgather_overlapped_collective"),
-                                     "p2p": line("allgather_overlapped_p2p"),
-                                     "chunks": len(self.bounds)},
+            "allgather_overlapped": {"collective": line(best["collective"]) if "collective" in best else None,
+                                     "p2p": line(best["p2p"]) if "p2p" in best else None,
+                                     "chunks": {t: int(best[t].rsplit("_c", 1)[1]) for t in best},
+                                     "by_chunks": by_chunks},
             "exchange_only": {"collective": link("exchange_only_collective"),
                               "p2p": link("exchange_only_p2p")},
             "bytes_sent_per_rank_per_peer": self.bytes_per_peer,
             "bytes_received_per_rank": self.bytes_per_peer * (self.world - 1),
             "gathered_bytes_per_rank": self.bytes_per_peer * self.world,
-            "xgmi_model": {"links_per_gpu": 7, "gbs_per_link": 153.0,
-                           "direct_exchange_floor_ms": self.bytes_per_peer / 153.0e6
-                           if self.world > 1 else 0.0},
+            "xgmi_model": model,
         }
 
 
@@ -414,6 +452,39 @@ def other_ops(dev):
         del big
     except Exception as e2:  # noqa: BLE001 - extra metric, best effort
         res["spmm_projection_c3"] = {"error": str(e2)[:200]}
+    # "many mask" family (one mask per batch element, shared by its 8 heads; mixed
+    # sparsity as tests/test_attention_many_masks.py:26-36 draws it): b = 8, S = 1024
+    try:
+        b_mm, h_mm = 8, 8
+        dens = (0.1, 0.2, 0.05, 0.5)
+        topo = [random_csr(s, s, dens[i % len(dens)], dev, seed=70 + i) for i in range(b_mm)]
+        nn = torch.tensor([t4[3] for t4 in topo], dtype=torch.int32)          # host, like utils.py:36
+        width = int(nn.max())
+        mri = torch.cat([t4[0] for t4 in topo])
+        mro = torch.cat([t4[1] for t4 in topo])
+        mci = torch.cat([t4[2] for t4 in topo])
+        r_mm = b_mm * h_mm
+        mscores = torch.zeros(r_mm, width, device=dev)
+        mprobs = torch.zeros_like(mscores)
+        mws = torch.empty(max(capi.sddmm_many_mask_workspace_bytes(b_mm, s, d, s, width),
+                              capi.spmm_workspace_bytes(s, s, d, width)) + 16,
+                          dtype=torch.uint8, device=dev)
+        total = float(nn.sum()) * h_mm
+        t = event_time_ms(lambda: capi.sddmm_many_mask(b_mm, s, d, s, nn, r_mm, mri, mro, mci, q, kk,
+                                                       mscores, mws), 20)
+        res["many_mask_sddmm"] = {"ms": t, "gflops": 2.0 * total * d / t / 1e6}
+        t = event_time_ms(lambda: capi.sparse_softmax_many_mask(b_mm, s, nn, r_mm, mscores, mri, mro,
+                                                                mci, d ** -0.5, mprobs), 20)
+        res["many_mask_softmax"] = {"ms": t, "alg_gbs": 8.0 * total / t / 1e6,
+                                    "hbm_frac": 8.0 * total / t / 1e6 / HBM_PEAK_GBS}
+        t = event_time_ms(lambda: capi.spmm_many_mask(b_mm, s, s, d, nn, r_mm, mri, mprobs, mro, mci,
+                                                      v, ctx, mws), 20)
+        res["many_mask_spmm"] = {"ms": t, "gflops": 2.0 * total * d / t / 1e6}
+        res["many_mask_note"] = ("b 8 x 8 heads, S 1024, head_dim 64, mask densities 0.1/0.2/0.05/0.5 "
+                                 "repeated: one launch per operator for all masks")
+        del mscores, mprobs, mws
+    except Exception as e3:  # noqa: BLE001 - extra metric, best effort
+        res["many_mask_sddmm"] = {"error": str(e3)[:200]}
     # the same chain as ONE kernel (online softmax; scores / weights never reach HBM)
     aws = torch.empty(capi.sparse_attention_workspace_bytes(s, s, d, nnz), dtype=torch.uint8,
                       device=dev)
@@ -569,9 +640,10 @@ def main():
                     help="seconds of untimed steps before the W warm-up steps (clock ramp)")
     ap.add_argument("--compute-only", action="store_true",
                     help="N>1: time the local launches only (no all-gather of C)")
-    ap.add_argument("--overlap-chunks", type=int, default=4,
+    ap.add_argument("--overlap-chunks", type=str, default="4,8,16",
                     help="N>1: the overlapped schedules split a rank's replicas into this many "
-                         "chunks and exchange chunk i (side stream) while chunk i+1 is computed")
+                         "chunks and exchange chunk i (side stream) while chunk i+1 is computed; "
+                         "a comma list is swept and the best chunk count per transport reported")
     ap.add_argument("--replicas-per-gpu", type=int, default=0,
                     help="override (default 1 at --gpus 1, 16 otherwise)")
     ap.add_argument("--no-extras", action="store_true", help="skip sweep / cpu baseline / other ops")
@@ -729,16 +801,26 @@ def main():
         #   allgather_{collective,p2p}        launch, then exchange (unoverlapped)
         #   allgather_overlapped_{...}        chunk i exchanged while chunk i+1 computes
         # `value` is the best schedule that includes the all-gather.
-        ex = Exchange(problem, world, rank, dev, max(1, min(args.overlap_chunks, replicas)))
+        chunk_counts = sorted({max(1, min(int(c), replicas)) for c in str(args.overlap_chunks).split(",")})
+        ex = Exchange(problem, world, rank, dev, chunk_counts[0])
+        p2p = os.environ.get("BENCH_NO_P2P") != "1"
+
+        def overlapped(chunks, exchange_chunk):
+            def run():
+                ex.overlapped(exchange_chunk)
+            run.chunks = chunks     # (the chunk layout is switched before the schedule's warm-up)
+            return run
+
         variants = {"compute_only": problem.step,
                     "exchange_only_collective": ex.collective,
-                    "allgather_collective": lambda: (problem.step(), ex.collective()),
-                    "allgather_overlapped_collective": lambda: ex.overlapped(ex.collective_chunk)}
-        if os.environ.get("BENCH_NO_P2P") != "1":
-            variants.update({
-                "exchange_only_p2p": ex.p2p,
-                "allgather_p2p": lambda: (problem.step(), ex.p2p()),
-                "allgather_overlapped_p2p": lambda: ex.overlapped(ex.p2p_chunk)})
+                    "allgather_collective": lambda: (problem.step(), ex.collective())}
+        if p2p:
+            variants.update({"exchange_only_p2p": ex.p2p,
+                             "allgather_p2p": lambda: (problem.step(), ex.p2p())})
+        for c in chunk_counts:
+            variants[f"allgather_overlapped_collective_c{c}"] = overlapped(c, ex.collective_chunk)
+            if p2p:
+                variants[f"allgather_overlapped_p2p_c{c}"] = overlapped(c, ex.p2p_chunk)
         if args.compute_only:
             variants = {"compute_only": problem.step}
         timings = {}
@@ -760,6 +842,8 @@ def main():
             try:
                 if os.environ.get("BENCH_TEST_HANG") == name:   # (test of the watchdog)
                     time.sleep(1e6)
+                if hasattr(fn, "chunks"):
+                    ex.set_chunks(fn.chunks)
                 ex.poison()
                 timings[name] = run_timed(fn)
                 # (the schedules share one gathered buffer in different layouts: each is

@@ -442,13 +442,20 @@ SPUTNIK_HIP_API int sputnik_hip_sparse_attention_forward_planned(int m, int n, i
  * `replicas` (a multiple of `masks`) value / dense slices; replica r uses
  * mask r / (replicas / masks), i.e. the heads of one batch element share its
  * mask (tests/test_attention_many_masks.py:107-150).  Replica r keeps its
- * nonzeros[mask] values at values + r * values_stride; the stride is
- * normally max(nonzeros) and anything past a replica's own count is never
- * read or written.
+ * nonzeros[mask] values at values + r * values_stride; the stride is at least
+ * max(nonzeros), and anything past a replica's own count is never written (it
+ * may be read: the rows are moved in aligned 16-byte pieces).
  * Call sites: torch_sputnik.{sddmm,sparse_softmax,spmm,csr_transpose}_many_mask,
  * tests/transformer/functions.py:20,41,50,59,81,135,156,165,177.
- * Workspaces: the single-mask query at max(nonzeros).
+ * One launch per operator serves all masks (softmax pair; SDDMM; SpMM where the
+ * panel-resident kernel applies, n = head_dim), see csrc/many_mask.hip.
+ * Workspaces: the single-mask query at max(nonzeros); for SDDMM
+ * sputnik_hip_sddmm_many_mask_workspace_bytes (one plan per mask; with less the
+ * call still works, on the workspace-free kernel).
  * ---------------------------------------------------------------------- */
+SPUTNIK_HIP_API size_t sputnik_hip_sddmm_many_mask_workspace_bytes(int masks, int m, int k, int n,
+                                                                   int largest_nonzeros);
+
 SPUTNIK_HIP_API int sputnik_hip_spmm_many_mask(int masks, int m, int k, int n,
                              const int* nonzeros, int replicas, const int* row_indices,
                              const float* values, int64_t values_stride,

@@ -56,20 +56,39 @@ def _worker(rank, world, port, replicas, chunks, results):
             for _ in range(2):
                 fn()
             ex.verify(name)
+        # the chunk-count sweep of the benchmark line: the layout is switched between
+        # schedules on the same buffer (16 chunks = one replica each when there are 16)
+        for c in (4, 16, 2):
+            got = ex.set_chunks(c)
+            assert got == len(ex.bounds) <= min(c, replicas) and ex.bounds[-1][1] == replicas
+            for name, chunk_fn in ((f"allgather_overlapped_collective_c{c}", ex.collective_chunk),
+                                   (f"allgather_overlapped_p2p_c{c}", ex.p2p_chunk)):
+                ex.poison()
+                ex.overlapped(chunk_fn)
+                ex.verify(name)
+        ex.set_chunks(chunks)
         # the global replica order of the rank-major layout
         problem.step()
         ex.collective()
         want = torch.arange(world, dtype=torch.float32).view(-1, 1) * 1000
         got = ex.rank_major[:, :, 0, 0] - ex.rank_major[:, :, 0, 0] % 10
         assert torch.equal(got - torch.arange(replicas, dtype=torch.float32) * 10, want.expand(-1, replicas))
-        report = ex.report({"compute_only": 1.0, "allgather_collective": 2.0}, world)
+        report = ex.report({"compute_only": 1.0, "allgather_collective": 2.0,
+                            "allgather_overlapped_p2p_c4": 1.5, "allgather_overlapped_p2p_c16": 1.25,
+                            "allgather_overlapped_collective_c4": 1.75}, world)
         assert report["bytes_received_per_rank"] == replicas * 6 * 5 * 4.0 * (world - 1)
+        assert report["allgather_overlapped"]["chunks"] == {"p2p": 16, "collective": 4}
+        assert report["allgather_overlapped"]["p2p"]["ms_per_step"] == 1.25
+        assert set(report["allgather_overlapped"]["by_chunks"]) == {"4", "16"}
+        assert report["per_gpu_share"]["replicas"] == replicas
+        floors = report["xgmi_model"]["allgather_overlapped_floor_ms"]
+        assert floors["16"] <= floors["4"]
         results[rank] = True
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,replicas,chunks", [(2, 4, 2), (3, 5, 4), (2, 3, 1)])
+@pytest.mark.parametrize("world,replicas,chunks", [(2, 4, 2), (3, 5, 4), (2, 3, 1), (2, 16, 16), (3, 16, 8)])
 def test_exchange_schedules_over_gloo(world, replicas, chunks):
     ctx = mp.get_context("spawn")
     results = ctx.Manager().dict()

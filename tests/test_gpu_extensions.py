@@ -186,14 +186,21 @@ def _many_mask_inputs(b, heads, s, hn, sparsities, seed):
     (3, 2, 24, 8, (0.2, 0.5, 0.8)),
     (4, 8, 512, 64, (0.2, 0.5)),      # tests/test_attention_many_masks.py:26-36 sparsities
     (2, 4, 256, 64, (0.9,)),          # equal counts: no padding anywhere
+    (8, 8, 1024, 64, (0.9, 0.8, 0.95, 0.5)),   # attention size, mixed sparsity: every op ONE launch
 ])
-def test_many_mask_chain_capi_vs_oracle(capi, dev, b, heads, s, hn, sparsities):
+@pytest.mark.parametrize("plan_per_mask", [False, True],
+                         ids=["single_mask_workspace", "many_mask_workspace"])
+def test_many_mask_chain_capi_vs_oracle(capi, dev, b, heads, s, hn, sparsities, plan_per_mask):
+    """plan_per_mask: the SDDMM workspace holds one plan per mask, so all masks run on
+    the LDS-tiled kernel in one launch; with the single-mask workspace the (also
+    single-launch) row-wave kernel takes the call."""
     masks, ri, ro, ci, nn, q, k, v = _many_mask_inputs(b, heads, s, hn, sparsities, seed=s + b)
     r, width = b * heads, int(nn.max())
     scale = 1.0 / np.sqrt(hn)
     d_ri, d_ro, d_ci = T(ri, dev), T(ro, dev), T(ci, dev)
-    ws = torch.empty(max(capi.sddmm_workspace_bytes(s, hn, s, width),
-                         capi.spmm_workspace_bytes(s, s, hn, width),
+    sddmm_ws = (capi.sddmm_many_mask_workspace_bytes(b, s, hn, s, width) if plan_per_mask
+                else capi.sddmm_workspace_bytes(s, hn, s, width))
+    ws = torch.empty(max(sddmm_ws, capi.spmm_workspace_bytes(s, s, hn, width),
                          capi.csr_transpose_workspace_bytes(s, s, width)) + 16,
                      dtype=torch.uint8, device=dev)
     scores = torch.zeros(r, width, device=dev)

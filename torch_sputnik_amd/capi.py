@@ -36,6 +36,7 @@ SIGNATURES = {
                                                                 _c_i64, _c_ptr, _c_size, _c_ptr]),
     "sputnik_hip_sddmm": (_c_int, [_c_int] * 4 + [_c_ptr] * 7),
     "sputnik_hip_sddmm_workspace_bytes": (_c_size, [_c_int] * 4),
+    "sputnik_hip_sddmm_many_mask_workspace_bytes": (_c_size, [_c_int] * 5),
     "sputnik_hip_sddmm_batched": (_c_int, [_c_int] * 5 + [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64,
                                                          _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr,
                                                          _c_size, _c_ptr]),
@@ -348,6 +349,11 @@ def spmm_many_mask(masks, m, k, n, nonzeros, replicas, row_indices, values, row_
         _ptr(row_offsets), _ptr(column_indices), _ptr(dense), k * n, _ptr(out), m * n,
         _ptr(workspace), _ws_bytes(workspace), _stream(out)), "sputnik_hip_spmm_many_mask")
     return out
+
+
+def sddmm_many_mask_workspace_bytes(masks, m, k, n, largest_nonzeros):
+    """One plan per mask: with it all masks run on the LDS-tiled kernel in one launch."""
+    return lib().sputnik_hip_sddmm_many_mask_workspace_bytes(masks, m, k, n, largest_nonzeros)
 
 
 def sddmm_many_mask(masks, m, k, n, nonzeros, replicas, row_indices, row_offsets, column_indices,

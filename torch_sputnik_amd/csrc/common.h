@@ -50,6 +50,29 @@ __device__ __forceinline__ float4 apply_epilogue(float4 v, const Epilogue& e, in
   return v;
 }
 
+// "Many mask" batches (tests/transformer/functions.py of the reference: one mask
+// per batch element, shared by its heads): the topologies are concatenated --
+// row_offsets [masks][m + 1] (each zero based), row_indices [masks][m],
+// column_indices back to back -- and replica r works under topology r / heads.
+// A kernel that serves such a batch in ONE launch moves its topology pointers
+// by what select_mask returns (wave-uniform: scalar loads); heads = 0 means one
+// topology for all replicas (nothing moves).
+struct MaskPlace {
+  int mask;      // topology number of the replica
+  int first;     // its first entry in the concatenated column_indices
+  int nonzeros;  // its entry count
+};
+__device__ __forceinline__ MaskPlace select_mask(int heads, int replica, int m, int nonzeros,
+                                                 const int* row_offsets) {
+  if (heads <= 0) return MaskPlace{0, 0, nonzeros};
+  const int mask = replica / heads;
+  int first = 0;
+  for (int j = 0; j < mask; ++j) first += row_offsets[static_cast<int64_t>(j) * (m + 1) + m];
+  return MaskPlace{mask, first, row_offsets[static_cast<int64_t>(mask) * (m + 1) + m]};
+}
+// (the kernels then do:  row_offsets += place.mask * (m + 1); column_indices += place.first;
+//  row_indices += place.mask * m; nonzeros = place.nonzeros)
+
 template <int VEC>
 struct FloatVec;
 template <>

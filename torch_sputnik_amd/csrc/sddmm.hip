@@ -26,7 +26,12 @@ int sddmm_tiled_plan(int m, int k, int n, int nonzeros, const int* row_indices,
 int sddmm_tiled_launch(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
                        const int* row_offsets, const int* column_indices, const float* lhs,
                        int64_t lhs_stride, const float* rhs, int64_t rhs_stride, float* out,
-                       int64_t out_stride, const void* workspace, hipStream_t stream);
+                       int64_t out_stride, const void* workspace, hipStream_t stream,
+                       int mask_heads = 0, int64_t mask_plan_ints = 0);
+// Bytes between the plans of consecutive masks in a "many mask" workspace.
+inline size_t sddmm_many_mask_plan_bytes(int m, int k, int n, int nonzeros) {
+  return (sddmm_tiled_workspace_bytes(m, k, n, nonzeros) + 255) / 256 * 256;
+}
 
 int sddmm_tiled_panels(int m, int k, int n, int nonzeros);
 int sddmm_tiled_launch_partials(int m, int k, int n, int nonzeros, int replicas,
@@ -45,7 +50,7 @@ __global__ __launch_bounds__(kBlock) void sddmm_rowwave_kernel(
     int m, int k, const int* __restrict__ row_indices, const int* __restrict__ row_offsets,
     const int* __restrict__ column_indices, const float* __restrict__ lhs, int64_t lhs_stride,
     const float* __restrict__ rhs, int64_t rhs_stride, float* __restrict__ out,
-    int64_t out_stride) {
+    int64_t out_stride, int mask_heads, int first_replica) {
   constexpr int kGroups = kWave / LPN;
   constexpr int kPanel = LPN * VEC * KSL;
   const int wave = threadIdx.x / kWave;
@@ -58,6 +63,12 @@ __global__ __launch_bounds__(kBlock) void sddmm_rowwave_kernel(
   lhs += replica * lhs_stride;
   rhs += replica * rhs_stride;
   out += replica * out_stride;
+  {
+    const MaskPlace place = select_mask(mask_heads, first_replica + replica, m, 0, row_offsets);
+    row_offsets += static_cast<int64_t>(place.mask) * (m + 1);
+    column_indices += place.first;
+    row_indices += static_cast<int64_t>(place.mask) * m;
+  }
 
   const int row = row_indices[slot];
   const int p0 = row_offsets[row];
@@ -117,14 +128,15 @@ __global__ __launch_bounds__(kBlock) void sddmm_rowwave_kernel(
 template <int VEC, int LPN, int KSL>
 int launch(int m, int k, int replicas, const int* row_indices, const int* row_offsets,
            const int* column_indices, const float* lhs, int64_t lhs_stride, const float* rhs,
-           int64_t rhs_stride, float* out, int64_t out_stride, hipStream_t stream) {
+           int64_t rhs_stride, float* out, int64_t out_stride, hipStream_t stream,
+           int mask_heads) {
   const int gx = ceil_div(m, kWavesPerBlock);
   for (int r0 = 0; r0 < replicas; r0 += kMaxGridYZ) {
     const int ry = min(replicas - r0, kMaxGridYZ);
     hipLaunchKernelGGL((sddmm_rowwave_kernel<VEC, LPN, KSL>), dim3(gx, ry), dim3(kBlock), 0,
                        stream, m, k, row_indices, row_offsets, column_indices,
                        lhs + r0 * lhs_stride, lhs_stride, rhs + r0 * rhs_stride, rhs_stride,
-                       out + r0 * out_stride, out_stride);
+                       out + r0 * out_stride, out_stride, mask_heads, r0);
     const int st = launch_status();
     if (st != 0) return st;
   }
@@ -134,11 +146,12 @@ int launch(int m, int k, int replicas, const int* row_indices, const int* row_of
 template <int VEC>
 int launch_vec(int m, int k, int replicas, const int* row_indices, const int* row_offsets,
                const int* column_indices, const float* lhs, int64_t lhs_stride, const float* rhs,
-               int64_t rhs_stride, float* out, int64_t out_stride, hipStream_t stream) {
+               int64_t rhs_stride, float* out, int64_t out_stride, hipStream_t stream,
+               int mask_heads = 0) {
   const int lanes = ceil_div(k, VEC);
 #define SPUTNIK_HIP_SD(LPN, KSL)                                                              \
   return launch<VEC, LPN, KSL>(m, k, replicas, row_indices, row_offsets, column_indices, lhs, \
-                               lhs_stride, rhs, rhs_stride, out, out_stride, stream)
+                               lhs_stride, rhs, rhs_stride, out, out_stride, stream, mask_heads)
   if (lanes <= 4) SPUTNIK_HIP_SD(4, 1);
   if (lanes <= 8) SPUTNIK_HIP_SD(8, 1);
   if (lanes <= 16) SPUTNIK_HIP_SD(16, 1);
@@ -207,7 +220,11 @@ int sddmm_exec(int m, int k, int n, int nonzeros, int replicas, const int* row_i
                const int* row_offsets, const int* column_indices, const float* lhs,
                int64_t lhs_stride, const float* rhs, int64_t rhs_stride, float* out,
                int64_t out_stride, void* workspace, size_t workspace_bytes, bool planned,
-               hipStream_t stream) {
+               hipStream_t stream, int mask_heads = 0, const int* mask_nonzeros = nullptr) {
+  // mask_heads > 0 ("many mask", many_mask.hip): concatenated topologies, replica r
+  // under number r / mask_heads; `nonzeros` = the largest mask's count (kernel choice
+  // and plan size), mask_nonzeros (host) = every mask's count; `workspace` holds one
+  // plan per mask, sddmm_many_mask_plan_bytes apart.
   if (m < 0 || k < 0 || n < 0 || nonzeros < 0 || replicas < 0) return SPUTNIK_HIP_INVALID_ARGUMENT;
   if (m == 0 || nonzeros == 0 || replicas == 0) return 0;
   if (k == 0) {
@@ -218,33 +235,54 @@ int sddmm_exec(int m, int k, int n, int nonzeros, int replicas, const int* row_i
     }
     return 0;
   }
+  const int masks = mask_heads > 0 ? replicas / mask_heads : 1;
+  const size_t plan_bytes = sddmm_many_mask_plan_bytes(m, k, n, nonzeros);
   if (takes_tiled(m, k, n, nonzeros, replicas, lhs, lhs_stride, rhs, rhs_stride, workspace,
-                  workspace_bytes)) {
+                  mask_heads > 0 ? workspace_bytes / masks : workspace_bytes) &&
+      (mask_heads == 0 || plan_bytes * masks <= workspace_bytes)) {
     if (!planned) {
-      const int st = sddmm_tiled_plan(m, k, n, nonzeros, row_indices, row_offsets,
-                                      column_indices, workspace, stream);
-      if (st != 0) return st;
+      int64_t first = 0;
+      for (int i = 0; i < masks; ++i) {   // (one pre-pass per topology)
+        const int st = sddmm_tiled_plan(
+            m, k, n, mask_heads > 0 ? mask_nonzeros[i] : nonzeros, row_indices + static_cast<int64_t>(i) * m,
+            row_offsets + static_cast<int64_t>(i) * (m + 1), column_indices + first,
+            static_cast<char*>(workspace) + i * plan_bytes, stream);
+        if (st != 0) return st;
+        if (mask_heads > 0) first += mask_nonzeros[i];
+      }
     }
     return sddmm_tiled_launch(m, k, n, nonzeros, replicas, row_indices, row_offsets,
                               column_indices, lhs, lhs_stride, rhs, rhs_stride, out, out_stride,
-                              workspace, stream);
+                              workspace, stream, mask_heads, static_cast<int64_t>(plan_bytes / sizeof(int)));
   }
   int vec = vector_width(lhs, k, lhs_stride);
   vec = min(vec, vector_width(rhs, k, rhs_stride));
   switch (vec) {
     case 4:
       return launch_vec<4>(m, k, replicas, row_indices, row_offsets, column_indices, lhs,
-                           lhs_stride, rhs, rhs_stride, out, out_stride, stream);
+                           lhs_stride, rhs, rhs_stride, out, out_stride, stream, mask_heads);
     case 2:
       return launch_vec<2>(m, k, replicas, row_indices, row_offsets, column_indices, lhs,
-                           lhs_stride, rhs, rhs_stride, out, out_stride, stream);
+                           lhs_stride, rhs, rhs_stride, out, out_stride, stream, mask_heads);
     default:
       return launch_vec<1>(m, k, replicas, row_indices, row_offsets, column_indices, lhs,
-                           lhs_stride, rhs, rhs_stride, out, out_stride, stream);
+                           lhs_stride, rhs, rhs_stride, out, out_stride, stream, mask_heads);
   }
 }
 
 }  // namespace
+
+// One launch for all masks of a "many mask" batch (many_mask.hip; C linkage like its
+// surroundings, hidden visibility: not part of the ABI).
+int sputnik_hip_internal_sddmm_many_mask(int masks, int m, int k, int n, const int* nonzeros, int largest, int replicas,
+                    const int* row_indices, const int* row_offsets, const int* column_indices,
+                    const float* lhs, int64_t lhs_stride, const float* rhs, int64_t rhs_stride,
+                    float* out, int64_t out_stride, void* workspace, size_t workspace_bytes,
+                    hipStream_t stream) {
+  return sddmm_exec(m, k, n, largest, replicas, row_indices, row_offsets, column_indices, lhs,
+                    lhs_stride, rhs, rhs_stride, out, out_stride, workspace, workspace_bytes,
+                    /*planned=*/false, stream, replicas / masks, nonzeros);
+}
 
 int sputnik_hip_sddmm_batched(int m, int k, int n, int nonzeros, int replicas,
                               const int* row_indices, const int* row_offsets,

@@ -74,7 +74,7 @@ void sddmm_stationary_kernel(
     const float* __restrict__ lhs, int64_t lhs_stride, const float* __restrict__ rhs,
     int64_t rhs_stride, int ld /* floats between rows of lhs / rhs */, int accumulate,
     float* __restrict__ out, int64_t out_stride, int panels /* of one replica along grid z */,
-    int debug) {
+    int debug, int mask_heads, int64_t mask_plan_ints, int first_replica) {
   using S = Slab<KV>;
   constexpr int kdim = S::kdim;  // panel width; lhs / rhs point at the panel's first column
   constexpr int kRowBytes = kdim * 4;
@@ -99,7 +99,16 @@ void sddmm_stationary_kernel(
   rhs += replica * rhs_stride + panel * kdim;
   out += z * out_stride;
   const int jc = slab * S::kRows;
-  const int last = nonzeros - 1;
+  {  // "many mask": this replica's topology and plan (common.h, select_mask)
+    const MaskPlace place = select_mask(mask_heads, first_replica + replica, m, nonzeros, row_offsets);
+    row_offsets += static_cast<int64_t>(place.mask) * (m + 1);
+    column_indices += place.first;
+    row_indices += static_cast<int64_t>(place.mask) * m;
+    table += place.mask * mask_plan_ints;
+    row_ok += place.mask * mask_plan_ints;
+    nonzeros = place.nonzeros;
+  }
+  const int last = max(nonzeros - 1, 0);
 
   if (!(debug & 2)) {  // stage the slab in 1 KiB pieces (64 lanes x 16 B, lane-linear in LDS)
     constexpr int kPieces = S::kBytes / 1024;
@@ -330,7 +339,8 @@ template <int KV>
 int launch(int m, int k, int n, int nonzeros, int replicas, int slots, const int* row_indices,
            const int* row_offsets, const int* column_indices, const int* table,
            const int* row_ok, const float* lhs, int64_t lhs_stride, const float* rhs,
-           int64_t rhs_stride, float* out, int64_t out_stride, int debug, hipStream_t stream) {
+           int64_t rhs_stride, float* out, int64_t out_stride, int debug, hipStream_t stream,
+           int mask_heads, int64_t mask_plan_ints) {
   using S = Slab<KV>;
   const int slabs = ceil_div(n, S::kRows);
   int st = 0;
@@ -343,7 +353,7 @@ int launch(int m, int k, int n, int nonzeros, int replicas, int slots, const int
                          dim3(S::kThreads), 0, stream, m, n, nonzeros, slots, row_indices,
                          row_offsets, column_indices, table, row_ok, lhs + r0 * lhs_stride + k0,
                          lhs_stride, rhs + r0 * rhs_stride + k0, rhs_stride, k, k0 != 0,
-                         out + r0 * out_stride, out_stride, 1, debug);
+                         out + r0 * out_stride, out_stride, 1, debug, mask_heads, mask_plan_ints, r0);
       st = launch_status();
       if (st != 0) return st;
     }
@@ -370,7 +380,7 @@ int launch_partials(int m, int k, int n, int nonzeros, int replicas, int slots,
   hipLaunchKernelGGL(sddmm_stationary_kernel<KV>, dim3(slabs, row_blocks, replicas * panels),
                      dim3(S::kThreads), 0, stream, m, n, nonzeros, slots, row_indices, row_offsets,
                      column_indices, table, row_ok, lhs, lhs_stride, rhs, rhs_stride, k, 0,
-                     partials, static_cast<int64_t>(nonzeros), panels, debug);
+                     partials, static_cast<int64_t>(nonzeros), panels, debug, 0, int64_t{0}, 0);
   return launch_status();
 }
 
@@ -439,7 +449,8 @@ int sddmm_tiled_plan(int m, int k, int n, int nonzeros, const int* row_indices,
 int sddmm_tiled_launch(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
                        const int* row_offsets, const int* column_indices, const float* lhs,
                        int64_t lhs_stride, const float* rhs, int64_t rhs_stride, float* out,
-                       int64_t out_stride, const void* workspace, hipStream_t stream) {
+                       int64_t out_stride, const void* workspace, hipStream_t stream,
+                       int mask_heads, int64_t mask_plan_ints) {
   const int debug = options().sddmm_debug;  // timing experiments only
   const int slots = slots_of(m);
   const int* row_ok = static_cast<const int*>(workspace);
@@ -448,7 +459,7 @@ int sddmm_tiled_launch(int m, int k, int n, int nonzeros, int replicas, const in
 #define SPUTNIK_HIP_SD(KV)                                                               \
   return launch<KV>(m, k, n, nonzeros, replicas, slots, row_indices, row_offsets,        \
                     column_indices, table, row_ok, lhs, lhs_stride, rhs, rhs_stride, out, \
-                    out_stride, debug, stream)
+                    out_stride, debug, stream, mask_heads, mask_plan_ints)
   switch (panel_width(k)) {
     case 64: SPUTNIK_HIP_SD(1);
     case 128: SPUTNIK_HIP_SD(2);

@@ -64,12 +64,16 @@ template <int LPR, int BASE, int V, bool BACKWARD, int DEPTH, int NT>
 __global__ __launch_bounds__(kBlock) void sparse_softmax_rows_kernel(
     int m, int rows_per_group, int nonzeros, const float* __restrict__ a, int64_t a_stride,
     const float* __restrict__ b, int64_t b_stride, const int* __restrict__ row_offsets,
-    float* __restrict__ out, int64_t out_stride, float scale, int same_phase) {
+    float* __restrict__ out, int64_t out_stride, float scale, int same_phase, int mask_heads,
+    int first_replica) {
   constexpr int kWindow = LPR * 4 * V;
   const int l = threadIdx.x % LPR;
   const int group = (blockIdx.x * kBlock + threadIdx.x) / LPR;
   const int replica = blockIdx.y;
   const int replicas = gridDim.y;
+  // "many mask": the topology of replica r is number r / mask_heads of the
+  // concatenated ones (row offsets [masks][m + 1], each zero based)
+  if (mask_heads > 0) row_offsets += static_cast<int64_t>((first_replica + replica) / mask_heads) * (m + 1);
   a += replica * a_stride;
   if constexpr (BACKWARD) b += replica * b_stride;
   out += replica * out_stride;
@@ -251,7 +255,7 @@ inline int phase_of(const void* p, int64_t stride) {
 template <int LPR, int BASE, int V, bool BACKWARD>
 int launch_rows(int m, int nonzeros, int replicas, const float* a, int64_t a_stride, const float* b,
                 int64_t b_stride, const int* row_offsets, float* out, int64_t out_stride,
-                float scale, hipStream_t stream) {
+                float scale, hipStream_t stream, int mask_heads) {
   // Two rows per group once the grid fills the chip (256 CUs x 8 workgroups):
   // measured at config 3's mask with 64 and 512 replicas (tools/softmax_sweep.sh),
   // short workgroups whose dispatch staggers the read and the write phases beat
@@ -281,7 +285,7 @@ int launch_rows(int m, int nonzeros, int replicas, const float* a, int64_t a_str
 #define SPUTNIK_HIP_SOFTMAX_LAUNCH(DEPTH, NT)                                                     \
   hipLaunchKernelGGL((sparse_softmax_rows_kernel<LPR, BASE, V, BACKWARD, DEPTH, NT>), dim3(gx, ry), \
                      dim3(kBlock), 0, stream, m, rows_per_group, nonzeros, a_r, a_stride, b_r,   \
-                     b_stride, row_offsets, out_r, out_stride, scale, same_phase)
+                     b_stride, row_offsets, out_r, out_stride, scale, same_phase, mask_heads, r0)
     // Nontemporal STORES in the forward pass when the output is larger than the
     // caches can hand to the next kernel anyway (measured, 1024^2 mask at density
     // 0.1: 512 replicas, 215 MB out, 88.4 -> 75.8 us; 64 replicas 12.5 -> 12.2 us
@@ -312,14 +316,18 @@ int launch_rows(int m, int nonzeros, int replicas, const float* a, int64_t a_str
 template <bool BACKWARD>
 int dispatch_rows(int m, int nonzeros, int replicas, const float* a, int64_t a_stride,
                   const float* b, int64_t b_stride, const int* row_offsets, float* out,
-                  int64_t out_stride, float scale, hipStream_t stream) {
-  const int64_t mean = nonzeros / m;
+                  int64_t out_stride, float scale, hipStream_t stream, int mask_heads = 0,
+                  int typical_nonzeros = -1) {
+  // (many masks: `nonzeros` is the width of a value row -- what may be read --, the
+  // window is sized for the largest mask)
+  const int64_t mean = (typical_nonzeros >= 0 ? typical_nonzeros : nonzeros) / m;
   int64_t dev = 1;
   while (dev * dev < 5 * mean) ++dev;   // ~ 2.2 * sqrt(mean)
   const int64_t need = mean + dev + 3;
 #define SPUTNIK_HIP_SOFTMAX_CASE(LPR, BASE, V)                                                    \
   return launch_rows<LPR, BASE, V, BACKWARD>(m, nonzeros, replicas, a, a_stride, b, b_stride,     \
-                                             row_offsets, out, out_stride, scale, stream)
+                                             row_offsets, out, out_stride, scale, stream,         \
+                                             mask_heads)
   if (need <= 64) SPUTNIK_HIP_SOFTMAX_CASE(16, 1, 2);
   if (need <= 128) SPUTNIK_HIP_SOFTMAX_CASE(16, 2, 3);
   if (need <= 192) SPUTNIK_HIP_SOFTMAX_CASE(16, 3, 4);
@@ -330,6 +338,20 @@ int dispatch_rows(int m, int nonzeros, int replicas, const float* a, int64_t a_s
 }
 
 }  // namespace
+
+// One launch for all masks of a "many mask" batch (many_mask.hip): value rows
+// [replicas][width], replica r under the topology number r / heads.
+int softmax_many_mask(bool backward, int m, int width, int largest_nonzeros, int replicas, int heads,
+                      const float* a, int64_t a_stride, const float* b, int64_t b_stride,
+                      const int* row_offsets, float* out, int64_t out_stride, float scale,
+                      hipStream_t stream) {
+  if (m == 0 || width == 0 || replicas == 0 || largest_nonzeros == 0) return 0;
+  return backward ? dispatch_rows<true>(m, width, replicas, a, a_stride, b, b_stride, row_offsets,
+                                        out, out_stride, scale, stream, heads, largest_nonzeros)
+                  : dispatch_rows<false>(m, width, replicas, a, a_stride, nullptr, 0, row_offsets,
+                                         out, out_stride, scale, stream, heads, largest_nonzeros);
+}
+
 }  // namespace sputnik_hip
 
 using namespace sputnik_hip;

@@ -51,7 +51,8 @@ int spmm_panel_launch(int m, int k, int n, int nonzeros, int replicas, const int
                       const float* values, int64_t values_stride, const int* row_offsets,
                       const int* column_indices, const float* dense, int64_t dense_stride,
                       float* out, int64_t out_stride, hipStream_t stream, Epilogue epi,
-                      const int* value_permutation = nullptr, int block_rows = 0);
+                      const int* value_permutation = nullptr, int block_rows = 0,
+                      int mask_heads = 0);
 
 namespace {
 

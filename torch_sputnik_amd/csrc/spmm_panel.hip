@@ -332,7 +332,7 @@ __global__ __launch_bounds__(kPThreads) void spmm_panel64_kernel(
     int64_t values_stride, const int* __restrict__ row_offsets,
     const int* __restrict__ column_indices, const int* __restrict__ value_permutation,
     const float* __restrict__ dense, int64_t dense_stride, float* __restrict__ out,
-    int64_t out_stride, Epilogue epi, int block_rows) {
+    int64_t out_stride, Epilogue epi, int block_rows, int mask_heads, int first_replica) {
   extern __shared__ float panel[];   // [min(k, 512)][64]
 
   const int lane = threadIdx.x % kWave;
@@ -344,7 +344,14 @@ __global__ __launch_bounds__(kPThreads) void spmm_panel64_kernel(
   dense += replica * dense_stride;
   out += replica * out_stride;
   const int n0 = ntile * kPBN;
-  const int last = nonzeros - 1;
+  {
+    const MaskPlace place_m = select_mask(mask_heads, first_replica + replica, m, nonzeros, row_offsets);
+    row_offsets += static_cast<int64_t>(place_m.mask) * (m + 1);
+    column_indices += place_m.first;
+    if (row_indices != nullptr) row_indices += static_cast<int64_t>(place_m.mask) * m;
+    nonzeros = place_m.nonzeros;
+  }
+  const int last = max(nonzeros - 1, 0);
 
   // the rows' bounds first: their latency overlaps the panel copy
   Rows rows;
@@ -500,7 +507,7 @@ int spmm_panel_launch(int m, int k, int n, int nonzeros, int replicas, const int
                       const float* values, int64_t values_stride, const int* row_offsets,
                       const int* column_indices, const float* dense, int64_t dense_stride,
                       float* out, int64_t out_stride, hipStream_t stream, Epilogue epi,
-                      const int* value_permutation, int block_rows) {
+                      const int* value_permutation, int block_rows, int mask_heads) {
   const int slots = ceil_div(m, kPBM) * kPBM;
   const int n_tiles = ceil_div(n, kPBN);
   const int64_t blocks = static_cast<int64_t>(slots / kPBM) * n_tiles;
@@ -541,7 +548,7 @@ int spmm_panel_launch(int m, int k, int n, int nonzeros, int replicas, const int
                        stream, m, k, n, nonzeros, slots, n_tiles, row_indices,
                        values + r0 * values_stride, values_stride, row_offsets, column_indices,
                        value_permutation, dense + r0 * dense_stride, dense_stride,
-                       out + r0 * out_stride, out_stride, epi, block_rows);
+                       out + r0 * out_stride, out_stride, epi, block_rows, mask_heads, r0);
     const int st = launch_status();
     if (st != 0) return st;
   }

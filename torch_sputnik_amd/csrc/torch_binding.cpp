@@ -983,7 +983,9 @@ Tensor sddmm_many_mask(int64_t b, int64_t m64, int64_t n64, const Tensor& nonzer
   // Entries past a replica's own count stay zero.
   Tensor out = mm.uniform ? at::empty({mm.replicas, mm.width}, lhs.options())
                           : at::zeros({mm.replicas, mm.width}, lhs.options());
-  const size_t ws_bytes = sputnik_hip_sddmm_workspace_bytes(mm.m, k, n, mm.width);
+  // (one plan per mask: all masks run in one launch, csrc/many_mask.hip)
+  const size_t ws_bytes = sputnik_hip_sddmm_many_mask_workspace_bytes(
+      mm.masks, mm.m, k, n, mm.width);
   Tensor workspace;
   if (ws_bytes > 0)
     workspace = at::empty({static_cast<int64_t>(ws_bytes)}, lhs.options().dtype(at::kByte));
