@@ -21,7 +21,13 @@ class GraphedForward:
         if not all(torch.is_tensor(t) and t.is_cuda for t in example_inputs):
             raise ValueError("capture_forward needs GPU tensors as example inputs")
         self.module = module
-        self.static_inputs = [t.detach().clone() for t in example_inputs]
+        # Inputs that are ONE tensor in the example (self-attention: module(x, x, x)) stay
+        # one static buffer: the module takes its shared-input paths (the three projections
+        # as one group launch) in the captured graph as it does eagerly, and a replay copies
+        # the input once, not three times.
+        clones = {}
+        self.static_inputs = [clones.setdefault(id(t), t.detach().clone()) for t in example_inputs]
+        self._alias = [id(t) for t in example_inputs]
         side = torch.cuda.Stream(device=self.static_inputs[0].device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():
@@ -35,11 +41,17 @@ class GraphedForward:
     def __call__(self, *inputs):
         if len(inputs) != len(self.static_inputs):
             raise ValueError(f"expected {len(self.static_inputs)} inputs, got {len(inputs)}")
-        for dst, src in zip(self.static_inputs, inputs):
+        first, copied = {}, set()
+        for dst, src, alias in zip(self.static_inputs, inputs, self._alias):
             if dst.shape != src.shape or dst.dtype != src.dtype:
                 raise ValueError("input shape / dtype differs from the captured example")
-            if dst.data_ptr() != src.data_ptr():
+            if first.setdefault(alias, src) is not src:
+                raise ValueError("inputs that were one tensor in the captured example must be "
+                                 "one tensor in every replay")
+            # (callers that fill `static_inputs` in place skip the copy)
+            if alias not in copied and dst.data_ptr() != src.data_ptr():
                 dst.copy_(src)
+            copied.add(alias)
         self.graph.replay()
         return self.static_output
 
