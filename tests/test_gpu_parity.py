@@ -385,6 +385,68 @@ def test_spmm_flat_loops_vs_oracle(capi, dev, flat_loop, m, k, n, sparsity, repl
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
+@pytest.mark.parametrize("m,k,n,replicas", [
+    (300, 1000, 1001, 2),      # n % 4 = 1, two column tiles, the second almost empty
+    (2048, 512, 4095, 1),      # n = 4095 stays on the LDS kernels
+    (256, 128, 1535, 1),       # n % 4 = 3, three tiles, the last one a column short
+    (128, 96, 510, 1),         # one partial tile
+])
+def test_spmm_flat_any_n(capi, dev, flat_loop, m, k, n, replicas):
+    """n need not be a multiple of 4 (the reference takes any n, src/spmm_cuda.cu:32):
+    rows of B and C then start at odd dwords, and the lanes at the end of a row work on
+    its last four columns.  Guard zones around the output must stay untouched."""
+    _, vals, ri, ro, ci = make_csr(m, k, 0.8, seed=n, round_to=1, order="random")
+    rng = np.random.default_rng(n + 1)
+    b = rng.uniform(-1, 1, size=(replicas, k, n)).astype(np.float32)
+    v = rng.uniform(-1, 1, size=(replicas, len(vals))).astype(np.float32)
+    want = c_oracle.spmm(m, k, v, ro, ci, b)
+    guard = 64
+    for loop in (2, 4):
+        flat_loop(loop)
+        assert capi.spmm_kernel_name(m, k, n, len(ci), replicas).startswith("spmm_flat_kernel")
+        buf = torch.full((guard + replicas * m * n + guard,), 12345.0, device=dev)
+        out = buf[guard:guard + replicas * m * n].view(replicas, m, n)
+        out.fill_(float("nan"))
+        ws = torch.empty(capi.spmm_workspace_bytes(m, k, n, len(ci)) + 16, dtype=torch.uint8, device=dev)
+        capi.spmm_batched(m, k, n, replicas, T(ri, dev), T(v, dev), len(vals), T(ro, dev), T(ci, dev),
+                          T(b, dev), out, ws)
+        got = out.cpu().numpy()
+        assert not np.isnan(got).any(), "some output elements were never written"
+        assert rel_err(got, want) < TOL
+        assert bool((buf[:guard] == 12345.0).all()) and bool((buf[-guard:] == 12345.0).all())
+
+
+@pytest.mark.parametrize("m,k,n,replicas,kernel", [
+    # VERDICT r2: n in {66, 71, 4095} off the row-gather kernel (a lone product this narrow is
+    # below the dispatcher's small-call threshold whatever n % 4 is: 8 replicas of it are not)
+    (4096, 4096, 66, 8, "spmm_tiled64_kernel"),
+    (4096, 4096, 71, 8, "spmm_tiled64_kernel"),
+    (4096, 1024, 4095, 1, "spmm_flat_kernel"),
+    (2048, 2048, 131, 8, "spmm_tiled64_kernel"),    # three 64-column tiles, the last 3 columns wide
+])
+def test_spmm_any_n_stays_on_the_lds_kernels(capi, dev, m, k, n, replicas, kernel):
+    """The automatic dispatch for widths that are not a multiple of 4, against the
+    dense float64 product on the device, with guard zones around the output."""
+    from torch_sputnik_amd.synthetic import random_csr, uniform
+    ri, ro, ci, nnz = random_csr(m, k, 0.1, dev, seed=n)
+    assert capi.spmm_kernel_name(m, k, n, nnz, replicas).startswith(kernel)
+    values = uniform((replicas, nnz), dev, 3)
+    dense = uniform((replicas, k, n), dev, 4)
+    guard = 64
+    buf = torch.full((guard + replicas * m * n + guard,), 12345.0, device=dev)
+    out = buf[guard:guard + replicas * m * n].view(replicas, m, n)
+    out.fill_(float("nan"))
+    ws = torch.empty(capi.spmm_workspace_bytes(m, k, n, nnz) + 16, dtype=torch.uint8, device=dev)
+    capi.spmm_batched(m, k, n, replicas, ri, values, nnz, ro, ci, dense, out, ws)
+    assert not torch.isnan(out).any()
+    assert bool((buf[:guard] == 12345.0).all()) and bool((buf[-guard:] == 12345.0).all())
+    rows = torch.repeat_interleave(torch.arange(m, device=dev), torch.diff(ro.long()))
+    for r in range(replicas):
+        a = torch.zeros(m, k, dtype=torch.float64, device=dev)
+        a[rows, ci.long()] = values[r].double()
+        assert rel_err_torch(out[r], a @ dense[r].double()) < TOL
+
+
 def test_spmm_flat_mixed_sorted_and_unsorted_rows(capi, dev, flat_loop):
     """Row blocks with a row whose columns do not ascend take the order-independent
     path inside the same launch; their part of the stream is never read, but the

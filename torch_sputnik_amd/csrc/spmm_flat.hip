@@ -119,13 +119,6 @@ __global__ __launch_bounds__(kRPW * 64) void spmm_flat_fill_kernel(
   unsigned* wprefix = nzmask + nchunks;                         // [nchunks * 2]: entries before word i, a byte each
   int* scratch = reinterpret_cast<int*>(wprefix + 2 * nchunks); // [2 * RPW + 2]
 
-  auto slot_len = [&](int slot) {
-    const int entry = dealt_index(slot, slots, kDealPer);
-    if (entry >= m) return 0;
-    const int row = row_indices[entry];
-    return row_offsets[row + 1] - row_offsets[row];
-  };
-
   for (int i = tid; i < nchunks * WPC; i += NT) maskw[i] = 0;
   // (1) this wave's row; windows of all groups before this one
   const int slot = g * RPW + wave;
@@ -138,9 +131,22 @@ __global__ __launch_bounds__(kRPW * 64) void spmm_flat_fill_kernel(
   }
   int before = 0;
   for (int gp = tid; gp < g; gp += NT) {
+    // (two rounds of independent loads -- row ids, then row bounds -- instead of eight
+    // dependent pairs: this loop was most of the pre-pass's 20 us)
+    int rows[RPW], lo[RPW], hi[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const int e = dealt_index(gp * RPW + r, slots, kDealPer);
+      rows[r] = e < m ? row_indices[e] : -1;
+    }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      lo[r] = rows[r] >= 0 ? row_offsets[rows[r]] : 0;
+      hi[r] = rows[r] >= 0 ? row_offsets[rows[r] + 1] : 0;
+    }
     int len = 0;
 #pragma unroll
-    for (int r = 0; r < RPW; ++r) len += slot_len(gp * RPW + r);
+    for (int r = 0; r < RPW; ++r) len += hi[r] - lo[r];
     before += (len + kWindow - 1) / kWindow;
   }
   before = wave_sum(before);
@@ -352,8 +358,8 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_flat_kernel(
       const int row = row_indices[entry];
 #pragma unroll
       for (int h = 0; h < PPR; ++h) {
-        const int col = n0 + h * 256 + lane * 4;
-        if (col >= n) continue;
+        if (n0 + h * 256 + lane * 4 >= n) continue;
+        const int col = min(n0 + h * 256 + lane * 4, n - 4);   // (see the store phase below)
         const float4 acc4 = gather_row_strip(values, column_indices, row_offsets[row],
                                              row_offsets[row + 1], dense + col, n);
         *reinterpret_cast<float4*>(out + static_cast<int64_t>(row) * n + col) =
@@ -401,8 +407,15 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_flat_kernel(
 #pragma unroll
       for (int h = 0; h < PPR; ++h)
         if (n0 + h * 256 + lane * 4 < n) {
+          // ANY n (the reference takes any, src/spmm_cuda.cu:32): a lane whose four
+          // columns would cross the end of the row works on the row's LAST four columns
+          // instead -- in the copies of B (stage_off) and here alike -- so it recomputes up
+          // to three columns of its neighbour and stores the same values again.  Rows of B
+          // and C then start at any multiple of 4 bytes: the 16-byte accesses are dword
+          // aligned, which global memory accesses need no more than.
+          const int col = min(n0 + h * 256 + lane * 4, n - 4);
           const int f = r * VEC + 4 * h;   // first of the four registers
-          *reinterpret_cast<float4*>(out + static_cast<int64_t>(row) * n + n0 + h * 256 + lane * 4) =
+          *reinterpret_cast<float4*>(out + static_cast<int64_t>(row) * n + col) =
               apply_epilogue(make_float4(acc[f / 8][f % 8], acc[f / 8][f % 8 + 1],
                                          acc[f / 8][f % 8 + 2], acc[f / 8][f % 8 + 3]),
                              epi, row);
@@ -460,12 +473,12 @@ int flat_mode(int m, int k, int nonzeros) {
 
 }  // namespace
 
-// The shapes the flat kernel can serve: any n that is a multiple of 4 whose column
-// tiles are at most a quarter padding, within the pre-pass's LDS (a row mask per
+// The shapes the flat kernel can serve: any n whose column tiles are at most a
+// quarter padding (n need not be a multiple of 4: see the kernel's store phase), within the pre-pass's LDS (a row mask per
 // column) and its per-group prefix sum over the groups before.  (Whether it is
 // TAKEN is the dispatcher's matter: spmm_tiled.hip, use_flat.)
 bool spmm_flat_applicable(int m, int k, int n, int nonzeros) {
-  if (n % 4 != 0 || k < kBK || m < 64 || nonzeros < 16 * static_cast<int64_t>(m) ||
+  if (n < 4 || k < kBK || m < 64 || nonzeros < 16 * static_cast<int64_t>(m) ||
       nonzeros >= (1 << 29))
     return false;
   if (static_cast<int64_t>(ceil_div(n, kBN)) * kBN * 3 > static_cast<int64_t>(n) * 4) return false;

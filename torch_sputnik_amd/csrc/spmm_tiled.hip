@@ -681,9 +681,13 @@ int spmm_tiled_exec(int m, int k, int n, int nonzeros, int replicas, const int* 
   *handled = false;
   const Kernel which = choose_kernel(m, k, n, nonzeros, replicas);
   if (which == Kernel::kNone || workspace == nullptr || !aligned_to(workspace, 16) ||
-      workspace_bytes < spmm_tiled_workspace_bytes(m, k, n, nonzeros) || !aligned_to(dense, 16) ||
-      !aligned_to(out, 16) || dense_stride % 4 != 0 || out_stride % 4 != 0 ||
-      replicas > kMaxGridYZ)
+      workspace_bytes < spmm_tiled_workspace_bytes(m, k, n, nonzeros) || replicas > kMaxGridYZ)
+    return 0;
+  // (the flat and the 64-column kernel's 16-byte accesses need dword alignment only:
+  // any n, any stride)
+  if (which != Kernel::kFlat && which != Kernel::kNarrow &&
+      (!aligned_to(dense, 16) || !aligned_to(out, 16) || dense_stride % 4 != 0 ||
+       out_stride % 4 != 0))
     return 0;
   if (which == Kernel::kNarrow) {
     const bool both_possible = choose_kernel(m, k, n, nonzeros, -1) == Kernel::kEither;

@@ -98,9 +98,10 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled64_kernel(
       const int entry = dealt_index(slot0 + 4 * t + g, slots, kBM);
       if (entry < m && n0 + i * 4 < n) {
         const int row = row_indices[entry];
+        const int col = min(n0 + i * 4, n - 4);   // (any n: see the store phase below)
         const float4 acc4 = gather_row_strip(values, column_indices, row_offsets[row],
-                                             row_offsets[row + 1], dense + n0 + i * 4, n);
-        *reinterpret_cast<float4*>(out + static_cast<int64_t>(row) * n + n0 + i * 4) =
+                                             row_offsets[row + 1], dense + col, n);
+        *reinterpret_cast<float4*>(out + static_cast<int64_t>(row) * n + col) =
             apply_epilogue(acc4, epi, row);
       }
     }
@@ -250,7 +251,12 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled64_kernel(
     const int entry = dealt_index(slot0 + 4 * t + g, slots, kBM);
     if (entry < m && n0 + i * 4 < n) {   // (the last column tile may be partial)
       const int row = row_indices[entry];
-      *reinterpret_cast<float4*>(out + static_cast<int64_t>(row) * n + n0 + i * 4) =
+      // ANY n (src/spmm_cuda.cu:32): a lane whose four columns would cross the end of
+      // the row works on the row's last four columns instead, in the copies of B and
+      // here alike (it stores up to three of its neighbour's values again); the 16-byte
+      // accesses are then dword aligned, which is all global memory asks for
+      const int col = min(n0 + i * 4, n - 4);
+      *reinterpret_cast<float4*>(out + static_cast<int64_t>(row) * n + col) =
           apply_epilogue(make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]), epi, row);
     }
   }
@@ -263,7 +269,7 @@ inline int chunks_of(int k) { return ceil_div(k, kBK); }
 
 bool spmm_tiled64_applicable(int m, int k, int n, int nonzeros) {
   // B rows are addressed with 32-bit byte offsets; enough work per staged tile.
-  return n % 4 == 0 && n >= kBN && k >= 32 && m >= 16 && nonzeros >= 4 * static_cast<int64_t>(m) &&
+  return n >= kBN && k >= 32 && m >= 16 && nonzeros >= 4 * static_cast<int64_t>(m) &&
          static_cast<int64_t>(k) * n * 4 < (int64_t{1} << 32);
 }
 
