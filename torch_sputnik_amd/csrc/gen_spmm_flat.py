@@ -358,6 +358,8 @@ def generate():
     emit(f"{label('bnodrain')}:")
     emit(f"s_cmp_eq_u32 {S_MINE}, 0")          # no copies of the next chunk pending
     emit(f"s_cbranch_scc1 {label('bvd')}")
+    emit(f"s_bitcmp1_b32 {S_DEBUG}, 5")        # timing experiment: do not wait for the copies
+    emit(f"s_cbranch_scc1 {label('bvd')}")
     for n in range(3):
         emit(f"s_cmp_eq_u32 {S_NSW}, {n}")
         emit(f"s_cbranch_scc1 {label(f'bv{n}')}")
