@@ -396,6 +396,14 @@ def other_ops(dev):
     t = event_time_ms(lambda: capi.sddmm_batched(s, d, s, reps, ri, ro, ci, q, kk, scores, sd_ws), 20)
     by = reps * (8.0 * s * d + 4.0 * nnz) + 4.0 * nnz + 4.0 * (2 * s + 1)
     res["sddmm_c3"] = {"ms": t, "gflops": 2.0 * nnz * d * reps / t / 1e6, "alg_gbs": by / t / 1e6}
+    try:   # the same on a planned workspace (static mask: kernel only, no pre-pass launch)
+        capi.sddmm_plan(s, d, s, ri, ro, ci, sd_ws)
+        tp = event_time_ms(lambda: capi.sddmm_batched_planned(s, d, s, reps, ri, ro, ci, q, kk, scores,
+                                                              sd_ws), 20)
+        res["sddmm_c3"]["planned_ms"] = tp
+        res["sddmm_c3"]["planned_hbm_frac"] = by / tp / 1e6 / HBM_PEAK_GBS
+    except Exception as e0:  # noqa: BLE001 - extra metric, best effort
+        res["sddmm_c3"]["planned_error"] = str(e0)[:200]
     t = event_time_ms(lambda: capi.sparse_softmax_batched(s, reps, scores, ri, ro, ci, probs), 50)
     by = reps * 8.0 * nnz + 4.0 * (2 * s + 1)
     res["softmax_c3"] = {"ms": t, "alg_gbs": by / t / 1e6, "hbm_frac": by / t / 1e6 / HBM_PEAK_GBS,

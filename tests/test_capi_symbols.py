@@ -41,7 +41,8 @@ def test_workspace_queries_are_host_only():
     assert capi.spmm_workspace_bytes(4096, 4096, 4096, 1677724) > 0
     assert capi.spmm_workspace_bytes(64, 64, 64, 2048) > 0       # 64-column tiled kernel
     assert capi.spmm_workspace_bytes(72, 64, 72, 464) > 0        # n = 64 + 8: partial column tile
-    assert capi.spmm_workspace_bytes(72, 64, 70, 464) == 0       # n % 4 != 0: row-gather kernel
+    assert capi.spmm_workspace_bytes(72, 64, 70, 464) > 0        # any n >= 64 stays on the 64-column kernel
+    assert capi.spmm_workspace_bytes(72, 64, 7, 464) == 0        # narrower than a tile: row-gather kernel
     assert capi.sddmm_workspace_bytes(1024, 64, 1024, 104860) > 0
     assert capi.sddmm_workspace_bytes(72, 72, 72, 500) == 0
     assert capi.csr_transpose_workspace_bytes(2048, 2048, 838864) >= 4 * 2048

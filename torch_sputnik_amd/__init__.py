@@ -24,4 +24,4 @@ from .topology import dense_to_sparse, diffsort, generate_mask  # noqa: F401
 from .functional import Sddmm, SparseLinearFunction, SparseSoftmax, Spmm  # noqa: F401
 from .modules import SparseAttention, SparseLinear  # noqa: F401
 
-__version__ = "0.2.0"
+__version__ = "0.3.0"
