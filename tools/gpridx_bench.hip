@@ -186,7 +186,7 @@ __global__ void k_touch(float* out) {
                  "s_waitcnt lgkmcnt(0)\n"                                                         \
                  :                                                                                \
                  : "v"(base), "s"(iters), "v"(woff), "v"(wval)                                    \
-                 : "memory", "m0", "s20", "s40", "s41", "s42", "s43", "s44", WORK, ACC64);               \
+                 : "memory", "m0", "s20", "s40", "s41", "s42", "s43", "s44", "s45", WORK, ACC64);               \
     unsigned long long t1 = __builtin_amdgcn_s_memtime();                                         \
     if (threadIdx.x % 64 == 0)                                                                    \
       out[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;                           \
@@ -239,6 +239,11 @@ DEF_STEP(k_colgroup_d50, V2_BODY_D50)
 DEF_STEP(k_colgroup_d10_ahead, V2_BODY_D10_AHEAD)
 DEF_STEP(k_colgroup_d50_ahead, V2_BODY_D50_AHEAD)
 
+// e) 256-column tile (4 columns per lane, 16 rows per wave): entries in PAIRS -- one
+//    chunk test and one index-mode region per two entries, one ds_read_b128 and two
+//    v_pk_fma_f32 per entry, FMAs three pairs behind the reads.  8 entries per body.
+DEF_STEP(k_pair256, "s_mov_b32 s45, 0x7fffffff\n" V4_PAIR_BODY)
+
 typedef void (*kern_t)(unsigned long long*, int, int);
 
 static void run(const char* name, kern_t k, int rnd, int per_iter = 16) {
@@ -288,6 +293,7 @@ int main() {
     run("pipe_plain", k_pipe_plain, rnd);
     run("pipe_idx", k_pipe_idx, rnd);
     run("pipe_idx_salu", k_pipe_idx_salu, rnd);
+    run("pair256(per 256-col entry)", k_pair256, rnd, 32);
     run("colgroup_d10", k_colgroup_d10, rnd, 64);
     run("colgroup_d50", k_colgroup_d50, rnd, 64);
     run("colgroup_d10_ahead", k_colgroup_d10_ahead, rnd, 64);
