@@ -417,6 +417,24 @@ def other_ops(dev):
     t = event_time_ms(lambda: capi.sparse_softmax_backward_batched(s, reps, probs, scores, ro, 1.0, grad), 50)
     res["softmax_backward_c3"] = {"ms": t, "alg_gbs": reps * 12.0 * nnz / t / 1e6,
                                   "hbm_frac": reps * 12.0 * nnz / t / 1e6 / HBM_PEAK_GBS}
+    try:   # native half storage (round 3): 2 + 2 bytes per entry forward, 6 backward
+        for name, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+            sh, ph, gh = scores.to(dt), probs.to(dt), torch.empty(reps, nnz, device=dev, dtype=dt)
+            t = event_time_ms(lambda: capi.sparse_softmax_typed(s, reps, sh, ri, ro, ci, 1.0, ph), 50)
+            byh = reps * 4.0 * nnz + 4.0 * (2 * s + 1)
+            res["softmax_c3_" + name] = {"ms": t, "alg_gbs": byh / t / 1e6,
+                                         "hbm_frac": byh / t / 1e6 / HBM_PEAK_GBS}
+            t = event_time_ms(lambda: capi.sparse_softmax_backward_typed(s, reps, ph, sh, ro, 1.0, gh), 50)
+            res["softmax_backward_c3_" + name] = {"ms": t, "hbm_frac": reps * 6.0 * nnz / t / 1e6 / HBM_PEAK_GBS}
+        bigh = uniform((512, nnz), dev, 32).half()
+        bigh_out = torch.empty_like(bigh)
+        t = event_time_ms(lambda: capi.sparse_softmax_typed(s, 512, bigh, ri, ro, ci, 1.0, bigh_out), 20)
+        res["softmax_c3_r512_fp16"] = {"ms": t, "hbm_frac": 512 * 4.0 * nnz / t / 1e6 / HBM_PEAK_GBS}
+        t = event_time_ms(lambda: capi.sparse_softmax_backward_typed(s, 512, bigh_out, bigh, ro, 1.0, bigh), 20)
+        res["softmax_backward_c3_r512_fp16"] = {"ms": t, "hbm_frac": 512 * 6.0 * nnz / t / 1e6 / HBM_PEAK_GBS}
+        del bigh, bigh_out, sh, ph, gh
+    except Exception as e:  # noqa: BLE001
+        res["softmax_c3_fp16"] = {"error": str(e)[:200]}
     try:   # 512 replicas: the launch ramp amortised
         big = uniform((512, nnz), dev, 31)
         big_out = torch.empty_like(big)

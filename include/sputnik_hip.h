@@ -50,6 +50,14 @@ typedef struct ihipStream_t* sputnik_hip_stream_t;
 /* Exported-symbol marker (the library is built with -fvisibility=hidden). */
 #define SPUTNIK_HIP_API __attribute__((visibility("default")))
 
+/* Storage types of the *_typed entry points (round 3).  The reference is float32
+ * only (data_ptr<float>(), src/spmm_cuda.cu:51); float16 / bfloat16 operands are an
+ * extension (BASELINE.json config 5) that the kernels read and write directly --
+ * all arithmetic stays float32. */
+#define SPUTNIK_HIP_F32 0
+#define SPUTNIK_HIP_F16 1
+#define SPUTNIK_HIP_BF16 2
+
 /* Library / build identification: "sputnik_hip <version> gfx950". */
 SPUTNIK_HIP_API const char* sputnik_hip_version(void);
 
@@ -394,6 +402,25 @@ SPUTNIK_HIP_API int sputnik_hip_sparse_softmax_backward_batched(int m, int nonze
                              int64_t grad_values_stride, sputnik_hip_stream_t stream);
 
 /*
+ * The softmax pair on values stored as `dtype` (SPUTNIK_HIP_F32 / F16 / BF16; inputs
+ * and output alike; strides in elements).  Half types move 2 + 2 bytes per entry
+ * forward, 2 + 2 + 2 backward -- half the HBM traffic of src/softmax_cuda.cu:38-42 --
+ * and are widened / rounded to nearest even in registers; max, exp, sum and the
+ * gradient's row dot product are float32.  The float entry points above are
+ * dtype = SPUTNIK_HIP_F32 of these.
+ */
+SPUTNIK_HIP_API int sputnik_hip_sparse_softmax_typed(int m, int n, int nonzeros, int replicas,
+                             const void* values, int64_t values_stride, const int* row_indices,
+                             const int* row_offsets, const int* column_indices, float scale,
+                             void* out, int64_t out_stride, int dtype,
+                             sputnik_hip_stream_t stream);
+SPUTNIK_HIP_API int sputnik_hip_sparse_softmax_backward_typed(int m, int nonzeros, int replicas,
+                             const void* softmax_out, int64_t out_stride, const void* grad_out,
+                             int64_t grad_out_stride, const int* row_offsets, float scale,
+                             void* grad_values, int64_t grad_values_stride, int dtype,
+                             sputnik_hip_stream_t stream);
+
+/*
  * Fused sparse attention forward, one launch for
  *   out = spmm(softmax(scale * sddmm(q, k)), v)
  * i.e. the chain of modules/sparse_attention.py:66-82 (sddmm :68-71, the
@@ -558,9 +585,6 @@ SPUTNIK_HIP_API int sputnik_hip_transpose_batched(int batches, int rows, int col
  * inside the layout pass in front of left_spmm, the narrowing of the gradient
  * inside the pass behind it -- no pass of its own.
  */
-#define SPUTNIK_HIP_F32 0
-#define SPUTNIK_HIP_F16 1
-#define SPUTNIK_HIP_BF16 2
 SPUTNIK_HIP_API int sputnik_hip_transpose_cast_batched(int batches, int rows, int cols, const void* in,
                                        int in_type, int64_t in_batch_stride, void* out,
                                        int out_type, int64_t out_batch_stride,

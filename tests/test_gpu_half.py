@@ -1,0 +1,162 @@
+"""Native half-precision storage (BASELINE config 5): the
+kernels read and write float16 / bfloat16 directly, all arithmetic is float32.
+
+The reference has no half path (data_ptr<float>(), src/spmm_cuda.cu:42,51), so
+the oracle is the float64 / C restatement evaluated ON THE ROUNDED INPUTS; what
+differs from the float32 tests is only the rounding of a half OUTPUT: `half_err`
+takes one unit in the last place of the storage type off the difference and holds
+the rest to the north star's 1e-4.  Outputs that stay float32 are held to 1e-4
+as they are.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle
+from oracle import sputnik_oracle as O
+from tests.helpers import make_csr, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4                                                  # float32 outputs
+HALF_TYPES = [torch.float16, torch.bfloat16]
+
+
+def ulp(want, dtype):
+    """Spacing of the storage type at |want| (float16 subnormals included)."""
+    a = np.abs(np.asarray(want, np.float64))
+    if dtype == torch.float16:
+        return np.spacing(np.minimum(a, 65000.0).astype(np.float16)).astype(np.float64)
+    if dtype == torch.bfloat16:
+        return 2.0 ** (np.floor(np.log2(np.maximum(a, 2.0 ** -126))) - 7)
+    return np.zeros_like(a)
+
+
+def half_err(got, want, dtype, row_offsets=None):
+    """rel_err of what is left of |got - want| after ONE unit in the last place of
+    the output's storage type (its rounding) has been taken off: the test is
+    ``half_err(...) < 1e-4``, the float32 bound on the arithmetic."""
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    diff = got - want
+    rest = np.sign(diff) * np.maximum(np.abs(diff) - ulp(want, dtype), 0.0)
+    return rel_err(want + rest, want, row_offsets)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from torch_sputnik_amd import capi
+    assert "gfx950" in capi.version()
+    return capi
+
+
+@pytest.fixture(scope="module")
+def ts():
+    import torch_sputnik
+    return torch_sputnik
+
+
+def T(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def rounded(x, dtype, dev):
+    """(device tensor in `dtype`, the same values as float32 numpy)."""
+    t = T(np.asarray(x, np.float32), dev).to(dtype)
+    return t, t.float().cpu().numpy()
+
+
+# ----------------------------------------------------------------------------
+# sparse softmax and its gradient
+# ----------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", HALF_TYPES)
+@pytest.mark.parametrize("m,n,sparsity,replicas", [
+    (72, 72, 0.5, 1), (300, 700, 0.85, 3), (1024, 1024, 0.9, 4), (64, 3000, 0.5, 2),
+    (100, 2000, 0.97, 2),   # short rows
+    (40, 9000, 0.5, 1),     # rows longer than the largest window: strided passes
+])
+def test_softmax_half_capi_vs_oracle(capi, dev, dtype, m, n, sparsity, replicas):
+    _, vals, ri, ro, ci = make_csr(m, n, sparsity, seed=m + n, round_to=1, empty_rows=(0, m - 1))
+    rng = np.random.default_rng(m)
+    v, v32 = rounded(rng.uniform(-8, 8, size=(replicas, len(vals))), dtype, dev)
+    want = c_oracle.sparse_softmax(v32, ro, ci)
+    out = torch.full((replicas, len(vals)), float("nan"), device=dev, dtype=dtype)
+    capi.sparse_softmax_typed(m, replicas, v, T(ri, dev), T(ro, dev), T(ci, dev), 1.0, out)
+    got = out.float().cpu().numpy()
+    assert not np.isnan(got).any()
+    assert half_err(got, want, dtype, ro) < TOL
+    # scale folded in
+    capi.sparse_softmax_typed(m, replicas, v, T(ri, dev), T(ro, dev), T(ci, dev), 0.125, out)
+    want = c_oracle.sparse_softmax((v32.astype(np.float64) * 0.125).astype(np.float32), ro, ci)
+    assert half_err(out.float().cpu().numpy(), want, dtype, ro) < 2 * TOL
+
+
+@pytest.mark.parametrize("dtype", HALF_TYPES)
+@pytest.mark.parametrize("in_phase,out_phase", [(0, 0), (1, 1), (3, 2), (2, 0), (5, 5), (7, 3)])
+def test_softmax_half_unaligned_buffers(capi, dev, dtype, in_phase, out_phase):
+    """Half rows move as aligned 8-byte pieces: any 2-byte aligned start, odd
+    replica strides and outputs aligned differently from the inputs give the same
+    answer, and nothing outside the output is written."""
+    m, n, replicas = 300, 700, 3
+    _, vals, ri, ro, ci = make_csr(m, n, 0.85, seed=m + n, round_to=1, empty_rows=(0, m // 2))
+    nnz = len(vals)
+    rng = np.random.default_rng(m)
+    v, v32 = rounded(rng.uniform(-6, 6, size=(replicas, nnz)), dtype, dev)
+    want = c_oracle.sparse_softmax(v32, ro, ci)
+    src = torch.zeros(replicas * nnz + 16, device=dev, dtype=dtype)
+    src[in_phase:in_phase + replicas * nnz] = v.reshape(-1)
+    dst = torch.full((replicas * nnz + 16,), 7.0, device=dev, dtype=dtype)
+    capi.sparse_softmax_typed(m, replicas, src[in_phase:in_phase + replicas * nnz].view(replicas, nnz),
+                              T(ri, dev), T(ro, dev), T(ci, dev), 1.0,
+                              dst[out_phase:out_phase + replicas * nnz].view(replicas, nnz))
+    got = dst.float().cpu().numpy()
+    assert np.all(got[:out_phase] == 7.0) and np.all(got[out_phase + replicas * nnz:] == 7.0)
+    assert half_err(got[out_phase:out_phase + replicas * nnz].reshape(replicas, nnz), want, dtype,
+                    ro) < TOL
+
+
+@pytest.mark.parametrize("dtype", HALF_TYPES)
+@pytest.mark.parametrize("m,n,sparsity,replicas", [(72, 72, 0.5, 1), (300, 700, 0.85, 3),
+                                                   (1024, 1024, 0.9, 4), (40, 9000, 0.5, 1)])
+def test_softmax_backward_half_capi_vs_oracle(capi, dev, dtype, m, n, sparsity, replicas):
+    _, vals, ri, ro, ci = make_csr(m, n, sparsity, seed=m + n, round_to=1, empty_rows=(0,))
+    rng = np.random.default_rng(m + 1)
+    x = rng.uniform(-4, 4, size=(replicas, len(vals))).astype(np.float32)
+    y, y32 = rounded(c_oracle.sparse_softmax(x, ro, ci), dtype, dev)
+    g, g32 = rounded(rng.uniform(-1, 1, size=y32.shape), dtype, dev)
+    scale = 0.25
+    want = O.sparse_softmax_backward(y32, g32, ro, scale)
+    out = torch.full(y.shape, float("nan"), device=dev, dtype=dtype)
+    capi.sparse_softmax_backward_typed(m, replicas, y, g, T(ro, dev), scale, out)
+    got = out.float().cpu().numpy()
+    assert not np.isnan(got).any()
+    assert half_err(got, want, dtype, ro) < TOL
+
+
+@pytest.mark.parametrize("dtype", HALF_TYPES)
+def test_softmax_half_op_keeps_the_storage_type(ts, dev, dtype):
+    """The torch op hands half values to the kernel as they are (no widening
+    copy) and returns the values' type; mixed operands of the gradient take the
+    wider type."""
+    import torch_sputnik_amd as tsa
+    m, n = 128, 512
+    _, vals, ri, ro, ci = make_csr(m, n, 0.8, seed=9, round_to=1)
+    v, v32 = rounded(np.random.default_rng(2).uniform(-5, 5, size=(2, len(vals))), dtype, dev)
+    y = ts.sparse_softmax(v, T(ri, dev), T(ro, dev), T(ci, dev))
+    assert y.dtype == dtype and y.shape == v.shape
+    want = c_oracle.sparse_softmax(v32, ro, ci)
+    assert half_err(y.float().cpu().numpy(), want, dtype, ro) < TOL
+    g = T(np.random.default_rng(3).uniform(-1, 1, size=tuple(y.shape)).astype(np.float32), dev).to(dtype)
+    dx = tsa.ops.sparse_softmax_backward(y, g, T(ro, dev), 1.0)
+    assert dx.dtype == dtype
+    dx32 = tsa.ops.sparse_softmax_backward(y.float(), g, T(ro, dev), 1.0)
+    assert dx32.dtype == torch.float32
+    want_dx = O.sparse_softmax_backward(y.float().cpu().numpy(), g.float().cpu().numpy(), ro, 1.0)
+    assert rel_err(dx32.cpu().numpy(), want_dx, ro) < TOL
+    assert half_err(dx.float().cpu().numpy(), want_dx, dtype, ro) < TOL

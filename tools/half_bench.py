@@ -1,0 +1,44 @@
+"""Timing of the natively typed operators at config 3 (float32 against float16 /
+bfloat16 storage).  Usage: python tools/half_bench.py [softmax] [sddmm] [spmm]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from torch_sputnik_amd import capi  # noqa: E402
+from torch_sputnik_amd.synthetic import random_csr, uniform  # noqa: E402
+
+
+def ev(fn, iters=50):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3   # us
+
+
+def main():
+    what = set(sys.argv[1:]) or {"softmax", "sddmm", "spmm"}
+    dev = torch.device("cuda:0")
+    s, d = 1024, 64
+    ri, ro, ci, nnz = random_csr(s, s, 0.1, dev, seed=7)
+    for reps in (64, 512):
+        x = uniform((reps, nnz), dev, 3) * 8 - 4
+        if "softmax" in what:
+            for dt in (torch.float32, torch.float16, torch.bfloat16):
+                a, y, g = x.to(dt), torch.empty(reps, nnz, device=dev, dtype=dt), torch.empty(reps, nnz, device=dev, dtype=dt)
+                tf = ev(lambda: capi.sparse_softmax_typed(s, reps, a, ri, ro, ci, 1.0, y))
+                tb = ev(lambda: capi.sparse_softmax_backward_typed(s, reps, y, a, ro, 1.0, g))
+                eb = a.element_size()
+                print(f"softmax R={reps} {str(dt):16s} fwd {tf:7.2f} us ({2 * eb * reps * nnz / tf / 8e6:.3f} of 8 TB/s)  "
+                      f"bwd {tb:7.2f} us ({3 * eb * reps * nnz / tb / 8e6:.3f})", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -87,6 +87,10 @@ SIGNATURES = {
         _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_float, _c_ptr, _c_i64, _c_ptr]),
     "sputnik_hip_sparse_softmax_backward_batched": (_c_int, [_c_int] * 3 + [
         _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_float, _c_ptr, _c_i64, _c_ptr]),
+    "sputnik_hip_sparse_softmax_typed": (_c_int, [_c_int] * 4 + [
+        _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_float, _c_ptr, _c_i64, _c_int, _c_ptr]),
+    "sputnik_hip_sparse_softmax_backward_typed": (_c_int, [_c_int] * 3 + [
+        _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_float, _c_ptr, _c_i64, _c_int, _c_ptr]),
     "sputnik_hip_sparse_attention_supported": (_c_int, [_c_int] * 4),
     "sputnik_hip_sparse_attention_workspace_bytes": (_c_size, [_c_int] * 4),
     "sputnik_hip_sparse_attention_forward": (_c_int, [_c_int] * 5 + [
@@ -332,6 +336,43 @@ def sparse_softmax_backward_batched(m, replicas, softmax_out, grad_out, row_offs
         m, nonzeros, replicas, _ptr(softmax_out), nonzeros, _ptr(grad_out), nonzeros,
         _ptr(row_offsets), float(scale), _ptr(grad_values), nonzeros, _stream(grad_values)),
         "sputnik_hip_sparse_softmax_backward_batched")
+    return grad_values
+
+
+TYPE_CODES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}   # SPUTNIK_HIP_F32 / F16 / BF16
+
+
+def _type_code(*tensors):
+    dtype = tensors[0].dtype
+    if dtype not in TYPE_CODES or any(t.dtype != dtype for t in tensors):
+        raise TypeError("operands must share one of float32 / float16 / bfloat16, got "
+                        + ", ".join(str(t.dtype) for t in tensors))
+    return TYPE_CODES[dtype]
+
+
+def sparse_softmax_typed(m, replicas, values, row_indices, row_offsets, column_indices, scale, out):
+    """softmax(scale * values) on float32 / float16 / bfloat16 storage (in and out alike)."""
+    nonzeros = column_indices.numel()
+    for t, nm in ((row_indices, "row_indices"), (row_offsets, "row_offsets"),
+                  (column_indices, "column_indices")):
+        _require(t, torch.int32, nm)
+    code = _type_code(values, out)
+    _check(lib().sputnik_hip_sparse_softmax_typed(
+        m, -1, nonzeros, replicas, _ptr(values), nonzeros, _ptr(row_indices), _ptr(row_offsets),
+        _ptr(column_indices), float(scale), _ptr(out), nonzeros, code, _stream(out)),
+        "sputnik_hip_sparse_softmax_typed")
+    return out
+
+
+def sparse_softmax_backward_typed(m, replicas, softmax_out, grad_out, row_offsets, scale,
+                                  grad_values):
+    nonzeros = softmax_out.shape[-1]
+    _require(row_offsets, torch.int32, "row_offsets")
+    code = _type_code(softmax_out, grad_out, grad_values)
+    _check(lib().sputnik_hip_sparse_softmax_backward_typed(
+        m, nonzeros, replicas, _ptr(softmax_out), nonzeros, _ptr(grad_out), nonzeros,
+        _ptr(row_offsets), float(scale), _ptr(grad_values), nonzeros, code, _stream(grad_values)),
+        "sputnik_hip_sparse_softmax_backward_typed")
     return grad_values
 
 

@@ -66,6 +66,20 @@ Tensor as_float(const Tensor& t, const char* name) {
   return t.to(at::kFloat).contiguous();
 }
 
+// Operands of the natively typed kernels (softmax pair, SDDMM): float32, float16 or
+// bfloat16 storage is handed to the kernel as it is -- no widening copy.
+Tensor as_storage(const Tensor& t, const char* name) {
+  TORCH_CHECK(t.is_cuda(), name, " must be a GPU (HIP) tensor, got ", t.device());
+  const auto st = t.scalar_type();
+  TORCH_CHECK(st == at::kFloat || st == at::kHalf || st == at::kBFloat16, name,
+              " must be float32, float16 or bfloat16, got ", st);
+  return t.contiguous();
+}
+int type_code(at::ScalarType t) {   // -1: not a storage type of the library
+  return t == at::kFloat ? SPUTNIK_HIP_F32 : t == at::kHalf ? SPUTNIK_HIP_F16
+         : t == at::kBFloat16 ? SPUTNIK_HIP_BF16 : -1;
+}
+
 struct Topology {
   Tensor row_indices, row_offsets, column_indices;
   int nonzeros;
@@ -627,7 +641,9 @@ Tensor sddmm_sum_planned(int64_t m, int64_t n, const Tensor& row_indices,
 Tensor sparse_softmax_scaled(const Tensor& values_in, const Tensor& row_indices,
                              const Tensor& row_offsets, const Tensor& column_indices,
                              double scale) {
-  const Tensor values = as_float(values_in, "values");
+  // float16 / bfloat16 values are read and written as such (half the traffic of
+  // src/softmax_cuda.cu:38-42), the result has the values' type
+  const Tensor values = as_storage(values_in, "values");
   TORCH_CHECK(values.dim() == 1 || values.dim() == 2,
               "values should have 1 or 2 dimensions, got ", values.dim());
   const c10::DeviceGuard guard(values.device());
@@ -638,11 +654,12 @@ Tensor sparse_softmax_scaled(const Tensor& values_in, const Tensor& row_indices,
   const int replicas = values.dim() == 2 ? to_int(values.size(0), "replicas") : 1;
 
   Tensor out = at::empty_like(values);
-  check_status(sputnik_hip_sparse_softmax_scaled_batched(
-                   m, /*n=*/-1, topo.nonzeros, replicas, values.data_ptr<float>(), topo.nonzeros,
+  check_status(sputnik_hip_sparse_softmax_typed(
+                   m, /*n=*/-1, topo.nonzeros, replicas, values.data_ptr(), topo.nonzeros,
                    topo.row_indices.data_ptr<int>(), topo.row_offsets.data_ptr<int>(),
                    topo.column_indices.data_ptr<int>(), static_cast<float>(scale),
-                   out.data_ptr<float>(), topo.nonzeros, current_stream(values)),
+                   out.data_ptr(), topo.nonzeros, type_code(values.scalar_type()),
+                   current_stream(values)),
                "sparse_softmax");
   return out;
 }
@@ -655,8 +672,10 @@ Tensor sparse_softmax(const Tensor& values, const Tensor& row_indices, const Ten
 // grad of softmax(scale * x) w.r.t. x; softmax_out / grad_out [nnz] or [R,nnz].
 Tensor sparse_softmax_backward(const Tensor& softmax_out_in, const Tensor& grad_out_in,
                                const Tensor& row_offsets_in, double scale) {
-  const Tensor y = as_float(softmax_out_in, "softmax_out");
-  const Tensor g = as_float(grad_out_in, "grad_out");
+  // one storage type for both operands and the result (the wider one if they differ)
+  const auto st = at::promote_types(softmax_out_in.scalar_type(), grad_out_in.scalar_type());
+  const Tensor y = as_storage(softmax_out_in, "softmax_out").to(st);
+  const Tensor g = as_storage(grad_out_in, "grad_out").to(st);
   TORCH_CHECK(y.sizes() == g.sizes(), "softmax_out and grad_out must have one shape, got ",
               y.sizes(), " and ", g.sizes());
   TORCH_CHECK(y.dim() == 1 || y.dim() == 2, "softmax_out should have 1 or 2 dimensions, got ",
@@ -669,10 +688,10 @@ Tensor sparse_softmax_backward(const Tensor& softmax_out_in, const Tensor& grad_
   const int nonzeros = to_int(y.size(-1), "nonzeros");
   const int replicas = y.dim() == 2 ? to_int(y.size(0), "replicas") : 1;
   Tensor out = at::empty_like(y);
-  check_status(sputnik_hip_sparse_softmax_backward_batched(
-                   m, nonzeros, replicas, y.data_ptr<float>(), nonzeros, g.data_ptr<float>(),
-                   nonzeros, row_offsets.data_ptr<int>(), static_cast<float>(scale),
-                   out.data_ptr<float>(), nonzeros, current_stream(y)),
+  check_status(sputnik_hip_sparse_softmax_backward_typed(
+                   m, nonzeros, replicas, y.data_ptr(), nonzeros, g.data_ptr(), nonzeros,
+                   row_offsets.data_ptr<int>(), static_cast<float>(scale), out.data_ptr(),
+                   nonzeros, type_code(st), current_stream(y)),
                "sparse_softmax_backward");
   return out;
 }
@@ -1097,11 +1116,6 @@ std::vector<Tensor> csr_transpose_many_mask(int64_t b, int64_t m64, int64_t n64,
 // i.e. `x.transpose(-1, -2).contiguous()` as ONE tiled kernel, optionally
 // changing the storage type on the way (out_type: -1 keep, 0 float32, 1 float16,
 // 2 bfloat16; half <-> float and equal types).
-int type_code(at::ScalarType t) {
-  return t == at::kFloat ? SPUTNIK_HIP_F32 : t == at::kHalf ? SPUTNIK_HIP_F16
-         : t == at::kBFloat16 ? SPUTNIK_HIP_BF16 : -1;
-}
-
 Tensor transpose_last2_as(const Tensor& x_in, int64_t out_type) {
   TORCH_CHECK(x_in.is_cuda(), "transpose_last2: expected a GPU (HIP) tensor, got ", x_in.device());
   TORCH_CHECK(x_in.dim() >= 2, "transpose_last2: expected at least 2 dimensions, got ", x_in.dim());
