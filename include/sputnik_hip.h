@@ -164,6 +164,34 @@ SPUTNIK_HIP_API int sputnik_hip_sddmm_batched_planned(int m, int k, int n, int n
                               float* out, int64_t out_stride, const void* workspace,
                               size_t workspace_bytes, sputnik_hip_stream_t stream);
 
+/*
+ * SDDMM on operands stored as `in_type` (SPUTNIK_HIP_F32 / F16 / BF16; lhs and rhs
+ * alike; strides in elements), output stored as `out_type` (F32, or in_type).  Half
+ * operands are read as they are -- the LDS slab of rhs rows holds half values (half
+ * the staging and half the LDS traffic of the float form), products are exact
+ * (v_dot2_f32_f16 / _bf16), sums float32 -- where src/sddmm_cuda.cu:48-53 knows float
+ * only.  workspace / planned as sputnik_hip_sddmm_batched{,_planned} (same size, same
+ * plan: it does not depend on the types).  Returns SPUTNIK_HIP_UNSUPPORTED for a half
+ * OUTPUT whose product needs more than one pass over the output (k wider than one
+ * panel): take a float output then.
+ */
+/* sum over the replicas (sputnik_hip_sddmm_sum_batched{,_planned}) on operands stored as
+ * `in_type`; the partial vectors and the result are float32.  Workspace / scratch sizes as
+ * the float form's (sputnik_hip_sddmm_sum_workspace_bytes / _scratch_bytes). */
+SPUTNIK_HIP_API int sputnik_hip_sddmm_sum_typed(int m, int k, int n, int nonzeros, int replicas,
+                              const int* row_indices, const int* row_offsets,
+                              const int* column_indices, const void* lhs, int64_t lhs_stride,
+                              const void* rhs, int64_t rhs_stride, int in_type, float* out,
+                              void* workspace, size_t workspace_bytes, int planned,
+                              void* scratch, size_t scratch_bytes, sputnik_hip_stream_t stream);
+
+SPUTNIK_HIP_API int sputnik_hip_sddmm_typed(int m, int k, int n, int nonzeros, int replicas,
+                              const int* row_indices, const int* row_offsets,
+                              const int* column_indices, const void* lhs, int64_t lhs_stride,
+                              const void* rhs, int64_t rhs_stride, int in_type, void* out,
+                              int64_t out_stride, int out_type, void* workspace,
+                              size_t workspace_bytes, int planned, sputnik_hip_stream_t stream);
+
 /* Sum of the replicas' products, out[nonzeros] = sum_r sddmm(lhs_r, rhs_r): the
  * gradient of sparse values shared by a batch.  The reference returns the
  * [replicas, nonzeros] products (tests/test_linear_3d.py:64-69,

@@ -222,6 +222,11 @@ def _left_spmm_group_sum(m, k, values, permutations, row_indices, row_offsets, c
     return total
 
 
+def _sddmm_narrow(m, n, row_indices, row_offsets, column_indices, lhs, rhs):
+    out = _sddmm(m, n, row_indices, row_offsets, column_indices, lhs.float(), rhs.float())
+    return out.to(torch.promote_types(lhs.dtype, rhs.dtype))
+
+
 def _sddmm_sum(m, n, row_indices, row_offsets, column_indices, lhs, rhs):
     out = _sddmm(m, n, row_indices, row_offsets, column_indices, lhs, rhs)
     return out.sum(dim=0) if out.dim() == 2 else out
@@ -246,6 +251,7 @@ def install():
     _lib.impl("spmm", _spmm, "CPU")
     _lib.impl("left_spmm", _left_spmm, "CPU")
     _lib.impl("sddmm", _sddmm, "CPU")
+    _lib.impl("sddmm_narrow", _sddmm_narrow, "CPU")
     _lib.impl("sparse_softmax", _sparse_softmax, "CPU")
     _lib.impl("csr_transpose", _csr_transpose, "CPU")
     _lib.impl("csr_transpose_with_permutation", _csr_transpose_with_permutation, "CPU")

@@ -160,3 +160,147 @@ def test_softmax_half_op_keeps_the_storage_type(ts, dev, dtype):
     want_dx = O.sparse_softmax_backward(y.float().cpu().numpy(), g.float().cpu().numpy(), ro, 1.0)
     assert rel_err(dx32.cpu().numpy(), want_dx, ro) < TOL
     assert half_err(dx.float().cpu().numpy(), want_dx, dtype, ro) < TOL
+
+
+# ----------------------------------------------------------------------------
+# SDDMM: half operands read as they are (LDS slab in half, v_dot2 products)
+# ----------------------------------------------------------------------------
+SDDMM_SHAPES = [
+    # m, k, n, sparsity, replicas
+    (72, 64, 72, 0.0, 1),      # tests/test_sddmm.py: dense mask
+    (72, 64, 72, 0.9, 4),
+    (50, 7, 60, 0.7, 2),       # odd k: scalar loads (row-wave kernel)
+    (50, 10, 60, 0.7, 1),
+    (128, 32, 128, 0.9, 3),
+    (1024, 64, 1024, 0.9, 2),  # attention block geometry (config 3)
+    (200, 300, 150, 0.8, 1),
+    (64, 1100, 96, 0.9, 2),    # k > 1024 on the row-wave kernel: several panels
+    (300, 64, 500, 0.8, 3),    # quad kernel, ragged row / column blocks
+    (256, 128, 256, 0.5, 2),   # k = 128, > 32 entries per row and slab
+    (64, 64, 64, 0.0, 1),      # dense mask: full windows
+    (300, 256, 200, 0.8, 2),   # k = 256 (128-row slabs)
+    (512, 512, 512, 0.8, 2),   # k = 512: the plan's 64-row slabs, two panels of 256
+    (130, 512, 70, 0.3, 1),
+    (256, 1024, 96, 0.7, 2),   # four panels of 256 accumulate
+    (200, 768, 130, 0.8, 2),
+    (96, 320, 200, 0.6, 1),    # five panels of 64
+]
+
+
+@pytest.fixture(params=["auto", "tiled", "wave"])
+def sddmm_kernel(request, monkeypatch):
+    from torch_sputnik_amd import capi
+    if request.param == "auto":
+        monkeypatch.delenv("SPUTNIK_HIP_SDDMM_KERNEL", raising=False)
+    else:
+        monkeypatch.setenv("SPUTNIK_HIP_SDDMM_KERNEL", request.param)
+    capi.reload_options()
+    yield request.param
+    monkeypatch.delenv("SPUTNIK_HIP_SDDMM_KERNEL", raising=False)
+    capi.reload_options()
+
+
+@pytest.mark.parametrize("dtype", HALF_TYPES)
+@pytest.mark.parametrize("m,k,n,sparsity,replicas", SDDMM_SHAPES)
+def test_sddmm_half_capi_vs_oracle(capi, dev, sddmm_kernel, dtype, m, k, n, sparsity, replicas):
+    """float32 output of half operands: exact products, float32 sums -- the float32
+    bound against the oracle on the rounded operands."""
+    _, _, ri, ro, ci = make_csr(m, n, sparsity, seed=m + k + n, round_to=1, empty_rows=(m // 2,))
+    rng = np.random.default_rng(k)
+    lhs, lhs32 = rounded(rng.uniform(-1, 1, size=(replicas, m, k)), dtype, dev)
+    rhs, rhs32 = rounded(rng.uniform(-1, 1, size=(replicas, n, k)), dtype, dev)
+    want = c_oracle.sddmm(m, n, ro, ci, lhs32, rhs32)
+    out = torch.full((replicas, len(ci)), float("nan"), device=dev)
+    ws = torch.empty(capi.sddmm_workspace_bytes(m, k, n, len(ci)) + 16, dtype=torch.uint8, device=dev)
+    topo = (T(ri, dev), T(ro, dev), T(ci, dev))
+    capi.sddmm_typed(m, k, n, replicas, *topo, lhs, rhs, out, ws)
+    got = out.cpu().numpy()
+    assert not np.isnan(got).any()
+    assert rel_err(got, want, ro) < TOL
+    # planned form: same plan as the float operator's, bit-identical result
+    capi.sddmm_plan(m, k, n, *topo, ws)
+    out2 = torch.full_like(out, float("nan"))
+    capi.sddmm_typed(m, k, n, replicas, *topo, lhs, rhs, out2, ws, planned=True)
+    assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("dtype", HALF_TYPES)
+@pytest.mark.parametrize("m,k,n,sparsity,replicas", [
+    (1024, 64, 1024, 0.9, 2), (300, 64, 500, 0.8, 3), (256, 128, 256, 0.5, 2),
+    (300, 256, 200, 0.8, 2), (50, 10, 60, 0.7, 1), (128, 32, 128, 0.9, 3)])
+def test_sddmm_half_output(capi, dev, sddmm_kernel, dtype, m, k, n, sparsity, replicas):
+    """Half OUTPUT (single-pass shapes): the float32 sum rounded once."""
+    _, _, ri, ro, ci = make_csr(m, n, sparsity, seed=m + k + n, round_to=1)
+    rng = np.random.default_rng(k + 7)
+    lhs, lhs32 = rounded(rng.uniform(-1, 1, size=(replicas, m, k)), dtype, dev)
+    rhs, rhs32 = rounded(rng.uniform(-1, 1, size=(replicas, n, k)), dtype, dev)
+    want = c_oracle.sddmm(m, n, ro, ci, lhs32, rhs32)
+    out = torch.full((replicas, len(ci)), float("nan"), device=dev, dtype=dtype)
+    ws = torch.empty(capi.sddmm_workspace_bytes(m, k, n, len(ci)) + 16, dtype=torch.uint8, device=dev)
+    capi.sddmm_typed(m, k, n, replicas, T(ri, dev), T(ro, dev), T(ci, dev), lhs, rhs, out, ws)
+    got = out.float().cpu().numpy()
+    assert not np.isnan(got).any()
+    assert half_err(got, want, dtype, ro) < TOL
+
+
+def test_sddmm_half_output_needs_one_pass(capi, dev):
+    m, k, n = 256, 2048, 96
+    _, _, ri, ro, ci = make_csr(m, n, 0.7, seed=3, round_to=1)
+    lhs = torch.zeros(1, m, k, device=dev, dtype=torch.float16)
+    rhs = torch.zeros(1, n, k, device=dev, dtype=torch.float16)
+    out = torch.zeros(1, len(ci), device=dev, dtype=torch.float16)
+    ws = torch.empty(capi.sddmm_workspace_bytes(m, k, n, len(ci)) + 16, dtype=torch.uint8, device=dev)
+    with pytest.raises(RuntimeError, match="status -2"):    # SPUTNIK_HIP_UNSUPPORTED
+        capi.sddmm_typed(m, k, n, 1, T(ri, dev), T(ro, dev), T(ci, dev), lhs, rhs, out, ws)
+
+
+@pytest.mark.parametrize("dtype", HALF_TYPES)
+@pytest.mark.parametrize("planned", [False, True])
+@pytest.mark.parametrize("m,k,n,sparsity,replicas", [
+    (512, 1024, 512, 0.9, 8), (512, 512, 512, 0.8, 3), (256, 1024, 96, 0.7, 1),
+    (200, 768, 130, 0.8, 2), (100, 40, 60, 0.5, 5), (128, 384, 200, 0.8, 3),
+    (2048, 512, 2048, 0.8, 2)])
+def test_sddmm_sum_half_capi_vs_oracle(capi, dev, dtype, planned, m, k, n, sparsity, replicas):
+    _, _, ri, ro, ci = make_csr(m, n, sparsity, seed=m + k + n, empty_rows=(m // 2,))
+    rng = np.random.default_rng(k + 1)
+    lhs, lhs32 = rounded(rng.uniform(-1, 1, size=(replicas, m, k)), dtype, dev)
+    rhs, rhs32 = rounded(rng.uniform(-1, 1, size=(replicas, n, k)), dtype, dev)
+    want = c_oracle.sddmm(m, n, ro, ci, lhs32, rhs32).astype(np.float64).sum(axis=0)
+    out = torch.full((len(ci),), float("nan"), device=dev)
+    ws = torch.empty(capi.sddmm_sum_workspace_bytes(m, k, n, len(ci)) + 16, dtype=torch.uint8, device=dev)
+    scratch = torch.empty(capi.sddmm_sum_scratch_bytes(m, k, n, len(ci), replicas) + 16,
+                          dtype=torch.uint8, device=dev)
+    topo = (T(ri, dev), T(ro, dev), T(ci, dev))
+    if planned:
+        capi.sddmm_sum_plan(m, k, n, *topo, ws)
+    capi.sddmm_sum_typed(m, k, n, replicas, *topo, lhs, rhs, out, ws, scratch, planned=planned)
+    got = out.cpu().numpy()
+    assert not np.isnan(got).any()
+    assert rel_err(got[None, :], want[None, :].astype(np.float32), ro) < TOL
+
+
+@pytest.mark.parametrize("dtype", HALF_TYPES)
+def test_sddmm_half_ops(ts, dev, dtype):
+    """torch ops: half operands go to the kernel as they are; `sddmm` returns float32
+    (the reference's output type), `sddmm_narrow` the operands' type (also when the
+    product takes several passes: float32 result rounded once)."""
+    import torch_sputnik_amd as tsa
+    for m, k, n in ((300, 64, 500), (256, 1024, 96)):
+        _, _, ri, ro, ci = make_csr(m, n, 0.8, seed=k, round_to=1)
+        topo = (T(ri, dev), T(ro, dev), T(ci, dev))
+        rng = np.random.default_rng(k)
+        lhs, lhs32 = rounded(rng.uniform(-1, 1, size=(2, m, k)), dtype, dev)
+        rhs, rhs32 = rounded(rng.uniform(-1, 1, size=(2, n, k)), dtype, dev)
+        want = c_oracle.sddmm(m, n, ro, ci, lhs32, rhs32)
+        out = ts.sddmm(m, n, *topo, lhs, rhs)
+        assert out.dtype == torch.float32
+        assert rel_err(out.cpu().numpy(), want, ro) < TOL
+        narrow = tsa.ops.sddmm_narrow(m, n, *topo, lhs, rhs)
+        assert narrow.dtype == dtype
+        assert half_err(narrow.float().cpu().numpy(), want, dtype, ro) < TOL
+        # mixed operands take the wider type
+        mixed = ts.sddmm(m, n, *topo, lhs, rhs.float())
+        assert rel_err(mixed.cpu().numpy(), want, ro) < TOL
+        total = tsa.ops.sddmm_sum(m, n, *topo, lhs, rhs)
+        assert total.dtype == torch.float32
+        assert rel_err(total.cpu().numpy()[None], want.astype(np.float64).sum(0)[None], ro) < TOL

@@ -38,6 +38,25 @@ def main():
                 eb = a.element_size()
                 print(f"softmax R={reps} {str(dt):16s} fwd {tf:7.2f} us ({2 * eb * reps * nnz / tf / 8e6:.3f} of 8 TB/s)  "
                       f"bwd {tb:7.2f} us ({3 * eb * reps * nnz / tb / 8e6:.3f})", flush=True)
+    if "sddmm" in what:
+        for (m, k, n, dens, reps, tag) in ((1024, 64, 1024, 0.1, 64, "c3 attention scores"),
+                                           (1024, 128, 1024, 0.1, 64, "k=128"),
+                                           (2048, 512, 2048, 0.2, 8, "c5 weight gradient (per replica)")):
+            ri, ro, ci, nnz = random_csr(m, n, dens, dev, seed=7)
+            ws = torch.empty(capi.sddmm_workspace_bytes(m, k, n, nnz) + 16, dtype=torch.uint8, device=dev)
+            for dt in (torch.float32, torch.float16, torch.bfloat16):
+                q = (uniform((reps, m, k), dev, 11) - 0.5).to(dt)
+                kk = (uniform((reps, n, k), dev, 12) - 0.5).to(dt)
+                out = torch.empty(reps, nnz, device=dev)
+                t = ev(lambda: capi.sddmm_typed(m, k, n, reps, ri, ro, ci, q, kk, out, ws), 20)
+                capi.sddmm_plan(m, k, n, ri, ro, ci, ws)
+                tp = ev(lambda: capi.sddmm_typed(m, k, n, reps, ri, ro, ci, q, kk, out, ws, planned=True), 20)
+                line = f"sddmm {tag:34s} {str(dt):15s} {t:8.2f} us  planned {tp:8.2f} us ({2.0 * nnz * k * reps / tp / 1e6:7.1f} TFLOP/s)"
+                if dt != torch.float32 and k <= 256:
+                    oh = torch.empty(reps, nnz, device=dev, dtype=dt)
+                    th = ev(lambda: capi.sddmm_typed(m, k, n, reps, ri, ro, ci, q, kk, oh, ws, planned=True), 20)
+                    line += f"  half out {th:8.2f} us"
+                print(line, flush=True)
 
 
 if __name__ == "__main__":

@@ -87,6 +87,12 @@ SIGNATURES = {
         _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_float, _c_ptr, _c_i64, _c_ptr]),
     "sputnik_hip_sparse_softmax_backward_batched": (_c_int, [_c_int] * 3 + [
         _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_float, _c_ptr, _c_i64, _c_ptr]),
+    "sputnik_hip_sddmm_typed": (_c_int, [_c_int] * 5 + [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64,
+                                                       _c_ptr, _c_i64, _c_int, _c_ptr, _c_i64,
+                                                       _c_int, _c_ptr, _c_size, _c_int, _c_ptr]),
+    "sputnik_hip_sddmm_sum_typed": (_c_int, [_c_int] * 5 + [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64,
+                                                           _c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr,
+                                                           _c_size, _c_int, _c_ptr, _c_size, _c_ptr]),
     "sputnik_hip_sparse_softmax_typed": (_c_int, [_c_int] * 4 + [
         _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_float, _c_ptr, _c_i64, _c_int, _c_ptr]),
     "sputnik_hip_sparse_softmax_backward_typed": (_c_int, [_c_int] * 3 + [
@@ -350,6 +356,26 @@ def _type_code(*tensors):
     return TYPE_CODES[dtype]
 
 
+def sddmm_typed(m, k, n, replicas, row_indices, row_offsets, column_indices, lhs, rhs, out,
+                workspace=None, planned=False):
+    """SDDMM on float32 / float16 / bfloat16 operands (lhs, rhs alike); out float32 or
+    the operands' type."""
+    nonzeros = column_indices.numel()
+    for t, nm in ((row_indices, "row_indices"), (row_offsets, "row_offsets"),
+                  (column_indices, "column_indices")):
+        _require(t, torch.int32, nm)
+    in_code = _type_code(lhs, rhs)
+    out_code = _type_code(out)
+    for t, nm in ((lhs, "lhs"), (rhs, "rhs"), (out, "out")):
+        if not (t.is_cuda and t.is_contiguous()):
+            raise ValueError(f"{nm}: expected a contiguous GPU tensor")
+    _check(lib().sputnik_hip_sddmm_typed(
+        m, k, n, nonzeros, replicas, _ptr(row_indices), _ptr(row_offsets), _ptr(column_indices),
+        _ptr(lhs), m * k, _ptr(rhs), n * k, in_code, _ptr(out), nonzeros, out_code, _ptr(workspace),
+        _ws_bytes(workspace), int(bool(planned)), _stream(out)), "sputnik_hip_sddmm_typed")
+    return out
+
+
 def sparse_softmax_typed(m, replicas, values, row_indices, row_offsets, column_indices, scale, out):
     """softmax(scale * values) on float32 / float16 / bfloat16 storage (in and out alike)."""
     nonzeros = column_indices.numel()
@@ -557,6 +583,19 @@ def sddmm_sum_batched(m, k, n, replicas, row_indices, row_offsets, column_indice
               _ptr(column_indices), _ptr(lhs), m * k, _ptr(rhs), n * k, _ptr(out), _ptr(workspace),
               _ws_bytes(workspace), _ptr(scratch), _ws_bytes(scratch), _stream(out)),
            "sputnik_hip_sddmm_sum_batched")
+    return out
+
+
+def sddmm_sum_typed(m, k, n, replicas, row_indices, row_offsets, column_indices, lhs, rhs, out,
+                    workspace, scratch, planned=False):
+    """sddmm_sum_batched on float32 / float16 / bfloat16 operands; out float32."""
+    nonzeros = column_indices.numel()
+    _require(out, torch.float32, "out")
+    _check(lib().sputnik_hip_sddmm_sum_typed(
+        m, k, n, nonzeros, replicas, _ptr(row_indices), _ptr(row_offsets), _ptr(column_indices),
+        _ptr(lhs), m * k, _ptr(rhs), n * k, _type_code(lhs, rhs), _ptr(out), _ptr(workspace),
+        _ws_bytes(workspace), int(bool(planned)), _ptr(scratch), _ws_bytes(scratch), _stream(out)),
+        "sputnik_hip_sddmm_sum_typed")
     return out
 
 

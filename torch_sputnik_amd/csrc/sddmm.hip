@@ -11,6 +11,8 @@
 // (no LDS crossbar up to 16 lanes).  Lane t keeps result t, so the LPN
 // results leave as one coalesced store.  Long inner dimensions are walked in
 // panels of LPN*VEC*KSL elements; later panels add into the output.
+#include <type_traits>
+
 #include "common.h"
 #include "options.h"
 #include "wave_utils.h"
@@ -40,16 +42,50 @@ int sddmm_tiled_launch_partials(int m, int k, int n, int nonzeros, int replicas,
                                 const float* rhs, int64_t rhs_stride, float* partials,
                                 const void* workspace, hipStream_t stream);
 
+// native half operands (sddmm_tiled.hip)
+bool sddmm_tiled_applicable_half(int m, int k, int n, int nonzeros, const void* lhs,
+                                 int64_t lhs_stride, const void* rhs, int64_t rhs_stride);
+int sddmm_tiled_passes_half(int k);
+int sddmm_tiled_launch_half(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
+                            const int* row_offsets, const int* column_indices, const void* lhs,
+                            int64_t lhs_stride, const void* rhs, int64_t rhs_stride, void* out,
+                            int64_t out_stride, int in_type, int out_type, const void* workspace,
+                            hipStream_t stream, int mask_heads = 0, int64_t mask_plan_ints = 0);
+bool sddmm_tiled_sum_half_served(int m, int k, int n, int nonzeros);
+int sddmm_tiled_launch_partials_half(int m, int k, int n, int nonzeros, int replicas,
+                                     const int* row_indices, const int* row_offsets,
+                                     const int* column_indices, const void* lhs,
+                                     int64_t lhs_stride, const void* rhs, int64_t rhs_stride,
+                                     int in_type, float* partials, const void* workspace,
+                                     hipStream_t stream);
+
 namespace {
 
 constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / kWave;
 
-template <int VEC, int LPN, int KSL>
+// VEC elements of storage type T, widened to float (T = float: load_vec of common.h).
+template <int VEC, typename T>
+__device__ __forceinline__ void load_elems(float (&dst)[VEC], const T* __restrict__ src) {
+  if constexpr (std::is_same_v<T, float>) {
+    load_vec<VEC>(dst, src);
+  } else if constexpr (VEC == 1) {
+    dst[0] = static_cast<float>(*src);
+  } else {
+    using V = T __attribute__((ext_vector_type(VEC)));
+    const V v = *reinterpret_cast<const V*>(src);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) dst[e] = static_cast<float>(v[e]);
+  }
+}
+
+// T: storage type of lhs / rhs (float; _Float16 / __bf16 = native half operands, widened
+// in registers), TO: of the output.  All arithmetic is float.
+template <typename T, typename TO, int VEC, int LPN, int KSL>
 __global__ __launch_bounds__(kBlock) void sddmm_rowwave_kernel(
     int m, int k, const int* __restrict__ row_indices, const int* __restrict__ row_offsets,
-    const int* __restrict__ column_indices, const float* __restrict__ lhs, int64_t lhs_stride,
-    const float* __restrict__ rhs, int64_t rhs_stride, float* __restrict__ out,
+    const int* __restrict__ column_indices, const T* __restrict__ lhs, int64_t lhs_stride,
+    const T* __restrict__ rhs, int64_t rhs_stride, TO* __restrict__ out,
     int64_t out_stride, int mask_heads, int first_replica) {
   constexpr int kGroups = kWave / LPN;
   constexpr int kPanel = LPN * VEC * KSL;
@@ -74,7 +110,7 @@ __global__ __launch_bounds__(kBlock) void sddmm_rowwave_kernel(
   const int p0 = row_offsets[row];
   const int p1 = row_offsets[row + 1];
   const int nblocks = (p1 - p0 + LPN - 1) / LPN;
-  const float* __restrict__ lhs_row = lhs + static_cast<int64_t>(row) * k;
+  const T* __restrict__ lhs_row = lhs + static_cast<int64_t>(row) * k;
 
   for (int kp = 0; kp < k; kp += kPanel) {
     // lhs fragment of this panel: slice s covers columns kp + (s*LPN + l)*VEC.
@@ -83,7 +119,7 @@ __global__ __launch_bounds__(kBlock) void sddmm_rowwave_kernel(
     for (int s = 0; s < KSL; ++s) {
       const int c = kp + (s * LPN + l) * VEC;
       if (c < k) {
-        load_vec<VEC>(a[s], lhs_row + c);
+        load_elems<VEC, T>(a[s], lhs_row + c);
       } else {
 #pragma unroll
         for (int v = 0; v < VEC; ++v) a[s][v] = 0.f;
@@ -99,14 +135,14 @@ __global__ __launch_bounds__(kBlock) void sddmm_rowwave_kernel(
 #pragma unroll 2
       for (int t = 0; t < cnt; ++t) {
         const int j = __shfl(j_mine, t, LPN);
-        const float* __restrict__ rhs_row = rhs + static_cast<int64_t>(j) * k;
+        const T* __restrict__ rhs_row = rhs + static_cast<int64_t>(j) * k;
         float partial = 0.f;
 #pragma unroll
         for (int s = 0; s < KSL; ++s) {
           const int c = kp + (s * LPN + l) * VEC;
           if (c < k) {
             float bv[VEC];
-            load_vec<VEC>(bv, rhs_row + c);
+            load_elems<VEC, T>(bv, rhs_row + c);
 #pragma unroll
             for (int v = 0; v < VEC; ++v) partial = fmaf(a[s][v], bv[v], partial);
           }
@@ -116,24 +152,24 @@ __global__ __launch_bounds__(kBlock) void sddmm_rowwave_kernel(
       }
       if (q < p1) {
         if (kp == 0) {
-          out[q] = result;
+          out[q] = static_cast<TO>(result);
         } else {
-          out[q] += result;
+          out[q] = static_cast<TO>(static_cast<float>(out[q]) + result);
         }
       }
     }
   }
 }
 
-template <int VEC, int LPN, int KSL>
+template <typename T, typename TO, int VEC, int LPN, int KSL>
 int launch(int m, int k, int replicas, const int* row_indices, const int* row_offsets,
-           const int* column_indices, const float* lhs, int64_t lhs_stride, const float* rhs,
-           int64_t rhs_stride, float* out, int64_t out_stride, hipStream_t stream,
+           const int* column_indices, const T* lhs, int64_t lhs_stride, const T* rhs,
+           int64_t rhs_stride, TO* out, int64_t out_stride, hipStream_t stream,
            int mask_heads) {
   const int gx = ceil_div(m, kWavesPerBlock);
   for (int r0 = 0; r0 < replicas; r0 += kMaxGridYZ) {
     const int ry = min(replicas - r0, kMaxGridYZ);
-    hipLaunchKernelGGL((sddmm_rowwave_kernel<VEC, LPN, KSL>), dim3(gx, ry), dim3(kBlock), 0,
+    hipLaunchKernelGGL((sddmm_rowwave_kernel<T, TO, VEC, LPN, KSL>), dim3(gx, ry), dim3(kBlock), 0,
                        stream, m, k, row_indices, row_offsets, column_indices,
                        lhs + r0 * lhs_stride, lhs_stride, rhs + r0 * rhs_stride, rhs_stride,
                        out + r0 * out_stride, out_stride, mask_heads, r0);
@@ -143,15 +179,16 @@ int launch(int m, int k, int replicas, const int* row_indices, const int* row_of
   return 0;
 }
 
-template <int VEC>
+template <int VEC, typename T = float, typename TO = float>
 int launch_vec(int m, int k, int replicas, const int* row_indices, const int* row_offsets,
-               const int* column_indices, const float* lhs, int64_t lhs_stride, const float* rhs,
-               int64_t rhs_stride, float* out, int64_t out_stride, hipStream_t stream,
+               const int* column_indices, const T* lhs, int64_t lhs_stride, const T* rhs,
+               int64_t rhs_stride, TO* out, int64_t out_stride, hipStream_t stream,
                int mask_heads = 0) {
   const int lanes = ceil_div(k, VEC);
-#define SPUTNIK_HIP_SD(LPN, KSL)                                                              \
-  return launch<VEC, LPN, KSL>(m, k, replicas, row_indices, row_offsets, column_indices, lhs, \
-                               lhs_stride, rhs, rhs_stride, out, out_stride, stream, mask_heads)
+#define SPUTNIK_HIP_SD(LPN, KSL)                                                                \
+  return launch<T, TO, VEC, LPN, KSL>(m, k, replicas, row_indices, row_offsets, column_indices, \
+                                      lhs, lhs_stride, rhs, rhs_stride, out, out_stride, stream, \
+                                      mask_heads)
   if (lanes <= 4) SPUTNIK_HIP_SD(4, 1);
   if (lanes <= 8) SPUTNIK_HIP_SD(8, 1);
   if (lanes <= 16) SPUTNIK_HIP_SD(16, 1);
@@ -181,6 +218,33 @@ __global__ __launch_bounds__(kBlock) void sum_partials_kernel(int count /* of VE
   }
 #pragma unroll
   for (int e = 0; e < VEC; ++e) out[static_cast<int64_t>(i) * VEC + e] = acc[e];
+}
+
+// Widest vector (4, 2 or 1 ELEMENTS of `elem` bytes) every row start supports.
+int vector_width_of(const void* p, int64_t width, int64_t stride, size_t elem) {
+  if (width % 4 == 0 && stride % 4 == 0 && aligned_to(p, 4 * elem)) return 4;
+  if (width % 2 == 0 && stride % 2 == 0 && aligned_to(p, 2 * elem)) return 2;
+  return 1;
+}
+
+// Row-wave kernel on half operands.  single: the whole k in one panel (64 lanes x VEC x 4).
+template <typename T, typename TO>
+int rowwave_half(int m, int k, int replicas, const int* row_indices, const int* row_offsets,
+                 const int* column_indices, const void* lhs, int64_t lhs_stride, const void* rhs,
+                 int64_t rhs_stride, void* out, int64_t out_stride, hipStream_t stream) {
+  const T* l = static_cast<const T*>(lhs);
+  const T* r = static_cast<const T*>(rhs);
+  TO* o = static_cast<TO*>(out);
+  const int vec = min(vector_width_of(lhs, k, lhs_stride, sizeof(T)),
+                      vector_width_of(rhs, k, rhs_stride, sizeof(T)));
+  switch (vec) {
+    case 4: return launch_vec<4, T, TO>(m, k, replicas, row_indices, row_offsets, column_indices, l,
+                                        lhs_stride, r, rhs_stride, o, out_stride, stream);
+    case 2: return launch_vec<2, T, TO>(m, k, replicas, row_indices, row_offsets, column_indices, l,
+                                        lhs_stride, r, rhs_stride, o, out_stride, stream);
+    default: return launch_vec<1, T, TO>(m, k, replicas, row_indices, row_offsets, column_indices, l,
+                                         lhs_stride, r, rhs_stride, o, out_stride, stream);
+  }
 }
 
 }  // namespace
@@ -272,6 +336,66 @@ int sddmm_exec(int m, int k, int n, int nonzeros, int replicas, const int* row_i
 
 }  // namespace
 
+namespace {
+
+// SDDMM on float16 / bfloat16 operands read as they are (in_type), output float or
+// in_type.  A half OUTPUT needs the product in one pass (later passes would add into
+// rounded values): SPUTNIK_HIP_UNSUPPORTED otherwise, the caller takes a float output.
+int sddmm_exec_half(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
+                    const int* row_offsets, const int* column_indices, const void* lhs,
+                    int64_t lhs_stride, const void* rhs, int64_t rhs_stride, void* out,
+                    int64_t out_stride, int in_type, int out_type, void* workspace,
+                    size_t workspace_bytes, bool planned, hipStream_t stream) {
+  if (m < 0 || k < 0 || n < 0 || nonzeros < 0 || replicas < 0) return SPUTNIK_HIP_INVALID_ARGUMENT;
+  if ((in_type != SPUTNIK_HIP_F16 && in_type != SPUTNIK_HIP_BF16) ||
+      (out_type != SPUTNIK_HIP_F32 && out_type != in_type))
+    return SPUTNIK_HIP_INVALID_ARGUMENT;
+  if (m == 0 || nonzeros == 0 || replicas == 0) return 0;
+  const size_t out_elem = out_type == SPUTNIK_HIP_F32 ? 4 : 2;
+  if (!aligned_to(lhs, 2) || !aligned_to(rhs, 2) || !aligned_to(out, out_elem))
+    return SPUTNIK_HIP_INVALID_ARGUMENT;
+  if (k == 0) {
+    for (int r = 0; r < replicas; ++r) {
+      const hipError_t e = hipMemsetAsync(static_cast<char*>(out) + r * out_stride * out_elem, 0,
+                                          out_elem * static_cast<size_t>(nonzeros), stream);
+      if (e != hipSuccess) return static_cast<int>(e);
+    }
+    return 0;
+  }
+  const bool half_out = out_type != SPUTNIK_HIP_F32;
+  const bool force_tiled = options().sddmm_kernel == 1;
+  const bool force_wave = options().sddmm_kernel == 2;
+  const bool small = static_cast<double>(nonzeros) * k * k * replicas < 17179869184.0;  // 2^34
+  const bool tiled = !force_wave && (force_tiled || !small) && workspace != nullptr &&
+                     aligned_to(workspace, 16) &&
+                     sddmm_tiled_applicable_half(m, k, n, nonzeros, lhs, lhs_stride, rhs, rhs_stride) &&
+                     workspace_bytes >= sddmm_tiled_workspace_bytes(m, k, n, nonzeros) &&
+                     (!half_out || sddmm_tiled_passes_half(k) == 1);
+  if (tiled) {
+    if (!planned) {
+      const int st = sddmm_tiled_plan(m, k, n, nonzeros, row_indices, row_offsets, column_indices,
+                                      workspace, stream);
+      if (st != 0) return st;
+    }
+    return sddmm_tiled_launch_half(m, k, n, nonzeros, replicas, row_indices, row_offsets,
+                                   column_indices, lhs, lhs_stride, rhs, rhs_stride, out, out_stride,
+                                   in_type, out_type, workspace, stream);
+  }
+  if (half_out && k > 1024) return SPUTNIK_HIP_UNSUPPORTED;   // (row-wave panel: 64 lanes x 4 x 4)
+  if (half_out && min(vector_width_of(lhs, k, lhs_stride, 2), vector_width_of(rhs, k, rhs_stride, 2)) * 256 < k)
+    return SPUTNIK_HIP_UNSUPPORTED;
+#define SPUTNIK_HIP_RW(T, TO)                                                                   \
+  return rowwave_half<T, TO>(m, k, replicas, row_indices, row_offsets, column_indices, lhs,      \
+                             lhs_stride, rhs, rhs_stride, out, out_stride, stream)
+  if (in_type == SPUTNIK_HIP_F16 && !half_out) SPUTNIK_HIP_RW(_Float16, float);
+  if (in_type == SPUTNIK_HIP_F16) SPUTNIK_HIP_RW(_Float16, _Float16);
+  if (!half_out) SPUTNIK_HIP_RW(__bf16, float);
+  SPUTNIK_HIP_RW(__bf16, __bf16);
+#undef SPUTNIK_HIP_RW
+}
+
+}  // namespace
+
 // One launch for all masks of a "many mask" batch (many_mask.hip; C linkage like its
 // surroundings, hidden visibility: not part of the ABI).
 int sputnik_hip_internal_sddmm_many_mask(int masks, int m, int k, int n, const int* nonzeros, int largest, int replicas,
@@ -359,6 +483,68 @@ int sddmm_sum_exec(int m, int k, int n, int nonzeros, int replicas, const int* r
   return launch_status();
 }
 
+// The same on float16 / bfloat16 operands read as they are; partial vectors and the
+// sum are float32.
+int sddmm_sum_exec_half(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
+                        const int* row_offsets, const int* column_indices, const void* lhs,
+                        int64_t lhs_stride, const void* rhs, int64_t rhs_stride, int in_type,
+                        float* out, void* workspace, size_t workspace_bytes, bool planned,
+                        void* scratch, size_t scratch_bytes, hipStream_t stream) {
+  if (m < 0 || k < 0 || n < 0 || nonzeros < 0 || replicas < 0) return SPUTNIK_HIP_INVALID_ARGUMENT;
+  if (in_type != SPUTNIK_HIP_F16 && in_type != SPUTNIK_HIP_BF16) return SPUTNIK_HIP_INVALID_ARGUMENT;
+  if (m == 0 || nonzeros == 0) return 0;
+  if (k == 0 || replicas == 0) {
+    const hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * static_cast<size_t>(nonzeros), stream);
+    return static_cast<int>(e);
+  }
+  const bool force_tiled = options().sddmm_kernel == 1;
+  const bool force_wave = options().sddmm_kernel == 2;
+  const bool small = static_cast<double>(nonzeros) * k * k * replicas < 17179869184.0;  // 2^34
+  bool tiled = !force_wave && (force_tiled || !small) && workspace != nullptr &&
+               aligned_to(workspace, 16) &&
+               sddmm_tiled_applicable_half(m, k, n, nonzeros, lhs, lhs_stride, rhs, rhs_stride) &&
+               sddmm_tiled_sum_half_served(m, k, n, nonzeros) &&
+               workspace_bytes >= sddmm_tiled_workspace_bytes(m, k, n, nonzeros, /*summed=*/true);
+  if (tiled && static_cast<int64_t>(replicas) * sddmm_tiled_panels(m, k, n, nonzeros) > kMaxGridYZ)
+    tiled = false;
+  const int panels = tiled ? sddmm_tiled_panels(m, k, n, nonzeros) : 1;
+  const int64_t parts = static_cast<int64_t>(replicas) * panels;
+  if (parts == 1)
+    return sddmm_exec_half(m, k, n, nonzeros, 1, row_indices, row_offsets, column_indices, lhs,
+                           lhs_stride, rhs, rhs_stride, out, 0, in_type, SPUTNIK_HIP_F32, workspace,
+                           workspace_bytes, planned, stream);
+  if (scratch == nullptr || !aligned_to(scratch, 16) ||
+      scratch_bytes < sizeof(float) * static_cast<size_t>(parts) * nonzeros)
+    return SPUTNIK_HIP_INVALID_ARGUMENT;
+  float* partials = static_cast<float*>(scratch);
+  int st;
+  if (tiled) {
+    if (!planned) {
+      st = sddmm_tiled_plan(m, k, n, nonzeros, row_indices, row_offsets, column_indices,
+                            workspace, stream, /*summed=*/true);
+      if (st != 0) return st;
+    }
+    st = sddmm_tiled_launch_partials_half(m, k, n, nonzeros, replicas, row_indices, row_offsets,
+                                          column_indices, lhs, lhs_stride, rhs, rhs_stride, in_type,
+                                          partials, workspace, stream);
+  } else {
+    st = sddmm_exec_half(m, k, n, nonzeros, replicas, row_indices, row_offsets, column_indices, lhs,
+                         lhs_stride, rhs, rhs_stride, partials, nonzeros, in_type, SPUTNIK_HIP_F32,
+                         nullptr, 0, false, stream);
+  }
+  if (st != 0) return st;
+  const int nparts = static_cast<int>(parts);
+  if (nonzeros % 4 == 0 && aligned_to(out, 16)) {
+    hipLaunchKernelGGL(sum_partials_kernel<4>, dim3(ceil_div(nonzeros / 4, kBlock)), dim3(kBlock),
+                       0, stream, nonzeros / 4, nparts, static_cast<int64_t>(nonzeros), partials,
+                       out);
+  } else {
+    hipLaunchKernelGGL(sum_partials_kernel<1>, dim3(ceil_div(nonzeros, kBlock)), dim3(kBlock), 0,
+                       stream, nonzeros, nparts, static_cast<int64_t>(nonzeros), partials, out);
+  }
+  return launch_status();
+}
+
 }  // namespace
 
 size_t sputnik_hip_sddmm_sum_workspace_bytes(int m, int k, int n, int nonzeros) {
@@ -409,6 +595,22 @@ int sputnik_hip_sddmm_sum_batched_planned(int m, int k, int n, int nonzeros, int
                         workspace_bytes, /*planned=*/true, scratch, scratch_bytes, stream);
 }
 
+int sputnik_hip_sddmm_sum_typed(int m, int k, int n, int nonzeros, int replicas,
+                                const int* row_indices, const int* row_offsets,
+                                const int* column_indices, const void* lhs, int64_t lhs_stride,
+                                const void* rhs, int64_t rhs_stride, int in_type, float* out,
+                                void* workspace, size_t workspace_bytes, int planned,
+                                void* scratch, size_t scratch_bytes, sputnik_hip_stream_t stream) {
+  if (in_type == SPUTNIK_HIP_F32)
+    return sddmm_sum_exec(m, k, n, nonzeros, replicas, row_indices, row_offsets, column_indices,
+                          static_cast<const float*>(lhs), lhs_stride,
+                          static_cast<const float*>(rhs), rhs_stride, out, workspace,
+                          workspace_bytes, planned != 0, scratch, scratch_bytes, stream);
+  return sddmm_sum_exec_half(m, k, n, nonzeros, replicas, row_indices, row_offsets, column_indices,
+                             lhs, lhs_stride, rhs, rhs_stride, in_type, out, workspace,
+                             workspace_bytes, planned != 0, scratch, scratch_bytes, stream);
+}
+
 int sputnik_hip_sddmm_plan(int m, int k, int n, int nonzeros, const int* row_indices,
                            const int* row_offsets, const int* column_indices, void* workspace,
                            size_t workspace_bytes, sputnik_hip_stream_t stream) {
@@ -432,6 +634,24 @@ int sputnik_hip_sddmm_batched_planned(int m, int k, int n, int nonzeros, int rep
   return sddmm_exec(m, k, n, nonzeros, replicas, row_indices, row_offsets, column_indices, lhs,
                     lhs_stride, rhs, rhs_stride, out, out_stride, const_cast<void*>(workspace),
                     workspace_bytes, /*planned=*/true, stream);
+}
+
+int sputnik_hip_sddmm_typed(int m, int k, int n, int nonzeros, int replicas,
+                            const int* row_indices, const int* row_offsets,
+                            const int* column_indices, const void* lhs, int64_t lhs_stride,
+                            const void* rhs, int64_t rhs_stride, int in_type, void* out,
+                            int64_t out_stride, int out_type, void* workspace,
+                            size_t workspace_bytes, int planned, sputnik_hip_stream_t stream) {
+  if (in_type == SPUTNIK_HIP_F32) {
+    if (out_type != SPUTNIK_HIP_F32) return SPUTNIK_HIP_INVALID_ARGUMENT;
+    return sddmm_exec(m, k, n, nonzeros, replicas, row_indices, row_offsets, column_indices,
+                      static_cast<const float*>(lhs), lhs_stride, static_cast<const float*>(rhs),
+                      rhs_stride, static_cast<float*>(out), out_stride, workspace, workspace_bytes,
+                      planned != 0, stream);
+  }
+  return sddmm_exec_half(m, k, n, nonzeros, replicas, row_indices, row_offsets, column_indices, lhs,
+                         lhs_stride, rhs, rhs_stride, out, out_stride, in_type, out_type, workspace,
+                         workspace_bytes, planned != 0, stream);
 }
 
 int sputnik_hip_sddmm(int m, int k, int n, int nonzeros, const int* row_indices,

@@ -64,7 +64,11 @@ struct Slab {
 // Occupancy is set by LDS: two 64 KiB workgroups (4 waves per SIMD) or one of
 // 128 KiB (2 waves per SIMD); telling the compiler stops it from spilling to
 // keep a wave count the LDS footprint rules out anyway.
-template <int KV>
+// ACC: a later k panel adds into the output.  A compile-time flag on purpose: as a
+// run-time one the conditional load of the previous value made the compiler put
+// `s_waitcnt vmcnt(0)` in front of EVERY result store, i.e. every window waited for
+// all rows fetched ahead and all earlier stores (10 us of 52 at config 3).
+template <int KV, bool ACC>
 __global__ __launch_bounds__(Slab<KV>::kThreads)
 __attribute__((amdgpu_waves_per_eu(2, (KV <= 2 || KV == 4 ? 4 : 2))))
 void sddmm_stationary_kernel(
@@ -72,7 +76,7 @@ void sddmm_stationary_kernel(
     const int* __restrict__ row_offsets, const int* __restrict__ column_indices,
     const int* __restrict__ table, const int* __restrict__ row_ok,
     const float* __restrict__ lhs, int64_t lhs_stride, const float* __restrict__ rhs,
-    int64_t rhs_stride, int ld /* floats between rows of lhs / rhs */, int accumulate,
+    int64_t rhs_stride, int ld /* floats between rows of lhs / rhs */,
     float* __restrict__ out, int64_t out_stride, int panels /* of one replica along grid z */,
     int debug, int mask_heads, int64_t mask_plan_ints, int first_replica) {
   using S = Slab<KV>;
@@ -236,7 +240,7 @@ void sddmm_stationary_kernel(
         load_row(b, reinterpret_cast<const char*>(
                         rhs + static_cast<int64_t>(column_indices[p]) * ld + 4 * i));
         const float total = group_sum<16>(dot(b));
-        if (i == 0) out[p] = accumulate ? out[p] + total : total;
+        if (i == 0) out[p] = ACC ? out[p] + total : total;
       }
     }
     const int n_here = (debug & 1) ? 0 : max(cnt[r], 0);
@@ -273,7 +277,8 @@ void sddmm_stationary_kernel(
       }
       if (valid) {
         float* dst = out + cur_ps + w0 + i;
-        *dst = accumulate ? *dst + result : result;
+        if constexpr (ACC) *dst += result;
+        else *dst = result;
       }
     };
 #pragma unroll
@@ -284,6 +289,282 @@ void sddmm_stationary_kernel(
             max(__builtin_amdgcn_readlane(n_here, 32), __builtin_amdgcn_readlane(n_here, 48)));
     for (int w0 = 16 * kWin; w0 < longest; w0 += 16)
       window(column_indices[min(cur_ps + w0 + i, last)], w0);
+  });
+}
+
+// ----------------------------------------------------------------------------
+// Quad form (round 3): FOUR lanes share an entry instead of sixteen.
+//
+// The kernel above spends, per entry and 16-lane group, one broadcast, one
+// ds_read_b128, two v_pk_fma_f32 -- and then 1.9 selects, 0.9 DPP adds and the
+// s_nop hazards of the transposing reduction that folds 16 partial sums per lane:
+// 9.4 issued instructions for 2 useful ones at k = 64 (ISA count), a SIMD 92 % busy
+// issuing.  Here a 16-lane group still owns one mask row at a time, but its four
+// QUADS work on four different entries of the row: lane (quad q, t) keeps a QUARTER
+// of the lhs row (k/4 elements) in registers, reads the matching quarter of the rhs
+// row of "its" entry from LDS and the dot product is closed by two quad_perm DPP
+// adds (one VALU instruction each for all 16 entries a wave has in flight): per
+// step of 16 entries and wave C address adds (the quad broadcast of the row offset
+// rides on them as a DPP operand), C ds_read_b128, 2C v_pk_fma_f32 (float; C
+// v_dot2 pairs for the half types), 4 reduction / select instructions -- about one
+// instruction per entry at k = 64.
+//
+//   * lane (q, t) of a group holds the column of entry 4t + q of each 16-entry
+//     window, so the row offset the quads need in step s (entries 4s + q) is a
+//     quad_perm:[s,s,s,s] broadcast, and after four steps lane (q, t) holds the
+//     result of entry 4t + q: the 16 results leave as one 64-byte store;
+//   * bank conflicts: the 16 lanes of a group read four different rhs rows in one
+//     instruction; rows are multiples of 256 bytes (all 64 banks), so lane (q, t)
+//     takes its quarter's 16-byte chunks in the order (c + q [+ 4t..]) mod C and
+//     the 16 lanes together touch every bank exactly once (the lhs quarter is
+//     loaded in the same rotated order, once per mask row).
+//
+// Storage type T: float, or _Float16 / __bf16 (native half operands, round 3): the
+// slab is staged as raw bytes (half the LDS DMA and half the LDS read traffic), the
+// products are v_dot2_f32_f16 / v_dot2_f32_bf16 -- exact products, float32 sums.
+// The slab keeps the ROW COUNT of the float form, so plans do not depend on T.
+template <typename T> struct Dot;
+template <> struct Dot<float> {
+  using chunk = float __attribute__((ext_vector_type(4)));   // 16 bytes of a row
+  static __device__ __forceinline__ void mac(v2f& acc, const chunk& a, const chunk& b) {
+    acc = __builtin_elementwise_fma(v2f{a.x, a.y}, v2f{b.x, b.y}, acc);
+    acc = __builtin_elementwise_fma(v2f{a.z, a.w}, v2f{b.z, b.w}, acc);
+  }
+};
+using h2v = _Float16 __attribute__((ext_vector_type(2)));
+using b2v = __bf16 __attribute__((ext_vector_type(2)));
+using HalfChunk = unsigned __attribute__((ext_vector_type(4)));   // 8 half values
+// (the words are copied out first: __builtin_bit_cast applied to `a[1]` directly reads
+// element 0 of the vector with this compiler)
+__device__ __forceinline__ float dot2_f16(unsigned a, unsigned b, float c) {
+  return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2v, a), __builtin_bit_cast(h2v, b), c, false);
+}
+__device__ __forceinline__ float dot2_bf16(unsigned a, unsigned b, float c) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2v, a), __builtin_bit_cast(b2v, b), c, false);
+}
+template <> struct Dot<_Float16> {
+  using chunk = HalfChunk;
+  static __device__ __forceinline__ void mac(v2f& acc, const chunk& a, const chunk& b) {
+    const unsigned a0 = a.x, a1 = a.y, a2 = a.z, a3 = a.w, b0 = b.x, b1 = b.y, b2 = b.z, b3 = b.w;
+    acc.x = dot2_f16(a0, b0, acc.x);
+    acc.y = dot2_f16(a1, b1, acc.y);
+    acc.x = dot2_f16(a2, b2, acc.x);
+    acc.y = dot2_f16(a3, b3, acc.y);
+  }
+};
+template <> struct Dot<__bf16> {
+  using chunk = HalfChunk;
+  static __device__ __forceinline__ void mac(v2f& acc, const chunk& a, const chunk& b) {
+    const unsigned a0 = a.x, a1 = a.y, a2 = a.z, a3 = a.w, b0 = b.x, b1 = b.y, b2 = b.z, b3 = b.w;
+    acc.x = dot2_bf16(a0, b0, acc.x);
+    acc.y = dot2_bf16(a1, b1, acc.y);
+    acc.x = dot2_bf16(a2, b2, acc.x);
+    acc.y = dot2_bf16(a3, b3, acc.y);
+  }
+};
+
+template <int KV, int ROWS, typename T>
+struct Quad {
+  static constexpr int kdim = 64 * KV;
+  static constexpr int kRowBytes = kdim * static_cast<int>(sizeof(T));
+  static constexpr int kRows = ROWS;   // of the float slab the PLAN was made for: plans are shared
+  static constexpr int kBytes = kRows * kRowBytes;
+  static constexpr int kQuarter = kRowBytes / 4;          // bytes of a row per lane
+  static constexpr int C = kQuarter / 16;                 // 16-byte chunks per lane
+  static constexpr int kWaves = kSWaves;
+  static constexpr int kThreads = kWaves * kWave;
+  static_assert(C >= 2 && C <= 8, "quad form: 32 .. 128 bytes of a row per lane");
+};
+
+template <int S>
+__device__ __forceinline__ int quad_bcast_add(int v, int add) {
+  // add + (v of lane S of the quad): v_add_u32_dpp quad_perm:[S,S,S,S]
+  return __builtin_amdgcn_update_dpp(0, v, S * 0x55, 0xF, 0xF, true) + add;
+}
+
+template <int KV, int ROWS, typename T, typename TO, bool ACC>
+__global__ __launch_bounds__((Quad<KV, ROWS, T>::kThreads))
+__attribute__((amdgpu_waves_per_eu((Quad<KV, ROWS, T>::C <= 4 ? 4 : 2), 4)))   // <= 128 registers: two workgroups per CU
+void sddmm_quad_kernel(
+    int m, int n, int nonzeros, int slots, const int* __restrict__ row_indices,
+    const int* __restrict__ row_offsets, const int* __restrict__ column_indices,
+    const int* __restrict__ table, const int* __restrict__ row_ok,
+    const T* __restrict__ lhs, int64_t lhs_stride, const T* __restrict__ rhs,
+    int64_t rhs_stride, int ld /* elements between rows of lhs / rhs */,
+    TO* __restrict__ out, int64_t out_stride, int panels /* of one replica along grid z */,
+    int debug, int mask_heads, int64_t mask_plan_ints, int first_replica) {
+  using Q = Quad<KV, ROWS, T>;
+  using chunk = typename Dot<T>::chunk;
+  constexpr int C = Q::C;
+  constexpr int kRowBytes = Q::kRowBytes;
+  __shared__ __attribute__((aligned(1024))) char tile[Q::kBytes];
+  __shared__ __attribute__((aligned(16))) char line[Q::kWaves * 4 * kRowBytes];   // lhs rows in transit
+
+  const int lane = threadIdx.x % kWave;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int g = lane >> 4, i = lane & 15;
+  const int q = i >> 2, t = i & 3;       // quad of the group, lane of the quad
+  const int e = 4 * t + q;               // this lane's entry of a 16-entry window
+  const unsigned long long work = xcd_local_index();
+  const int slab = static_cast<int>(work % gridDim.x);
+  const int row_block = static_cast<int>((work / gridDim.x) % gridDim.y);
+  const int z = static_cast<int>(work / (static_cast<unsigned long long>(gridDim.x) * gridDim.y));
+  const int replica = panels > 1 ? z / panels : z;
+  const int panel = z - replica * panels;
+  lhs += replica * lhs_stride + panel * Q::kdim;
+  rhs += replica * rhs_stride + panel * Q::kdim;
+  out += z * out_stride;
+  const int jc = slab * Q::kRows;
+  {
+    const MaskPlace place = select_mask(mask_heads, first_replica + replica, m, nonzeros, row_offsets);
+    row_offsets += static_cast<int64_t>(place.mask) * (m + 1);
+    column_indices += place.first;
+    row_indices += static_cast<int64_t>(place.mask) * m;
+    table += place.mask * mask_plan_ints;
+    row_ok += place.mask * mask_plan_ints;
+    nonzeros = place.nonzeros;
+  }
+  const int last = max(nonzeros - 1, 0);
+
+  if (!(debug & 2)) {  // stage the slab in 1 KiB pieces (64 lanes x 16 B, lane-linear in LDS)
+    constexpr int kPieces = Q::kBytes / 1024;
+    static_assert(kPieces % Q::kWaves == 0, "whole pieces per wave");
+#pragma unroll
+    for (int j = 0; j < kPieces / Q::kWaves; ++j) {
+      const int piece = wave + j * Q::kWaves;
+      const unsigned b = static_cast<unsigned>(piece) * 1024u + lane * 16u;  // byte in the slab
+      const int src_row = min(jc + static_cast<int>(b / kRowBytes), n - 1);  // past the end: last row
+      const unsigned off = static_cast<unsigned>(src_row) *
+                               (static_cast<unsigned>(ld) * static_cast<unsigned>(sizeof(T))) +
+                           b % kRowBytes;
+      lds_dma_row(reinterpret_cast<const float*>(rhs), off,
+                  reinterpret_cast<const float*>(tile + piece * 1024));
+    }
+  }
+
+  const int slot_begin = row_block * (kSGroups * kSRows);
+  const int gid = wave * 4 + g;
+  const int* __restrict__ tab0 = table + static_cast<int64_t>(slab) * slots;
+  const int* __restrict__ tab1 = tab0 + slots;
+  constexpr int kRowsHere = kSRows;
+  int row[kRowsHere], ps[kRowsHere], cnt[kRowsHere];
+#pragma unroll
+  for (int r = 0; r < kRowsHere; ++r) {
+    const int sl = slot_begin + r * kSGroups + gid;
+    const int entry = dealt_index(sl, slots, kSGroups * kSRows);
+    const bool live = entry < m;
+    row[r] = row_indices[live ? entry : 0];
+    const int a0 = tab0[sl], a1 = tab1[sl];
+    const bool ok = row_ok[sl] != 0;
+    ps[r] = ok ? a0 : row_offsets[row[r]];
+    const int len = ok ? a1 - a0 : row_offsets[row[r] + 1] - ps[r];
+    cnt[r] = !live ? 0 : ok ? len : (slab == 0 ? -len : 0);
+  }
+
+  // this lane's chunks of a row, in its rotated order (see the header)
+  const int rot = q + 4 * ((t * C) >> 4);
+  int coff[C];    // byte offsets inside a row
+#pragma unroll
+  for (int c = 0; c < C; ++c) coff[c] = t * Q::kQuarter + 16 * ((c + rot) % C);
+
+  // A row's lhs fragment is fetched ONCE by its group (lane i: piece i of the row,
+  // kRowBytes / 16 bytes), kRing - 1 rows ahead; when the row's turn comes the pieces
+  // go through a wave-private LDS line and come back as this lane's quarter in its
+  // rotated chunk order (four quads x one quarter each would otherwise load every
+  // row four times: 27 against 19 us of launch skeleton at config 3).
+  constexpr int kRing = 3;
+  constexpr int kPiece = kRowBytes / 16;           // bytes of a row per lane when fetched
+  constexpr int kPieceWords = kPiece / 4;
+  using piece_t = unsigned __attribute__((ext_vector_type(kPieceWords)));
+  int wcol[kRing][kWin];
+  piece_t lp[kRing];
+  auto fetch = [&](int r, int slot_in_ring) {
+#pragma unroll
+    for (int w = 0; w < kWin; ++w)
+      wcol[slot_in_ring][w] = column_indices[min(ps[r] + 16 * w + e, last)];
+    const char* lrow = reinterpret_cast<const char*>(lhs + static_cast<int64_t>(row[r]) * ld);
+    lp[slot_in_ring] = *reinterpret_cast<const piece_t*>(lrow + i * kPiece);
+  };
+#pragma unroll
+  for (int r = 0; r < kRing - 1; ++r) fetch(r, r);
+  wait_vm<0>();
+  __syncthreads();
+
+  const unsigned tile_base =
+      static_cast<unsigned>(reinterpret_cast<uintptr_t>(AS_LDS(reinterpret_cast<float*>(tile))));
+  char* const my_line = line + (wave * 4 + g) * kRowBytes;
+
+  static_for<kRowsHere>([&](auto R) {
+    constexpr int r = decltype(R)::value;
+    if constexpr (r + kRing - 1 < kRowsHere) fetch(r + kRing - 1, (r + kRing - 1) % kRing);
+    const int cur_ps = ps[r];
+    chunk cur_lf[C];
+    *reinterpret_cast<piece_t*>(my_line + i * kPiece) = lp[r % kRing];
+#pragma unroll
+    for (int c = 0; c < C; ++c) cur_lf[c] = *reinterpret_cast<const chunk*>(my_line + coff[c]);
+
+    if (cnt[r] < 0) {
+      // unsorted row (rare): rhs rows gathered from global memory, any column;
+      // every quad computes the same entry
+      const int p1 = cur_ps - cnt[r];
+      for (int p = cur_ps; p < p1; ++p) {
+        const char* rrow =
+            reinterpret_cast<const char*>(rhs + static_cast<int64_t>(column_indices[p]) * ld);
+        v2f acc = {0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+          Dot<T>::mac(acc, cur_lf[c], *reinterpret_cast<const chunk*>(rrow + coff[c]));
+        const float total = group_sum<4>(acc.x + acc.y);
+        if (i == 0) {
+          if constexpr (ACC) out[p] = static_cast<TO>(static_cast<float>(out[p]) + total);
+          else out[p] = static_cast<TO>(total);
+        }
+      }
+    }
+    const int n_here = (debug & 1) ? 0 : max(cnt[r], 0);
+    auto window = [&](int ecol, int w0) {
+      const int left = n_here - w0;
+      const bool valid = e < left;
+      // a window no group of the wave has entries in is skipped (wave-uniform)
+      if (__builtin_amdgcn_ballot_w64(valid) == 0) return;
+      asm volatile("" : : : "memory");   // (a window's reads stay behind the previous window's work)
+      // (debug bit 4, wrong results: every entry reads slab row 0 -- what bank conflicts cost)
+      const int roff = static_cast<int>(tile_base) + ((valid && !(debug & 4)) ? ((ecol - jc) * kRowBytes) : 0);
+      float result = 0.f;
+      // kGang steps (4 entries per group each) have their reads in flight together
+      constexpr int kGang = C <= 2 ? 4 : C <= 4 ? 2 : 1;
+      static_for<4 / kGang>([&](auto Gc) {
+        constexpr int kG = decltype(Gc)::value * kGang;
+        chunk b[kGang][C];
+        static_for<kGang>([&](auto Sc) {
+          constexpr int kS = kG + decltype(Sc)::value;
+#pragma unroll
+          for (int c = 0; c < C; ++c)
+            b[kS - kG][c] = *reinterpret_cast<const __attribute__((address_space(3))) chunk*>(
+                static_cast<unsigned>(quad_bcast_add<kS>(roff, coff[c])));
+        });
+        static_for<kGang>([&](auto Sc) {
+          constexpr int kS = kG + decltype(Sc)::value;
+          v2f acc = {0.f, 0.f};
+#pragma unroll
+          for (int c = 0; c < C; ++c) Dot<T>::mac(acc, cur_lf[c], b[kS - kG][c]);
+          const float total = group_sum<4>(acc.x + acc.y);
+          result = (t == kS) ? total : result;
+        });
+      });
+      if (valid && !(debug & 16)) {   // (bit 16, wrong results: no stores)
+        TO* dst = out + cur_ps + w0 + e;
+        if constexpr (ACC) *dst = static_cast<TO>(static_cast<float>(*dst) + result);
+        else *dst = static_cast<TO>(result);
+      }
+    };
+#pragma unroll
+    for (int w = 0; w < kWin; ++w) window(wcol[r % kRing][w], 16 * w);
+    const int longest =
+        max(max(__builtin_amdgcn_readlane(n_here, 0), __builtin_amdgcn_readlane(n_here, 16)),
+            max(__builtin_amdgcn_readlane(n_here, 32), __builtin_amdgcn_readlane(n_here, 48)));
+    for (int w0 = 16 * kWin; w0 < longest; w0 += 16)
+      window(column_indices[min(cur_ps + w0 + e, last)], w0);
   });
 }
 
@@ -349,16 +630,100 @@ int launch(int m, int k, int n, int nonzeros, int replicas, int slots, const int
   for (int k0 = 0; k0 < k; k0 += S::kdim) {  // one launch per panel; later panels accumulate
     for (int r0 = 0; r0 < replicas; r0 += kMaxGridYZ) {
       const int rz = min(replicas - r0, kMaxGridYZ);
-      hipLaunchKernelGGL(sddmm_stationary_kernel<KV>, dim3(slabs, row_blocks, rz),
-                         dim3(S::kThreads), 0, stream, m, n, nonzeros, slots, row_indices,
-                         row_offsets, column_indices, table, row_ok, lhs + r0 * lhs_stride + k0,
-                         lhs_stride, rhs + r0 * rhs_stride + k0, rhs_stride, k, k0 != 0,
-                         out + r0 * out_stride, out_stride, 1, debug, mask_heads, mask_plan_ints, r0);
+      if constexpr (KV == 1) {   // quad form (debug bit 8: the 16-lanes-per-entry kernel; k = 128:
+                                 // 8 chunks per lane and step ran at 128 against 79 us)
+        if (!(debug & 8)) {
+#define SPUTNIK_HIP_QUAD(ACC)                                                                     \
+  hipLaunchKernelGGL((sddmm_quad_kernel<KV, S::kRows, float, float, ACC>),                        \
+                     dim3(slabs, row_blocks, rz), dim3(Quad<KV, S::kRows, float>::kThreads), 0,   \
+                     stream, m, n, nonzeros, slots, row_indices, row_offsets, column_indices,     \
+                     table, row_ok, lhs + r0 * lhs_stride + k0, lhs_stride,                       \
+                     rhs + r0 * rhs_stride + k0, rhs_stride, k, out + r0 * out_stride,            \
+                     out_stride, 1, debug, mask_heads, mask_plan_ints, r0)
+          if (k0 != 0) SPUTNIK_HIP_QUAD(true);
+          else SPUTNIK_HIP_QUAD(false);
+#undef SPUTNIK_HIP_QUAD
+          st = launch_status();
+          if (st != 0) return st;
+          continue;
+        }
+      }
+#define SPUTNIK_HIP_STAT(ACC)                                                                     \
+  hipLaunchKernelGGL((sddmm_stationary_kernel<KV, ACC>), dim3(slabs, row_blocks, rz),             \
+                     dim3(S::kThreads), 0, stream, m, n, nonzeros, slots, row_indices,            \
+                     row_offsets, column_indices, table, row_ok, lhs + r0 * lhs_stride + k0,      \
+                     lhs_stride, rhs + r0 * rhs_stride + k0, rhs_stride, k,                       \
+                     out + r0 * out_stride, out_stride, 1, debug, mask_heads, mask_plan_ints, r0)
+      if (k0 != 0) SPUTNIK_HIP_STAT(true);
+      else SPUTNIK_HIP_STAT(false);
+#undef SPUTNIK_HIP_STAT
       st = launch_status();
       if (st != 0) return st;
     }
   }
   return 0;
+}
+
+// Half operands (T = _Float16 / __bf16), output float or T.  W = width the plan was
+// made for (its slab rows); the kernel's panels are at most 256 wide.
+template <int KV, int ROWS, typename T, typename TO>
+int launch_half(int m, int k, int n, int nonzeros, int replicas, int slots, const int* row_indices,
+                const int* row_offsets, const int* column_indices, const int* table,
+                const int* row_ok, const T* lhs, int64_t lhs_stride, const T* rhs,
+                int64_t rhs_stride, TO* out, int64_t out_stride, int panels_z, int debug,
+                hipStream_t stream, int mask_heads, int64_t mask_plan_ints) {
+  using Q = Quad<KV, ROWS, T>;
+  const int slabs = ceil_div(n, ROWS);
+  const int row_blocks = slots / (kSGroups * kSRows);
+  if (row_blocks > kMaxGridYZ) return SPUTNIK_HIP_INVALID_ARGUMENT;
+  if (panels_z > 1) {   // every (replica, panel) pair at once, each into its own vector
+    if (static_cast<int64_t>(replicas) * panels_z > kMaxGridYZ) return SPUTNIK_HIP_INVALID_ARGUMENT;
+    hipLaunchKernelGGL((sddmm_quad_kernel<KV, ROWS, T, TO, false>), dim3(slabs, row_blocks, replicas * panels_z),
+                       dim3(Q::kThreads), 0, stream, m, n, nonzeros, slots, row_indices, row_offsets,
+                       column_indices, table, row_ok, lhs, lhs_stride, rhs, rhs_stride, k, out,
+                       out_stride, panels_z, debug, 0, int64_t{0}, 0);
+    return launch_status();
+  }
+  for (int k0 = 0; k0 < k; k0 += Q::kdim) {
+    for (int r0 = 0; r0 < replicas; r0 += kMaxGridYZ) {
+      const int rz = min(replicas - r0, kMaxGridYZ);
+#define SPUTNIK_HIP_QUADH(ACC)                                                                    \
+  hipLaunchKernelGGL((sddmm_quad_kernel<KV, ROWS, T, TO, ACC>), dim3(slabs, row_blocks, rz),      \
+                     dim3(Q::kThreads), 0, stream, m, n, nonzeros, slots, row_indices,            \
+                     row_offsets, column_indices, table, row_ok, lhs + r0 * lhs_stride + k0,      \
+                     lhs_stride, rhs + r0 * rhs_stride + k0, rhs_stride, k,                       \
+                     out + r0 * out_stride, out_stride, 1, debug, mask_heads, mask_plan_ints, r0)
+      if (k0 != 0) SPUTNIK_HIP_QUADH(true);
+      else SPUTNIK_HIP_QUADH(false);
+#undef SPUTNIK_HIP_QUADH
+      const int st = launch_status();
+      if (st != 0) return st;
+    }
+  }
+  return 0;
+}
+
+template <typename T, typename TO>
+int launch_half_width(int width, int m, int k, int n, int nonzeros, int replicas, int slots,
+                      const int* row_indices, const int* row_offsets, const int* column_indices,
+                      const int* table, const int* row_ok, const void* lhs, int64_t lhs_stride,
+                      const void* rhs, int64_t rhs_stride, void* out, int64_t out_stride,
+                      int panels_z, int debug, hipStream_t stream, int mask_heads,
+                      int64_t mask_plan_ints) {
+#define SPUTNIK_HIP_SDH(KV, ROWS)                                                                  \
+  return launch_half<KV, ROWS, T, TO>(m, k, n, nonzeros, replicas, slots, row_indices, row_offsets, \
+                                      column_indices, table, row_ok, static_cast<const T*>(lhs),   \
+                                      lhs_stride, static_cast<const T*>(rhs), rhs_stride,          \
+                                      static_cast<TO*>(out), out_stride, panels_z, debug, stream,  \
+                                      mask_heads, mask_plan_ints)
+  switch (width) {
+    case 64: SPUTNIK_HIP_SDH(1, 256);
+    case 128: SPUTNIK_HIP_SDH(2, 128);
+    case 256: SPUTNIK_HIP_SDH(4, 128);
+    case 512: SPUTNIK_HIP_SDH(4, 64);   // the plan's slabs (64 rows), panels of 256
+    default: return SPUTNIK_HIP_INVALID_ARGUMENT;
+  }
+#undef SPUTNIK_HIP_SDH
 }
 
 // Every (replica, panel) pair in ONE launch, each writing its own [nonzeros]
@@ -377,9 +742,9 @@ int launch_partials(int m, int k, int n, int nonzeros, int replicas, int slots,
   const int panels = k / S::kdim;
   if (row_blocks > kMaxGridYZ || static_cast<int64_t>(replicas) * panels > kMaxGridYZ)
     return SPUTNIK_HIP_INVALID_ARGUMENT;
-  hipLaunchKernelGGL(sddmm_stationary_kernel<KV>, dim3(slabs, row_blocks, replicas * panels),
+  hipLaunchKernelGGL((sddmm_stationary_kernel<KV, false>), dim3(slabs, row_blocks, replicas * panels),
                      dim3(S::kThreads), 0, stream, m, n, nonzeros, slots, row_indices, row_offsets,
-                     column_indices, table, row_ok, lhs, lhs_stride, rhs, rhs_stride, k, 0,
+                     column_indices, table, row_ok, lhs, lhs_stride, rhs, rhs_stride, k,
                      partials, static_cast<int64_t>(nonzeros), panels, debug, 0, int64_t{0}, 0);
   return launch_status();
 }
@@ -468,6 +833,76 @@ int sddmm_tiled_launch(int m, int k, int n, int nonzeros, int replicas, const in
     default: return SPUTNIK_HIP_INVALID_ARGUMENT;
   }
 #undef SPUTNIK_HIP_SD
+}
+
+
+// Native half operands (in_type SPUTNIK_HIP_F16 / BF16; out_type float or in_type).
+bool sddmm_tiled_applicable_half(int m, int k, int n, int nonzeros, const void* lhs,
+                                 int64_t lhs_stride, const void* rhs, int64_t rhs_stride) {
+  return served(k) && n >= 16 && m >= 16 && nonzeros >= 4 * static_cast<int64_t>(m) &&
+         static_cast<int64_t>(n) * k * 2 < (int64_t{1} << 32) && aligned_to(lhs, 16) &&
+         aligned_to(rhs, 16) && lhs_stride % 8 == 0 && rhs_stride % 8 == 0;
+}
+// Kernel launches the plain product makes for one replica (more than one: later
+// passes add into the output, which a half OUTPUT would round every time).
+int sddmm_tiled_passes_half(int k) { return served(k) ? k / min(panel_width(k), 256) : 1; }
+
+int sddmm_tiled_launch_half(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
+                            const int* row_offsets, const int* column_indices, const void* lhs,
+                            int64_t lhs_stride, const void* rhs, int64_t rhs_stride, void* out,
+                            int64_t out_stride, int in_type, int out_type, const void* workspace,
+                            hipStream_t stream, int mask_heads, int64_t mask_plan_ints) {
+  const int debug = options().sddmm_debug;
+  const int slots = slots_of(m);
+  const int* row_ok = static_cast<const int*>(workspace);
+  const int* table =
+      reinterpret_cast<const int*>(static_cast<const char*>(workspace) + row_ok_bytes(slots));
+  const int width = panel_width(k);
+#define SPUTNIK_HIP_SDT(T, TO)                                                                    \
+  return launch_half_width<T, TO>(width, m, k, n, nonzeros, replicas, slots, row_indices,         \
+                                  row_offsets, column_indices, table, row_ok, lhs, lhs_stride,    \
+                                  rhs, rhs_stride, out, out_stride, 1, debug, stream, mask_heads, \
+                                  mask_plan_ints)
+  if (in_type == SPUTNIK_HIP_F16 && out_type == SPUTNIK_HIP_F32) SPUTNIK_HIP_SDT(_Float16, float);
+  if (in_type == SPUTNIK_HIP_F16 && out_type == SPUTNIK_HIP_F16) SPUTNIK_HIP_SDT(_Float16, _Float16);
+  if (in_type == SPUTNIK_HIP_BF16 && out_type == SPUTNIK_HIP_F32) SPUTNIK_HIP_SDT(__bf16, float);
+  if (in_type == SPUTNIK_HIP_BF16 && out_type == SPUTNIK_HIP_BF16) SPUTNIK_HIP_SDT(__bf16, __bf16);
+#undef SPUTNIK_HIP_SDT
+  return SPUTNIK_HIP_INVALID_ARGUMENT;
+}
+
+// Summed form on half operands: float partial vectors, one per (replica, panel).
+// Served when the summed plan's panel width is at most 256 (always, up to k = 4096).
+bool sddmm_tiled_sum_half_served(int m, int k, int n, int nonzeros) {
+  return served(k) && sum_panel_width(m, k, n, nonzeros) <= 256;
+}
+int sddmm_tiled_launch_partials_half(int m, int k, int n, int nonzeros, int replicas,
+                                     const int* row_indices, const int* row_offsets,
+                                     const int* column_indices, const void* lhs,
+                                     int64_t lhs_stride, const void* rhs, int64_t rhs_stride,
+                                     int in_type, float* partials, const void* workspace,
+                                     hipStream_t stream) {
+  const int debug = options().sddmm_debug;
+  const int slots = slots_of(m);
+  const int* row_ok = static_cast<const int*>(workspace);
+  const int* table =
+      reinterpret_cast<const int*>(static_cast<const char*>(workspace) + row_ok_bytes(slots));
+  const int width = sum_panel_width(m, k, n, nonzeros);
+  if (width > 256) return SPUTNIK_HIP_UNSUPPORTED;
+  const int panels = k / width;
+  if (in_type == SPUTNIK_HIP_F16)
+    return launch_half_width<_Float16, float>(width, m, k, n, nonzeros, replicas, slots, row_indices,
+                                              row_offsets, column_indices, table, row_ok, lhs,
+                                              lhs_stride, rhs, rhs_stride, partials,
+                                              static_cast<int64_t>(nonzeros), panels, debug, stream,
+                                              0, int64_t{0});
+  if (in_type == SPUTNIK_HIP_BF16)
+    return launch_half_width<__bf16, float>(width, m, k, n, nonzeros, replicas, slots, row_indices,
+                                            row_offsets, column_indices, table, row_ok, lhs,
+                                            lhs_stride, rhs, rhs_stride, partials,
+                                            static_cast<int64_t>(nonzeros), panels, debug, stream,
+                                            0, int64_t{0});
+  return SPUTNIK_HIP_INVALID_ARGUMENT;
 }
 
 }  // namespace sputnik_hip

@@ -449,12 +449,18 @@ Tensor left_spmm(int64_t m, int64_t k, const Tensor& values, const Tensor& row_i
                    "left_spmm");
 }
 
+// lhs / rhs float32, float16 or bfloat16 (handed to the kernels as they are; operands
+// of different types take the wider one).  out_type: -1 / SPUTNIK_HIP_F32 = float32 --
+// the reference's output type (src/sddmm_cuda.cu:43) --, or the operands' half type.
 Tensor sddmm_impl(int64_t m64, int64_t n64, const Tensor& row_indices, const Tensor& row_offsets,
                   const Tensor& column_indices, const Tensor& lhs_in, const Tensor& rhs_in,
-                  const c10::optional<Tensor>& plan, bool sum_replicas = false) {
+                  const c10::optional<Tensor>& plan, bool sum_replicas = false,
+                  int64_t out_type = -1) {
   const int m = to_int(m64, "m"), n = to_int(n64, "n");
-  const Tensor lhs = as_float(lhs_in, "lhs_matrix");
-  const Tensor rhs = as_float(rhs_in, "rhs_matrix");
+  const auto st = at::promote_types(lhs_in.scalar_type(), rhs_in.scalar_type());
+  const Tensor lhs = as_storage(lhs_in, "lhs_matrix").to(st);
+  const Tensor rhs = as_storage(rhs_in, "rhs_matrix").to(st);
+  const int in_code = type_code(st);
   TORCH_CHECK(lhs.device() == rhs.device(), "lhs_matrix and rhs_matrix must be on one device");
   TORCH_CHECK(lhs.dim() == 2 || lhs.dim() == 3, "expected 2-dim or 3-dim lhs_matrix, got ",
               lhs.dim());
@@ -473,69 +479,65 @@ Tensor sddmm_impl(int64_t m64, int64_t n64, const Tensor& row_indices, const Ten
               ") must match output cols n = ", n);
   TORCH_CHECK(replicas == 1 || rhs.size(0) == replicas,
               "first dim of lhs_matrix and rhs_matrix must match");
+  const int out_code = out_type < 0 ? SPUTNIK_HIP_F32 : static_cast<int>(out_type);
+  TORCH_CHECK(out_code == SPUTNIK_HIP_F32 || (out_code == in_code && !sum_replicas),
+              "sddmm: the output is float32 or has the operands' (half) type");
+  const auto out_options = lhs.options().dtype(out_code == SPUTNIK_HIP_F32 ? at::kFloat : st);
 
   // 1-D whenever there is a single replica, as src/sddmm_cuda.cu:43 does.
   Tensor out = (replicas == 1 || sum_replicas)
-                   ? at::empty({topo.nonzeros}, lhs.options())
-                   : at::empty({replicas, topo.nonzeros}, lhs.options());
+                   ? at::empty({topo.nonzeros}, out_options)
+                   : at::empty({replicas, topo.nonzeros}, out_options);
   const size_t ws_bytes = sum_replicas
                               ? sputnik_hip_sddmm_sum_workspace_bytes(m, k, n, topo.nonzeros)
                               : sputnik_hip_sddmm_workspace_bytes(m, k, n, topo.nonzeros);
+  Tensor workspace;
+  void* ws = nullptr;
+  if (plan.has_value()) {
+    check_plan(*plan, ws_bytes, lhs);
+    ws = ws_bytes ? plan->data_ptr() : nullptr;
+  } else if (ws_bytes > 0) {
+    workspace = at::empty({static_cast<int64_t>(ws_bytes)}, lhs.options().dtype(at::kByte));
+    ws = workspace.data_ptr();
+  }
+  const int planned = plan.has_value() ? 1 : 0;
   if (sum_replicas) {
     // sum over the batch inside the call (sputnik_hip.h: sddmm_sum_batched)
     const size_t scratch_bytes =
         sputnik_hip_sddmm_sum_scratch_bytes(m, k, n, topo.nonzeros, replicas);
-    Tensor scratch, workspace;
+    Tensor scratch;
     if (scratch_bytes > 0)
       scratch = at::empty({static_cast<int64_t>(scratch_bytes)}, lhs.options().dtype(at::kByte));
-    if (plan.has_value()) {
-      check_plan(*plan, ws_bytes, lhs);
-      check_status(sputnik_hip_sddmm_sum_batched_planned(
-                       m, k, n, topo.nonzeros, replicas, topo.row_indices.data_ptr<int>(),
-                       topo.row_offsets.data_ptr<int>(), topo.column_indices.data_ptr<int>(),
-                       lhs.data_ptr<float>(), static_cast<int64_t>(m) * k, rhs.data_ptr<float>(),
-                       static_cast<int64_t>(n) * k, out.data_ptr<float>(),
-                       ws_bytes ? plan->data_ptr() : nullptr, ws_bytes,
-                       scratch_bytes ? scratch.data_ptr() : nullptr, scratch_bytes,
-                       current_stream(lhs)),
-                   "sddmm_sum_planned");
-      return out;
-    }
-    if (ws_bytes > 0)
-      workspace = at::empty({static_cast<int64_t>(ws_bytes)}, lhs.options().dtype(at::kByte));
-    check_status(sputnik_hip_sddmm_sum_batched(
+    check_status(sputnik_hip_sddmm_sum_typed(
                      m, k, n, topo.nonzeros, replicas, topo.row_indices.data_ptr<int>(),
                      topo.row_offsets.data_ptr<int>(), topo.column_indices.data_ptr<int>(),
-                     lhs.data_ptr<float>(), static_cast<int64_t>(m) * k, rhs.data_ptr<float>(),
-                     static_cast<int64_t>(n) * k, out.data_ptr<float>(),
-                     ws_bytes ? workspace.data_ptr() : nullptr, ws_bytes,
-                     scratch_bytes ? scratch.data_ptr() : nullptr, scratch_bytes,
+                     lhs.data_ptr(), static_cast<int64_t>(m) * k, rhs.data_ptr(),
+                     static_cast<int64_t>(n) * k, in_code, out.data_ptr<float>(), ws, ws_bytes,
+                     planned, scratch_bytes ? scratch.data_ptr() : nullptr, scratch_bytes,
                      current_stream(lhs)),
-                 "sddmm_sum");
+                 planned ? "sddmm_sum_planned" : "sddmm_sum");
     return out;
   }
-  if (plan.has_value()) {
-    check_plan(*plan, ws_bytes, lhs);
-    check_status(sputnik_hip_sddmm_batched_planned(
-                     m, k, n, topo.nonzeros, replicas, topo.row_indices.data_ptr<int>(),
-                     topo.row_offsets.data_ptr<int>(), topo.column_indices.data_ptr<int>(),
-                     lhs.data_ptr<float>(), static_cast<int64_t>(m) * k, rhs.data_ptr<float>(),
-                     static_cast<int64_t>(n) * k, out.data_ptr<float>(), topo.nonzeros,
-                     ws_bytes ? plan->data_ptr() : nullptr, ws_bytes, current_stream(lhs)),
-                 "sddmm_planned");
-    return out;
+  const int status = sputnik_hip_sddmm_typed(
+      m, k, n, topo.nonzeros, replicas, topo.row_indices.data_ptr<int>(),
+      topo.row_offsets.data_ptr<int>(), topo.column_indices.data_ptr<int>(), lhs.data_ptr(),
+      static_cast<int64_t>(m) * k, rhs.data_ptr(), static_cast<int64_t>(n) * k, in_code,
+      out.data_ptr(), topo.nonzeros, out_code, ws, ws_bytes, planned, current_stream(lhs));
+  if (status == SPUTNIK_HIP_UNSUPPORTED && out_code != SPUTNIK_HIP_F32) {
+    // a half output of a product that takes several passes: float32 result, rounded once
+    return sddmm_impl(m64, n64, row_indices, row_offsets, column_indices, lhs, rhs, plan, false,
+                      SPUTNIK_HIP_F32).to(st);
   }
-  Tensor workspace;
-  if (ws_bytes > 0)
-    workspace = at::empty({static_cast<int64_t>(ws_bytes)}, lhs.options().dtype(at::kByte));
-  check_status(sputnik_hip_sddmm_batched(
-                   m, k, n, topo.nonzeros, replicas, topo.row_indices.data_ptr<int>(),
-                   topo.row_offsets.data_ptr<int>(), topo.column_indices.data_ptr<int>(),
-                   lhs.data_ptr<float>(), static_cast<int64_t>(m) * k, rhs.data_ptr<float>(),
-                   static_cast<int64_t>(n) * k, out.data_ptr<float>(), topo.nonzeros,
-                   ws_bytes ? workspace.data_ptr() : nullptr, ws_bytes, current_stream(lhs)),
-               "sddmm");
+  check_status(status, planned ? "sddmm_planned" : "sddmm");
   return out;
+}
+
+// sddmm with the result stored in the operands' half type (float32 operands: as sddmm)
+Tensor sddmm_narrow(int64_t m, int64_t n, const Tensor& row_indices, const Tensor& row_offsets,
+                    const Tensor& column_indices, const Tensor& lhs, const Tensor& rhs) {
+  const int code = type_code(at::promote_types(lhs.scalar_type(), rhs.scalar_type()));
+  return sddmm_impl(m, n, row_indices, row_offsets, column_indices, lhs, rhs, c10::nullopt, false,
+                    code);
 }
 
 Tensor sddmm(int64_t m, int64_t n, const Tensor& row_indices, const Tensor& row_offsets,
@@ -1208,6 +1210,9 @@ TORCH_LIBRARY(torch_sputnik, m) {
       "sddmm(int m, int n, Tensor row_indices, Tensor row_offsets, Tensor column_indices, "
       "Tensor lhs_matrix, Tensor rhs_matrix) -> Tensor");
   m.def(
+      "sddmm_narrow(int m, int n, Tensor row_indices, Tensor row_offsets, Tensor column_indices, "
+      "Tensor lhs_matrix, Tensor rhs_matrix) -> Tensor");
+  m.def(
       "sparse_softmax(Tensor values, Tensor row_indices, Tensor row_offsets, "
       "Tensor column_indices) -> Tensor");
   m.def(
@@ -1312,6 +1317,7 @@ TORCH_LIBRARY_IMPL(torch_sputnik, CUDA, m) {
   m.impl("spmm", &spmm);
   m.impl("left_spmm", &left_spmm);
   m.impl("sddmm", &sddmm);
+  m.impl("sddmm_narrow", &sddmm_narrow);
   m.impl("sparse_softmax", &sparse_softmax);
   m.impl("csr_transpose", &csr_transpose);
   m.impl("csr_transpose_with_permutation", &csr_transpose_with_permutation);

@@ -41,6 +41,13 @@ def sddmm(m, n, row_indices, row_offsets, column_indices, lhs_matrix, rhs_matrix
                       rhs_matrix)
 
 
+def sddmm_narrow(m, n, row_indices, row_offsets, column_indices, lhs_matrix, rhs_matrix):
+    """sddmm whose result is stored in the operands' type: float16 / bfloat16 operands
+    give float16 / bfloat16 scores (float32 sums, rounded once); float32 as sddmm."""
+    return _ops.sddmm_narrow(int(m), int(n), row_indices, row_offsets, column_indices, lhs_matrix,
+                             rhs_matrix)
+
+
 def sparse_softmax(values, row_indices, row_offsets, column_indices):
     """Row-wise softmax over the stored entries.  src/softmax_cuda.cu:7-46."""
     return _ops.sparse_softmax(values, row_indices, row_offsets, column_indices)
