@@ -175,6 +175,29 @@ SPUTNIK_HIP_API int sputnik_hip_sddmm_batched_planned(int m, int k, int n, int n
  * OUTPUT whose product needs more than one pass over the output (k wider than one
  * panel): take a float output then.
  */
+/*
+ * SpMM / left_spmm (values_stride = 0) with operands stored as float32, float16 or
+ * bfloat16 -- values and dense independently, a half pair of ONE kind -- product
+ * float32, optional bias / ReLU epilogue as sputnik_hip_spmm_bias_batched.  Half
+ * operands are read as they are (src/spmm_cuda.cu:42,51 knows float only): the
+ * panel-resident kernel widens the rows of B on their way into LDS (half the bytes
+ * from memory, same compute loop) and serves up to two panels (k <= 1024) with
+ * n >= 64; larger products, where the chunked float kernels win by a factor of two,
+ * are widened into the workspace by one pass inside this call when the workspace has
+ * sputnik_hip_spmm_typed_workspace_bytes; everything else (and every call without
+ * that room) takes the row-gather kernel, which reads half rows of B from L2.
+ */
+SPUTNIK_HIP_API size_t sputnik_hip_spmm_typed_workspace_bytes(int m, int k, int n, int nonzeros,
+                              int replicas, int values_type, int64_t values_stride,
+                              int dense_type);
+SPUTNIK_HIP_API int sputnik_hip_spmm_typed(int m, int k, int n, int nonzeros, int replicas,
+                              const int* row_indices, const void* values, int values_type,
+                              int64_t values_stride, const int* row_offsets,
+                              const int* column_indices, const void* dense, int dense_type,
+                              int64_t dense_stride, const float* bias, int relu, float* out,
+                              int64_t out_stride, void* workspace, size_t workspace_bytes,
+                              sputnik_hip_stream_t stream);
+
 /* sum over the replicas (sputnik_hip_sddmm_sum_batched{,_planned}) on operands stored as
  * `in_type`; the partial vectors and the result are float32.  Workspace / scratch sizes as
  * the float form's (sputnik_hip_sddmm_sum_workspace_bytes / _scratch_bytes). */

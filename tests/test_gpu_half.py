@@ -304,3 +304,104 @@ def test_sddmm_half_ops(ts, dev, dtype):
         total = tsa.ops.sddmm_sum(m, n, *topo, lhs, rhs)
         assert total.dtype == torch.float32
         assert rel_err(total.cpu().numpy()[None], want.astype(np.float64).sum(0)[None], ro) < TOL
+
+
+# ----------------------------------------------------------------------------
+# SpMM / left_spmm: half values and / or half dense operand, float32 product
+# ----------------------------------------------------------------------------
+SPMM_SHAPES = [
+    # m, k, n, sparsity, replicas
+    (72, 64, 72, 0.5, 1),        # tests/test_spmm.py size: row-gather kernel
+    (128, 96, 64, 0.8, 2),
+    (50, 60, 7, 0.7, 2),         # n = 7: scalar gather
+    (50, 60, 10, 0.7, 1),
+    (1024, 1024, 64, 0.9, 8),    # attention P.V geometry: two panels, widened on the way in
+    (512, 512, 1024, 0.9, 4),    # projection geometry: one panel
+    (300, 200, 132, 0.8, 3),     # ragged tiles (n = 132: partial last column tile)
+    (256, 1500, 128, 0.9, 2),    # three panels
+    (128, 3000, 64, 0.95, 1),    # k > 2048: row gather
+]
+SPMM_TYPES = [(torch.float16, torch.float16), (torch.bfloat16, torch.bfloat16),
+              (torch.float16, torch.float32), (torch.float32, torch.bfloat16)]
+
+
+@pytest.fixture(params=["auto", "panel", "gather"])
+def half_spmm_kernel(request, monkeypatch):
+    from torch_sputnik_amd import capi
+    if request.param == "auto":
+        monkeypatch.delenv("SPUTNIK_HIP_SPMM_KERNEL", raising=False)
+    else:
+        monkeypatch.setenv("SPUTNIK_HIP_SPMM_KERNEL", request.param)
+    capi.reload_options()
+    yield request.param
+    monkeypatch.delenv("SPUTNIK_HIP_SPMM_KERNEL", raising=False)
+    capi.reload_options()
+
+
+@pytest.mark.parametrize("tv,tb", SPMM_TYPES)
+@pytest.mark.parametrize("m,k,n,sparsity,replicas", SPMM_SHAPES)
+def test_spmm_half_capi_vs_oracle(capi, dev, half_spmm_kernel, tv, tb, m, k, n, sparsity, replicas):
+    _, vals, ri, ro, ci = make_csr(m, k, sparsity, seed=m + k + n, round_to=1, empty_rows=(m // 3,))
+    rng = np.random.default_rng(n)
+    v, v32 = rounded(rng.uniform(-1, 1, size=(replicas, len(vals))), tv, dev)
+    b, b32 = rounded(rng.uniform(-1, 1, size=(replicas, k, n)), tb, dev)
+    want = np.stack([O.spmm(m, k, v32[r], ri, ro, ci, b32[r]) for r in range(replicas)])
+    out = torch.full((replicas, m, n), float("nan"), device=dev)
+    topo = (T(ri, dev), T(ro, dev), T(ci, dev))
+    capi.spmm_typed(m, k, n, replicas, topo[0], v, len(vals), topo[1], topo[2], b, out)
+    got = out.cpu().numpy()
+    assert not np.isnan(got).any()
+    assert rel_err(got, want) < TOL
+    # shared values (left_spmm): stride 0
+    capi.spmm_typed(m, k, n, replicas, topo[0], v[0].contiguous(), 0, topo[1], topo[2], b, out)
+    want0 = np.stack([O.spmm(m, k, v32[0], ri, ro, ci, b32[r]) for r in range(replicas)])
+    assert rel_err(out.cpu().numpy(), want0) < TOL
+
+
+@pytest.mark.parametrize("dtype", HALF_TYPES)
+def test_spmm_half_ops(ts, dev, dtype):
+    """The torch ops hand half operands to the kernels as they are; the product is
+    float32 (src/spmm_cuda.cu:42); bias / ReLU epilogue included."""
+    import torch_sputnik_amd as tsa
+    m, k, n, r = 512, 512, 256, 3
+    _, vals, ri, ro, ci = make_csr(m, k, 0.85, seed=71)
+    topo = (T(ri, dev), T(ro, dev), T(ci, dev))
+    rng = np.random.default_rng(72)
+    v, v32 = rounded(vals, dtype, dev)
+    b, b32 = rounded(rng.uniform(-1, 1, size=(r, k, n)), dtype, dev)
+    out = ts.left_spmm(m, k, v, *topo, b)
+    assert out.dtype == torch.float32 and tuple(out.shape) == (r, m, n)
+    want = O.left_spmm(m, k, v32, ri, ro, ci, b32)
+    assert rel_err(out.cpu().numpy(), want) < TOL
+    out2 = ts.spmm(m, k, v, *topo, b[0])
+    assert tuple(out2.shape) == (m, n)
+    assert rel_err(out2.cpu().numpy(), want[0]) < TOL
+    bias = T(rng.uniform(-1, 1, size=(m,)).astype(np.float32), dev)
+    fused = tsa.ops.spmm_bias_relu(m, k, v, *topo, bias, b[0])
+    want_f = np.maximum(want[0].astype(np.float64) + bias.cpu().numpy()[:, None], 0.0)
+    assert np.max(np.abs(fused.cpu().numpy() - want_f)) < 1e-3 * max(1.0, np.abs(want_f).max())
+
+
+@pytest.mark.parametrize("tv,tb", SPMM_TYPES)
+def test_spmm_half_large_k_is_widened_inside_the_call(capi, dev, tv, tb):
+    """k = 2048 (four panels would lose by a factor of two): with the typed workspace
+    the call widens the operands itself and runs the chunked float kernels; without
+    it the row-gather kernel reads the half rows.  Same answer either way."""
+    m, k, n, replicas = 2048, 2048, 512, 2
+    _, vals, ri, ro, ci = make_csr(m, k, 0.8, seed=5)
+    rng = np.random.default_rng(6)
+    v, v32 = rounded(vals, tv, dev)
+    b, b32 = rounded(rng.uniform(-1, 1, size=(replicas, k, n)), tb, dev)
+    topo = (T(ri, dev), T(ro, dev), T(ci, dev))
+    need = capi.spmm_typed_workspace_bytes(m, k, n, len(vals), replicas, v, 0, b)
+    assert need > 0
+    ws = torch.empty(need + 256, dtype=torch.uint8, device=dev)
+    ws = ws[(256 - ws.data_ptr() % 256) % 256:]
+    out = torch.full((replicas, m, n), float("nan"), device=dev)
+    capi.spmm_typed(m, k, n, replicas, topo[0], v, 0, topo[1], topo[2], b, out, ws)
+    want = torch.matmul(T(O.csr_to_dense(m, k, v32, ro, ci), dev).double(), T(b32, dev).double())
+    from tests.helpers import rel_err_torch
+    assert rel_err_torch(out, want) < TOL
+    out2 = torch.full_like(out, float("nan"))
+    capi.spmm_typed(m, k, n, replicas, topo[0], v, 0, topo[1], topo[2], b, out2, None)
+    assert rel_err_torch(out2, want) < TOL

@@ -57,6 +57,25 @@ def main():
                     th = ev(lambda: capi.sddmm_typed(m, k, n, reps, ri, ro, ci, q, kk, oh, ws, planned=True), 20)
                     line += f"  half out {th:8.2f} us"
                 print(line, flush=True)
+    if "spmm" in what:
+        for (m, k, n, dens, reps, shared, tag) in ((1024, 1024, 64, 0.1, 64, False, "c3 attention P.V"),
+                                                   (512, 512, 1024, 0.1, 8, True, "c3 projection"),
+                                                   (2048, 2048, 512, 0.2, 8, True, "c5 left_spmm")):
+            ri, ro, ci, nnz = random_csr(m, k, dens, dev, seed=7)
+            out = torch.empty(reps, m, n, device=dev)
+            for dt in (torch.float32, torch.float16, torch.bfloat16):
+                v = (uniform((nnz,) if shared else (reps, nnz), dev, 11) - 0.5).to(dt)
+                b = (uniform((reps, k, n), dev, 12) - 0.5).to(dt)
+                need = max(capi.spmm_typed_workspace_bytes(m, k, n, nnz, reps, v, 0 if shared else nnz, b),
+                           capi.spmm_workspace_bytes(m, k, n, nnz))
+                ws = torch.empty(need + 256, dtype=torch.uint8, device=dev)
+                t = ev(lambda: capi.spmm_typed(m, k, n, reps, ri, v, 0 if shared else nnz, ro, ci, b, out, ws), 20)
+                line = f"spmm  {tag:34s} {str(dt):15s} {t:8.2f} us ({2.0 * nnz * n * reps / t / 1e6:7.1f} TFLOP/s)"
+                if dt != torch.float32:   # what the widening path costs: cast both, then the float kernels
+                    tw = ev(lambda: capi.spmm_typed(m, k, n, reps, ri, v.float(), 0 if shared else nnz, ro, ci,
+                                                    b.float(), out, ws), 20)
+                    line += f"   widen + float kernels {tw:8.2f} us"
+                print(line, flush=True)
 
 
 if __name__ == "__main__":

@@ -87,6 +87,10 @@ SIGNATURES = {
         _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_float, _c_ptr, _c_i64, _c_ptr]),
     "sputnik_hip_sparse_softmax_backward_batched": (_c_int, [_c_int] * 3 + [
         _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_float, _c_ptr, _c_i64, _c_ptr]),
+    "sputnik_hip_spmm_typed_workspace_bytes": (_c_size, [_c_int] * 6 + [_c_i64, _c_int]),
+    "sputnik_hip_spmm_typed": (_c_int, [_c_int] * 5 + [_c_ptr, _c_ptr, _c_int, _c_i64, _c_ptr, _c_ptr,
+                                                      _c_ptr, _c_int, _c_i64, _c_ptr, _c_int, _c_ptr,
+                                                      _c_i64, _c_ptr, _c_size, _c_ptr]),
     "sputnik_hip_sddmm_typed": (_c_int, [_c_int] * 5 + [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64,
                                                        _c_ptr, _c_i64, _c_int, _c_ptr, _c_i64,
                                                        _c_int, _c_ptr, _c_size, _c_int, _c_ptr]),
@@ -354,6 +358,31 @@ def _type_code(*tensors):
         raise TypeError("operands must share one of float32 / float16 / bfloat16, got "
                         + ", ".join(str(t.dtype) for t in tensors))
     return TYPE_CODES[dtype]
+
+
+def spmm_typed_workspace_bytes(m, k, n, nonzeros, replicas, values, values_stride, dense):
+    return lib().sputnik_hip_spmm_typed_workspace_bytes(m, k, n, nonzeros, replicas,
+                                                        _type_code(values), values_stride,
+                                                        _type_code(dense))
+
+
+def spmm_typed(m, k, n, replicas, row_indices, values, values_stride, row_offsets, column_indices,
+               dense, out, workspace=None, bias=None, relu=False):
+    """SpMM with values / dense stored as float32, float16 or bfloat16; out float32."""
+    nonzeros = column_indices.numel()
+    for t, nm in ((row_indices, "row_indices"), (row_offsets, "row_offsets"),
+                  (column_indices, "column_indices")):
+        _require(t, torch.int32, nm)
+    _require(out, torch.float32, "out")
+    for t, nm in ((values, "values"), (dense, "dense")):
+        if not (t.is_cuda and t.is_contiguous()):
+            raise ValueError(f"{nm}: expected a contiguous GPU tensor")
+    _check(lib().sputnik_hip_spmm_typed(
+        m, k, n, nonzeros, replicas, _ptr(row_indices), _ptr(values), _type_code(values),
+        values_stride, _ptr(row_offsets), _ptr(column_indices), _ptr(dense), _type_code(dense),
+        k * n, _ptr(bias), int(bool(relu)), _ptr(out), m * n, _ptr(workspace),
+        _ws_bytes(workspace), _stream(out)), "sputnik_hip_spmm_typed")
+    return out
 
 
 def sddmm_typed(m, k, n, replicas, row_indices, row_offsets, column_indices, lhs, rhs, out,

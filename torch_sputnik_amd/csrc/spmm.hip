@@ -12,6 +12,8 @@
 // with one VEC-wide load per lane: every B read is a contiguous
 // LPR*VEC*4-byte segment.  It needs no workspace and places no requirement
 // on the order of column indices inside a row.
+#include <type_traits>
+
 #include "common.h"
 #include "options.h"
 #include "wave_utils.h"
@@ -54,15 +56,42 @@ int spmm_panel_launch(int m, int k, int n, int nonzeros, int replicas, const int
                       const int* value_permutation = nullptr, int block_rows = 0,
                       int mask_heads = 0);
 
+bool spmm_panel_applicable_typed(int m, int k, int n, int nonzeros, const void* dense,
+                                 int dense_type, int64_t dense_stride, const float* out,
+                                 int64_t out_stride);
+int spmm_panel_launch_typed(int m, int k, int n, int nonzeros, int replicas,
+                            const int* row_indices, const void* values, int values_type,
+                            int64_t values_stride, const int* row_offsets,
+                            const int* column_indices, const void* dense, int dense_type,
+                            int64_t dense_stride, float* out, int64_t out_stride,
+                            hipStream_t stream, Epilogue epi);
+
 namespace {
 
 constexpr int kBlock = 256;
 
-template <int VEC, int LPR>
+// VEC elements of storage type T, widened to float.
+template <int VEC, typename T>
+__device__ __forceinline__ void load_widened(float (&dst)[VEC], const T* __restrict__ src) {
+  if constexpr (std::is_same_v<T, float>) {
+    load_vec<VEC>(dst, src);
+  } else if constexpr (VEC == 1) {
+    dst[0] = static_cast<float>(*src);
+  } else {
+    using V = T __attribute__((ext_vector_type(VEC)));
+    const V v = *reinterpret_cast<const V*>(src);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) dst[e] = static_cast<float>(v[e]);
+  }
+}
+
+// TV / TB: storage type of the values / the dense operand (float; _Float16 / __bf16 =
+// native half operands, round 3: widened in registers, half the gather traffic).
+template <int VEC, int LPR, typename TV = float, typename TB = float>
 __global__ __launch_bounds__(kBlock) void spmm_rowgather_kernel(
-    int m, int n, const int* __restrict__ row_indices, const float* __restrict__ values,
+    int m, int n, const int* __restrict__ row_indices, const TV* __restrict__ values,
     int64_t values_stride, const int* __restrict__ row_offsets,
-    const int* __restrict__ column_indices, const float* __restrict__ dense,
+    const int* __restrict__ column_indices, const TB* __restrict__ dense,
     int64_t dense_stride, float* __restrict__ out, int64_t out_stride, Epilogue epi) {
   constexpr int kRowsPerBlock = kBlock / LPR;
   const int sub = threadIdx.x / LPR;
@@ -81,7 +110,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rowgather_kernel(
   int p = row_ok ? row_offsets[row] : 0;
   const int p_end = row_ok ? row_offsets[row + 1] : 0;
 
-  const float* __restrict__ b_col = dense + (col_ok ? c0 : 0);
+  const TB* __restrict__ b_col = dense + (col_ok ? c0 : 0);
   float acc[VEC];
 #pragma unroll
   for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
@@ -92,7 +121,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rowgather_kernel(
     float a = 0.f;
     if (q < p_end) {
       j = column_indices[q];
-      a = values[q];
+      a = static_cast<float>(values[q]);
     }
     const int cnt = min(LPR, p_end - p);
 #pragma unroll 4
@@ -100,7 +129,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rowgather_kernel(
       const int jj = group_broadcast<LPR>(j, t);
       const float aa = group_broadcast<LPR>(a, t);
       float b[VEC];
-      load_vec<VEC>(b, b_col + static_cast<int64_t>(jj) * n);
+      load_widened<VEC, TB>(b, b_col + static_cast<int64_t>(jj) * n);
 #pragma unroll
       for (int v = 0; v < VEC; ++v) acc[v] = fmaf(aa, b[v], acc[v]);
     }
@@ -116,10 +145,10 @@ __global__ __launch_bounds__(kBlock) void spmm_rowgather_kernel(
   }
 }
 
-template <int VEC, int LPR>
-int launch_rowgather(int m, int n, int replicas, const int* row_indices, const float* values,
+template <int VEC, int LPR, typename TV = float, typename TB = float>
+int launch_rowgather(int m, int n, int replicas, const int* row_indices, const TV* values,
                      int64_t values_stride, const int* row_offsets, const int* column_indices,
-                     const float* dense, int64_t dense_stride, float* out, int64_t out_stride,
+                     const TB* dense, int64_t dense_stride, float* out, int64_t out_stride,
                      hipStream_t stream, Epilogue epi) {
   constexpr int kRowsPerBlock = kBlock / LPR;
   const int gx = ceil_div(m, kRowsPerBlock);
@@ -127,7 +156,7 @@ int launch_rowgather(int m, int n, int replicas, const int* row_indices, const f
   if (gy > kMaxGridYZ) return SPUTNIK_HIP_INVALID_ARGUMENT;
   for (int r0 = 0; r0 < replicas; r0 += kMaxGridYZ) {
     const int rz = min(replicas - r0, kMaxGridYZ);
-    hipLaunchKernelGGL((spmm_rowgather_kernel<VEC, LPR>), dim3(gx, gy, rz), dim3(kBlock), 0,
+    hipLaunchKernelGGL((spmm_rowgather_kernel<VEC, LPR, TV, TB>), dim3(gx, gy, rz), dim3(kBlock), 0,
                        stream, m, n, row_indices, values + r0 * values_stride, values_stride,
                        row_offsets, column_indices, dense + r0 * dense_stride, dense_stride,
                        out + r0 * out_stride, out_stride, epi);
@@ -137,16 +166,16 @@ int launch_rowgather(int m, int n, int replicas, const int* row_indices, const f
   return 0;
 }
 
-template <int VEC>
-int launch_rowgather_vec(int m, int n, int replicas, const int* row_indices, const float* values,
+template <int VEC, typename TV = float, typename TB = float>
+int launch_rowgather_vec(int m, int n, int replicas, const int* row_indices, const TV* values,
                          int64_t values_stride, const int* row_offsets,
-                         const int* column_indices, const float* dense, int64_t dense_stride,
+                         const int* column_indices, const TB* dense, int64_t dense_stride,
                          float* out, int64_t out_stride, hipStream_t stream, Epilogue epi) {
   const int lanes_needed = ceil_div(n, VEC);
-#define SPUTNIK_HIP_RG(LPR)                                                                  \
-  return launch_rowgather<VEC, LPR>(m, n, replicas, row_indices, values, values_stride,      \
-                                    row_offsets, column_indices, dense, dense_stride, out,   \
-                                    out_stride, stream, epi)
+#define SPUTNIK_HIP_RG(LPR)                                                                       \
+  return launch_rowgather<VEC, LPR, TV, TB>(m, n, replicas, row_indices, values, values_stride,   \
+                                            row_offsets, column_indices, dense, dense_stride,     \
+                                            out, out_stride, stream, epi)
   if (lanes_needed <= 8) SPUTNIK_HIP_RG(8);
   if (lanes_needed <= 16) SPUTNIK_HIP_RG(16);
   if (lanes_needed <= 32) SPUTNIK_HIP_RG(32);
@@ -176,6 +205,83 @@ int spmm_rowgather_launch(int m, int n, int replicas, const int* row_indices,
                                      row_offsets, column_indices, dense, dense_stride, out,
                                      out_stride, stream, epi);
   }
+}
+
+namespace {
+// count8 pieces of 8 elements (16 bytes in, 32 out) + a scalar tail.
+template <typename T>
+__global__ __launch_bounds__(256) void widen_kernel(const T* __restrict__ in, float* __restrict__ out,
+                                                    int64_t count) {
+  using raw8 = T __attribute__((ext_vector_type(8)));
+  using f8v = float __attribute__((ext_vector_type(8)));
+  const int64_t i = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) * 8;
+  if (i + 8 <= count) {
+    *reinterpret_cast<f8v*>(out + i) = __builtin_convertvector(*reinterpret_cast<const raw8*>(in + i), f8v);
+  } else {
+    for (int64_t j = i; j < count; ++j) out[j] = static_cast<float>(in[j]);
+  }
+}
+int widen_to(const void* in, int type, float* out, int64_t count, hipStream_t stream) {
+  if (count == 0) return 0;
+  const int64_t blocks = ceil_div64(ceil_div64(count, 8), 256);
+  if (blocks > 0x7fffffff) return SPUTNIK_HIP_INVALID_ARGUMENT;
+  // (16-byte vector loads: a source that is not 16-byte aligned goes element by element)
+  if (!aligned_to(in, 16)) return SPUTNIK_HIP_UNSUPPORTED;
+  if (type == SPUTNIK_HIP_F16)
+    hipLaunchKernelGGL(widen_kernel<_Float16>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
+                       stream, static_cast<const _Float16*>(in), out, count);
+  else
+    hipLaunchKernelGGL(widen_kernel<__bf16>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
+                       stream, static_cast<const __bf16*>(in), out, count);
+  return launch_status();
+}
+size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+
+template <typename TV, typename TB>
+int rowgather_typed(int m, int n, int replicas, const int* row_indices, const void* values,
+                    int64_t values_stride, const int* row_offsets, const int* column_indices,
+                    const void* dense, int64_t dense_stride, float* out, int64_t out_stride,
+                    hipStream_t stream, Epilogue epi) {
+  const TV* v = static_cast<const TV*>(values);
+  const TB* d = static_cast<const TB*>(dense);
+  // widest vector of ELEMENTS both the dense rows and the output rows support
+  int vec = vector_width(out, n, out_stride);
+  if (!(n % 4 == 0 && dense_stride % 4 == 0 && aligned_to(dense, 4 * sizeof(TB)))) vec = min(vec, 2);
+  if (!(n % 2 == 0 && dense_stride % 2 == 0 && aligned_to(dense, 2 * sizeof(TB)))) vec = 1;
+  switch (vec) {
+    case 4:
+      return launch_rowgather_vec<4, TV, TB>(m, n, replicas, row_indices, v, values_stride,
+                                             row_offsets, column_indices, d, dense_stride, out,
+                                             out_stride, stream, epi);
+    case 2:
+      return launch_rowgather_vec<2, TV, TB>(m, n, replicas, row_indices, v, values_stride,
+                                             row_offsets, column_indices, d, dense_stride, out,
+                                             out_stride, stream, epi);
+    default:
+      return launch_rowgather_vec<1, TV, TB>(m, n, replicas, row_indices, v, values_stride,
+                                             row_offsets, column_indices, d, dense_stride, out,
+                                             out_stride, stream, epi);
+  }
+}
+}  // namespace
+
+int spmm_rowgather_launch_typed(int m, int n, int replicas, const int* row_indices,
+                                const void* values, int values_type, int64_t values_stride,
+                                const int* row_offsets, const int* column_indices,
+                                const void* dense, int dense_type, int64_t dense_stride, float* out,
+                                int64_t out_stride, hipStream_t stream, Epilogue epi) {
+#define SPUTNIK_HIP_RGT(TV, TB)                                                                  \
+  return rowgather_typed<TV, TB>(m, n, replicas, row_indices, values, values_stride, row_offsets, \
+                                 column_indices, dense, dense_stride, out, out_stride, stream, epi)
+  const int F = SPUTNIK_HIP_F32, H = SPUTNIK_HIP_F16, B = SPUTNIK_HIP_BF16;
+  if (values_type == H && dense_type == H) SPUTNIK_HIP_RGT(_Float16, _Float16);
+  if (values_type == B && dense_type == B) SPUTNIK_HIP_RGT(__bf16, __bf16);
+  if (values_type == H && dense_type == F) SPUTNIK_HIP_RGT(_Float16, float);
+  if (values_type == B && dense_type == F) SPUTNIK_HIP_RGT(__bf16, float);
+  if (values_type == F && dense_type == H) SPUTNIK_HIP_RGT(float, _Float16);
+  if (values_type == F && dense_type == B) SPUTNIK_HIP_RGT(float, __bf16);
+#undef SPUTNIK_HIP_RGT
+  return SPUTNIK_HIP_UNSUPPORTED;
 }
 
 }  // namespace sputnik_hip
@@ -382,6 +488,110 @@ int sputnik_hip_spmm_group_batched(int m, int k, int n, int replicas, int count,
   return spmm_panel_group_launch(m, k, n, replicas, count,
                                  reinterpret_cast<const GroupProblemHost*>(problems),
                                  dense_stride, out_stride, block_rows, accumulate != 0, stream);
+}
+
+// Workspace of sputnik_hip_spmm_typed: the float form's, plus room for float copies of
+// the half operands for the shapes the half-reading kernels do not serve well.
+size_t sputnik_hip_spmm_typed_workspace_bytes(int m, int k, int n, int nonzeros, int replicas,
+                                              int values_type, int64_t values_stride,
+                                              int dense_type) {
+  if (m <= 0 || k <= 0 || n <= 0 || replicas <= 0) return 0;
+  // (shapes the half-reading kernels take need none: see sputnik_hip_spmm_typed)
+  const bool panel_shape = n % 4 == 0 && n >= 64 && m >= 16 &&
+                           (k <= 512 || (k <= 1024 && nonzeros <= 320 * static_cast<int64_t>(m)));
+  const bool big = static_cast<int64_t>(nonzeros) * n * replicas >= (int64_t{1} << 28);
+  if (panel_shape || !big || (values_type == SPUTNIK_HIP_F32 && dense_type == SPUTNIK_HIP_F32))
+    return 0;
+  size_t bytes = align256(spmm_tiled_workspace_bytes(m, k, n, nonzeros));
+  if (dense_type != SPUTNIK_HIP_F32)
+    bytes += align256(sizeof(float) * static_cast<size_t>(replicas) * k * n);
+  if (values_type != SPUTNIK_HIP_F32)
+    bytes += align256(sizeof(float) * static_cast<size_t>(nonzeros) * (values_stride == 0 ? 1 : replicas));
+  return bytes;
+}
+
+int sputnik_hip_spmm_typed(int m, int k, int n, int nonzeros, int replicas,
+                           const int* row_indices, const void* values, int values_type,
+                           int64_t values_stride, const int* row_offsets,
+                           const int* column_indices, const void* dense, int dense_type,
+                           int64_t dense_stride, const float* bias, int relu, float* out,
+                           int64_t out_stride, void* workspace, size_t workspace_bytes,
+                           sputnik_hip_stream_t stream) {
+  const auto known = [](int t) {
+    return t == SPUTNIK_HIP_F32 || t == SPUTNIK_HIP_F16 || t == SPUTNIK_HIP_BF16;
+  };
+  if (!known(values_type) || !known(dense_type)) return SPUTNIK_HIP_INVALID_ARGUMENT;
+  if (values_type == SPUTNIK_HIP_F32 && dense_type == SPUTNIK_HIP_F32)
+    return sputnik_hip_spmm_bias_batched(m, k, n, nonzeros, replicas, row_indices,
+                                         static_cast<const float*>(values), values_stride,
+                                         row_offsets, column_indices,
+                                         static_cast<const float*>(dense), dense_stride, bias, relu,
+                                         out, out_stride, workspace, workspace_bytes, stream);
+  if (values_type != SPUTNIK_HIP_F32 && dense_type != SPUTNIK_HIP_F32 && values_type != dense_type)
+    return SPUTNIK_HIP_UNSUPPORTED;   // float16 against bfloat16
+  if (m < 0 || k < 0 || n < 0 || nonzeros < 0 || replicas < 0) return SPUTNIK_HIP_INVALID_ARGUMENT;
+  if (m == 0 || n == 0 || replicas == 0) return 0;
+  if (!aligned_to(values, values_type == SPUTNIK_HIP_F32 ? 4 : 2) ||
+      !aligned_to(dense, dense_type == SPUTNIK_HIP_F32 ? 4 : 2) || !aligned_to(out, 4))
+    return SPUTNIK_HIP_INVALID_ARGUMENT;
+  Epilogue epi;
+  epi.bias = bias;
+  epi.relu = relu != 0;
+  // Panel-resident kernel (the half panel is widened on its way into LDS) wherever it
+  // applies and is not hopeless (at most four panels, i.e. k <= 2048; forced by the
+  // "panel" knob up to its limit), otherwise the row-gather kernel, which reads half
+  // rows of B straight from L2.  Neither needs the workspace.
+  // (measured, tools/half_bench.py: attention P.V 1024^2 x 64 x 64 replicas 42.8 us native
+  // against 61 for cast + float kernels, projection 19 against 36; 2048^2 x 512 x 8, four
+  // panels: 366 against 189 -- so beyond two panels the operands are widened into the
+  // workspace by one pass of this library and the chunked float kernels run)
+  const int forced = options().spmm_kernel;
+  const bool panel_ok = nonzeros > 0 && (forced == 0 || forced == 3) &&
+                        spmm_panel_applicable_typed(m, k, n, nonzeros, dense, dense_type,
+                                                    dense_stride, out, out_stride) &&
+                        (forced == 3 || k <= 512 ||
+                         (k <= 1024 && nonzeros <= 320 * static_cast<int64_t>(m))) &&
+                        static_cast<int64_t>(nonzeros) * n * replicas >= (int64_t{1} << 22);
+  if (panel_ok)
+    return spmm_panel_launch_typed(m, k, n, nonzeros, replicas, row_indices, values, values_type,
+                                   values_stride, row_offsets, column_indices, dense, dense_type,
+                                   dense_stride, out, out_stride, stream, epi);
+  const bool big = static_cast<int64_t>(nonzeros) * n * replicas >= (int64_t{1} << 28);
+  if (forced == 0 && big && workspace != nullptr && aligned_to(workspace, 256) &&
+      dense_stride == static_cast<int64_t>(k) * n && (values_stride == 0 || values_stride == nonzeros) &&
+      sputnik_hip_spmm_typed_workspace_bytes(m, k, n, nonzeros, replicas, values_type,
+                                             values_stride, dense_type) != 0 &&
+      workspace_bytes >= sputnik_hip_spmm_typed_workspace_bytes(m, k, n, nonzeros, replicas,
+                                                                values_type, values_stride,
+                                                                dense_type)) {
+    char* at = static_cast<char*>(workspace);
+    void* float_ws = at;
+    const size_t float_ws_bytes = align256(spmm_tiled_workspace_bytes(m, k, n, nonzeros));
+    at += float_ws_bytes;
+    const float* dense_f = static_cast<const float*>(dense);
+    const float* values_f = static_cast<const float*>(values);
+    int st = 0;
+    if (dense_type != SPUTNIK_HIP_F32) {
+      const int64_t count = static_cast<int64_t>(replicas) * k * n;
+      st = widen_to(dense, dense_type, reinterpret_cast<float*>(at), count, stream);
+      dense_f = reinterpret_cast<const float*>(at);
+      at += align256(sizeof(float) * static_cast<size_t>(count));
+    }
+    if (st == 0 && values_type != SPUTNIK_HIP_F32) {
+      const int64_t count = static_cast<int64_t>(nonzeros) * (values_stride == 0 ? 1 : replicas);
+      st = widen_to(values, values_type, reinterpret_cast<float*>(at), count, stream);
+      values_f = reinterpret_cast<const float*>(at);
+    }
+    if (st == 0)
+      return sputnik_hip_spmm_bias_batched(m, k, n, nonzeros, replicas, row_indices, values_f,
+                                           values_stride, row_offsets, column_indices, dense_f,
+                                           dense_stride, bias, relu, out, out_stride, float_ws,
+                                           float_ws_bytes, stream);
+    if (st != SPUTNIK_HIP_UNSUPPORTED) return st;
+  }
+  return spmm_rowgather_launch_typed(m, n, replicas, row_indices, values, values_type,
+                                     values_stride, row_offsets, column_indices, dense, dense_type,
+                                     dense_stride, out, out_stride, stream, epi);
 }
 
 int sputnik_hip_spmm(int m, int k, int n, int nonzeros, const int* row_indices,

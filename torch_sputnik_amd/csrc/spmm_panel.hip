@@ -20,6 +20,7 @@
 // quad.  The last column tile may be partial (n a multiple of 4).
 #include <algorithm>
 #include <atomic>
+#include <type_traits>
 
 #include "options.h"
 #include "spmm_tiled_common.h"
@@ -135,18 +136,18 @@ __device__ __forceinline__ void copy_panel(float* panel, const float* __restrict
 // First 16-entry window of every row quad, requested as soon as the rows' bounds
 // are known: with ~50 entries per row a quad has only four windows, and a window
 // fetched only when its quad starts costs a whole memory latency per quad pair.
-template <bool PERM>
+template <bool PERM, typename TV = float>
 __device__ __forceinline__ void fetch_first_windows(const Rows& r, int (&ecol)[kPQuads],
                                                     float (&eval)[kPQuads],
                                                     const int* __restrict__ column_indices,
-                                                    const float* __restrict__ values,
+                                                    const TV* __restrict__ values,
                                                     const int* __restrict__ value_permutation,
                                                     int last, int i) {
 #pragma unroll
   for (int t = 0; t < kPQuads; ++t) {
     const int idx = max(min(r.p0[t] + i, last), 0);
     ecol[t] = column_indices[idx];
-    eval[t] = values[PERM ? value_permutation[idx] : idx];
+    eval[t] = static_cast<float>(values[PERM ? value_permutation[idx] : idx]);
   }
 }
 
@@ -154,12 +155,12 @@ __device__ __forceinline__ void fetch_first_windows(const Rows& r, int (&ecol)[k
 // of B's rows: k <= 512), two row quads side by side.  Window w0 = entries w0 ..
 // w0+15 of a group's row, the next one requested before the current one is
 // worked on.  PERM: entry p takes values[value_permutation[p]].
-template <bool PERM>
+template <bool PERM, typename TV = float>
 __device__ __forceinline__ void stream_pairs(float (&acc)[kPQuads][4], const Rows& r,
                                              const int (&first_col)[kPQuads],
                                              const float (&first_val)[kPQuads],
                                              const int* __restrict__ column_indices,
-                                             const float* __restrict__ values,
+                                             const TV* __restrict__ values,
                                              const int* __restrict__ value_permutation, int last,
                                              int i, const char* __restrict__ lane_base) {
 #pragma unroll
@@ -180,8 +181,8 @@ __device__ __forceinline__ void stream_pairs(float (&acc)[kPQuads][4], const Row
         idx_b = min(r.p0[t + 1] + w0 + 16 + i, last);
         ecol_a = column_indices[idx_a];
         ecol_b = column_indices[idx_b];
-        eval_a = values[PERM ? value_permutation[idx_a] : idx_a];
-        eval_b = values[PERM ? value_permutation[idx_b] : idx_b];
+        eval_a = static_cast<float>(values[PERM ? value_permutation[idx_a] : idx_a]);
+        eval_b = static_cast<float>(values[PERM ? value_permutation[idx_b] : idx_b]);
       }
       const int left_a = n_a - w0, left_b = n_b - w0;
       const int roff_a = i < left_a ? col_a * (kPBN * 4) : 0;
@@ -204,11 +205,11 @@ __device__ __forceinline__ void stream_pairs(float (&acc)[kPQuads][4], const Row
 // in which any of the wave's four rows held an entry of a LATER panel: the
 // windows before it are done for good, whatever the order of the columns (rows
 // with ascending columns thus walk each window about once over all passes).
-template <bool PERM>
+template <bool PERM, typename TV = float>
 __device__ __forceinline__ void stream_masked(float (&acc)[kPQuads][4], const Rows& r, int kbase,
                                               int (&start)[kPQuads],
                                               const int* __restrict__ column_indices,
-                                              const float* __restrict__ values,
+                                              const TV* __restrict__ values,
                                               const int* __restrict__ value_permutation, int last,
                                               int g, int i, const char* __restrict__ lane_base) {
 #pragma unroll
@@ -222,14 +223,14 @@ __device__ __forceinline__ void stream_masked(float (&acc)[kPQuads][4], const Ro
     bool seen_later = false;
     int idx = max(min(r.p0[t] + begin + i, last), 0);
     int ecol = column_indices[idx];
-    float eval = values[PERM ? value_permutation[idx] : idx];
+    float eval = static_cast<float>(values[PERM ? value_permutation[idx] : idx]);
     for (int w0 = begin; w0 < longest; w0 += 16) {
       const int cur_col = ecol - kbase;
       const float cur_val = eval;
       if (w0 + 16 < longest) {
         idx = min(r.p0[t] + w0 + 16 + i, last);
         ecol = column_indices[idx];
-        eval = values[PERM ? value_permutation[idx] : idx];
+        eval = static_cast<float>(values[PERM ? value_permutation[idx] : idx]);
       }
       const int left = n_here - w0;   // entries of this group's row at or after the window start
       const bool in_row = i < left;
@@ -385,6 +386,88 @@ __global__ __launch_bounds__(kPThreads) void spmm_panel64_kernel(
     store_rows(acc, rows, out, n, n0, i, epi);
   else
     store_transposed<kPBM>(panel, acc, rows, out, m, n, n0, mblock, block_rows, wave, g, i, epi);
+}
+
+// ---------------------------------------------------------------------------
+// Native half operands (round 3; the reference is float only, src/spmm_cuda.cu:42,51).
+// TV / TB: storage type of the values / of the dense operand (float, _Float16,
+// __bf16); the product is float.  A direct global->LDS copy cannot convert, so a
+// half panel goes through registers: one 8-byte load per lane and row (its four
+// columns), widened, one 16-byte LDS write -- half the bytes from HBM / L2, the
+// panel in LDS and the whole compute loop as in the float kernel.  Values are
+// widened as their 16-entry windows arrive.
+// ---------------------------------------------------------------------------
+template <typename TB>
+__device__ __forceinline__ void copy_panel_widened(float* panel, const TB* __restrict__ dense, int k,
+                                                   int n, int kbase, int col, int wave, int g,
+                                                   int lane) {
+  using raw4 = TB __attribute__((ext_vector_type(4)));
+  using f4v = float __attribute__((ext_vector_type(4)));
+  constexpr int kTrips = kPMaxK / 4 / kPWaves;   // rows 4j .. 4j+3 per wave instruction
+  const int rows_here = min(k - kbase, kPMaxK);
+  raw4 raw[kTrips];
+#pragma unroll
+  for (int u = 0; u < kTrips; ++u) {
+    const int j = wave + u * kPWaves;
+    const int src_row = min(kbase + 4 * j + g, k - 1);   // (past the end: valid bytes, never used)
+    raw[u] = *reinterpret_cast<const raw4*>(dense + static_cast<int64_t>(src_row) * n + col);
+  }
+#pragma unroll
+  for (int u = 0; u < kTrips; ++u) {
+    const int j = wave + u * kPWaves;
+    if (j * 4 < rows_here)
+      *reinterpret_cast<f4v*>(panel + 4 * j * kPBN + lane * 4) = __builtin_convertvector(raw[u], f4v);
+  }
+}
+
+template <bool MULTI, typename TV, typename TB>
+__global__ __launch_bounds__(kPThreads) void spmm_panel64_typed_kernel(
+    int m, int k, int n, int nonzeros, int slots, int n_tiles,
+    const int* __restrict__ row_indices, const TV* __restrict__ values, int64_t values_stride,
+    const int* __restrict__ row_offsets, const int* __restrict__ column_indices,
+    const TB* __restrict__ dense, int64_t dense_stride, float* __restrict__ out,
+    int64_t out_stride, Epilogue epi) {
+  extern __shared__ float panel[];   // [min(k, 512)][64]
+  const int lane = threadIdx.x % kWave;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int g = lane >> 4, i = lane & 15;
+  const Place place = place_of_workgroup(n_tiles);
+  const int ntile = place.ntile, mblock = place.mblock, replica = place.replica;
+  values += replica * values_stride;
+  dense += replica * dense_stride;
+  out += replica * out_stride;
+  const int n0 = ntile * kPBN;
+  const int last = max(nonzeros - 1, 0);
+
+  Rows rows;
+  load_rows<false>(rows, m, slots, mblock, wave, g, row_indices, row_offsets);
+  float acc[kPQuads][4];
+#pragma unroll
+  for (int t = 0; t < kPQuads; ++t) acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0.f;
+  const int col = min(n0 + i * 4, n - 4);
+  const char* __restrict__ lane_base = reinterpret_cast<const char*>(panel + i * 4);
+
+  int first_col[kPQuads];
+  float first_val[kPQuads];
+  int start[kPQuads] = {};
+  if constexpr (!MULTI)
+    fetch_first_windows<false, TV>(rows, first_col, first_val, column_indices, values, nullptr,
+                                   last, i);
+  for (int kbase = 0; kbase < k; kbase += kPMaxK) {
+    if (MULTI && kbase > 0) __syncthreads();   // every wave is done with the previous panel
+    if constexpr (std::is_same_v<TB, float>)
+      copy_panel(panel, dense, k, n, kbase, col, wave, g);
+    else
+      copy_panel_widened<TB>(panel, dense, k, n, kbase, col, wave, g, lane);
+    __syncthreads();
+    if constexpr (!MULTI)
+      stream_pairs<false, TV>(acc, rows, first_col, first_val, column_indices, values, nullptr,
+                              last, i, lane_base);
+    else
+      stream_masked<false, TV>(acc, rows, kbase, start, column_indices, values, nullptr, last, g,
+                               i, lane_base);
+  }
+  store_rows(acc, rows, out, n, n0, i, epi);
 }
 
 // ---------------------------------------------------------------------------
@@ -553,6 +636,81 @@ int spmm_panel_launch(int m, int k, int n, int nonzeros, int replicas, const int
     if (st != 0) return st;
   }
   return 0;
+}
+
+// Typed form (any operand float16 / bfloat16): plain product, no permutation, no
+// transposed store.  element sizes: alignment of the dense operand's 4-column pieces.
+bool spmm_panel_applicable_typed(int m, int k, int n, int nonzeros, const void* dense,
+                                 int dense_type, int64_t dense_stride, const float* out,
+                                 int64_t out_stride) {
+  if (device_lds_bytes() < kPMaxK * kPBN * sizeof(float)) return false;
+  const size_t piece = dense_type == SPUTNIK_HIP_F32 ? 16 : 8;
+  return k >= 1 && k <= kPMaxK * kPMaxPasses && n % 4 == 0 && n >= kPBN && m >= 16 &&
+         static_cast<int64_t>(k) * n * 4 < (int64_t{1} << 32) && aligned_to(dense, piece) &&
+         aligned_to(out, 16) && dense_stride % 4 == 0 && out_stride % 4 == 0 && nonzeros >= 0;
+}
+
+template <typename TV, typename TB>
+static int panel_launch_typed(int m, int k, int n, int nonzeros, int replicas,
+                              const int* row_indices, const void* values_v, int64_t values_stride,
+                              const int* row_offsets, const int* column_indices,
+                              const void* dense_v, int64_t dense_stride, float* out,
+                              int64_t out_stride, hipStream_t stream, Epilogue epi) {
+  const TV* values = static_cast<const TV*>(values_v);
+  const TB* dense = static_cast<const TB*>(dense_v);
+  const int slots = ceil_div(m, kPBM) * kPBM;
+  const int n_tiles = ceil_div(n, kPBN);
+  const int64_t blocks = static_cast<int64_t>(slots / kPBM) * n_tiles;
+  if (blocks > 0x7fffffff) return SPUTNIK_HIP_INVALID_ARGUMENT;
+  const size_t lds = static_cast<size_t>(ceil_div(min(k, kPMaxK), 4) * 4) * kPBN * sizeof(float);
+  const bool multi = k > kPMaxK;
+  static std::atomic<uint64_t> asked{0};   // (one per instantiation)
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) return launch_status();
+  const uint64_t bit = uint64_t{1} << (device & 63);
+  if (!(asked.load(std::memory_order_acquire) & bit)) {
+    for (const void* f : {reinterpret_cast<const void*>(spmm_panel64_typed_kernel<false, TV, TB>),
+                          reinterpret_cast<const void*>(spmm_panel64_typed_kernel<true, TV, TB>)}) {
+      const hipError_t st = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                kPMaxK * kPBN * sizeof(float));
+      if (st != hipSuccess) return static_cast<int>(st);
+    }
+    asked.fetch_or(bit, std::memory_order_release);
+  }
+  for (int r0 = 0; r0 < replicas; r0 += kMaxGridYZ) {
+    const int ry = min(replicas - r0, kMaxGridYZ);
+    const auto kernel = multi ? spmm_panel64_typed_kernel<true, TV, TB>
+                              : spmm_panel64_typed_kernel<false, TV, TB>;
+    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(blocks), ry), dim3(kPThreads), lds,
+                       stream, m, k, n, nonzeros, slots, n_tiles, row_indices,
+                       values + r0 * values_stride, values_stride, row_offsets, column_indices,
+                       dense + r0 * dense_stride, dense_stride, out + r0 * out_stride, out_stride,
+                       epi);
+    const int st = launch_status();
+    if (st != 0) return st;
+  }
+  return 0;
+}
+
+int spmm_panel_launch_typed(int m, int k, int n, int nonzeros, int replicas,
+                            const int* row_indices, const void* values, int values_type,
+                            int64_t values_stride, const int* row_offsets,
+                            const int* column_indices, const void* dense, int dense_type,
+                            int64_t dense_stride, float* out, int64_t out_stride,
+                            hipStream_t stream, Epilogue epi) {
+#define SPUTNIK_HIP_PT(TV, TB)                                                                    \
+  return panel_launch_typed<TV, TB>(m, k, n, nonzeros, replicas, row_indices, values,             \
+                                    values_stride, row_offsets, column_indices, dense,            \
+                                    dense_stride, out, out_stride, stream, epi)
+  const int F = SPUTNIK_HIP_F32, H = SPUTNIK_HIP_F16, B = SPUTNIK_HIP_BF16;
+  if (values_type == H && dense_type == H) SPUTNIK_HIP_PT(_Float16, _Float16);
+  if (values_type == B && dense_type == B) SPUTNIK_HIP_PT(__bf16, __bf16);
+  if (values_type == H && dense_type == F) SPUTNIK_HIP_PT(_Float16, float);
+  if (values_type == B && dense_type == F) SPUTNIK_HIP_PT(__bf16, float);
+  if (values_type == F && dense_type == H) SPUTNIK_HIP_PT(float, _Float16);
+  if (values_type == F && dense_type == B) SPUTNIK_HIP_PT(float, __bf16);
+#undef SPUTNIK_HIP_PT
+  return SPUTNIK_HIP_UNSUPPORTED;   // (float / float: the untyped launch; half types of two kinds)
 }
 
 // Host side of the group kernel.  `problems`: host array of `count` entries.

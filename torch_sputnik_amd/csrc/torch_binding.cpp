@@ -127,8 +127,17 @@ Tensor spmm_impl(int64_t m64, int64_t k64, const Tensor& values_in, const Tensor
                  bool relu = false, const c10::optional<Tensor>& plan = c10::nullopt,
                  const c10::optional<Tensor>& permutation = c10::nullopt, int64_t block_rows = 0) {
   const int m = to_int(m64, "m"), k = to_int(k64, "k");
-  Tensor values = as_float(values_in, "values");
-  const Tensor dense = as_float(dense_in, "dense");
+  // float16 / bfloat16 operands of the plain product go to the kernels as they are
+  // (sputnik_hip_spmm_typed); the permuted / transposed-store forms, which the modules
+  // reach with float32 operands, and a float16 / bfloat16 mix take the widened path.
+  const auto is_half = [](const Tensor& t) {
+    return t.scalar_type() == at::kHalf || t.scalar_type() == at::kBFloat16;
+  };
+  const bool native_half =
+      (is_half(values_in) || is_half(dense_in)) && !permutation.has_value() && block_rows == 0 &&
+      !(is_half(values_in) && is_half(dense_in) && values_in.scalar_type() != dense_in.scalar_type());
+  Tensor values = native_half ? as_storage(values_in, "values") : as_float(values_in, "values");
+  const Tensor dense = native_half ? as_storage(dense_in, "dense") : as_float(dense_in, "dense");
   TORCH_CHECK(dense.device() == values.device(), "values and dense must be on one device");
   TORCH_CHECK(dense.dim() == 2 || dense.dim() == 3, "dense should have 2 or 3 dimensions, got ",
               dense.dim());
@@ -157,7 +166,7 @@ Tensor spmm_impl(int64_t m64, int64_t k64, const Tensor& values_in, const Tensor
                 ") and dense (", replicas, ") must match");
   }
 
-  const auto options = values.options();
+  const auto options = values.options().dtype(at::kFloat);   // the product is float32
   const int64_t values_stride = (left || values.dim() == 1) ? 0 : topo.nonzeros;
   if (block_rows > 0) {
     // The product stored as the transposes of its blocks of `block_rows` rows,
@@ -225,6 +234,34 @@ Tensor spmm_impl(int64_t m64, int64_t k64, const Tensor& values_in, const Tensor
       return out;
     }
     values = permute_last(values, *permutation);
+  }
+  if (native_half) {   // (a plan has nothing to add: the half-reading kernels have no pre-pass)
+    Tensor bias;
+    if (bias_in.has_value()) {
+      bias = as_float(*bias_in, "bias");
+      TORCH_CHECK(bias.device() == values.device() && bias.dim() == 1 && bias.size(0) == m,
+                  "bias should have m = ", m, " elements on ", values.device());
+    }
+    const size_t typed_ws = sputnik_hip_spmm_typed_workspace_bytes(
+        m, k, n, topo.nonzeros, replicas, type_code(values.scalar_type()), values_stride,
+        type_code(dense.scalar_type()));
+    Tensor workspace;
+    char* ws = nullptr;
+    if (typed_ws > 0) {
+      workspace = at::empty({static_cast<int64_t>(typed_ws + 256)}, options.dtype(at::kByte));
+      ws = static_cast<char*>(workspace.data_ptr());
+      ws += (256 - reinterpret_cast<uintptr_t>(ws) % 256) % 256;
+    }
+    check_status(sputnik_hip_spmm_typed(
+                     m, k, n, topo.nonzeros, replicas, topo.row_indices.data_ptr<int>(),
+                     values.data_ptr(), type_code(values.scalar_type()), values_stride,
+                     topo.row_offsets.data_ptr<int>(), topo.column_indices.data_ptr<int>(),
+                     dense.data_ptr(), type_code(dense.scalar_type()), static_cast<int64_t>(k) * n,
+                     bias.defined() ? bias.data_ptr<float>() : nullptr, relu ? 1 : 0,
+                     out.data_ptr<float>(), static_cast<int64_t>(m) * n, ws, typed_ws,
+                     current_stream(values)),
+                 what);
+    return out;
   }
   const size_t ws_bytes = sputnik_hip_spmm_workspace_bytes(m, k, n, topo.nonzeros);
   if (plan.has_value()) {
