@@ -404,6 +404,22 @@ def other_ops(dev):
         res["sddmm_c3"]["planned_hbm_frac"] = by / tp / 1e6 / HBM_PEAK_GBS
     except Exception as e0:  # noqa: BLE001 - extra metric, best effort
         res["sddmm_c3"]["planned_error"] = str(e0)[:200]
+    try:   # half operands read as they are (round 3): LDS slab in half, v_dot2 products
+        for name, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+            qh, kh = q.to(dt), kk.to(dt)
+            capi.sddmm_plan(s, d, s, ri, ro, ci, sd_ws)
+            tp = event_time_ms(lambda: capi.sddmm_typed(s, d, s, reps, ri, ro, ci, qh, kh, scores, sd_ws,
+                                                        planned=True), 20)
+            sh = torch.empty(reps, nnz, device=dev, dtype=dt)
+            th = event_time_ms(lambda: capi.sddmm_typed(s, d, s, reps, ri, ro, ci, qh, kh, sh, sd_ws,
+                                                        planned=True), 20)
+            byh = reps * (4.0 * s * d + 4.0 * nnz) + 4.0 * nnz + 4.0 * (2 * s + 1)
+            res["sddmm_c3_" + name] = {"planned_ms": tp, "gflops": 2.0 * nnz * d * reps / tp / 1e6,
+                                       "planned_hbm_frac": byh / tp / 1e6 / HBM_PEAK_GBS,
+                                       "half_output_planned_ms": th}
+        del qh, kh, sh
+    except Exception as e0:  # noqa: BLE001 - extra metric, best effort
+        res["sddmm_c3_fp16"] = {"error": str(e0)[:200]}
     t = event_time_ms(lambda: capi.sparse_softmax_batched(s, reps, scores, ri, ro, ci, probs), 50)
     by = reps * 8.0 * nnz + 4.0 * (2 * s + 1)
     res["softmax_c3"] = {"ms": t, "alg_gbs": by / t / 1e6, "hbm_frac": by / t / 1e6 / HBM_PEAK_GBS,
@@ -449,6 +465,14 @@ def other_ops(dev):
     t = event_time_ms(lambda: capi.spmm_batched(s, s, d, reps, ri, probs, nnz, ro, ci, v, ctx, ws3), 20)
     by = reps * (4.0 * nnz + 8.0 * s * d) + 4.0 * nnz + 4.0 * (2 * s + 1)
     res["spmm_c3"] = {"ms": t, "gflops": 2.0 * nnz * d * reps / t / 1e6, "alg_gbs": by / t / 1e6}
+    try:   # half weights and half V, widened on the way into LDS (no pass of their own)
+        for name, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+            ph, vh = probs.to(dt), v.to(dt)
+            t = event_time_ms(lambda: capi.spmm_typed(s, s, d, reps, ri, ph, nnz, ro, ci, vh, ctx, ws3), 20)
+            res["spmm_c3_" + name] = {"ms": t, "gflops": 2.0 * nnz * d * reps / t / 1e6}
+        del ph, vh
+    except Exception as e0:  # noqa: BLE001 - extra metric, best effort
+        res["spmm_c3_fp16"] = {"error": str(e0)[:200]}
     try:
         # config 3's projections (modules/sparse_attention.py:108-126): a 512 x 512 weight at
         # density 0.1 against [512, 1024] x batch 8 (panel-resident kernel), its transposed
