@@ -479,9 +479,15 @@ void sddmm_quad_kernel(
   int wcol[kRing][kWin];
   piece_t lp[kRing];
   auto fetch = [&](int r, int slot_in_ring) {
-#pragma unroll
-    for (int w = 0; w < kWin; ++w)
-      wcol[slot_in_ring][w] = column_indices[min(ps[r] + 16 * w + e, last)];
+    // the first 32 entries of the row in this slab, as PAIRS: lane (q, t) takes entries
+    // 2e and 2e + 1 (e = 4t + q) -- one 8-byte load here, one 8-byte result store later
+    // (half the window-load and store instructions of one 16-entry window after the other)
+    // (the pair that would start at the very last entry is read one entry earlier)
+    // (nonzeros >= 4 m >= 64 on this path: last - 1 is a valid index)
+    const int want = ps[r] + 2 * e;
+    const int2 c2 = *reinterpret_cast<const int2*>(column_indices + min(want, last - 1));
+    wcol[slot_in_ring][0] = want >= last ? c2.y : c2.x;
+    wcol[slot_in_ring][1] = c2.y;
     const char* lrow = reinterpret_cast<const char*>(lhs + static_cast<int64_t>(row[r]) * ld);
     lp[slot_in_ring] = *reinterpret_cast<const piece_t*>(lrow + i * kPiece);
   };
@@ -522,19 +528,23 @@ void sddmm_quad_kernel(
       }
     }
     const int n_here = (debug & 1) ? 0 : max(cnt[r], 0);
-    auto window = [&](int ecol, int w0) {
-      const int left = n_here - w0;
-      const bool valid = e < left;
-      // a window no group of the wave has entries in is skipped (wave-uniform)
-      if (__builtin_amdgcn_ballot_w64(valid) == 0) return;
+    // the dot products of the entries whose (column, validity) the lanes hold: lane
+    // (q, t) gets the result of ITS entry
+    auto products = [&](int ecol, bool valid) -> float {
       asm volatile("" : : : "memory");   // (a window's reads stay behind the previous window's work)
       // (debug bit 4, wrong results: every entry reads slab row 0 -- what bank conflicts cost)
       const int roff = static_cast<int>(tile_base) + ((valid && !(debug & 4)) ? ((ecol - jc) * kRowBytes) : 0);
       float result = 0.f;
       // kGang steps (4 entries per group each) have their reads in flight together
       constexpr int kGang = C <= 2 ? 4 : C <= 4 ? 2 : 1;
+      // lane (q, t) is valid <=> its entry exists: step s is needed iff some lane with
+      // t == s is valid; a gang none of whose steps is needed is skipped (wave-uniform)
+      const unsigned long long need = __builtin_amdgcn_ballot_w64(valid);
       static_for<4 / kGang>([&](auto Gc) {
         constexpr int kG = decltype(Gc)::value * kGang;
+        constexpr unsigned long long kMask =
+            0x1111111111111111ull * ((1ull << (kG + kGang)) - (1ull << kG));
+        if ((need & kMask) == 0) return;   // (k = 128 in half, 13 entries per row and slab: 68 against 84 us)
         chunk b[kGang][C];
         static_for<kGang>([&](auto Sc) {
           constexpr int kS = kG + decltype(Sc)::value;
@@ -552,14 +562,37 @@ void sddmm_quad_kernel(
           result = (t == kS) ? total : result;
         });
       });
-      if (valid && !(debug & 16)) {   // (bit 16, wrong results: no stores)
-        TO* dst = out + cur_ps + w0 + e;
-        if constexpr (ACC) *dst = static_cast<TO>(static_cast<float>(*dst) + result);
-        else *dst = static_cast<TO>(result);
-      }
+      return result;
     };
-#pragma unroll
-    for (int w = 0; w < kWin; ++w) window(wcol[r % kRing][w], 16 * w);
+    auto put = [&](TO* dst, float result) {
+      if constexpr (ACC) *dst = static_cast<TO>(static_cast<float>(*dst) + result);
+      else *dst = static_cast<TO>(result);
+    };
+    // entries 0 .. 31 of the row in this slab: pairs (2e, 2e + 1)
+    {
+      const bool valid0 = 2 * e < n_here, valid1 = 2 * e + 1 < n_here;
+      // (a half no group of the wave has entries in is skipped: wave-uniform)
+      const float r0 = __builtin_amdgcn_ballot_w64(valid0) != 0 ? products(wcol[r % kRing][0], valid0) : 0.f;
+      const float r1 = __builtin_amdgcn_ballot_w64(valid1) != 0 ? products(wcol[r % kRing][1], valid1) : 0.f;
+      if (!(debug & 16)) {   // (bit 16, wrong results: no stores)
+        TO* dst = out + cur_ps + 2 * e;
+        if constexpr (!ACC && std::is_same_v<TO, float>) {
+          if (valid1) *reinterpret_cast<v2f*>(dst) = v2f{r0, r1};   // 8 bytes, 4-byte aligned
+          else if (valid0) *dst = r0;
+        } else {
+          if (valid0) put(dst, r0);
+          if (valid1) put(dst + 1, r1);
+        }
+      }
+    }
+    // beyond 32 entries of one row inside the slab: 16 at a time, fetched on demand
+    auto window = [&](int ecol, int w0) {
+      const int left = n_here - w0;
+      const bool valid = e < left;
+      if (__builtin_amdgcn_ballot_w64(valid) == 0) return;
+      const float result = products(ecol, valid);
+      if (valid && !(debug & 16)) put(out + cur_ps + w0 + e, result);
+    };
     const int longest =
         max(max(__builtin_amdgcn_readlane(n_here, 0), __builtin_amdgcn_readlane(n_here, 16)),
             max(__builtin_amdgcn_readlane(n_here, 32), __builtin_amdgcn_readlane(n_here, 48)));
