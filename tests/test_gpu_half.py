@@ -405,3 +405,74 @@ def test_spmm_half_large_k_is_widened_inside_the_call(capi, dev, tv, tb):
     out2 = torch.full_like(out, float("nan"))
     capi.spmm_typed(m, k, n, replicas, topo[0], v, 0, topo[1], topo[2], b, out2, None)
     assert rel_err_torch(out2, want) < TOL
+
+
+# ----------------------------------------------------------------------------
+# Fuzz: seeded random shapes around the tile boundaries, every row order, empty
+# rows, 1..4 replicas, both half types and the mixed pairings, each typed entry
+# point against the oracle on the rounded inputs.
+# ----------------------------------------------------------------------------
+ORDERS = ("descending", "ascending", "random", "identity")
+
+
+def _dims(rng, choices):
+    return max(1, int(rng.choice(choices)) + int(rng.integers(-3, 4)) * int(rng.random() < 0.5))
+
+
+def test_fuzz_typed_operators(capi, dev, sddmm_kernel):
+    rng = np.random.default_rng(20261004)
+    dummy_i = torch.zeros(1, dtype=torch.int32, device=dev)
+    for it in range(36):
+        m = _dims(rng, [16, 64, 128, 256, 300])
+        n = _dims(rng, [32, 64, 128, 256, 520])
+        sparsity = float(rng.choice([0.0, 0.5, 0.8, 0.9, 0.97]))
+        empty = tuple(int(x) for x in rng.integers(0, m, size=int(rng.integers(0, 3))))
+        order = ORDERS[int(rng.integers(0, len(ORDERS)))]
+        replicas = int(rng.integers(1, 5))
+        dtype = HALF_TYPES[it % 2]
+        _, vals, ri, ro, ci = make_csr(m, n, sparsity, seed=1000 + it, round_to=1, empty_rows=empty,
+                                       order=order)
+        nnz = len(ci)
+        topo = (T(ri, dev), T(ro, dev), T(ci, dev) if nnz else dummy_i)
+        what = (it, m, n, sparsity, order, replicas, str(dtype))
+
+        # SDDMM: [m, k] x [n, k] sampled at the mask
+        k = int(rng.choice([7, 32, 64, 64, 128, 192, 256, 512]))
+        lhs, lhs32 = rounded(rng.uniform(-1, 1, (replicas, m, k)), dtype, dev)
+        rhs, rhs32 = rounded(rng.uniform(-1, 1, (replicas, n, k)), dtype, dev)
+        want = c_oracle.sddmm(m, n, ro, ci, lhs32, rhs32)
+        out = torch.full((replicas, max(nnz, 1)), float("nan"), device=dev)[:, :nnz].contiguous()
+        ws = torch.empty(capi.sddmm_workspace_bytes(m, k, n, nnz) + 16, dtype=torch.uint8, device=dev)
+        capi.sddmm_typed(m, k, n, replicas, *topo, lhs, rhs, out, ws)
+        if nnz:
+            got = out.cpu().numpy()
+            assert not np.isnan(got).any(), what
+            assert rel_err(got, want, ro) < TOL, what + (k,)
+
+        # softmax pair on half scores
+        if nnz:
+            sc, sc32 = rounded(rng.uniform(-6, 6, (replicas, nnz)), dtype, dev)
+            y = torch.full_like(sc, float("nan"))
+            capi.sparse_softmax_typed(m, replicas, sc, *topo, 0.5, y)
+            want_y = c_oracle.sparse_softmax((sc32.astype(np.float64) * 0.5).astype(np.float32), ro, ci)
+            assert half_err(y.float().cpu().numpy(), want_y, dtype, ro) < 2 * TOL, what
+            g, g32 = rounded(rng.uniform(-1, 1, (replicas, nnz)), dtype, dev)
+            dx = torch.full_like(sc, float("nan"))
+            capi.sparse_softmax_backward_typed(m, replicas, y, g, topo[1], 0.5, dx)
+            want_dx = O.sparse_softmax_backward(y.float().cpu().numpy(), g32, ro, 0.5)
+            assert half_err(dx.float().cpu().numpy(), want_dx, dtype, ro) < TOL, what
+
+        # SpMM: the mask as A [m, n], B [n, cols]
+        cols = int(rng.choice([1, 7, 18, 64, 128, 192, 256]))
+        shared = bool(rng.random() < 0.5)
+        tv, tb = [(dtype, dtype), (dtype, torch.float32), (torch.float32, dtype)][it % 3]
+        v, v32 = rounded(rng.uniform(-1, 1, (nnz,) if shared else (replicas, nnz)), tv, dev)
+        b, b32 = rounded(rng.uniform(-1, 1, (replicas, n, cols)), tb, dev)
+        want_c = np.stack([O.spmm(m, n, v32 if shared else v32[r], ri, ro, ci, b32[r])
+                           for r in range(replicas)])
+        c = torch.full((replicas, m, cols), float("nan"), device=dev)
+        capi.spmm_typed(m, n, cols, replicas, topo[0], v if nnz else torch.zeros(1, device=dev, dtype=tv),
+                        0 if shared else nnz, topo[1], topo[2], b, c)
+        got_c = c.cpu().numpy()
+        assert not np.isnan(got_c).any(), what
+        assert rel_err(got_c, want_c) < TOL, what + (cols, shared, str(tv), str(tb))
