@@ -485,11 +485,15 @@ void sddmm_quad_kernel(
     // (the pair that would start at the very last entry is read one entry earlier)
     // (nonzeros >= 4 m >= 64 on this path: last - 1 is a valid index)
     const int want = ps[r] + 2 * e;
-    const int2 c2 = *reinterpret_cast<const int2*>(column_indices + min(want, last - 1));
+    // (uniform base + 32-bit byte offset: no 64-bit vector arithmetic per address)
+    const int2 c2 = *reinterpret_cast<const int2*>(
+        reinterpret_cast<const char*>(column_indices) + static_cast<unsigned>(min(want, last - 1)) * 4u);
     wcol[slot_in_ring][0] = want >= last ? c2.y : c2.x;
     wcol[slot_in_ring][1] = c2.y;
-    const char* lrow = reinterpret_cast<const char*>(lhs + static_cast<int64_t>(row[r]) * ld);
-    lp[slot_in_ring] = *reinterpret_cast<const piece_t*>(lrow + i * kPiece);
+    lp[slot_in_ring] = *reinterpret_cast<const piece_t*>(
+        reinterpret_cast<const char*>(lhs) +
+        (static_cast<unsigned>(row[r]) * static_cast<unsigned>(ld) * static_cast<unsigned>(sizeof(T)) +
+         static_cast<unsigned>(i * kPiece)));
   };
 #pragma unroll
   for (int r = 0; r < kRing - 1; ++r) fetch(r, r);
@@ -553,14 +557,25 @@ void sddmm_quad_kernel(
             b[kS - kG][c] = *reinterpret_cast<const __attribute__((address_space(3))) chunk*>(
                 static_cast<unsigned>(quad_bcast_add<kS>(roff, coff[c])));
         });
-        static_for<kGang>([&](auto Sc) {
-          constexpr int kS = kG + decltype(Sc)::value;
-          v2f acc = {0.f, 0.f};
+        // the gang's dot products side by side: every multiply-add and every reduction
+        // step has an independent neighbour (alone, each chain paid a hazard nop per link)
+        v2f acc[kGang];
 #pragma unroll
-          for (int c = 0; c < C; ++c) Dot<T>::mac(acc, cur_lf[c], b[kS - kG][c]);
-          const float total = group_sum<4>(acc.x + acc.y);
-          result = (t == kS) ? total : result;
-        });
+        for (int u = 0; u < kGang; ++u) acc[u] = v2f{0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+#pragma unroll
+          for (int u = 0; u < kGang; ++u) Dot<T>::mac(acc[u], cur_lf[c], b[u][c]);
+        }
+        float d[kGang];
+#pragma unroll
+        for (int u = 0; u < kGang; ++u) d[u] = acc[u].x + acc[u].y;
+#pragma unroll
+        for (int u = 0; u < kGang; ++u) d[u] += dpp_f32<kDppQuadXor1>(d[u]);
+#pragma unroll
+        for (int u = 0; u < kGang; ++u) d[u] += dpp_f32<kDppQuadXor2>(d[u]);
+#pragma unroll
+        for (int u = 0; u < kGang; ++u) result = (t == kG + u) ? d[u] : result;
       });
       return result;
     };
@@ -568,6 +583,17 @@ void sddmm_quad_kernel(
       if constexpr (ACC) *dst = static_cast<TO>(static_cast<float>(*dst) + result);
       else *dst = static_cast<TO>(result);
     };
+    // More than 32 entries of a row inside the slab (9 % of the visits at config 3,
+    // i.e. a third of the wave steps): their columns are requested BEFORE the pairs are
+    // worked on, each further window one ahead -- fetched on demand, every such step
+    // waited a whole memory latency.
+    const int longest =
+        max(max(__builtin_amdgcn_readlane(n_here, 0), __builtin_amdgcn_readlane(n_here, 16)),
+            max(__builtin_amdgcn_readlane(n_here, 32), __builtin_amdgcn_readlane(n_here, 48)));
+    int col_next = 0;
+    if (longest > 32)
+      col_next = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(column_indices) +
+                                               static_cast<unsigned>(min(cur_ps + 32 + e, last)) * 4u);
     // entries 0 .. 31 of the row in this slab: pairs (2e, 2e + 1)
     {
       const bool valid0 = 2 * e < n_here, valid1 = 2 * e + 1 < n_here;
@@ -575,7 +601,8 @@ void sddmm_quad_kernel(
       const float r0 = __builtin_amdgcn_ballot_w64(valid0) != 0 ? products(wcol[r % kRing][0], valid0) : 0.f;
       const float r1 = __builtin_amdgcn_ballot_w64(valid1) != 0 ? products(wcol[r % kRing][1], valid1) : 0.f;
       if (!(debug & 16)) {   // (bit 16, wrong results: no stores)
-        TO* dst = out + cur_ps + 2 * e;
+        TO* dst = reinterpret_cast<TO*>(reinterpret_cast<char*>(out) +
+                                        static_cast<unsigned>(cur_ps + 2 * e) * static_cast<unsigned>(sizeof(TO)));
         if constexpr (!ACC && std::is_same_v<TO, float>) {
           if (valid1) *reinterpret_cast<v2f*>(dst) = v2f{r0, r1};   // 8 bytes, 4-byte aligned
           else if (valid0) *dst = r0;
@@ -593,11 +620,11 @@ void sddmm_quad_kernel(
       const float result = products(ecol, valid);
       if (valid && !(debug & 16)) put(out + cur_ps + w0 + e, result);
     };
-    const int longest =
-        max(max(__builtin_amdgcn_readlane(n_here, 0), __builtin_amdgcn_readlane(n_here, 16)),
-            max(__builtin_amdgcn_readlane(n_here, 32), __builtin_amdgcn_readlane(n_here, 48)));
-    for (int w0 = 16 * kWin; w0 < longest; w0 += 16)
-      window(column_indices[min(cur_ps + w0 + e, last)], w0);
+    for (int w0 = 32; w0 < longest; w0 += 16) {
+      const int col = col_next;
+      if (w0 + 16 < longest) col_next = column_indices[min(cur_ps + w0 + 16 + e, last)];
+      window(col, w0);
+    }
   });
 }
 
@@ -815,8 +842,9 @@ int sddmm_tiled_launch_partials(int m, int k, int n, int nonzeros, int replicas,
 bool sddmm_tiled_applicable(int m, int k, int n, int nonzeros, const float* lhs,
                             int64_t lhs_stride, const float* rhs, int64_t rhs_stride) {
   return served(k) && n >= 16 && m >= 16 && nonzeros >= 4 * static_cast<int64_t>(m) &&
-         static_cast<int64_t>(n) * k * 4 < (int64_t{1} << 32) && aligned_to(lhs, 16) &&
-         aligned_to(rhs, 16) && lhs_stride % 4 == 0 && rhs_stride % 4 == 0;
+         static_cast<int64_t>(n) * k * 4 < (int64_t{1} << 32) &&
+         static_cast<int64_t>(m) * k * 4 < (int64_t{1} << 32) && nonzeros < (1 << 29) &&
+         aligned_to(lhs, 16) && aligned_to(rhs, 16) && lhs_stride % 4 == 0 && rhs_stride % 4 == 0;
 }
 
 // `summed`: for sddmm_tiled_launch_partials (its panel width, hence its slabs and
@@ -873,8 +901,9 @@ int sddmm_tiled_launch(int m, int k, int n, int nonzeros, int replicas, const in
 bool sddmm_tiled_applicable_half(int m, int k, int n, int nonzeros, const void* lhs,
                                  int64_t lhs_stride, const void* rhs, int64_t rhs_stride) {
   return served(k) && n >= 16 && m >= 16 && nonzeros >= 4 * static_cast<int64_t>(m) &&
-         static_cast<int64_t>(n) * k * 2 < (int64_t{1} << 32) && aligned_to(lhs, 16) &&
-         aligned_to(rhs, 16) && lhs_stride % 8 == 0 && rhs_stride % 8 == 0;
+         static_cast<int64_t>(n) * k * 2 < (int64_t{1} << 32) &&
+         static_cast<int64_t>(m) * k * 2 < (int64_t{1} << 32) && nonzeros < (1 << 29) &&
+         aligned_to(lhs, 16) && aligned_to(rhs, 16) && lhs_stride % 8 == 0 && rhs_stride % 8 == 0;
 }
 // Kernel launches the plain product makes for one replica (more than one: later
 // passes add into the output, which a half OUTPUT would round every time).
