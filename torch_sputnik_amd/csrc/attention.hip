@@ -25,6 +25,15 @@
 //      offsets: the V tile sits at a fixed distance from the K tile).
 // Needs ascending columns inside rows (checked by the shared pre-pass); row
 // blocks that fail take an order-independent path (K, V gathered from L2).
+//
+// Round 3: step 1 in the QUAD form of sddmm_tiled.hip -- the four quads of a row group
+// work on four different entries, lane (quad q, t) holds a quarter of the scaled q row
+// (16 elements, chunk order rotated by q: no LDS bank conflict) and two quad_perm adds
+// close a dot product; lane (q, t) ends up with the score of entry 4t + q, which is
+// where that entry's column lives.  The kernel was 80 % busy issuing vector
+// instructions (profiles/r3e_pmc_sq_attention_ops.json: 46.5 M per launch), a third
+// of them the broadcasts and the 45-instruction transposing reduction of the 16-lane
+// form.  Steps 2 and 3 are unchanged (step 3 finds entry u in lane 4 (u % 4) + u / 4).
 #include "spmm_tiled_common.h"
 
 namespace sputnik_hip {
@@ -57,11 +66,20 @@ __device__ __forceinline__ void stage_kv(float* __restrict__ tile, const float* 
   }
 }
 
+using f4v = float __attribute__((ext_vector_type(4)));
+using v2f = float __attribute__((ext_vector_type(2)));
+
 struct RowAcc {
-  float4 q;    // scale * q fragment (elements 4i .. 4i+3)
+  f4v q[4];    // scale * q, elements 16t + 4((c + quad) % 4) .. +3 for c = 0..3 (lane = (quad, t))
   float4 acc;  // unnormalised output columns 4i .. 4i+3
   float mx, l;
 };
+
+template <int S>
+__device__ __forceinline__ int quad_bcast_add(int v, int add) {
+  // add + (v of lane S of the quad): v_add_u32_dpp quad_perm:[S,S,S,S]
+  return __builtin_amdgcn_update_dpp(0, v, S * 0x55, 0xF, 0xF, true) + add;
+}
 
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
   float s = a.x * b.x;
@@ -94,6 +112,8 @@ __global__ __launch_bounds__(kThreads) void sparse_attention_kernel(
   const int lane = threadIdx.x % kWave;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int g = lane >> 4, i = lane & 15;
+  const int qd = i >> 2, tq = i & 3;   // quad of the row group, lane of the quad
+  const int e16 = 4 * tq + qd;         // this lane's entry of a 16-entry window
   // (the row blocks of a replica read the same K and V: one XCD, see xcd_local_index)
   const unsigned long long work = xcd_local_index();
   const int mblock = static_cast<int>(work % gridDim.x);
@@ -112,10 +132,14 @@ __global__ __launch_bounds__(kThreads) void sparse_attention_kernel(
   for (int t = 0; t < kRQ; ++t) {
     const int entry = dealt_index(slot0 + 4 * t + g, slots, kBM);
     my_row[t] = entry < m ? row_indices[entry] : -1;
-    float4 qf = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (my_row[t] >= 0)
-      qf = *reinterpret_cast<const float4*>(q + static_cast<int64_t>(my_row[t]) * kD + 4 * i);
-    st[t].q = make_float4(qf.x * scale, qf.y * scale, qf.z * scale, qf.w * scale);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      f4v qf = {0.f, 0.f, 0.f, 0.f};
+      if (my_row[t] >= 0)
+        qf = *reinterpret_cast<const f4v*>(q + static_cast<int64_t>(my_row[t]) * kD + 16 * tq +
+                                           4 * ((c + qd) & 3));
+      st[t].q[c] = qf * scale;
+    }
     st[t].acc = make_float4(0.f, 0.f, 0.f, 0.f);
     st[t].mx = -INFINITY;
     st[t].l = 0.f;
@@ -140,11 +164,17 @@ __global__ __launch_bounds__(kThreads) void sparse_attention_kernel(
     for (int t = 0; t < kRQ; ++t) {
       const int p0 = my_row[t] >= 0 ? row_offsets[my_row[t]] : 0;
       const int p1 = my_row[t] >= 0 ? row_offsets[my_row[t] + 1] : 0;
+      float4 q16 = make_float4(0.f, 0.f, 0.f, 0.f);   // elements 4i .. 4i+3 of scale * q
+      if (my_row[t] >= 0) {
+        const float4 qf =
+            *reinterpret_cast<const float4*>(q + static_cast<int64_t>(my_row[t]) * kD + 4 * i);
+        q16 = make_float4(qf.x * scale, qf.y * scale, qf.z * scale, qf.w * scale);
+      }
       for (int p = p0; p < p1; ++p) {
         const int64_t base = static_cast<int64_t>(column_indices[p]) * kD + 4 * i;
         const float4 kf = *reinterpret_cast<const float4*>(k + base);
         const float4 vf = *reinterpret_cast<const float4*>(v + base);
-        const float s = group_sum<16>(dot4(st[t].q, kf));
+        const float s = group_sum<16>(dot4(q16, kf));
         if (s > st[t].mx) rescale(st[t], s);
         const float e = __expf(s - st[t].mx);
         st[t].l += e;
@@ -165,7 +195,7 @@ __global__ __launch_bounds__(kThreads) void sparse_attention_kernel(
     ps[t] = my_table[4 * t];
     pe[t] = my_table[slots + 4 * t];
 #pragma unroll
-    for (int w = 0; w < kWin; ++w) wcol[t][w] = column_indices[min(ps[t] + 16 * w + i, last)];
+    for (int w = 0; w < kWin; ++w) wcol[t][w] = column_indices[min(ps[t] + 16 * w + e16, last)];
   }
 
   stage_kv(tile[0], k, v, n, 0, wave, lane);
@@ -183,12 +213,14 @@ __global__ __launch_bounds__(kThreads) void sparse_attention_kernel(
       pe_next[t] = more ? my_table[static_cast<int64_t>(c + 2) * slots + 4 * t] : pe[t];
 #pragma unroll
       for (int w = 0; w < kWin; ++w)
-        ncol[t][w] = more ? column_indices[min(pe[t] + 16 * w + i, last)] : 0;
+        ncol[t][w] = more ? column_indices[min(pe[t] + 16 * w + e16, last)] : 0;
     }
 
     const char* __restrict__ k_base = reinterpret_cast<const char*>(&tile[buf][0] + i * 4);
     const char* __restrict__ v_base = k_base + kTileFloats * sizeof(float);
     const int jc = c * kBK;
+    const int k_lds = static_cast<int>(static_cast<unsigned>(
+        reinterpret_cast<uintptr_t>(AS_LDS(&tile[buf][0]))));   // LDS byte address of the K tile
 
 #pragma unroll
     for (int t = 0; t < kRQ; ++t) {
@@ -197,31 +229,32 @@ __global__ __launch_bounds__(kThreads) void sparse_attention_kernel(
       auto window = [&](int ecol, int w0) {
         const int left = cnt - w0;
         if (left <= 0) return;
-        const bool valid = i < left;
+        const bool valid = e16 < left;
         const int roff = valid ? ((ecol - jc) * (kD * 4)) : 0;
 
-        // 1. scores: partial dot products of entries G..G+3, then the transposing sum
-        float p[16];
+        // 1. scores, quad form: step S = entries 4S .. 4S+3, one per quad
+        float s = 0.f;
+        const int kq = k_lds + 64 * tq;   // this lane's quarter of tile row 0
+        auto scores4 = [&](auto Sc) {
+          constexpr int kS = decltype(Sc)::value;
+          f4v b[4];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) p[u] = 0.f;
-        auto scores4 = [&](auto G) {
-          constexpr int kG = decltype(G)::value;
-          const int o0 = row_bcast_i<kG + 0>(roff), o1 = row_bcast_i<kG + 1>(roff);
-          const int o2 = row_bcast_i<kG + 2>(roff), o3 = row_bcast_i<kG + 3>(roff);
-          const float4 b0 = *reinterpret_cast<const float4*>(k_base + o0);
-          const float4 b1 = *reinterpret_cast<const float4*>(k_base + o1);
-          const float4 b2 = *reinterpret_cast<const float4*>(k_base + o2);
-          const float4 b3 = *reinterpret_cast<const float4*>(k_base + o3);
-          p[kG + 0] = dot4(st[t].q, b0);
-          p[kG + 1] = dot4(st[t].q, b1);
-          p[kG + 2] = dot4(st[t].q, b2);
-          p[kG + 3] = dot4(st[t].q, b3);
+          for (int c = 0; c < 4; ++c)
+            b[c] = *reinterpret_cast<const __attribute__((address_space(3))) f4v*>(
+                static_cast<unsigned>(quad_bcast_add<kS>(roff, kq + 16 * ((c + qd) & 3))));
+          v2f a2 = {0.f, 0.f};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            a2 = __builtin_elementwise_fma(v2f{st[t].q[c].x, st[t].q[c].y}, v2f{b[c].x, b[c].y}, a2);
+            a2 = __builtin_elementwise_fma(v2f{st[t].q[c].z, st[t].q[c].w}, v2f{b[c].z, b[c].w}, a2);
+          }
+          const float total = group_sum<4>(a2.x + a2.y);
+          s = (tq == kS) ? total : s;
         };
         scores4(std::integral_constant<int, 0>{});
-        if (left > 4) scores4(std::integral_constant<int, 4>{});
-        if (left > 8) scores4(std::integral_constant<int, 8>{});
-        if (left > 12) scores4(std::integral_constant<int, 12>{});
-        float s = row_transpose_sum16(p, i);
+        if (left > 4) scores4(std::integral_constant<int, 1>{});
+        if (left > 8) scores4(std::integral_constant<int, 2>{});
+        if (left > 12) scores4(std::integral_constant<int, 3>{});
         s = valid ? s : -INFINITY;
 
         // 2. online softmax over the window (at least one entry is valid)
@@ -235,8 +268,9 @@ __global__ __launch_bounds__(kThreads) void sparse_attention_kernel(
         float a4[4] = {st[t].acc.x, st[t].acc.y, st[t].acc.z, st[t].acc.w};
         auto values4 = [&](auto G) {
           constexpr int kG = decltype(G)::value;
-          const entry_pair e0 = row_bcast_entry<kG + 0>(ent), e1 = row_bcast_entry<kG + 1>(ent);
-          const entry_pair e2 = row_bcast_entry<kG + 2>(ent), e3 = row_bcast_entry<kG + 3>(ent);
+          // (entries kG .. kG+3 of the window sit in lanes kG/4, 4 + kG/4, 8 + kG/4, 12 + kG/4)
+          const entry_pair e0 = row_bcast_entry<0 + kG / 4>(ent), e1 = row_bcast_entry<4 + kG / 4>(ent);
+          const entry_pair e2 = row_bcast_entry<8 + kG / 4>(ent), e3 = row_bcast_entry<12 + kG / 4>(ent);
           const float4 b0 = *reinterpret_cast<const float4*>(v_base + entry_off(e0));
           const float4 b1 = *reinterpret_cast<const float4*>(v_base + entry_off(e1));
           const float4 b2 = *reinterpret_cast<const float4*>(v_base + entry_off(e2));
@@ -258,7 +292,7 @@ __global__ __launch_bounds__(kThreads) void sparse_attention_kernel(
       const int longest = max(max(__builtin_amdgcn_readlane(cnt, 0), __builtin_amdgcn_readlane(cnt, 16)),
                               max(__builtin_amdgcn_readlane(cnt, 32), __builtin_amdgcn_readlane(cnt, 48)));
       for (int w0 = 16 * kWin; w0 < longest; w0 += 16)
-        window(column_indices[min(ps[t] + w0 + i, last)], w0);
+        window(column_indices[min(ps[t] + w0 + e16, last)], w0);
     }
 
 #pragma unroll
