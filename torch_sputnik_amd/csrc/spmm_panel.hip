@@ -39,6 +39,15 @@ constexpr int kPThreads = kPWaves * kWave;
 constexpr int kPMaxK = 512;   // rows of B per panel: 512 x 256 B = 128 KiB of LDS
 constexpr int kPMaxPasses = 8;
 
+// Element `idx` (>= 0) of an array behind a wave-uniform pointer: uniform base + 32-bit
+// byte offset, i.e. no 64-bit vector arithmetic per address (the window loads of the
+// stream loops: two per 16 entries and lane).
+template <typename E>
+__device__ __forceinline__ E at32(const E* __restrict__ base, int idx) {
+  return *reinterpret_cast<const E*>(reinterpret_cast<const char*>(base) +
+                                     static_cast<unsigned>(idx) * static_cast<unsigned>(sizeof(E)));
+}
+
 // Two independent row quads side by side: eight B strips in flight before the
 // first FMA, so that one quad's LDS latency is covered by the other's arithmetic.
 template <int G>
@@ -146,8 +155,8 @@ __device__ __forceinline__ void fetch_first_windows(const Rows& r, int (&ecol)[k
 #pragma unroll
   for (int t = 0; t < kPQuads; ++t) {
     const int idx = max(min(r.p0[t] + i, last), 0);
-    ecol[t] = column_indices[idx];
-    eval[t] = static_cast<float>(values[PERM ? value_permutation[idx] : idx]);
+    ecol[t] = at32(column_indices, idx);
+    eval[t] = static_cast<float>(at32(values, PERM ? at32(value_permutation, idx) : idx));
   }
 }
 
@@ -179,10 +188,10 @@ __device__ __forceinline__ void stream_pairs(float (&acc)[kPQuads][4], const Row
       if (w0 + 16 < longest) {
         idx_a = min(r.p0[t] + w0 + 16 + i, last);
         idx_b = min(r.p0[t + 1] + w0 + 16 + i, last);
-        ecol_a = column_indices[idx_a];
-        ecol_b = column_indices[idx_b];
-        eval_a = static_cast<float>(values[PERM ? value_permutation[idx_a] : idx_a]);
-        eval_b = static_cast<float>(values[PERM ? value_permutation[idx_b] : idx_b]);
+        ecol_a = at32(column_indices, idx_a);
+        ecol_b = at32(column_indices, idx_b);
+        eval_a = static_cast<float>(at32(values, PERM ? at32(value_permutation, idx_a) : idx_a));
+        eval_b = static_cast<float>(at32(values, PERM ? at32(value_permutation, idx_b) : idx_b));
       }
       const int left_a = n_a - w0, left_b = n_b - w0;
       const int roff_a = i < left_a ? col_a * (kPBN * 4) : 0;
@@ -222,15 +231,15 @@ __device__ __forceinline__ void stream_masked(float (&acc)[kPQuads][4], const Ro
     int first_later = longest;         // (rounded up below: "nothing left")
     bool seen_later = false;
     int idx = max(min(r.p0[t] + begin + i, last), 0);
-    int ecol = column_indices[idx];
-    float eval = static_cast<float>(values[PERM ? value_permutation[idx] : idx]);
+    int ecol = at32(column_indices, idx);
+    float eval = static_cast<float>(at32(values, PERM ? at32(value_permutation, idx) : idx));
     for (int w0 = begin; w0 < longest; w0 += 16) {
       const int cur_col = ecol - kbase;
       const float cur_val = eval;
       if (w0 + 16 < longest) {
         idx = min(r.p0[t] + w0 + 16 + i, last);
-        ecol = column_indices[idx];
-        eval = static_cast<float>(values[PERM ? value_permutation[idx] : idx]);
+        ecol = at32(column_indices, idx);
+        eval = static_cast<float>(at32(values, PERM ? at32(value_permutation, idx) : idx));
       }
       const int left = n_here - w0;   // entries of this group's row at or after the window start
       const bool in_row = i < left;
@@ -583,7 +592,8 @@ bool spmm_panel_applicable(int m, int k, int n, int nonzeros, const float* dense
   if (device_lds_bytes() < kPMaxK * kPBN * sizeof(float)) return false;
   return k >= 1 && k <= kPMaxK * kPMaxPasses && n % 4 == 0 && n >= kPBN && m >= 16 &&
          static_cast<int64_t>(k) * n * 4 < (int64_t{1} << 32) && aligned_to(dense, 16) &&
-         aligned_to(out, 16) && dense_stride % 4 == 0 && out_stride % 4 == 0 && nonzeros >= 0;
+         aligned_to(out, 16) && dense_stride % 4 == 0 && out_stride % 4 == 0 && nonzeros >= 0 &&
+         nonzeros < (1 << 29);   // (32-bit byte offsets into the entry arrays, at32)
 }
 
 int spmm_panel_launch(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
@@ -647,7 +657,8 @@ bool spmm_panel_applicable_typed(int m, int k, int n, int nonzeros, const void* 
   const size_t piece = dense_type == SPUTNIK_HIP_F32 ? 16 : 8;
   return k >= 1 && k <= kPMaxK * kPMaxPasses && n % 4 == 0 && n >= kPBN && m >= 16 &&
          static_cast<int64_t>(k) * n * 4 < (int64_t{1} << 32) && aligned_to(dense, piece) &&
-         aligned_to(out, 16) && dense_stride % 4 == 0 && out_stride % 4 == 0 && nonzeros >= 0;
+         aligned_to(out, 16) && dense_stride % 4 == 0 && out_stride % 4 == 0 && nonzeros >= 0 &&
+         nonzeros < (1 << 29);   // (32-bit byte offsets into the entry arrays, at32)
 }
 
 template <typename TV, typename TB>
@@ -746,7 +757,7 @@ int spmm_panel_group_launch(int m, int k, int n, int replicas, int count,
   bool all_perm = true, any_perm = false;
   for (int p = 0; p < count; ++p) {
     const GroupProblemHost& h = problems[p];
-    if (h.nonzeros <= 0 || !aligned_to(h.dense, 16) || !aligned_to(h.out, 16))
+    if (h.nonzeros <= 0 || h.nonzeros >= (1 << 29) || !aligned_to(h.dense, 16) || !aligned_to(h.out, 16))
       return SPUTNIK_HIP_UNSUPPORTED;
     if (accumulate && h.out != problems[0].out) return SPUTNIK_HIP_INVALID_ARGUMENT;
     all_perm = all_perm && h.value_permutation != nullptr;
