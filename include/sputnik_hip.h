@@ -274,6 +274,23 @@ SPUTNIK_HIP_API int sputnik_hip_sparse_softmax_batched(int m, int n, int nonzero
                                        int64_t out_stride,
                                        sputnik_hip_stream_t stream);
 
+/*
+ * csr_transpose of values stored as `values_type` (SPUTNIK_HIP_F32 / F16 / BF16); the
+ * transposed values are float32 (what the products of the backward passes take,
+ * modules/sparse_linear.py:52-63).  Half values are read through the permutation by
+ * the one gather that moves them: no widened copy of the input.  The half forms need
+ * `out_permutation` (nonzeros ints); workspace as sputnik_hip_csr_transpose; `checked`
+ * != 0 = sputnik_hip_csr_transpose_checked's behaviour (waits for the stream, reports a
+ * pattern the transpose is not defined for).
+ */
+SPUTNIK_HIP_API int sputnik_hip_csr_transpose_typed(int m, int n, int nonzeros, int replicas,
+                              const void* values, int values_type, int64_t values_stride,
+                              const int* row_offsets, const int* column_indices,
+                              float* out_values, int64_t out_values_stride,
+                              int* out_row_offsets, int* out_column_indices,
+                              int* out_permutation, void* workspace, size_t workspace_bytes,
+                              int checked, sputnik_hip_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * CSR transpose  CSR(m x n) -> CSR(n x m), stable (source rows ascend within
  * each output row: the ordering of cuSPARSE CSR2CSC_ALG1).

@@ -476,3 +476,46 @@ def test_fuzz_typed_operators(capi, dev, sddmm_kernel):
         got_c = c.cpu().numpy()
         assert not np.isnan(got_c).any(), what
         assert rel_err(got_c, want_c) < TOL, what + (cols, shared, str(tv), str(tb))
+
+
+# ----------------------------------------------------------------------------
+# csr_transpose of half values: topology bit-exact, values widened by the gather
+# ----------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", HALF_TYPES)
+@pytest.mark.parametrize("m,n,sparsity,replicas", [(72, 64, 0.8, 1), (257, 1000, 0.9, 1),
+                                                   (2048, 2048, 0.8, 1), (1500, 300, 0.5, 3),
+                                                   (64, 20000, 0.99, 1), (3000, 64, 0.3, 2)])
+def test_transpose_half_values_bit_exact(capi, dev, dtype, m, n, sparsity, replicas):
+    _, vals, _, ro, ci = make_csr(m, n, sparsity, seed=m + 3 * n, round_to=1)
+    rng = np.random.default_rng(n)
+    v, v32 = rounded(vals if replicas == 1 else rng.uniform(size=(replicas, len(vals))), dtype, dev)
+    want = O.csr_transpose(m, n, v32, ro, ci)
+    nnz = len(ci)
+    out_v = torch.full(v32.shape, float("nan"), device=dev)
+    out_ro = torch.full((n + 1,), -1, dtype=torch.int32, device=dev)
+    out_ci = torch.full((nnz,), -1, dtype=torch.int32, device=dev)
+    perm = torch.full((nnz,), -1, dtype=torch.int32, device=dev)
+    ws = torch.empty(capi.csr_transpose_workspace_bytes(m, n, nnz) + 16, dtype=torch.uint8, device=dev)
+    for checked in (False, True):
+        capi.csr_transpose_typed(m, n, replicas, v, T(ro, dev), T(ci, dev), out_v, out_ro, out_ci,
+                                 perm, ws, checked=checked)
+        assert np.array_equal(out_v.cpu().numpy(), np.asarray(want[0], np.float32))   # exact: a move
+        assert np.array_equal(out_ro.cpu().numpy(), want[1])
+        assert np.array_equal(out_ci.cpu().numpy(), want[2])
+        assert np.array_equal(v32.reshape(-1, nnz)[:, perm.cpu().numpy()].reshape(v32.shape),
+                              out_v.cpu().numpy())
+
+
+@pytest.mark.parametrize("dtype", HALF_TYPES)
+def test_transpose_half_op(ts, dev, dtype):
+    import torch_sputnik_amd as tsa
+    m, n = 300, 500
+    _, vals, _, ro, ci = make_csr(m, n, 0.8, seed=17, round_to=1)
+    v, v32 = rounded(vals, dtype, dev)
+    want = O.csr_transpose(m, n, v32, ro, ci)
+    vt, rot, cit = ts.csr_transpose(m, n, v, T(ro, dev), T(ci, dev))
+    assert vt.dtype == torch.float32
+    assert np.array_equal(vt.cpu().numpy(), np.asarray(want[0], np.float32))
+    assert np.array_equal(rot.cpu().numpy(), want[1]) and np.array_equal(cit.cpu().numpy(), want[2])
+    vt2, _, _, perm = tsa.ops.csr_transpose_with_permutation(m, n, v, T(ro, dev), T(ci, dev))
+    assert torch.equal(vt2, vt) and torch.equal(v.float()[perm.long()], vt)

@@ -87,6 +87,9 @@ SIGNATURES = {
         _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_float, _c_ptr, _c_i64, _c_ptr]),
     "sputnik_hip_sparse_softmax_backward_batched": (_c_int, [_c_int] * 3 + [
         _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_float, _c_ptr, _c_i64, _c_ptr]),
+    "sputnik_hip_csr_transpose_typed": (_c_int, [_c_int] * 4 + [_c_ptr, _c_int, _c_i64, _c_ptr, _c_ptr,
+                                                               _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr,
+                                                               _c_ptr, _c_size, _c_int, _c_ptr]),
     "sputnik_hip_spmm_typed_workspace_bytes": (_c_size, [_c_int] * 6 + [_c_i64, _c_int]),
     "sputnik_hip_spmm_typed": (_c_int, [_c_int] * 5 + [_c_ptr, _c_ptr, _c_int, _c_i64, _c_ptr, _c_ptr,
                                                       _c_ptr, _c_int, _c_i64, _c_ptr, _c_int, _c_ptr,
@@ -358,6 +361,20 @@ def _type_code(*tensors):
         raise TypeError("operands must share one of float32 / float16 / bfloat16, got "
                         + ", ".join(str(t.dtype) for t in tensors))
     return TYPE_CODES[dtype]
+
+
+def csr_transpose_typed(m, n, replicas, values, row_offsets, column_indices, out_values,
+                        out_row_offsets, out_column_indices, out_permutation, workspace,
+                        checked=False):
+    """csr_transpose of float32 / float16 / bfloat16 values; transposed values float32."""
+    nonzeros = column_indices.numel()
+    _require(out_values, torch.float32, "out_values")
+    _check(lib().sputnik_hip_csr_transpose_typed(
+        m, n, nonzeros, replicas, _ptr(values), _type_code(values), nonzeros, _ptr(row_offsets),
+        _ptr(column_indices), _ptr(out_values), nonzeros, _ptr(out_row_offsets),
+        _ptr(out_column_indices), _ptr(out_permutation), _ptr(workspace), _ws_bytes(workspace),
+        int(bool(checked)), _stream(out_values)), "sputnik_hip_csr_transpose_typed")
+    return out_values
 
 
 def spmm_typed_workspace_bytes(m, k, n, nonzeros, replicas, values, values_stride, dense):

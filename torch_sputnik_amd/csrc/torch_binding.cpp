@@ -741,7 +741,10 @@ std::vector<Tensor> csr_transpose_impl(int64_t m64, int64_t n64, const Tensor& v
                                        const Tensor& row_offsets_in,
                                        const Tensor& column_indices_in, bool want_permutation) {
   const int m = to_int(m64, "m"), n = to_int(n64, "n");
-  const Tensor values = as_float(values_in, "values");
+  // float16 / bfloat16 values are read as they are by the gather that moves them
+  // (sputnik_hip_csr_transpose_typed); the transposed values are float32 either way
+  const Tensor values = as_storage(values_in, "values");
+  const bool half_values = values.scalar_type() != at::kFloat;
   TORCH_CHECK(values.dim() == 1 || values.dim() == 2,
               "values should have 1 (or, as an extension, 2) dimensions, got ", values.dim());
   const c10::DeviceGuard guard(values.device());
@@ -756,11 +759,11 @@ std::vector<Tensor> csr_transpose_impl(int64_t m64, int64_t n64, const Tensor& v
   const int replicas = values.dim() == 2 ? to_int(values.size(0), "replicas") : 1;
 
   const auto index_options = values.options().dtype(at::kInt);
-  Tensor out_values = at::empty_like(values);
+  Tensor out_values = at::empty(values.sizes(), values.options().dtype(at::kFloat));
   Tensor out_row_offsets = at::empty({n + 1}, index_options);
   Tensor out_column_indices = at::empty({nonzeros}, index_options);
   Tensor permutation;
-  if (want_permutation) permutation = at::empty({nonzeros}, index_options);
+  if (want_permutation || half_values) permutation = at::empty({nonzeros}, index_options);
 
   const size_t ws_bytes = sputnik_hip_csr_transpose_workspace_bytes(m, n, nonzeros);
   Tensor workspace =
@@ -770,14 +773,24 @@ std::vector<Tensor> csr_transpose_impl(int64_t m64, int64_t n64, const Tensor& v
   // ONCE per static topology: it takes the checked entry, which waits for the stream and
   // reports a pattern the transpose is not defined for (a row storing a column twice, a
   // column out of range) instead of handing out a silently wrong permutation.
-  const auto entry = want_permutation ? sputnik_hip_csr_transpose_checked : sputnik_hip_csr_transpose;
-  const int status =
-      entry(m, n, nonzeros, replicas, values.data_ptr<float>(), nonzeros,
-            row_offsets.data_ptr<int>(), column_indices.data_ptr<int>(),
-            out_values.data_ptr<float>(), nonzeros, out_row_offsets.data_ptr<int>(),
-            out_column_indices.data_ptr<int>(),
-            want_permutation ? permutation.data_ptr<int>() : nullptr, workspace.data_ptr(),
-            ws_bytes, current_stream(values));
+  int status;
+  if (half_values) {
+    status = sputnik_hip_csr_transpose_typed(
+        m, n, nonzeros, replicas, values.data_ptr(), type_code(values.scalar_type()), nonzeros,
+        row_offsets.data_ptr<int>(), column_indices.data_ptr<int>(), out_values.data_ptr<float>(),
+        nonzeros, out_row_offsets.data_ptr<int>(), out_column_indices.data_ptr<int>(),
+        permutation.data_ptr<int>(), workspace.data_ptr(), ws_bytes, want_permutation ? 1 : 0,
+        current_stream(values));
+  } else {
+    const auto entry =
+        want_permutation ? sputnik_hip_csr_transpose_checked : sputnik_hip_csr_transpose;
+    status = entry(m, n, nonzeros, replicas, values.data_ptr<float>(), nonzeros,
+                   row_offsets.data_ptr<int>(), column_indices.data_ptr<int>(),
+                   out_values.data_ptr<float>(), nonzeros, out_row_offsets.data_ptr<int>(),
+                   out_column_indices.data_ptr<int>(),
+                   want_permutation ? permutation.data_ptr<int>() : nullptr, workspace.data_ptr(),
+                   ws_bytes, current_stream(values));
+  }
   TORCH_CHECK(!(want_permutation && status == SPUTNIK_HIP_INVALID_ARGUMENT),
               "torch_sputnik::csr_transpose_with_permutation: the pattern is not a valid CSR "
               "matrix for a transpose (a row stores a column twice, or a column index is out of "

@@ -234,14 +234,17 @@ __global__ __launch_bounds__(kBlock) void transpose_sparse_rank_kernel(
   }
 }
 
+// out_values[r][i] = values[r][permutation[i]], widened to float if T is a half type.
+template <typename T = float>
 __global__ __launch_bounds__(kBlock) void transpose_sparse_values_kernel(
-    int nonzeros, int replicas, const float* __restrict__ values, int64_t values_stride,
+    int nonzeros, int replicas, const T* __restrict__ values, int64_t values_stride,
     const int* __restrict__ permutation, float* __restrict__ out_values,
     int64_t out_values_stride) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= nonzeros) return;
   const int p = permutation[i];
-  for (int r = 0; r < replicas; ++r) out_values[r * out_values_stride + i] = values[r * values_stride + p];
+  for (int r = 0; r < replicas; ++r)
+    out_values[r * out_values_stride + i] = static_cast<float>(values[r * values_stride + p]);
 }
 
 // table[chunk][c] = sum of popc(gmask[chunk'][c]) over chunk' < chunk;
@@ -622,7 +625,7 @@ int sputnik_hip_csr_transpose(int m, int n, int nonzeros, int replicas, const fl
     hipLaunchKernelGGL(transpose_sparse_rank_kernel, dim3(ceil_div(n, kWaves)), dim3(kBlock), 0,
                        stream, n, out_row_offsets, tmp_row, tmp_src, out_column_indices, perm,
                        status);
-    hipLaunchKernelGGL(transpose_sparse_values_kernel, dim3(ceil_div(nonzeros, kBlock)),
+    hipLaunchKernelGGL(transpose_sparse_values_kernel<float>, dim3(ceil_div(nonzeros, kBlock)),
                        dim3(kBlock), 0, stream, nonzeros, replicas, values, values_stride, perm,
                        out_values, out_values_stride);
     return launch_status();
@@ -691,6 +694,41 @@ int sputnik_hip_csr_transpose_checked(int m, int n, int nonzeros, int replicas,
   if (e == hipSuccess) e = hipStreamSynchronize(stream);
   if (e != hipSuccess) return static_cast<int>(e);
   return status != 0 ? SPUTNIK_HIP_INVALID_ARGUMENT : 0;
+}
+
+// values stored as float16 / bfloat16: the transposition (topology and permutation) runs
+// without touching them, then ONE gather reads the half values through the permutation
+// and writes float32 -- the widening rides on the move every value makes anyway.
+int sputnik_hip_csr_transpose_typed(int m, int n, int nonzeros, int replicas, const void* values,
+                                    int values_type, int64_t values_stride,
+                                    const int* row_offsets, const int* column_indices,
+                                    float* out_values, int64_t out_values_stride,
+                                    int* out_row_offsets, int* out_column_indices,
+                                    int* out_permutation, void* workspace, size_t workspace_bytes,
+                                    int checked, sputnik_hip_stream_t stream) {
+  const auto base = checked ? sputnik_hip_csr_transpose_checked : sputnik_hip_csr_transpose;
+  if (values_type == SPUTNIK_HIP_F32)
+    return base(m, n, nonzeros, replicas, static_cast<const float*>(values), values_stride,
+                row_offsets, column_indices, out_values, out_values_stride, out_row_offsets,
+                out_column_indices, out_permutation, workspace, workspace_bytes, stream);
+  if ((values_type != SPUTNIK_HIP_F16 && values_type != SPUTNIK_HIP_BF16) || replicas < 0 ||
+      (out_permutation == nullptr && m > 0 && n > 0 && nonzeros > 0) || !aligned_to(values, 2))
+    return SPUTNIK_HIP_INVALID_ARGUMENT;   // (the half forms need the permutation array)
+  const int st = base(m, n, nonzeros, /*replicas=*/0, nullptr, 0, row_offsets, column_indices,
+                      nullptr, 0, out_row_offsets, out_column_indices, out_permutation, workspace,
+                      workspace_bytes, stream);
+  if (st != 0 || m <= 0 || n <= 0 || nonzeros <= 0 || replicas == 0) return st;
+  if (values_type == SPUTNIK_HIP_F16)
+    hipLaunchKernelGGL(transpose_sparse_values_kernel<_Float16>, dim3(ceil_div(nonzeros, kBlock)),
+                       dim3(kBlock), 0, stream, nonzeros, replicas,
+                       static_cast<const _Float16*>(values), values_stride, out_permutation,
+                       out_values, out_values_stride);
+  else
+    hipLaunchKernelGGL(transpose_sparse_values_kernel<__bf16>, dim3(ceil_div(nonzeros, kBlock)),
+                       dim3(kBlock), 0, stream, nonzeros, replicas,
+                       static_cast<const __bf16*>(values), values_stride, out_permutation,
+                       out_values, out_values_stride);
+  return launch_status();
 }
 
 }  // extern "C"
