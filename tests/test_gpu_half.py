@@ -519,3 +519,93 @@ def test_transpose_half_op(ts, dev, dtype):
     assert np.array_equal(rot.cpu().numpy(), want[1]) and np.array_equal(cit.cpu().numpy(), want[2])
     vt2, _, _, perm = tsa.ops.csr_transpose_with_permutation(m, n, v, T(ro, dev), T(ci, dev))
     assert torch.equal(vt2, vt) and torch.equal(v.float()[perm.long()], vt)
+
+
+# ----------------------------------------------------------------------------
+# The autograd Functions on half tensors (user code that calls Spmm / Sddmm /
+# SparseSoftmax with float16 / bfloat16 operands): forward float32 from the rounded
+# operands at 1e-4, gradients in the operands' types at their resolution.
+# ----------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def tsa():
+    import torch_sputnik_amd
+    return torch_sputnik_amd
+
+
+def _grad_tol(dtype):   # a gradient returned in `dtype`: its rounding on top of the chain's 5e-4
+    return 2e-3 if dtype == torch.float16 else 1.2e-2
+
+
+@pytest.mark.parametrize("dtype", HALF_TYPES)
+@pytest.mark.parametrize("m,k,n,replicas,sparsity", [(256, 192, 128, 1, 0.8), (512, 512, 512, 1, 0.9),
+                                                     (256, 320, 256, 3, 0.85)])
+def test_spmm_function_half_vs_dense_autograd(tsa, dev, dtype, m, k, n, replicas, sparsity):
+    from tests.helpers import rel_err_torch
+    _, vals, ri, ro, ci = make_csr(m, k, sparsity, seed=m + k, order="ascending")
+    rng = np.random.default_rng(n)
+    shape_v = (len(vals),) if replicas == 1 else (replicas, len(vals))
+    shape_b = (k, n) if replicas == 1 else (replicas, k, n)
+    v = T(rng.uniform(-1, 1, shape_v).astype(np.float32), dev).to(dtype).requires_grad_(True)
+    b = T(rng.uniform(-1, 1, shape_b).astype(np.float32), dev).to(dtype).requires_grad_(True)
+    go = T(rng.uniform(-1, 1, shape_b[:-2] + (m, n)).astype(np.float32), dev)
+    d_ri, d_ro, d_ci = T(ri, dev), T(ro, dev), T(ci, dev)
+    out = tsa.Spmm.apply(m, k, v, d_ri, d_ro, d_ci, b)
+    assert out.dtype == torch.float32
+    out.backward(go)
+    vd = v.detach().double().requires_grad_(True)
+    bd = b.detach().double().requires_grad_(True)
+    rows = torch.repeat_interleave(torch.arange(m, device=dev), (d_ro[1:] - d_ro[:-1]).long())
+    a = torch.zeros(shape_v[:-1] + (m, k), dtype=torch.float64, device=dev)
+    a[..., rows, d_ci.long()] = vd
+    want = torch.matmul(a, bd)
+    want.backward(go.double())
+    assert rel_err_torch(out.detach(), want.detach()) < TOL
+    assert b.grad.dtype == dtype and v.grad.dtype == dtype
+    assert rel_err_torch(b.grad.float(), bd.grad) < _grad_tol(dtype)
+    assert rel_err(v.grad.float().cpu().numpy(), vd.grad.cpu().numpy(), ro) < _grad_tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", HALF_TYPES)
+@pytest.mark.parametrize("m,k,n,replicas,sparsity", [(256, 64, 256, 1, 0.9), (512, 512, 384, 1, 0.8),
+                                                     (256, 128, 256, 4, 0.9)])
+def test_sddmm_function_half_vs_dense_autograd(tsa, dev, dtype, m, k, n, replicas, sparsity):
+    from tests.helpers import rel_err_torch
+    _, _, ri, ro, ci = make_csr(m, n, sparsity, seed=m + n, order="ascending")
+    rng = np.random.default_rng(k)
+    lead = () if replicas == 1 else (replicas,)
+    lhs = T(rng.uniform(-1, 1, lead + (m, k)).astype(np.float32), dev).to(dtype).requires_grad_(True)
+    rhs = T(rng.uniform(-1, 1, lead + (n, k)).astype(np.float32), dev).to(dtype).requires_grad_(True)
+    go = T(rng.uniform(-1, 1, lead + (len(ci),)).astype(np.float32), dev)
+    d_ri, d_ro, d_ci = T(ri, dev), T(ro, dev), T(ci, dev)
+    out = tsa.Sddmm.apply(m, n, d_ri, d_ro, d_ci, lhs, rhs)
+    assert out.dtype == torch.float32
+    out.backward(go)
+    ld = lhs.detach().double().requires_grad_(True)
+    rd = rhs.detach().double().requires_grad_(True)
+    rows = torch.repeat_interleave(torch.arange(m, device=dev), (d_ro[1:] - d_ro[:-1]).long())
+    want = torch.matmul(ld, rd.transpose(-1, -2))[..., rows, d_ci.long()]
+    want.backward(go.double())
+    assert rel_err(out.detach().cpu().numpy(), want.detach().cpu().numpy(), ro) < TOL
+    assert lhs.grad.dtype == dtype and rhs.grad.dtype == dtype
+    assert rel_err_torch(lhs.grad.float(), ld.grad) < _grad_tol(dtype)
+    assert rel_err_torch(rhs.grad.float(), rd.grad) < _grad_tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", HALF_TYPES)
+def test_softmax_function_half_autograd(tsa, dev, dtype):
+    m, n = 256, 512
+    _, vals, ri, ro, ci = make_csr(m, n, 0.85, seed=3, round_to=1)
+    rng = np.random.default_rng(4)
+    x = T(rng.uniform(-4, 4, (3, len(vals))).astype(np.float32), dev).to(dtype).requires_grad_(True)
+    go = T(rng.uniform(-1, 1, (3, len(vals))).astype(np.float32), dev).to(dtype)
+    topo = (T(ri, dev), T(ro, dev), T(ci, dev))
+    y = tsa.SparseSoftmax.apply(x, *topo, 0.5) if hasattr(tsa, "SparseSoftmax") else None
+    assert y is not None and y.dtype == dtype
+    y.backward(go)
+    assert x.grad.dtype == dtype
+    want_y = c_oracle.sparse_softmax((x.detach().float().cpu().numpy().astype(np.float64) * 0.5)
+                                     .astype(np.float32), ro, ci)
+    assert half_err(y.detach().float().cpu().numpy(), want_y, dtype, ro) < 2 * TOL
+    want_dx = O.sparse_softmax_backward(y.detach().float().cpu().numpy(),
+                                        go.float().cpu().numpy(), ro, 0.5)
+    assert half_err(x.grad.float().cpu().numpy(), want_dx, dtype, ro) < TOL
