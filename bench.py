@@ -562,7 +562,12 @@ def other_ops(dev):
         try:  # the same forward replayed from one hipGraph (torch_sputnik_amd/graphs.py)
             from torch_sputnik_amd.graphs import capture_forward
             fast = capture_forward(attn, x, x, x)
-            res["sparse_attention_forward_c3_hip_graph"] = {"ms": event_time_ms(lambda: fast(x, x, x), 10)}
+            # `ms`: a replay that first copies the caller's input into the graph's static
+            # buffer (16.8 MB here: what a caller with its own tensor pays); `in_place_ms`: the
+            # caller filled fast.static_inputs itself (the graph alone)
+            res["sparse_attention_forward_c3_hip_graph"] = {
+                "ms": event_time_ms(lambda: fast(x, x, x), 10),
+                "in_place_ms": event_time_ms(lambda: fast(*fast.static_inputs), 10)}
         except Exception as e:  # noqa: BLE001
             res["sparse_attention_forward_c3_hip_graph"] = {"error": str(e)[:200]}
         res["sparse_attention_forward_c3"] = {"ms": t, "batch": batch, "heads": heads, "seq": s,
@@ -626,6 +631,25 @@ def other_ops(dev):
     sws = torch.empty(capi.sddmm_workspace_bytes(m, seq, n, nnz) + 16, dtype=torch.uint8, device=dev)
     t = event_time_ms(lambda: capi.sddmm_batched(m, seq, n, batch, ri, ro, ci, gy, x, gw, sws), 10)
     res["sddmm_grad_values_c5"] = {"ms": t, "gflops": 2.0 * nnz * seq * batch / t / 1e6}
+    # the same operators at config 5's STATED size M = N = K = 2048 (N of left_spmm is the
+    # sequence length, modules/sparse_linear.py:28,89): batch 8 x seq 2048
+    try:
+        seq2 = 2048
+        x2 = uniform((batch, n, seq2), dev, 24)
+        gy2 = uniform((batch, m, seq2), dev, 25)
+        y2 = torch.empty(batch, m, seq2, device=dev)
+        ws52 = torch.empty(capi.spmm_workspace_bytes(m, n, seq2, nnz) + 16, dtype=torch.uint8, device=dev)
+        t = event_time_ms(lambda: capi.spmm_batched(m, n, seq2, batch, ri, vals, 0, ro, ci, x2, y2, ws52), 10)
+        res["left_spmm_c5_n2048"] = {"ms": t, "gflops": 2.0 * nnz * seq2 * batch / t / 1e6, "batch": batch,
+                                     "seq": seq2,
+                                     "kernel": capi.spmm_kernel_name(m, n, seq2, nnz, batch)}
+        gw2 = torch.empty(batch, nnz, device=dev)
+        sws2 = torch.empty(capi.sddmm_workspace_bytes(m, seq2, n, nnz) + 16, dtype=torch.uint8, device=dev)
+        t = event_time_ms(lambda: capi.sddmm_batched(m, seq2, n, batch, ri, ro, ci, gy2, x2, gw2, sws2), 10)
+        res["sddmm_grad_values_c5_n2048"] = {"ms": t, "gflops": 2.0 * nnz * seq2 * batch / t / 1e6}
+        del x2, gy2, y2, gw2, ws52, sws2
+    except Exception as e:  # noqa: BLE001 - extra metric, best effort
+        res["left_spmm_c5_n2048"] = {"error": str(e)[:200]}
     # config 5 end to end: SparseLinear forward + backward through the torch ops and the
     # autograd Function (left_spmm; sddmm + transposed topology + left_spmm), fp32 and with
     # the input stored in fp16.  Default = transposed topology and kernel plans cached per
@@ -637,9 +661,10 @@ def other_ops(dev):
         w = torch.randn(m, n, device=dev) * (torch.rand(m, n, device=dev) < 0.2)
         layer.weight = torch.nn.Parameter(w)
         layer.setup_sparse_tensors()
-        for name, dt in (("fp32", torch.float32), ("fp16_storage", torch.float16)):
-            xin = torch.randn(batch, seq, n, device=dev).to(dt).requires_grad_(True)
-            gout = torch.randn(batch, m, seq, device=dev)
+        for name, dt, sq in (("fp32", torch.float32, seq), ("fp16_storage", torch.float16, seq),
+                             ("n2048_fp32", torch.float32, 2048), ("n2048_fp16_storage", torch.float16, 2048)):
+            xin = torch.randn(batch, sq, n, device=dev).to(dt).requires_grad_(True)
+            gout = torch.randn(batch, m, sq, device=dev)
 
             def fwd_bwd():
                 layer.values.grad = None
@@ -647,7 +672,7 @@ def other_ops(dev):
                 layer(xin).backward(gout)
 
             res[f"sparse_linear_fwd_bwd_c5_{name}"] = {"ms": event_time_ms(fwd_bwd, 10), "batch": batch,
-                                                       "seq": seq}
+                                                       "seq": sq}
             if name == "fp32":
                 from torch_sputnik_amd import functional
                 functional.enable_transpose_cache(False)

@@ -53,7 +53,7 @@ def _csr_transpose(m, n, values, row_offsets, column_indices):
     return [torch.from_numpy(np.ascontiguousarray(v)), torch.from_numpy(ro), torch.from_numpy(ci)]
 
 
-def _csr_transpose_with_permutation(m, n, values, row_offsets, column_indices):
+def _csr_transpose_with_permutation(m, n, values, row_offsets, column_indices, checked=True):
     out = _csr_transpose(m, n, values, row_offsets, column_indices)
     perm = np.argsort(_np(column_indices).astype(np.int64), kind="stable").astype(np.int32)
     return out + [torch.from_numpy(perm)]

@@ -750,6 +750,52 @@ def test_transpose_very_sparse_path_bit_exact(capi, dev, m, n, nnz, replicas):
     assert torch.equal(out_v2, out_v)
 
 
+@pytest.mark.parametrize("m,n,nnz,passes", [(65536, 65536, 300000, 1), (300000, 40000, 200000, 2)])
+def test_transpose_very_sparse_with_global_token_columns(capi, dev, m, n, nnz, passes):
+    """a very sparse, very large mask in which a few columns are held by
+    EVERY row (a global-attention token) -- the O(n + nnz) path must not rank such an
+    output row by all pairs; bit-exact against scipy, in a bounded time."""
+    import time
+    import scipy.sparse as sp
+    ro, ci = _random_sparse_csr(m, n, nnz, seed=3 * m + n)
+    a = sp.csr_matrix((np.ones(len(ci), dtype=np.int8), ci, ro), shape=(m, n)).tolil()
+    a[:, 5] = 1
+    a[::2, n - 3] = 1          # every second row: a second long column
+    a = a.tocsr()
+    a.sort_indices()
+    ro, ci = a.indptr.astype(np.int32), a.indices.astype(np.int32)
+    nnz = len(ci)
+    v = np.random.default_rng(2).uniform(size=(1, nnz)).astype(np.float32)
+    ws_bytes = capi.csr_transpose_workspace_bytes(m, n, nnz)
+    assert ws_bytes <= 4 * (2 * n + 3 * nnz) + 64, "not the O(n + nnz) path"
+    out_v = torch.full(v.shape, float("nan"), device=dev)
+    out_ro = torch.full((n + 1,), -1, dtype=torch.int32, device=dev)
+    out_ci = torch.full((nnz,), -1, dtype=torch.int32, device=dev)
+    perm = torch.full((nnz,), -1, dtype=torch.int32, device=dev)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    args = (m, n, 1, T(v, dev), T(ro, dev), T(ci, dev), out_v, out_ro, out_ci, perm, ws)
+    capi.csr_transpose(*args, checked=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    capi.csr_transpose(*args, checked=True)
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 0.25, "a long output row is ranked by all pairs again"   # (microseconds now; seconds before)
+    want = sp.csr_matrix((np.arange(1, nnz + 1, dtype=np.int64), ci, ro), shape=(m, n)).tocsc()
+    assert np.array_equal(out_ro.cpu().numpy(), want.indptr.astype(np.int32))
+    assert np.array_equal(out_ci.cpu().numpy(), want.indices.astype(np.int32))
+    assert np.array_equal(perm.cpu().numpy(), (want.data - 1).astype(np.int64))
+    assert np.array_equal(out_v.cpu().numpy(), v[:, (want.data - 1).astype(np.int64)])
+    # a row that holds the long column twice is detected there too
+    bad = ci.copy()
+    row = m // 2
+    assert ro[row + 1] - ro[row] >= 2
+    bad[ro[row]:ro[row + 1]] = 5
+    with pytest.raises(RuntimeError):
+        capi.csr_transpose(m, n, 1, T(v, dev), T(ro, dev), T(bad, dev), out_v, out_ro, out_ci, perm,
+                           ws, checked=True)
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("m,n,sparsity", [(300, 200, 0.8), (4096, 4096, 0.9995)],
                          ids=["table_path", "histogram_path"])
 def test_transpose_detects_a_repeated_column(capi, ts, dev, m, n, sparsity):
@@ -776,6 +822,16 @@ def test_transpose_detects_a_repeated_column(capi, ts, dev, m, n, sparsity):
     with pytest.raises(RuntimeError, match="valid CSR"):
         torch.ops.torch_sputnik.csr_transpose_with_permutation(m, n, T(vals, dev), T(ro, dev),
                                                                T(bad, dev))
+    # the per-call form stays asynchronous and does not raise
+    torch.ops.torch_sputnik.csr_transpose_with_permutation(m, n, T(vals, dev), T(ro, dev),
+                                                           T(bad, dev), False)
+    # a column outside [0, n) is reported on both paths too (the table path
+    # used to skip it silently and hand back uninitialised slots)
+    for wrong in (n, n + 7, -3):
+        bad = ci.copy()
+        bad[ro[row]] = wrong
+        with pytest.raises(RuntimeError):
+            run(bad)
     torch.cuda.synchronize()
 
 

@@ -158,6 +158,42 @@ def test_default_caches_serve_registered_topologies_only(cpu_ops):
     assert len(cache) == 0 and not functional._static
 
 
+def test_unregistered_pattern_never_takes_the_synchronising_transpose(cpu_ops, monkeypatch):
+    """the transpose that also returns the permutation waits for the
+    stream when `checked`; that is for results a cache KEEPS.  A pattern no cache serves
+    must get the reference's asynchronous per-call transpose (modules/spmm.py:59-62) --
+    no host round trip in every backward, legal inside a stream capture."""
+    from torch_sputnik_amd import functional, ops
+    dense_a, vals, ri, ro, ci = make_csr(15, 11, 0.7, seed=4)
+    b = np.random.default_rng(5).uniform(-1, 1, (11, 8)).astype(np.float32)
+    calls = []
+    real = ops.csr_transpose_with_permutation
+
+    def spy(m, n, values, row_offsets, column_indices, checked=True):
+        calls.append(bool(checked))
+        return real(m, n, values, row_offsets, column_indices, checked)
+
+    monkeypatch.setattr(ops, "csr_transpose_with_permutation", spy)
+    functional.enable_transpose_cache(functional.TRANSPOSE_CACHE_DEFAULT)
+
+    def backward(topo):
+        v = T(vals).requires_grad_(True)
+        d = T(b).requires_grad_(True)
+        cpu_ops.Spmm.apply(15, 11, v, *topo, d).square().sum().backward()
+        lhs = T(np.ones((15, 4), np.float32)).requires_grad_(True)
+        rhs = T(np.ones((11, 4), np.float32)).requires_grad_(True)
+        cpu_ops.Sddmm.apply(15, 11, *topo, lhs, rhs).sum().backward()
+
+    topo = (T(ri), T(ro), T(ci))
+    backward(topo)
+    assert True not in calls, "an unregistered pattern took the checked (synchronising) transpose"
+    functional.register_static_topology(*topo)
+    backward(topo)
+    backward(topo)
+    assert calls.count(True) == 1, "a registered pattern is checked once, when it is cached"
+    functional.unregister_static_topology(*topo)
+
+
 def test_cache_is_bounded_by_bytes():
     from torch_sputnik_amd import functional
     lru = functional._Lru(capacity=100, max_bytes=4096)

@@ -68,7 +68,13 @@ __device__ __forceinline__ MaskPlace select_mask(int heads, int replica, int m, 
   const int mask = replica / heads;
   int first = 0;
   for (int j = 0; j < mask; ++j) first += row_offsets[static_cast<int64_t>(j) * (m + 1) + m];
-  return MaskPlace{mask, first, row_offsets[static_cast<int64_t>(mask) * (m + 1) + m]};
+  const int count = row_offsets[static_cast<int64_t>(mask) * (m + 1) + m];
+  // An EMPTY mask behind all the others would start one past the concatenated
+  // column_indices, and the kernels request the window at their (clamped) entry 0
+  // before they know that no row has any: it starts on the previous entry instead
+  // (never used -- every row is empty).
+  if (count == 0 && first > 0) --first;
+  return MaskPlace{mask, first, count};
 }
 // (the kernels then do:  row_offsets += place.mask * (m + 1); column_indices += place.first;
 //  row_indices += place.mask * m; nonzeros = place.nonzeros)

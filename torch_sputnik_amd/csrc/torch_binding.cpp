@@ -53,11 +53,22 @@ Tensor as_index(const Tensor& t, const char* name, const Tensor& like) {
   return t.to(at::kInt).contiguous();
 }
 
-// float32 is the reference's only dtype (data_ptr<float>(), src/spmm_cuda.cu:51).
-// float16 / bfloat16 storage is accepted as an extension (BASELINE.json config 5
-// names fp16): such operands are widened once here, all arithmetic and every
-// output stay float32, exactly as the reference's outputs always are
-// (src/spmm_cuda.cu:42).
+// float32 is the reference's only dtype (data_ptr<float>(), src/spmm_cuda.cu:51);
+// float16 / bfloat16 STORAGE is accepted as an extension (BASELINE.json config 5
+// names fp16), all arithmetic accumulates in float32.  THE RESULT-TYPE RULE, per op
+// (one place that says it):
+//   spmm, left_spmm, spmm_bias*, the planned / permuted / transposed-store / group
+//   forms, sddmm, sddmm_sum, csr_transpose (values_t), sparse_attention*, every
+//   many-mask op                         -> float32 results whatever the operand type
+//                                           (the reference's rule, src/spmm_cuda.cu:42);
+//   sparse_softmax, sparse_softmax_scaled, sparse_softmax_backward
+//                                        -> the type of `values` (an elementwise map of
+//                                           the stored values: half in, half out; float32
+//                                           in, float32 out exactly as the reference);
+//   sddmm_narrow                         -> the operands' (half) type, on request only;
+//   transpose_last2_as                   -> the type its out_type argument names.
+// Ops that take float32 only in their kernels widen half operands once with as_float
+// below; the ops whose kernels read half storage natively take as_storage.
 Tensor as_float(const Tensor& t, const char* name) {
   TORCH_CHECK(t.is_cuda(), name, " must be a GPU (HIP) tensor, got ", t.device());
   const auto st = t.scalar_type();
@@ -739,7 +750,8 @@ Tensor sparse_softmax_backward(const Tensor& softmax_out_in, const Tensor& grad_
 // asked).  values may be [nnz] (reference contract) or [R,nnz] (extension).
 std::vector<Tensor> csr_transpose_impl(int64_t m64, int64_t n64, const Tensor& values_in,
                                        const Tensor& row_offsets_in,
-                                       const Tensor& column_indices_in, bool want_permutation) {
+                                       const Tensor& column_indices_in, bool want_permutation,
+                                       bool checked) {
   const int m = to_int(m64, "m"), n = to_int(n64, "n");
   // float16 / bfloat16 values are read as they are by the gather that moves them
   // (sputnik_hip_csr_transpose_typed); the transposed values are float32 either way
@@ -769,21 +781,24 @@ std::vector<Tensor> csr_transpose_impl(int64_t m64, int64_t n64, const Tensor& v
   Tensor workspace =
       at::empty({static_cast<int64_t>(ws_bytes)}, values.options().dtype(at::kByte));
   // csr_transpose itself is asynchronous like the reference's (src/transpose_cuda.cu:90-99:
-  // no host round trip).  The form that also returns the permutation is what a cache calls
-  // ONCE per static topology: it takes the checked entry, which waits for the stream and
-  // reports a pattern the transpose is not defined for (a row storing a column twice, a
-  // column out of range) instead of handing out a silently wrong permutation.
+  // no host round trip).  The form that also returns the permutation takes a `checked` flag:
+  // a cache that is going to KEEP the result (once per static topology) sets it and gets the
+  // checked entry, which waits for the stream and reports a pattern the transpose is not
+  // defined for (a row storing a column twice, a column out of range) instead of handing out
+  // a silently wrong permutation; a per-call user leaves it off and stays asynchronous and
+  // capturable (the wait is illegal inside a stream capture).
+  checked = checked && want_permutation;
   int status;
   if (half_values) {
     status = sputnik_hip_csr_transpose_typed(
         m, n, nonzeros, replicas, values.data_ptr(), type_code(values.scalar_type()), nonzeros,
         row_offsets.data_ptr<int>(), column_indices.data_ptr<int>(), out_values.data_ptr<float>(),
         nonzeros, out_row_offsets.data_ptr<int>(), out_column_indices.data_ptr<int>(),
-        permutation.data_ptr<int>(), workspace.data_ptr(), ws_bytes, want_permutation ? 1 : 0,
+        permutation.data_ptr<int>(), workspace.data_ptr(), ws_bytes, checked ? 1 : 0,
         current_stream(values));
   } else {
     const auto entry =
-        want_permutation ? sputnik_hip_csr_transpose_checked : sputnik_hip_csr_transpose;
+        checked ? sputnik_hip_csr_transpose_checked : sputnik_hip_csr_transpose;
     status = entry(m, n, nonzeros, replicas, values.data_ptr<float>(), nonzeros,
                    row_offsets.data_ptr<int>(), column_indices.data_ptr<int>(),
                    out_values.data_ptr<float>(), nonzeros, out_row_offsets.data_ptr<int>(),
@@ -791,7 +806,7 @@ std::vector<Tensor> csr_transpose_impl(int64_t m64, int64_t n64, const Tensor& v
                    want_permutation ? permutation.data_ptr<int>() : nullptr, workspace.data_ptr(),
                    ws_bytes, current_stream(values));
   }
-  TORCH_CHECK(!(want_permutation && status == SPUTNIK_HIP_INVALID_ARGUMENT),
+  TORCH_CHECK(!(checked && status == SPUTNIK_HIP_INVALID_ARGUMENT),
               "torch_sputnik::csr_transpose_with_permutation: the pattern is not a valid CSR "
               "matrix for a transpose (a row stores a column twice, or a column index is out of "
               "range)");
@@ -803,13 +818,13 @@ std::vector<Tensor> csr_transpose_impl(int64_t m64, int64_t n64, const Tensor& v
 
 std::vector<Tensor> csr_transpose(int64_t m, int64_t n, const Tensor& values,
                                   const Tensor& row_offsets, const Tensor& column_indices) {
-  return csr_transpose_impl(m, n, values, row_offsets, column_indices, false);
+  return csr_transpose_impl(m, n, values, row_offsets, column_indices, false, false);
 }
 
 std::vector<Tensor> csr_transpose_with_permutation(int64_t m, int64_t n, const Tensor& values,
                                                    const Tensor& row_offsets,
-                                                   const Tensor& column_indices) {
-  return csr_transpose_impl(m, n, values, row_offsets, column_indices, true);
+                                                   const Tensor& column_indices, bool checked) {
+  return csr_transpose_impl(m, n, values, row_offsets, column_indices, true, checked);
 }
 
 // Fused softmax(scale * sddmm(q, k)) @ v over a fixed mask
@@ -1270,7 +1285,7 @@ TORCH_LIBRARY(torch_sputnik, m) {
       "-> Tensor[]");
   m.def(
       "csr_transpose_with_permutation(int m, int n, Tensor values, Tensor row_offsets, "
-      "Tensor column_indices) -> Tensor[]");
+      "Tensor column_indices, bool checked=True) -> Tensor[]");
   // extensions
   m.def(
       "spmm_bias(int m, int k, Tensor values, Tensor row_indices, Tensor row_offsets, "

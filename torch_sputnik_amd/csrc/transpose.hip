@@ -60,6 +60,7 @@ constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / kWave;
 constexpr int kScanGroups = 16;  // chunk groups per column in the table scan
 constexpr int kGroupCols = 256;  // columns per scatter workgroup (<= kColsPerRange columns)
+constexpr int kLongColumn = 2048; // O(n + nnz) path: output rows beyond this are ranked through a bitmap
 
 
 typedef unsigned int mask_t;
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(kMaskBlock) void transpose_mask_kernel(
     int m, int n, const int* __restrict__ row_offsets, const int* __restrict__ column_indices,
     mask_t* __restrict__ gmask, int* __restrict__ balances) {
   extern __shared__ mask_t masks[];
-  __shared__ int balance;   // entries put into the masks minus bits found set: 0 unless a row repeats a column
+  __shared__ int balance;   // entries seen minus bits found set: 0 unless a row repeats a column or holds one outside [0, n)
   if (threadIdx.x == 0) balance = 0;
   int entries = 0;
   const int chunk = blockIdx.x;
@@ -116,6 +117,9 @@ __global__ __launch_bounds__(kMaskBlock) void transpose_mask_kernel(
       if (c[j][u] >= c0 && c[j][u] < c1) {
         atomicOr(&masks[c[j][u] - c0], bit);
         ++entries;
+      } else if (blockIdx.y == 0 && (c[j][u] < 0 || c[j][u] >= n) &&
+                 p0[j] + lane + u * kWave < p1[j]) {
+        ++entries;   // a column outside [0, n): no mask takes it, so the chunk does not balance
       }
     // rows longer than kUnroll x 64 entries: the rest, one batch at a time
     for (int first = p0[j] + lane + kUnroll * kWave; first < p1[j]; first += kUnroll * kWave) {
@@ -129,6 +133,8 @@ __global__ __launch_bounds__(kMaskBlock) void transpose_mask_kernel(
       for (int u = 0; u < kUnroll; ++u)
         if (more[u] >= c0 && more[u] < c1) {
           atomicOr(&masks[more[u] - c0], bit);
+          ++entries;
+        } else if (blockIdx.y == 0 && (more[u] < 0 || more[u] >= n) && first + u * kWave < p1[j]) {
           ++entries;
         }
     }
@@ -217,6 +223,7 @@ __global__ __launch_bounds__(kBlock) void transpose_sparse_rank_kernel(
   const int c = blockIdx.x * kWaves + threadIdx.x / kWave;
   if (c >= n) return;
   const int o0 = out_row_offsets[c], o1 = out_row_offsets[c + 1];
+  if (o1 - o0 > kLongColumn) return;   // transpose_sparse_rank_long_kernel's
   for (int i = o0 + lane; i < o1; i += kWave) {
     const int mine = tmp_row[i];
     int rank = 0, same = 0;
@@ -231,6 +238,69 @@ __global__ __launch_bounds__(kBlock) void transpose_sparse_rank_kernel(
     }
     out_column_indices[o0 + rank] = mine;
     permutation[o0 + rank] = tmp_src[i];
+  }
+}
+
+// Output rows with more than kLongColumn entries (a "global token" column of a
+// very sparse 65536^2 attention pattern holds 65536 -- all-pairs ranking by one wave would
+// be 6.7e7 serial steps).  One workgroup per such row: a bitmap of the source rows in LDS
+// (kBitmapWords x 32 rows per pass), its prefix popcounts, and rank = set bits below the
+// entry's own -- O(m / 32 + entries) per pass.  A bit found set already = the row holds
+// the column twice.
+constexpr int kBitmapWords = 8192;   // 32 KiB bitmap + 32 KiB prefix: 262 144 source rows per pass
+__global__ __launch_bounds__(kBlock) void transpose_sparse_rank_long_kernel(
+    int m, const int* __restrict__ out_row_offsets, const int* __restrict__ tmp_row,
+    const int* __restrict__ tmp_src, int* __restrict__ out_column_indices,
+    int* __restrict__ permutation, int* __restrict__ status) {
+  __shared__ unsigned bitmap[kBitmapWords];
+  __shared__ int prefix[kBitmapWords];
+  __shared__ int partial[kBlock];
+  const int c = blockIdx.x, t = threadIdx.x;
+  const int o0 = out_row_offsets[c], o1 = out_row_offsets[c + 1];
+  if (o1 - o0 <= kLongColumn) return;
+  constexpr int kPer = kBitmapWords / kBlock;   // words per thread in the scan
+  int ranked = 0;                               // entries of earlier passes
+  for (int r0 = 0; r0 < m; r0 += kBitmapWords * 32) {
+    for (int w = t; w < kBitmapWords; w += kBlock) bitmap[w] = 0u;
+    __syncthreads();
+    for (int i = o0 + t; i < o1; i += kBlock) {
+      const unsigned rel = static_cast<unsigned>(tmp_row[i] - r0);
+      if (rel < static_cast<unsigned>(kBitmapWords * 32)) {
+        const unsigned bit = 1u << (rel & 31);
+        if (atomicOr(&bitmap[rel >> 5], bit) & bit) atomicOr(status, 1);
+      }
+    }
+    __syncthreads();
+    int sum = 0;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) sum += __popc(bitmap[t * kPer + j]);
+    partial[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < kBlock; off *= 2) {
+      const int v = t >= off ? partial[t - off] : 0;
+      __syncthreads();
+      partial[t] += v;
+      __syncthreads();
+    }
+    int run = partial[t] - sum;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      prefix[t * kPer + j] = run;
+      run += __popc(bitmap[t * kPer + j]);
+    }
+    const int pass_total = partial[kBlock - 1];
+    __syncthreads();
+    for (int i = o0 + t; i < o1; i += kBlock) {
+      const int row = tmp_row[i];
+      const unsigned rel = static_cast<unsigned>(row - r0);
+      if (rel < static_cast<unsigned>(kBitmapWords * 32)) {
+        const int rank = ranked + prefix[rel >> 5] + __popc(bitmap[rel >> 5] & ((1u << (rel & 31)) - 1u));
+        out_column_indices[o0 + rank] = row;
+        permutation[o0 + rank] = tmp_src[i];
+      }
+    }
+    ranked += pass_total;
+    __syncthreads();
   }
 }
 
@@ -625,6 +695,9 @@ int sputnik_hip_csr_transpose(int m, int n, int nonzeros, int replicas, const fl
     hipLaunchKernelGGL(transpose_sparse_rank_kernel, dim3(ceil_div(n, kWaves)), dim3(kBlock), 0,
                        stream, n, out_row_offsets, tmp_row, tmp_src, out_column_indices, perm,
                        status);
+    if (nonzeros > kLongColumn)   // (a workgroup per output row; all but the long rows leave at once)
+      hipLaunchKernelGGL(transpose_sparse_rank_long_kernel, dim3(n), dim3(kBlock), 0, stream, m,
+                         out_row_offsets, tmp_row, tmp_src, out_column_indices, perm, status);
     hipLaunchKernelGGL(transpose_sparse_values_kernel<float>, dim3(ceil_div(nonzeros, kBlock)),
                        dim3(kBlock), 0, stream, nonzeros, replicas, values, values_stride, perm,
                        out_values, out_values_stride);

@@ -185,7 +185,7 @@ class TransposeCache(_TopologyCache):
         if entry is None:
             _, row_offsets_t, column_indices_t, permutation = ops.csr_transpose_with_permutation(
                 m, n, probe_values.detach().reshape(-1, probe_values.shape[-1])[0].contiguous(),
-                row_offsets, column_indices)
+                row_offsets, column_indices, checked=cached)   # the wait only for a result that is kept
             entry = (diffsort(row_offsets_t), row_offsets_t, column_indices_t,
                      permutation.contiguous()) + self._keep(row_offsets, column_indices)
             if cached:
@@ -322,10 +322,11 @@ def _permute_cached(values, perm):
 def _transpose(m, n, values, row_offsets, column_indices):
     """(values_t, row_indices_t, row_offsets_t, column_indices_t)."""
     values = values.contiguous()
-    if _cache is not None:
+    if _cache is not None and _cache.serves(row_offsets, column_indices):
         row_indices_t, row_offsets_t, column_indices_t, perm = _cache.lookup(
             m, n, row_offsets, column_indices, values)
         return _permute_cached(values, perm), row_indices_t, row_offsets_t, column_indices_t
+    # a pattern no cache serves: the reference's per-call transpose (asynchronous, one pass)
     values_t, row_offsets_t, column_indices_t = ops.csr_transpose(
         m, n, values, row_offsets, column_indices)
     return values_t, diffsort(row_offsets_t), row_offsets_t, column_indices_t
@@ -338,7 +339,7 @@ def _spmm_transposed(m, n, values, row_offsets, column_indices, dense, left=Fals
     permutation (ops.spmm_permuted); without it the reference's per-call
     csr_transpose (modules/spmm.py:59-62).  ``block_rows``: the product comes
     back as ops.spmm_transposed_out stores it, [R * n / block_rows, width, block_rows]."""
-    if _cache is None:
+    if _cache is None or not _cache.serves(row_offsets, column_indices):
         values_t, row_indices_t, row_offsets_t, column_indices_t = _transpose(
             m, n, values, row_offsets, column_indices)
         perm = None
@@ -707,7 +708,7 @@ class SparseAttentionFunction(torch.autograd.Function):
             else:
                 _, row_offsets_t, column_indices_t, perm = ops.csr_transpose_with_permutation(
                     m, n, grad_scores.reshape(-1, grad_scores.shape[-1])[0].contiguous(),
-                    row_offsets, column_indices)
+                    row_offsets, column_indices, checked=False)
                 row_indices_t = diffsort(row_offsets_t)
             def transposed_product(values, dense):
                 if ops.spmm_permuted_fused(n, m, dense.size(-1), perm.numel()):

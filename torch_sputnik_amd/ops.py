@@ -59,12 +59,15 @@ def csr_transpose(m, n, values, row_offsets, column_indices):
     return _ops.csr_transpose(int(m), int(n), values, row_offsets, column_indices)
 
 
-def csr_transpose_with_permutation(m, n, values, row_offsets, column_indices):
+def csr_transpose_with_permutation(m, n, values, row_offsets, column_indices, checked=True):
     """Extension: as csr_transpose plus a 4th tensor,
     ``permutation`` with values_t == values[..., permutation], so a static
-    topology's transpose can be cached by the caller."""
+    topology's transpose can be cached by the caller.  ``checked`` (what a caller
+    that KEEPS the result wants): wait for the stream and raise on a pattern the
+    transpose is not defined for; ``checked=False`` is asynchronous like
+    csr_transpose itself (no host round trip, legal inside a stream capture)."""
     return _ops.csr_transpose_with_permutation(int(m), int(n), values, row_offsets,
-                                               column_indices)
+                                               column_indices, bool(checked))
 
 
 # ---------------------------------------------------------------------------
