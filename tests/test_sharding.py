@@ -1,4 +1,4 @@
-"""CPU: replica sharding over 2 processes (gloo).  Each rank computes its block
+"""CPU: replica sharding over 2 and 4 processes (gloo).  Each rank computes its block
 with the ops (oracle-backed on CPU) and the blocks are all-gathered; every mode
 must reproduce the single-process result bit for bit."""
 import os
@@ -99,3 +99,56 @@ def test_two_rank_sharding_gloo(replicas):
         p.join(timeout=240)
         assert p.exitcode == 0, f"rank exited with {p.exitcode}"
     assert dict(results) == {0: True, 1: True}
+
+
+def _worker_c4_shape(rank, world, port, replicas, results):
+    """Config 4's partitioning in small: `replicas` / `world` replicas per rank, every
+    rank holds ONLY its own block of the operands (shard at origin), and the whole C is
+    exchanged -- collective, peer to peer, and overlapped with 8 and 16 chunks per rank
+    (the schedules bench.py times on the GPUs)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import torch_cpu_backend
+        torch_cpu_backend.install()
+        from torch_sputnik_amd import ops, sharding
+
+        m, k, n = 12, 9, 5
+        _, vals, ri, ro, ci = make_csr(m, k, 0.6, seed=3)
+        rng = np.random.default_rng(4)      # same stream on every rank: the global operands
+        v = torch.from_numpy(rng.uniform(-1, 1, (replicas, len(vals))).astype(np.float32))
+        b = torch.from_numpy(rng.uniform(-1, 1, (replicas, k, n)).astype(np.float32))
+        topo = [torch.from_numpy(x) for x in (ri, ro, ci)]
+        full = ops.spmm(m, k, v, *topo, b).reshape(replicas, m, n)   # one process, all replicas
+        a, z = sharding.local_range(replicas, world, rank)
+        assert z - a == replicas // world
+        mine_v, mine_b = v[a:z].contiguous(), b[a:z].contiguous()
+        ok = True
+        for mode in ("collective", "p2p"):
+            got = sharding.spmm(m, k, mine_v, *topo, mine_b, gather_mode=mode, local_operands=True)
+            ok = ok and torch.equal(got, full)
+        for chunks in (8, 16):
+            for mode in ("collective", "p2p"):   # (the chunked exchange is peer to peer in both)
+                got = sharding.spmm(m, k, mine_v, *topo, mine_b, gather_mode=mode,
+                                    overlap_chunks=chunks, local_operands=True)
+                ok = ok and torch.equal(got, full)
+        results[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_four_rank_sharding_gloo_local_operands_overlapped():
+    """4 ranks, 16 replicas each, rank-local operands, chunked
+    overlap with 8 and 16 chunks, both transports -- bit-identical to one process."""
+    world, replicas = 4, 64
+    ctx = mp.get_context("spawn")
+    results = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_c4_shape, args=(r, world, port, replicas, results))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+    assert dict(results) == {r: True for r in range(world)}
