@@ -292,7 +292,8 @@ def test_spmm_full_size_soak_on_a_warm_gpu(capi, dev):
     (3, False, 130, 96, 136), (5, True, 130, 96, 136), (1, False, 130, 96, 136),
     (4, False, 512, 512, 64), (3, True, 300, 256, 128),       # 64-column tiled kernel
     (2, False, 512, 512, 256), (3, True, 256, 1024, 512),     # 256-column tiled kernel
-    (12, False, 2048, 256, 512), (13, True, 2000, 300, 1024)])  # 512-column kernel by replica count
+    (12, False, 2048, 256, 512), (13, True, 2000, 300, 1024),   # 512-column kernel by replica count
+    (24, False, 512, 128, 1024), (25, True, 500, 128, 1000)])   # flat-stream kernel by replica count
 def test_spmm_batched_capi(capi, dev, spmm_kernel, replicas, shared, m, k, n):
     _, vals, ri, ro, ci = make_csr(m, k, 0.85, seed=21)
     rng = np.random.default_rng(22)
@@ -471,8 +472,37 @@ def test_spmm_flat_mixed_sorted_and_unsorted_rows(capi, dev, flat_loop):
         assert rel_err(got, want) < TOL
 
 
+def test_spmm_one_plan_serves_any_replica_count(capi, dev):
+    """A plan is made from the topology alone (sputnik_hip_spmm_plan knows no replica
+    count), yet the kernel choice depends on it: 2 replicas of this shape run the
+    256-column tiles, 12 the 512-column tiles' 64-row form, 24 the flat-stream kernel
+    (round 4: taken when the tiles of ALL replicas fill the chip).  One planned
+    workspace must serve all of them."""
+    m, k, n = 512, 128, 1024
+    _, vals, ri, ro, ci = make_csr(m, k, 0.8, seed=31)
+    nnz = len(ci)
+    names = {r: capi.spmm_kernel_name(m, k, n, nnz, r) for r in (2, 12, 24)}
+    assert names[24].startswith("spmm_flat_kernel") and not names[2].startswith("spmm_flat_kernel")
+    ws = torch.empty(capi.spmm_workspace_bytes(m, k, n, nnz) + 16, dtype=torch.uint8, device=dev)
+    topo = (T(ri, dev), T(ro, dev), T(ci, dev))
+    capi.spmm_plan(m, k, n, topo[0], topo[1], topo[2], ws)
+    rng = np.random.default_rng(32)
+    for replicas in (24, 2, 12, 24):
+        b = rng.uniform(-1, 1, size=(replicas, k, n)).astype(np.float32)
+        v = rng.uniform(-1, 1, size=(replicas, nnz)).astype(np.float32)
+        out = torch.full((replicas, m, n), float("nan"), device=dev)
+        capi.spmm_batched_planned(m, k, n, replicas, topo[0], T(v, dev), nnz, topo[1], topo[2],
+                                  T(b, dev), out, ws)
+        got = out.cpu().numpy()
+        assert not np.isnan(got).any()
+        assert rel_err(got, c_oracle.spmm(m, k, v, ro, ci, b)) < TOL, f"{replicas} replicas"
+
+
 def test_spmm_kernel_name_reports_the_dispatch(capi):
     assert capi.spmm_kernel_name(4096, 4096, 4096, 1677724, 1).startswith("spmm_flat_kernel")
+    # config 5 at its stated size: 64 tiles per replica, the flat kernel from 3 replicas on
+    assert capi.spmm_kernel_name(2048, 2048, 2048, 838864, 8).startswith("spmm_flat_kernel")
+    assert not capi.spmm_kernel_name(2048, 2048, 2048, 838864, 1).startswith("spmm_flat_kernel")
     assert capi.spmm_kernel_name(64, 64, 64, 2048, 1) == "spmm_rowgather_kernel"
     assert len(capi.build_id()) == 12
 

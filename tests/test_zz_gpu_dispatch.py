@@ -27,6 +27,7 @@ SHAPES = [
     (4096, 4096, 4096, 0.05, 1),     # ... its sparse end
     (4096, 4096, 4096, 0.10, 4),     # config 4's batched form (a few replicas of it)
     (2048, 2048, 512, 0.20, 8),      # config 5: SparseLinear forward, batch 8 x seq 512
+    (2048, 2048, 2048, 0.20, 8),     # config 5 at its stated size (seq 2048): flat kernel by replica count
     (1024, 1024, 64, 0.10, 64),      # config 3: attention weights @ V
     (512, 512, 1024, 0.10, 8),       # config 3: a projection
     (2048, 2048, 2048, 0.10, 1),     # one mid-size product

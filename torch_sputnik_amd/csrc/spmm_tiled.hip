@@ -510,6 +510,19 @@ inline bool use_flat(int m, int k, int n, int nonzeros) {
   return (forced == -3 || (forced == 0 && spmm_flat_tiles(m, n) >= kTiles512From)) &&
          spmm_flat_applicable(m, k, n, nonzeros);
 }
+// The flat-stream kernel also serves shapes that need SEVERAL replicas to fill the chip
+// (round 4: config 5 at its stated size, 2048^2 x 2048 x batch 8 = 64 tiles per replica).
+// Its plan depends on the topology alone, so a workspace that has to serve any replica
+// count carries it BEHIND the tables of the other kernels (as wide512_possible below),
+// and the call decides.  (From 8 tiles per replica: fewer would need more than 24 replicas.)
+inline bool flat_possible(int m, int k, int n, int nonzeros) {
+  return forced_kernel() == 0 && !use_flat(m, k, n, nonzeros) && spmm_flat_tiles(m, n) >= 8 &&
+         spmm_flat_applicable(m, k, n, nonzeros);
+}
+inline bool flat_with_replicas(int m, int k, int n, int nonzeros, int replicas) {
+  return replicas > 1 && flat_possible(m, k, n, nonzeros) &&
+         spmm_flat_tiles(m, n) * replicas >= kTiles512From;
+}
 // A row has more than about two entries per 32-row chunk (below that the 64-row
 // chunks of the 256-column kernel win by 2 %: 4096^3 at density 0.05).
 inline bool long_enough_for_512(int m, int k, int nonzeros) {
@@ -551,7 +564,8 @@ inline Kernel choose_kernel(int m, int k, int n, int nonzeros, int replicas /* <
     if (work < (int64_t{1} << 27) || (replicas < 8 && work < (int64_t{1} << 29)))
       return Kernel::kNone;
   }
-  if (use_flat(m, k, n, nonzeros)) return Kernel::kFlat;
+  if (use_flat(m, k, n, nonzeros) || flat_with_replicas(m, k, n, nonzeros, replicas))
+    return Kernel::kFlat;
   // The 512-column kernel has one tile size: taken when the tiles of all replicas
   // give about one workgroup per CU.  (A plan made ahead of the call does not
   // know the replica count: when the shape alone does not decide, it builds this
@@ -595,6 +609,19 @@ size_t wide512_offset(int m, int k, int n, int nonzeros) {
              ? (base_workspace_bytes(m, k, n, nonzeros) + 255) / 256 * 256
              : 0;
 }
+// Everything but a flat plan that only the replica count selects.
+size_t bytes_before_flat(int m, int k, int n, int nonzeros) {
+  return wide512_possible(m, k, n, nonzeros)
+             ? wide512_offset(m, k, n, nonzeros) + wide512_workspace_bytes(m, k, n, nonzeros)
+             : base_workspace_bytes(m, k, n, nonzeros);
+}
+// Where the flat-stream plan starts: at the front when the shape alone selects the
+// kernel, behind everything else when only the replica count can.
+size_t flat_offset(int m, int k, int n, int nonzeros) {
+  return flat_possible(m, k, n, nonzeros)
+             ? (bytes_before_flat(m, k, n, nonzeros) + 255) / 256 * 256
+             : 0;
+}
 }  // namespace
 
 // 0 = row gather, 1 = 256-column, 2 = 64-column, 3 = either (by replica count), 4 = 512-column, 5 = flat stream
@@ -614,9 +641,9 @@ const char* spmm_tiled_kernel_name(int m, int k, int n, int nonzeros, int replic
 }
 
 size_t spmm_tiled_workspace_bytes(int m, int k, int n, int nonzeros) {
-  return wide512_possible(m, k, n, nonzeros)
-             ? wide512_offset(m, k, n, nonzeros) + wide512_workspace_bytes(m, k, n, nonzeros)
-             : base_workspace_bytes(m, k, n, nonzeros);
+  return flat_possible(m, k, n, nonzeros)
+             ? flat_offset(m, k, n, nonzeros) + spmm_flat_workspace_bytes(m, k, n, nonzeros)
+             : bytes_before_flat(m, k, n, nonzeros);
 }
 
 // Pre-pass only: topology -> per-row order status + chunk table in `workspace`.  Depends
@@ -630,7 +657,9 @@ int spmm_tiled_plan(int m, int k, int n, int nonzeros, int replicas, const int* 
   const Kernel which = choose_kernel(m, k, n, nonzeros, replicas);
   // replica count unknown: also the 512-column kernel's table when a later call may take it
   const bool also512 = replicas < 0 && wide512_possible(m, k, n, nonzeros);
-  if ((which == Kernel::kNone && !also512) || workspace == nullptr || !aligned_to(workspace, 16) ||
+  const bool also_flat = replicas < 0 && flat_possible(m, k, n, nonzeros);
+  if ((which == Kernel::kNone && !also512 && !also_flat) || workspace == nullptr ||
+      !aligned_to(workspace, 16) ||
       workspace_bytes < spmm_tiled_workspace_bytes(m, k, n, nonzeros))
     return 0;
   // the narrow kernel's tables follow the wide kernel's whenever both could be needed
@@ -652,9 +681,10 @@ int spmm_tiled_plan(int m, int k, int n, int nonzeros, int replicas, const int* 
     const int st = launch_status();
     if (st != 0) return st;
   }
-  if (which == Kernel::kFlat) {
+  if (which == Kernel::kFlat || also_flat) {
     const int st = spmm_flat_plan(m, k, n, nonzeros, row_indices, row_offsets, column_indices,
-                                  workspace, stream);
+                                  static_cast<char*>(workspace) + flat_offset(m, k, n, nonzeros),
+                                  stream);
     if (st != 0) return st;
   }
   if (which == Kernel::kWide512 || also512) {
@@ -705,7 +735,8 @@ int spmm_tiled_exec(int m, int k, int n, int nonzeros, int replicas, const int* 
     *handled = true;
     return spmm_flat_exec(m, k, n, nonzeros, replicas, row_indices, values, values_stride,
                           row_offsets, column_indices, dense, dense_stride, out, out_stride,
-                          workspace, stream, epi);
+                          static_cast<const char*>(workspace) + flat_offset(m, k, n, nonzeros),
+                          stream, epi);
   }
   const Plan plan = w512 ? make_plan<CfgWide512>(m, k, n) : make_plan<Cfg>(m, k, n);
   const char* ws_base =
