@@ -402,6 +402,16 @@ def other_ops(dev):
                                                               sd_ws), 20)
         res["sddmm_c3"]["planned_ms"] = tp
         res["sddmm_c3"]["planned_hbm_frac"] = by / tp / 1e6 / HBM_PEAK_GBS
+        res["sddmm_c3"]["planned_kernel"] = capi.sddmm_kernel_name(s, d, s, nnz, reps, 4, planned=True)
+        # the rhs-stationary quad kernel of round 3 on the same plan (SPUTNIK_HIP_SDDMM_FLAT=0)
+        os.environ["SPUTNIK_HIP_SDDMM_FLAT"] = "0"
+        capi.reload_options()
+        try:
+            res["sddmm_c3"]["planned_quad_kernel_ms"] = event_time_ms(
+                lambda: capi.sddmm_batched_planned(s, d, s, reps, ri, ro, ci, q, kk, scores, sd_ws), 20)
+        finally:
+            os.environ.pop("SPUTNIK_HIP_SDDMM_FLAT", None)
+            capi.reload_options()
     except Exception as e0:  # noqa: BLE001 - extra metric, best effort
         res["sddmm_c3"]["planned_error"] = str(e0)[:200]
     try:   # half operands read as they are (round 3): LDS slab in half, v_dot2 products

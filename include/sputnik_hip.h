@@ -72,6 +72,13 @@ SPUTNIK_HIP_API const char* sputnik_hip_build_id(void);
  * pointer is to a static string. */
 SPUTNIK_HIP_API const char* sputnik_hip_spmm_kernel_name(int m, int k, int n, int nonzeros,
                                                          int replicas);
+/* The same for an SDDMM call (sddmm.hip, sddmm_tiled.hip, sddmm_flat.hip): operands of
+ * `elem_bytes` (4: float32, 2: float16 / bfloat16), `planned` != 0 for a product on a
+ * workspace that sputnik_hip_sddmm_plan filled ("sddmm_flat_kernel", "sddmm_quad_kernel",
+ * "sddmm_stationary_kernel", "sddmm_rowwave_kernel"). */
+SPUTNIK_HIP_API const char* sputnik_hip_sddmm_kernel_name(int m, int k, int n, int nonzeros,
+                                                          int replicas, int elem_bytes,
+                                                          int planned);
 
 /* ------------------------------------------------------------------------
  * SpMM   C[m,n] = A_csr[m,k] * B[k,n]

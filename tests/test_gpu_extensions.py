@@ -509,8 +509,10 @@ def test_planned_ops_equal_the_per_call_ops(ts, dev, spmm_kernel, sddmm_kernel, 
         lhs = T(rng.uniform(-1, 1, (replicas, m, kk)).astype(np.float32), dev)
         rhs = T(rng.uniform(-1, 1, (replicas, k, kk)).astype(np.float32), dev)
         splan = ts.sddmm_plan(m, k, kk, *topo)
-        assert torch.equal(ts.sddmm_planned(m, k, *topo, lhs, rhs, splan),
-                           ts.sddmm(m, k, *topo, lhs, rhs))
+        # (a planned product may take another kernel than the per-call one -- the pair-flat
+        # kernel at kk = 64 -- whose partial sums are added in another order)
+        torch.testing.assert_close(ts.sddmm_planned(m, k, *topo, lhs, rhs, splan),
+                                   ts.sddmm(m, k, *topo, lhs, rhs), rtol=1e-5, atol=1e-5)
     from torch_sputnik_amd import capi
     if capi.spmm_workspace_bytes(m, k, n, len(ci)) > 4:
         with pytest.raises(RuntimeError):  # a plan made for other sizes is refused

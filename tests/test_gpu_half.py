@@ -217,11 +217,19 @@ def test_sddmm_half_capi_vs_oracle(capi, dev, sddmm_kernel, dtype, m, k, n, spar
     got = out.cpu().numpy()
     assert not np.isnan(got).any()
     assert rel_err(got, want, ro) < TOL
-    # planned form: same plan as the float operator's, bit-identical result
+    # planned form: same plan as the float operator's; bit-identical result when the same
+    # kernel runs, the pair-flat kernel (round 4: planned products with 128 / 256-byte rows)
+    # against the oracle -- which quad computes an entry decides the order of its partial sums
     capi.sddmm_plan(m, k, n, *topo, ws)
     out2 = torch.full_like(out, float("nan"))
     capi.sddmm_typed(m, k, n, replicas, *topo, lhs, rhs, out2, ws, planned=True)
-    assert torch.equal(out, out2)
+    if capi.sddmm_kernel_name(m, k, n, len(ci), replicas, lhs.element_size(), planned=True) == \
+            capi.sddmm_kernel_name(m, k, n, len(ci), replicas, lhs.element_size(), planned=False):
+        assert torch.equal(out, out2)
+    else:
+        got2 = out2.cpu().numpy()
+        assert not np.isnan(got2).any()
+        assert rel_err(got2, want, ro) < TOL
 
 
 @pytest.mark.parametrize("dtype", HALF_TYPES)

@@ -575,6 +575,69 @@ def test_sddmm_capi_vs_oracle(capi, dev, sddmm_kernel, m, k, n, sparsity, replic
     assert rel_err(got, want, ro) < TOL    # rows = the mask's CSR rows
 
 
+# The pair-flat kernel (csrc/sddmm_flat.hip, round 4) serves PLANNED products whose rows are
+# 128 / 256 bytes (k = 64 in float32): both operands in LDS, a flat list of entry pairs per
+# (row block, slab) tile.  Shapes: ragged blocks and slabs, rows of every length incl.
+# empty ones, one slab, many slabs, a dense mask, several replicas.
+SDDMM_FLAT_SHAPES = [
+    (1024, 1024, 0.9, 3),    # config 3's mask in small: 4 row blocks x 8 slabs
+    (300, 500, 0.8, 2),      # ragged: 2 row blocks (the second partial), 4 slabs (the last partial)
+    (128, 128, 0.5, 1),      # the smallest shape it takes: one partial block, one slab
+    (256, 4096, 0.97, 2),    # 32 slabs, about one entry per row and slab: mostly singles
+    (700, 130, 0.3, 1),      # two slabs, the second with two columns
+    (512, 256, 0.0, 2),      # dense mask: every step full
+]
+
+
+@pytest.fixture
+def sddmm_tiled_forced(monkeypatch):
+    """Small products take the one-launch row-wave kernel on their own; the test knob
+    puts them on the LDS kernels (tests/conftest.py, sddmm_kernel)."""
+    from torch_sputnik_amd import capi as _capi
+    monkeypatch.setenv("SPUTNIK_HIP_SDDMM_KERNEL", "tiled")
+    _capi.reload_options()
+    yield
+    monkeypatch.delenv("SPUTNIK_HIP_SDDMM_KERNEL", raising=False)
+    _capi.reload_options()
+
+
+@pytest.mark.parametrize("order", ["sorted", "unsorted"])
+@pytest.mark.parametrize("m,n,sparsity,replicas", SDDMM_FLAT_SHAPES)
+def test_sddmm_flat_planned_vs_oracle(capi, dev, sddmm_tiled_forced, m, n, sparsity, replicas, order):
+    k = 64
+    _, _, ri, ro, ci = make_csr(m, n, sparsity, seed=m + n, round_to=1, empty_rows=(m // 2, m - 1))
+    if order == "unsorted":   # the kernel pairs CSR neighbours wherever their columns lie
+        rng = np.random.default_rng(3)
+        ci = ci.copy()
+        for r in range(0, m, 3):
+            seg = ci[ro[r]:ro[r + 1]]
+            rng.shuffle(seg)
+    nnz = len(ci)
+    assert capi.sddmm_kernel_name(m, k, n, nnz, replicas, planned=True) == "sddmm_flat_kernel"
+    rng = np.random.default_rng(k + m)
+    lhs = rng.uniform(-1, 1, size=(replicas, m, k)).astype(np.float32)
+    rhs = rng.uniform(-1, 1, size=(replicas, n, k)).astype(np.float32)
+    want = c_oracle.sddmm(m, n, ro, ci, lhs, rhs)
+    topo = (T(ri, dev), T(ro, dev), T(ci, dev))
+    ws = torch.empty(capi.sddmm_workspace_bytes(m, k, n, nnz) + 16, dtype=torch.uint8, device=dev)
+    capi.sddmm_plan(m, k, n, *topo, ws)
+    out = torch.full((replicas, nnz), float("nan"), device=dev)
+    capi.sddmm_batched_planned(m, k, n, replicas, *topo, T(lhs, dev), T(rhs, dev), out, ws)
+    got = out.cpu().numpy()
+    assert not np.isnan(got).any(), "an entry was never written"
+    assert rel_err(got, want, ro) < TOL
+    # the per-call form plans its tables itself and takes the rhs-stationary kernel; it
+    # leaves the lists behind the tables alone, so the planned workspace still serves.
+    # (Not the same bits: which quad computes an entry decides the order of its partial
+    # sums; both kernels are held to the oracle.)
+    out2 = torch.full((replicas, nnz), float("nan"), device=dev)
+    capi.sddmm_batched(m, k, n, replicas, *topo, T(lhs, dev), T(rhs, dev), out2, ws)
+    assert rel_err(out2.cpu().numpy(), want, ro) < TOL
+    out3 = torch.full((replicas, nnz), float("nan"), device=dev)
+    capi.sddmm_batched_planned(m, k, n, replicas, *topo, T(lhs, dev), T(rhs, dev), out3, ws)
+    assert torch.equal(out, out3), "the planned product is not reproducible"
+
+
 # sum over the replicas inside the call (the gradient of values shared by a batch):
 # against the oracle's per-replica products added in float64
 SDDMM_SUM_SHAPES = [

@@ -24,6 +24,7 @@ SIGNATURES = {
     "sputnik_hip_version": (ctypes.c_char_p, []),
     "sputnik_hip_build_id": (ctypes.c_char_p, []),
     "sputnik_hip_spmm_kernel_name": (ctypes.c_char_p, [_c_int] * 5),
+    "sputnik_hip_sddmm_kernel_name": (ctypes.c_char_p, [_c_int] * 7),
     "sputnik_hip_reload_options": (None, []),
     "sputnik_hip_spmm": (_c_int, [_c_int] * 4 + [_c_ptr] * 7),
     "sputnik_hip_spmm_workspace_bytes": (_c_size, [_c_int] * 4),
@@ -159,6 +160,12 @@ def build_id():
 def spmm_kernel_name(m, k, n, nonzeros, replicas=1):
     """Device kernel the dispatcher picks for an SpMM call of this shape."""
     return lib().sputnik_hip_spmm_kernel_name(m, k, n, nonzeros, replicas).decode()
+
+
+def sddmm_kernel_name(m, k, n, nonzeros, replicas=1, elem_bytes=4, planned=False):
+    """Device kernel the dispatcher picks for an SDDMM call of this shape."""
+    return lib().sputnik_hip_sddmm_kernel_name(m, k, n, nonzeros, replicas, elem_bytes,
+                                               int(bool(planned))).decode()
 
 
 def reload_options():

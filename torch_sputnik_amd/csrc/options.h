@@ -12,7 +12,8 @@ struct Options {
   int spmm_tile = 0;      // SPUTNIK_HIP_SPMM_MEDIUM: 1 = medium, 2 = small tile
   int sddmm_kernel = 0;   // SPUTNIK_HIP_SDDMM_KERNEL: 0 auto, 1 "tiled", 2 "wave"
   int sddmm_panel = 0;    // SPUTNIK_HIP_SDDMM_PANEL (developer): forces the k-panel width of the tiled SDDMM
-  int sddmm_debug = 0;    // SPUTNIK_HIP_SDDMM_DEBUG: timing experiments only
+  int sddmm_debug = 0;    // SPUTNIK_HIP_SDDMM_DEBUG: timing experiments only (bits 8.. : the pair-flat kernel's)
+  int sddmm_flat = 1;     // SPUTNIK_HIP_SDDMM_FLAT: 0 = planned products keep the rhs-stationary kernels
   int softmax_rpg = 0;    // SPUTNIK_HIP_SOFTMAX_RPG: rows per group (0 = automatic)
   int softmax_nt = -1;    // SPUTNIK_HIP_SOFTMAX_NT (developer): nontemporal 0 none, 1 loads, 2 stores, 3 both; -1 default
   int softmax_depth = 1;  // SPUTNIK_HIP_SOFTMAX_DEPTH: rows in flight ahead (1..3)

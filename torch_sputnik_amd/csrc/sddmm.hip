@@ -24,18 +24,20 @@ bool sddmm_tiled_applicable(int m, int k, int n, int nonzeros, const float* lhs,
 size_t sddmm_tiled_workspace_bytes(int m, int k, int n, int nonzeros, bool summed = false);
 int sddmm_tiled_plan(int m, int k, int n, int nonzeros, const int* row_indices,
                      const int* row_offsets, const int* column_indices, void* workspace,
-                     hipStream_t stream, bool summed = false);
+                     hipStream_t stream, bool summed = false, bool with_flat = false);
 int sddmm_tiled_launch(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
                        const int* row_offsets, const int* column_indices, const float* lhs,
                        int64_t lhs_stride, const float* rhs, int64_t rhs_stride, float* out,
                        int64_t out_stride, const void* workspace, hipStream_t stream,
-                       int mask_heads = 0, int64_t mask_plan_ints = 0);
+                       int mask_heads = 0, int64_t mask_plan_ints = 0, bool flat = false);
 // Bytes between the plans of consecutive masks in a "many mask" workspace.
 inline size_t sddmm_many_mask_plan_bytes(int m, int k, int n, int nonzeros) {
   return (sddmm_tiled_workspace_bytes(m, k, n, nonzeros) + 255) / 256 * 256;
 }
 
 int sddmm_tiled_panels(int m, int k, int n, int nonzeros);
+bool sddmm_flat_applicable(int m, int k, int n, int nonzeros, int elem_bytes);   // sddmm_flat.hip
+int sddmm_tiled_panel_width(int k);
 int sddmm_tiled_launch_partials(int m, int k, int n, int nonzeros, int replicas,
                                 const int* row_indices, const int* row_offsets,
                                 const int* column_indices, const float* lhs, int64_t lhs_stride,
@@ -50,7 +52,8 @@ int sddmm_tiled_launch_half(int m, int k, int n, int nonzeros, int replicas, con
                             const int* row_offsets, const int* column_indices, const void* lhs,
                             int64_t lhs_stride, const void* rhs, int64_t rhs_stride, void* out,
                             int64_t out_stride, int in_type, int out_type, const void* workspace,
-                            hipStream_t stream, int mask_heads = 0, int64_t mask_plan_ints = 0);
+                            hipStream_t stream, int mask_heads = 0, int64_t mask_plan_ints = 0,
+                            bool flat = false);
 bool sddmm_tiled_sum_half_served(int m, int k, int n, int nonzeros);
 int sddmm_tiled_launch_partials_half(int m, int k, int n, int nonzeros, int replicas,
                                      const int* row_indices, const int* row_offsets,
@@ -315,9 +318,11 @@ int sddmm_exec(int m, int k, int n, int nonzeros, int replicas, const int* row_i
         if (mask_heads > 0) first += mask_nonzeros[i];
       }
     }
+    // (a plan that was made ahead of the call carries the pair-flat kernel's lists too)
     return sddmm_tiled_launch(m, k, n, nonzeros, replicas, row_indices, row_offsets,
                               column_indices, lhs, lhs_stride, rhs, rhs_stride, out, out_stride,
-                              workspace, stream, mask_heads, static_cast<int64_t>(plan_bytes / sizeof(int)));
+                              workspace, stream, mask_heads, static_cast<int64_t>(plan_bytes / sizeof(int)),
+                              /*flat=*/planned);
   }
   int vec = vector_width(lhs, k, lhs_stride);
   vec = min(vec, vector_width(rhs, k, rhs_stride));
@@ -379,7 +384,7 @@ int sddmm_exec_half(int m, int k, int n, int nonzeros, int replicas, const int* 
     }
     return sddmm_tiled_launch_half(m, k, n, nonzeros, replicas, row_indices, row_offsets,
                                    column_indices, lhs, lhs_stride, rhs, rhs_stride, out, out_stride,
-                                   in_type, out_type, workspace, stream);
+                                   in_type, out_type, workspace, stream, 0, 0, /*flat=*/planned);
   }
   if (half_out && k > 1024) return SPUTNIK_HIP_UNSUPPORTED;   // (row-wave panel: 64 lanes x 4 x 4)
   if (half_out && min(vector_width_of(lhs, k, lhs_stride, 2), vector_width_of(rhs, k, rhs_stride, 2)) * 256 < k)
@@ -622,7 +627,7 @@ int sputnik_hip_sddmm_plan(int m, int k, int n, int nonzeros, const int* row_ind
       workspace_bytes < sddmm_tiled_workspace_bytes(m, k, n, nonzeros))
     return 0;  // nothing to plan: the row-wave kernel needs no workspace
   return sddmm_tiled_plan(m, k, n, nonzeros, row_indices, row_offsets, column_indices, workspace,
-                          stream);
+                          stream, /*summed=*/false, /*with_flat=*/true);
 }
 
 int sputnik_hip_sddmm_batched_planned(int m, int k, int n, int nonzeros, int replicas,
@@ -652,6 +657,21 @@ int sputnik_hip_sddmm_typed(int m, int k, int n, int nonzeros, int replicas,
   return sddmm_exec_half(m, k, n, nonzeros, replicas, row_indices, row_offsets, column_indices, lhs,
                          lhs_stride, rhs, rhs_stride, out, out_stride, in_type, out_type, workspace,
                          workspace_bytes, planned != 0, stream);
+}
+
+const char* sputnik_hip_sddmm_kernel_name(int m, int k, int n, int nonzeros, int replicas,
+                                          int elem_bytes, int planned) {
+  if (m <= 0 || k <= 0 || n <= 0 || nonzeros <= 0 || replicas <= 0) return "none";
+  const bool force_tiled = options().sddmm_kernel == 1;
+  const bool force_wave = options().sddmm_kernel == 2;
+  const bool small = static_cast<double>(nonzeros) * k * k * replicas < 17179869184.0;  // 2^34
+  const bool shape = sddmm_tiled_workspace_bytes(m, k, n, nonzeros) != 0 &&
+                     static_cast<int64_t>(n) * k * elem_bytes < (int64_t{1} << 32) &&
+                     static_cast<int64_t>(m) * k * elem_bytes < (int64_t{1} << 32);
+  if (force_wave || !(force_tiled || !small) || !shape) return "sddmm_rowwave_kernel";
+  if (planned != 0 && sddmm_flat_applicable(m, k, n, nonzeros, elem_bytes)) return "sddmm_flat_kernel";
+  if (elem_bytes == 2 || sddmm_tiled_panel_width(k) == 64) return "sddmm_quad_kernel";
+  return "sddmm_stationary_kernel";
 }
 
 int sputnik_hip_sddmm(int m, int k, int n, int nonzeros, const int* row_indices,

@@ -28,13 +28,24 @@
 #include <type_traits>
 
 #include "options.h"
+#include "sddmm_dot.h"
 #include "spmm_tiled_common.h"
 
 namespace sputnik_hip {
+
+// sddmm_flat.hip: the pair-flat kernel for planned masks and rows of 128 / 256 bytes
+bool sddmm_flat_applicable(int m, int k, int n, int nonzeros, int elem_bytes);
+size_t sddmm_flat_plan_bytes(int m, int n, int nonzeros);
+int sddmm_flat_plan(int m, int n, int nonzeros, const int* row_indices, const int* row_offsets,
+                    const int* column_indices, void* plan, hipStream_t stream);
+int sddmm_flat_launch(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
+                      const void* lhs, int64_t lhs_stride, const void* rhs, int64_t rhs_stride,
+                      void* out, int64_t out_stride, int in_type, int out_type, const void* plan,
+                      hipStream_t stream);
+
 namespace {
 
 using namespace tiled;
-using v2f = float __attribute__((ext_vector_type(2)));
 
 constexpr int kSWaves = 8;
 constexpr int kSGroups = kSWaves * 4;  // 16-lane row groups per workgroup
@@ -323,46 +334,6 @@ void sddmm_stationary_kernel(
 // slab is staged as raw bytes (half the LDS DMA and half the LDS read traffic), the
 // products are v_dot2_f32_f16 / v_dot2_f32_bf16 -- exact products, float32 sums.
 // The slab keeps the ROW COUNT of the float form, so plans do not depend on T.
-template <typename T> struct Dot;
-template <> struct Dot<float> {
-  using chunk = float __attribute__((ext_vector_type(4)));   // 16 bytes of a row
-  static __device__ __forceinline__ void mac(v2f& acc, const chunk& a, const chunk& b) {
-    acc = __builtin_elementwise_fma(v2f{a.x, a.y}, v2f{b.x, b.y}, acc);
-    acc = __builtin_elementwise_fma(v2f{a.z, a.w}, v2f{b.z, b.w}, acc);
-  }
-};
-using h2v = _Float16 __attribute__((ext_vector_type(2)));
-using b2v = __bf16 __attribute__((ext_vector_type(2)));
-using HalfChunk = unsigned __attribute__((ext_vector_type(4)));   // 8 half values
-// (the words are copied out first: __builtin_bit_cast applied to `a[1]` directly reads
-// element 0 of the vector with this compiler)
-__device__ __forceinline__ float dot2_f16(unsigned a, unsigned b, float c) {
-  return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2v, a), __builtin_bit_cast(h2v, b), c, false);
-}
-__device__ __forceinline__ float dot2_bf16(unsigned a, unsigned b, float c) {
-  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2v, a), __builtin_bit_cast(b2v, b), c, false);
-}
-template <> struct Dot<_Float16> {
-  using chunk = HalfChunk;
-  static __device__ __forceinline__ void mac(v2f& acc, const chunk& a, const chunk& b) {
-    const unsigned a0 = a.x, a1 = a.y, a2 = a.z, a3 = a.w, b0 = b.x, b1 = b.y, b2 = b.z, b3 = b.w;
-    acc.x = dot2_f16(a0, b0, acc.x);
-    acc.y = dot2_f16(a1, b1, acc.y);
-    acc.x = dot2_f16(a2, b2, acc.x);
-    acc.y = dot2_f16(a3, b3, acc.y);
-  }
-};
-template <> struct Dot<__bf16> {
-  using chunk = HalfChunk;
-  static __device__ __forceinline__ void mac(v2f& acc, const chunk& a, const chunk& b) {
-    const unsigned a0 = a.x, a1 = a.y, a2 = a.z, a3 = a.w, b0 = b.x, b1 = b.y, b2 = b.z, b3 = b.w;
-    acc.x = dot2_bf16(a0, b0, acc.x);
-    acc.y = dot2_bf16(a1, b1, acc.y);
-    acc.x = dot2_bf16(a2, b2, acc.x);
-    acc.y = dot2_bf16(a3, b3, acc.y);
-  }
-};
-
 template <int KV, int ROWS, typename T>
 struct Quad {
   static constexpr int kdim = 64 * KV;
@@ -375,12 +346,6 @@ struct Quad {
   static constexpr int kThreads = kWaves * kWave;
   static_assert(C >= 2 && C <= 8, "quad form: 32 .. 128 bytes of a row per lane");
 };
-
-template <int S>
-__device__ __forceinline__ int quad_bcast_add(int v, int add) {
-  // add + (v of lane S of the quad): v_add_u32_dpp quad_perm:[S,S,S,S]
-  return __builtin_amdgcn_update_dpp(0, v, S * 0x55, 0xF, 0xF, true) + add;
-}
 
 template <int KV, int ROWS, typename T, typename TO, bool ACC>
 __global__ __launch_bounds__((Quad<KV, ROWS, T>::kThreads))
@@ -811,6 +776,8 @@ int launch_partials(int m, int k, int n, int nonzeros, int replicas, int slots,
 
 }  // namespace
 
+int sddmm_tiled_panel_width(int k) { return panel_width(k); }
+
 int sddmm_tiled_panels(int m, int k, int n, int nonzeros) {
   return served(k) ? k / sum_panel_width(m, k, n, nonzeros) : 1;
 }
@@ -849,16 +816,43 @@ bool sddmm_tiled_applicable(int m, int k, int n, int nonzeros, const float* lhs,
 
 // `summed`: for sddmm_tiled_launch_partials (its panel width, hence its slabs and
 // its chunk table, can differ from the plain product's).
-size_t sddmm_tiled_workspace_bytes(int m, int k, int n, int nonzeros, bool summed) {
+namespace {
+// Tables of the rhs-stationary kernels alone.
+size_t table_bytes(int m, int k, int n, int nonzeros, bool summed) {
   if (!served(k) || n < 16 || m < 16 || nonzeros < 4 * static_cast<int64_t>(m)) return 0;
   const int rows = slab_rows_of_width(width_for(m, k, n, nonzeros, summed));
   return row_ok_bytes(slots_of(m)) +
          sizeof(int) * static_cast<size_t>(ceil_div(n, rows) + 1) * slots_of(m);
 }
+// The plain (not summed) product of this shape can take the pair-flat kernel in SOME
+// storage type (the workspace does not know the operands' type): its plan sits behind
+// the tables.
+bool flat_shape(int m, int k, int n, int nonzeros) {
+  return sddmm_flat_applicable(m, k, n, nonzeros, 4) || sddmm_flat_applicable(m, k, n, nonzeros, 2);
+}
+size_t flat_plan_offset(int m, int k, int n, int nonzeros) {
+  return (table_bytes(m, k, n, nonzeros, false) + 255) / 256 * 256;
+}
+}  // namespace
 
+size_t sddmm_tiled_workspace_bytes(int m, int k, int n, int nonzeros, bool summed) {
+  const size_t tables = table_bytes(m, k, n, nonzeros, summed);
+  if (tables == 0 || summed || !flat_shape(m, k, n, nonzeros)) return tables;
+  return flat_plan_offset(m, k, n, nonzeros) + sddmm_flat_plan_bytes(m, n, nonzeros);
+}
+
+// with_flat: also the pair-flat kernel's plan (sddmm_flat.hip) -- for plans that are KEPT
+// (sputnik_hip_sddmm_plan: a static mask); a call that plans for itself and throws the
+// plan away takes the tables only (one 5 us launch against a memset and four launches).
 int sddmm_tiled_plan(int m, int k, int n, int nonzeros, const int* row_indices,
                      const int* row_offsets, const int* column_indices, void* workspace,
-                     hipStream_t stream, bool summed) {
+                     hipStream_t stream, bool summed, bool with_flat) {
+  if (with_flat && !summed && flat_shape(m, k, n, nonzeros)) {
+    const int st = sddmm_flat_plan(m, n, nonzeros, row_indices, row_offsets, column_indices,
+                                   static_cast<char*>(workspace) + flat_plan_offset(m, k, n, nonzeros),
+                                   stream);
+    if (st != 0) return st;
+  }
   const int slots = slots_of(m);
   int* row_ok = static_cast<int*>(workspace);
   int* table = reinterpret_cast<int*>(static_cast<char*>(workspace) + row_ok_bytes(slots));
@@ -876,7 +870,12 @@ int sddmm_tiled_launch(int m, int k, int n, int nonzeros, int replicas, const in
                        const int* row_offsets, const int* column_indices, const float* lhs,
                        int64_t lhs_stride, const float* rhs, int64_t rhs_stride, float* out,
                        int64_t out_stride, const void* workspace, hipStream_t stream,
-                       int mask_heads, int64_t mask_plan_ints) {
+                       int mask_heads, int64_t mask_plan_ints, bool flat) {
+  if (flat && mask_heads == 0 && sddmm_flat_applicable(m, k, n, nonzeros, 4))
+    return sddmm_flat_launch(m, k, n, nonzeros, replicas, row_indices, lhs, lhs_stride, rhs,
+                             rhs_stride, out, out_stride, SPUTNIK_HIP_F32, SPUTNIK_HIP_F32,
+                             static_cast<const char*>(workspace) + flat_plan_offset(m, k, n, nonzeros),
+                             stream);
   const int debug = options().sddmm_debug;  // timing experiments only
   const int slots = slots_of(m);
   const int* row_ok = static_cast<const int*>(workspace);
@@ -913,7 +912,12 @@ int sddmm_tiled_launch_half(int m, int k, int n, int nonzeros, int replicas, con
                             const int* row_offsets, const int* column_indices, const void* lhs,
                             int64_t lhs_stride, const void* rhs, int64_t rhs_stride, void* out,
                             int64_t out_stride, int in_type, int out_type, const void* workspace,
-                            hipStream_t stream, int mask_heads, int64_t mask_plan_ints) {
+                            hipStream_t stream, int mask_heads, int64_t mask_plan_ints, bool flat) {
+  if (flat && mask_heads == 0 && sddmm_flat_applicable(m, k, n, nonzeros, 2))
+    return sddmm_flat_launch(m, k, n, nonzeros, replicas, row_indices, lhs, lhs_stride, rhs,
+                             rhs_stride, out, out_stride, in_type, out_type,
+                             static_cast<const char*>(workspace) + flat_plan_offset(m, k, n, nonzeros),
+                             stream);
   const int debug = options().sddmm_debug;
   const int slots = slots_of(m);
   const int* row_ok = static_cast<const int*>(workspace);

@@ -88,6 +88,11 @@ struct ChunkInfo {
 // of the group holds the column.  The position of an entry is the number of set
 // bits in front of it, the first set bit of a byte starts a column group.
 // ---------------------------------------------------------------------------
+// masks (a byte per column) + per chunk: entries before, held columns, word prefixes;
+// scratch; rounded to 16 bytes (the staged stream behind it moves in 16-byte pieces)
+__host__ __device__ inline size_t fill_tables_bytes(int nchunks) {
+  return (sizeof(int) * (static_cast<size_t>(nchunks) * (kBK / 4 + 4) + 2 * kRPW + 2) + 15) / 16 * 16;
+}
 __device__ __forceinline__ int wave_sum(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -102,39 +107,11 @@ __device__ __forceinline__ int wave_inclusive_scan(int v, int lane) {
   return v;
 }
 
-// Windows of every group (round 4).  Until round 3 each fill workgroup summed the
-// windows of ALL groups before it from the row bounds themselves -- groups^2 / 2
-// evaluations of 8 + 16 scattered loads each, 3.1 M lane loads at 4096 rows: two
-// thirds of the pre-pass's 20 us.  One thread per group writes the count once; a fill
-// workgroup then adds up at most `groups` consecutive words.
-__global__ __launch_bounds__(64) void spmm_flat_count_kernel(
-    int m, int slots, int groups, const int* __restrict__ row_indices,
-    const int* __restrict__ row_offsets, int* __restrict__ gcount) {
-  constexpr int RPW = kRPW;
-  const int g = blockIdx.x * 64 + threadIdx.x;
-  if (g >= groups) return;
-  int rows[RPW], lo[RPW], hi[RPW];
-#pragma unroll
-  for (int r = 0; r < RPW; ++r) {
-    const int e = dealt_index(g * RPW + r, slots, kDealPer);
-    rows[r] = e < m ? row_indices[e] : -1;
-  }
-#pragma unroll
-  for (int r = 0; r < RPW; ++r) {
-    lo[r] = rows[r] >= 0 ? row_offsets[rows[r]] : 0;
-    hi[r] = rows[r] >= 0 ? row_offsets[rows[r] + 1] : 0;
-  }
-  int len = 0;
-#pragma unroll
-  for (int r = 0; r < RPW; ++r) len += hi[r] - lo[r];
-  gcount[g] = (len + kWindow - 1) / kWindow;
-}
-
 __global__ __launch_bounds__(kRPW * 64) void spmm_flat_fill_kernel(
     int m, int k, int slots, int nchunks, const int* __restrict__ row_indices,
     const int* __restrict__ row_offsets, const int* __restrict__ column_indices,
-    const int* __restrict__ gcount, int* __restrict__ row_ok, ChunkInfo* __restrict__ cinfo,
-    int* __restrict__ gwin, unsigned char* __restrict__ stream) {
+    int* __restrict__ row_ok, ChunkInfo* __restrict__ cinfo, int* __restrict__ gwin,
+    unsigned char* __restrict__ stream, int stage_windows, int debug) {
   extern __shared__ unsigned lds[];
   constexpr int RPW = kRPW, BK = kBK, NT = RPW * 64;
   constexpr int WPC = BK / 4;             // mask words per chunk (a byte per column)
@@ -146,6 +123,8 @@ __global__ __launch_bounds__(kRPW * 64) void spmm_flat_fill_kernel(
   unsigned* nzmask = reinterpret_cast<unsigned*>(ebase + nchunks);   // [nchunks]: bit j = column j is held
   unsigned* wprefix = nzmask + nchunks;                         // [nchunks * 2]: entries before word i, a byte each
   int* scratch = reinterpret_cast<int*>(wprefix + 2 * nchunks); // [2 * RPW + 2]
+  // [stage_windows * kWindowBytes], 16-byte aligned: the group's stream on its way out
+  unsigned char* sbuf = reinterpret_cast<unsigned char*>(lds) + fill_tables_bytes(nchunks);
 
   for (int i = tid; i < nchunks * WPC; i += NT) maskw[i] = 0;
   // (1) this wave's row; windows of all groups before this one
@@ -157,8 +136,26 @@ __global__ __launch_bounds__(kRPW * 64) void spmm_flat_fill_kernel(
     p0 = row_offsets[row];
     p1 = row_offsets[row + 1];
   }
+  // (Round 4 measured the alternative -- the groups' window counts from a small kernel of
+  // their own, summed here: that kernel alone takes 4.7 us, this loop 2.5.)
   int before = 0;
-  for (int gp = tid; gp < g; gp += NT) before += gcount[gp];   // (spmm_flat_count_kernel)
+  for (int gp = tid; gp < g; gp += NT) {
+    // two rounds of independent loads: row ids, then each row's two bounds as ONE 8-byte
+    // load (4-byte aligned: all a global load needs)
+    int rows[RPW], len = 0;
+    int2 bounds[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const int e = dealt_index(gp * RPW + r, slots, kDealPer);
+      rows[r] = e < m ? row_indices[e] : -1;
+    }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+      bounds[r] = rows[r] >= 0 ? *reinterpret_cast<const int2*>(row_offsets + rows[r]) : make_int2(0, 0);
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) len += bounds[r].y - bounds[r].x;
+    before += (len + kWindow - 1) / kWindow;
+  }
   before = wave_sum(before);
   if (lane == 0) {
     scratch[wave] = before;
@@ -184,7 +181,14 @@ __global__ __launch_bounds__(kRPW * 64) void spmm_flat_fill_kernel(
     for (int u = 0; u < UN; ++u) {
       const int p = base + u * 64 + lane;
       cur[u] = p < p1 ? column_indices[p] : -2;
-      prev[u] = (p < p1 && p > p0) ? column_indices[p - 1] : -1;
+    }
+    // the entry before: the neighbouring lane's (lane 0: the last lane of the round before)
+    const int before_base = base > p0 ? column_indices[base - 1] : -1;
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int up = __shfl_up(cur[u], 1);
+      const int carry = u == 0 ? before_base : __shfl(cur[u == 0 ? 0 : u - 1], 63);
+      prev[u] = lane == 0 ? carry : up;
     }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
@@ -212,29 +216,46 @@ __global__ __launch_bounds__(kRPW * 64) void spmm_flat_fill_kernel(
     return;
   }
 
+  if (debug & 0x100) return;   // timing experiment: phases 1-2 only
   // (3) per chunk: entries, column groups, the tile rows of the first groups, and what
-  // the entries' positions are computed from (held-column mask, entries before each word)
-  for (int c = tid; c < nchunks; c += NT) {
-    int entries = 0, cgroups = 0;
-    unsigned first = 0u, nz = 0u, pre[2] = {0u, 0u};
+  // the entries' positions are computed from (held-column mask, entries before each word).
+  // One lane per mask WORD (8 consecutive lanes = a chunk): a lane per chunk walked 32
+  // bytes serially on a quarter of the workgroup's lanes.
+  for (int t0 = 0; t0 < nchunks * WPC; t0 += NT) {
+    const int t = t0 + tid;
+    const bool live = t < nchunks * WPC;
+    const int c = t / WPC, i = t % WPC;
+    const unsigned w = live ? maskw[t] : 0u;
+    const int cnt = __popc(w);
+    unsigned nz = 0u;
 #pragma unroll
-    for (int i = 0; i < WPC; ++i) {
-      const unsigned w = maskw[c * WPC + i];
-      pre[i / 4] |= static_cast<unsigned>(entries) << (8 * (i % 4));
-      entries += __popc(w);
+    for (int b = 0; b < 4; ++b)
+      if ((w >> (8 * b)) & 0xffu) nz |= 1u << (4 * i + b);
+    int incl = cnt;   // inclusive scan over the chunk's 8 words
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
-        if ((w >> (8 * b)) & 0xffu) {
-          nz |= 1u << (4 * i + b);
-          if (cgroups < kAhead) first |= static_cast<unsigned>((c & 1) * BK + 4 * i + b) << (8 * cgroups);
-          ++cgroups;
-        }
+    for (int o = 1; o < WPC; o <<= 1) {
+      const int up = __shfl_up(incl, o, WPC);
+      if (i >= o) incl += up;
     }
-    ebase[c] = entries;
-    nzmask[c] = nz;
-    wprefix[2 * c] = pre[0];
-    wprefix[2 * c + 1] = pre[1];
-    my_info[c] = ChunkInfo{cgroups, first, 0u, entries};
+#pragma unroll
+    for (int o = 1; o < WPC; o <<= 1) nz |= static_cast<unsigned>(__shfl_xor(static_cast<int>(nz), o, WPC));
+    const int entries = __shfl(incl, WPC - 1, WPC);
+    if (live) {
+      reinterpret_cast<unsigned char*>(wprefix)[t] = static_cast<unsigned char>(incl - cnt);
+      if (i == 0) {
+        unsigned first = 0u, rest = nz;
+        const int cgroups = __popc(nz);
+#pragma unroll
+        for (int q = 0; q < kAhead; ++q)
+          if (rest) {
+            first |= static_cast<unsigned>((c & 1) * BK + __ffs(rest) - 1) << (8 * q);
+            rest &= rest - 1u;
+          }
+        ebase[c] = entries;
+        nzmask[c] = nz;
+        my_info[c] = ChunkInfo{cgroups, first, 0u, entries};
+      }
+    }
   }
   if (tid == 0) my_info[nchunks] = ChunkInfo{0, 0u, 0u, 0};   // (read one chunk ahead)
   __syncthreads();
@@ -250,8 +271,15 @@ __global__ __launch_bounds__(kRPW * 64) void spmm_flat_fill_kernel(
   }
   __syncthreads();
 
-  // (4) the entries
+  if (debug & 0x200) return;   // timing experiment: phases 1-3 only
+  // (4) the entries.  A row's entries land (column, row)-sorted among those of the other 7
+  // rows: 64 lanes of a store instruction hit 64 different windows.  Written straight to
+  // memory that was two scattered stores (8 bytes + 1 byte) per entry; the group's stream
+  // is therefore assembled in LDS when it fits and leaves in 16-byte pieces.
   static_assert(WPC == 8, "two prefix words per chunk");
+  const int nwin_out = windows + (g == groups - 1 ? kTailWindows : 0);
+  const bool staged = nwin_out <= stage_windows && !(debug & 0x1000);
+  unsigned char* const dst_stream = staged ? sbuf : my_stream;
   for (int base = p0; base < p1; base += 64 * UN) {
     int cols[UN];
 #pragma unroll
@@ -280,7 +308,8 @@ __global__ __launch_bounds__(kRPW * 64) void spmm_flat_fill_kernel(
         ahead &= ahead - 1u;
         if (ahead) tile_rows |= static_cast<unsigned>((c & 1) * BK + j + __ffs(ahead)) << 8;
       }
-      unsigned char* block = my_stream + static_cast<int64_t>(pos / kWindow) * kWindowBytes;
+      if (debug & 0x400) continue;   // timing experiment: no stream writes
+      unsigned char* block = dst_stream + static_cast<int64_t>(pos / kWindow) * kWindowBytes;
       const int e = pos % kWindow;
       *reinterpret_cast<uint2*>(block + 8 * e) = make_uint2(tile_rows, static_cast<unsigned>(p) * 4u);
       block[128 + e] = static_cast<unsigned char>(rowbyte);
@@ -289,14 +318,20 @@ __global__ __launch_bounds__(kRPW * 64) void spmm_flat_fill_kernel(
   // (5) unused entries of the last window, and the empty windows behind the last group:
   // flagged as group starts, so that the loop meets its end-of-chunk test there
   for (int pos = total + tid; pos < windows * kWindow; pos += NT) {
-    unsigned char* block = my_stream + static_cast<int64_t>(pos / kWindow) * kWindowBytes;
+    unsigned char* block = dst_stream + static_cast<int64_t>(pos / kWindow) * kWindowBytes;
     *reinterpret_cast<uint2*>(block + 8 * (pos % kWindow)) = make_uint2(0u, 0u);
     block[128 + pos % kWindow] = static_cast<unsigned char>(kNewGroup);
   }
   if (g == groups - 1) {
-    unsigned* w = reinterpret_cast<unsigned*>(my_stream + static_cast<int64_t>(windows) * kWindowBytes);
+    unsigned* w = reinterpret_cast<unsigned*>(dst_stream + static_cast<int64_t>(windows) * kWindowBytes);
     for (int i = tid; i < kTailWindows * (kWindowBytes / 4); i += NT)
       w[i] = i % (kWindowBytes / 4) >= 32 ? 0x80808080u : 0u;
+  }
+  if (staged) {
+    __syncthreads();
+    const uint4* src = reinterpret_cast<const uint4*>(sbuf);
+    uint4* dst = reinterpret_cast<uint4*>(my_stream);   // (window blocks are 144 = 9 x 16 bytes)
+    for (int i = tid; i < nwin_out * (kWindowBytes / 16); i += NT) dst[i] = src[i];
   }
 }
 
@@ -436,7 +471,7 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_flat_kernel(
 
 struct FlatPlan {
   int slots, nchunks, n_tiles, groups;
-  size_t row_ok_off, cinfo_off, gwin_off, gcount_off, stream_off, bytes;
+  size_t row_ok_off, cinfo_off, gwin_off, stream_off, bytes;
 };
 
 FlatPlan make_flat_plan(int m, int k, int n, int nonzeros) {
@@ -449,16 +484,24 @@ FlatPlan make_flat_plan(int m, int k, int n, int nonzeros) {
   p.row_ok_off = 0;
   p.cinfo_off = row_ok_bytes(p.slots);
   p.gwin_off = up(p.cinfo_off + sizeof(ChunkInfo) * static_cast<size_t>(p.nchunks + 1) * p.groups);
-  p.gcount_off = up(p.gwin_off + sizeof(int) * static_cast<size_t>(p.groups));
-  p.stream_off = up(p.gcount_off + sizeof(int) * static_cast<size_t>(p.groups));
+  p.stream_off = up(p.gwin_off + sizeof(int) * static_cast<size_t>(p.groups));
   const size_t windows = static_cast<size_t>(nonzeros) / kWindow + p.groups + kTailWindows;
   p.bytes = up(p.stream_off + windows * kWindowBytes);
   return p;
 }
 
-size_t fill_lds_bytes(int nchunks) {
-  // masks (a byte per column) + per chunk: entries before, held columns, word prefixes; scratch
-  return sizeof(int) * (static_cast<size_t>(nchunks) * (kBK / 4 + 4) + 2 * kRPW + 2);
+// Windows of a group's stream that the fill kernel can assemble in LDS: a quarter above
+// the average group (rows are dealt, groups differ by a few per cent), within 64 KiB per
+// workgroup together with the tables; a group beyond that writes straight to memory.
+int fill_stage_windows(int nchunks, int nonzeros, int groups) {
+  const size_t tables = fill_tables_bytes(nchunks);
+  if (tables + kWindowBytes > 64 * 1024) return 0;
+  const int64_t room = static_cast<int64_t>((64 * 1024 - tables) / kWindowBytes);
+  const int64_t want = (static_cast<int64_t>(nonzeros) / kWindow / groups) * 5 / 4 + kTailWindows + 2;
+  return static_cast<int>(std::min(room, want));
+}
+size_t fill_lds_bytes(int nchunks, int stage_windows) {
+  return fill_tables_bytes(nchunks) + static_cast<size_t>(stage_windows) * kWindowBytes;
 }
 
 // Which loop reads the stream.  p = share of the entries that start a column
@@ -518,19 +561,17 @@ int spmm_flat_plan(int m, int k, int n, int nonzeros, const int* row_indices,
   static const bool lds_ok = [] {   // more than the default 64 KiB for large k
     return hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_flat_fill_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                               static_cast<int>(fill_lds_bytes(kMaxColumns / kBK))) == hipSuccess;
+                               static_cast<int>(fill_lds_bytes(kMaxColumns / kBK, 0))) == hipSuccess;
   }();
-  if (!lds_ok && fill_lds_bytes(p.nchunks) > 64 * 1024) return SPUTNIK_HIP_UNSUPPORTED;
-  hipLaunchKernelGGL(spmm_flat_count_kernel, dim3(ceil_div(p.groups, 64)), dim3(64), 0, stream, m,
-                     p.slots, p.groups, row_indices, row_offsets,
-                     reinterpret_cast<int*>(base + p.gcount_off));
+  const int stage_windows = fill_stage_windows(p.nchunks, nonzeros, p.groups);
+  if (!lds_ok && fill_lds_bytes(p.nchunks, stage_windows) > 64 * 1024) return SPUTNIK_HIP_UNSUPPORTED;
   hipLaunchKernelGGL(spmm_flat_fill_kernel, dim3(p.groups), dim3(kRPW * 64),
-                     fill_lds_bytes(p.nchunks), stream, m, k, p.slots, p.nchunks, row_indices,
-                     row_offsets, column_indices, reinterpret_cast<const int*>(base + p.gcount_off),
-                     reinterpret_cast<int*>(base + p.row_ok_off),
+                     fill_lds_bytes(p.nchunks, stage_windows), stream, m, k, p.slots, p.nchunks, row_indices,
+                     row_offsets, column_indices, reinterpret_cast<int*>(base + p.row_ok_off),
                      reinterpret_cast<ChunkInfo*>(base + p.cinfo_off),
                      reinterpret_cast<int*>(base + p.gwin_off),
-                     reinterpret_cast<unsigned char*>(base + p.stream_off));
+                     reinterpret_cast<unsigned char*>(base + p.stream_off), stage_windows,
+                     options().spmm_debug);
   return launch_status();
 }
 
