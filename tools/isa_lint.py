@@ -257,6 +257,14 @@ def lint_kernel(name, instrs):
         # its one hand-written wait is the vmcnt(0) behind the panel copy, which
         # drains everything; all other loads are the compiler's, with its waits
         return errors
+    if "sddmm_flat_kernel" in name:
+        # its hand-written waits are vmcnt(0) drains of the copying wave, which issues
+        # nothing but copies; the compute waves issue no vector-memory load at all (their
+        # descriptors come from LDS) and nothing waits for their stores
+        for off, mn, ops, _t in instrs:
+            if mn == "s_waitcnt" and re.search(r"vmcnt\(([1-9]\d*)\)", ops):
+                errors.append(f"+0x{off:x}: counted vmcnt wait in sddmm_flat_kernel (only drains expected)")
+        return errors
     cfg = Cfg(instrs)
     loop = cfg.main_loop()
     if loop is None:
