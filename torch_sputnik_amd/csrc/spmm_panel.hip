@@ -130,15 +130,20 @@ __device__ __forceinline__ void load_rows(Rows& r, int m, int slots, int mblock,
 // bytes (l % 16) * 16).  Lanes past the end of a row of B (partial last column
 // tile) or past the last row re-read valid bytes that are never used.  Returns
 // with the wave's own copies landed; the caller joins the waves.
-__device__ __forceinline__ void copy_panel(float* panel, const float* __restrict__ dense, int k,
-                                           int n, int kbase, int col, int wave, int g) {
-  const int rows_here = min(k - kbase, kPMaxK);
+__device__ __forceinline__ void copy_panel_issue(float* panel, const float* __restrict__ dense,
+                                                 int k, int n, int kbase, int col, int wave, int g,
+                                                 bool skip = false /* timing experiment */) {
+  const int rows_here = skip ? 0 : min(k - kbase, kPMaxK);
   for (int j = wave; j * 4 < rows_here; j += kPWaves) {
     const int src_row = min(kbase + 4 * j + g, k - 1);
     const unsigned off = static_cast<unsigned>(src_row) * static_cast<unsigned>(n) * 4u +
                          static_cast<unsigned>(col) * 4u;
     lds_dma_row(dense, off, panel + 4 * j * kPBN);
   }
+}
+__device__ __forceinline__ void copy_panel(float* panel, const float* __restrict__ dense, int k,
+                                           int n, int kbase, int col, int wave, int g) {
+  copy_panel_issue(panel, dense, k, n, kbase, col, wave, g);
   wait_vm<0>();
 }
 
@@ -171,7 +176,8 @@ __device__ __forceinline__ void stream_pairs(float (&acc)[kPQuads][4], const Row
                                              const int* __restrict__ column_indices,
                                              const TV* __restrict__ values,
                                              const int* __restrict__ value_permutation, int last,
-                                             int i, const char* __restrict__ lane_base) {
+                                             int i, const char* __restrict__ lane_base,
+                                             int kbase = 0 /* first row of B in the panel */) {
 #pragma unroll
   for (int t = 0; t < kPQuads; t += 2) {
     const int n_a = r.cnt[t], n_b = r.cnt[t + 1];
@@ -194,8 +200,8 @@ __device__ __forceinline__ void stream_pairs(float (&acc)[kPQuads][4], const Row
         eval_b = static_cast<float>(at32(values, PERM ? at32(value_permutation, idx_b) : idx_b));
       }
       const int left_a = n_a - w0, left_b = n_b - w0;
-      const int roff_a = i < left_a ? col_a * (kPBN * 4) : 0;
-      const int roff_b = i < left_b ? col_b * (kPBN * 4) : 0;
+      const int roff_a = i < left_a ? (col_a - kbase) * (kPBN * 4) : 0;
+      const int roff_b = i < left_b ? (col_b - kbase) * (kPBN * 4) : 0;
       const float rval_a = i < left_a ? val_a : 0.f;
       const float rval_b = i < left_b ? val_b : 0.f;
       const int left = max(left_a, left_b);   // (entries past a row's end carry a zero value)
@@ -259,6 +265,48 @@ __device__ __forceinline__ void stream_masked(float (&acc)[kPQuads][4], const Ro
     }
     start[t] = seen_later ? first_later : ((longest + 15) & ~15);
   }
+}
+
+// Two panels, rows with ascending columns (round 4).  stream_masked above serves any
+// column order by walking every row's windows in every pass and masking: 11 window visits
+// per row for 6.4 windows of entries at the attention shape, the straddling window worked
+// on twice, 2.1 vector instructions per entry where the arithmetic step has 1.0
+// (profiles/r3e_pmc_sq_attention_ops.json).  A row whose columns ascend is simply CUT at
+// the first entry of the second panel: pass 0 runs entries [0, cut), pass 1 [cut, end),
+// both as plain counted windows (stream_pairs: two row quads side by side, no mask).
+// The cut and the order are found by one scan of the row's columns WHILE THE FIRST PANEL
+// IS BEING COPIED (the same windows the passes read again, from cache): cut = number of
+// columns below the panel boundary, order = every column above the one before it.
+// Returns false (wave-uniform) if a row of the wave is not in ascending order or holds a
+// column outside [0, k): the wave then takes stream_masked.
+__device__ __forceinline__ bool scan_cuts(const Rows& r, int (&cut)[kPQuads], int boundary, int k,
+                                          const int* __restrict__ column_indices, int last, int g,
+                                          int i) {
+  bool ok = true;
+#pragma unroll
+  for (int t = 0; t < kPQuads; ++t) {
+    const int n_here = r.cnt[t];
+    const int longest =
+        max(max(__builtin_amdgcn_readlane(n_here, 0), __builtin_amdgcn_readlane(n_here, 16)),
+            max(__builtin_amdgcn_readlane(n_here, 32), __builtin_amdgcn_readlane(n_here, 48)));
+    int below = 0, carry = -1;   // entries in front of the boundary; the column before the window
+    int ecol = at32(column_indices, max(min(r.p0[t] + i, last), 0));
+    for (int w0 = 0; w0 < longest; w0 += 16) {
+      const int cur = ecol;
+      if (w0 + 16 < longest) ecol = at32(column_indices, min(r.p0[t] + w0 + 16 + i, last));
+      const bool in_row = i < n_here - w0;
+      // the column before: the lane below (row_shr:1; lane 0 of the group: the window before)
+      const int shifted = __builtin_amdgcn_update_dpp(0, cur, 0x111, 0xF, 0xF, false);
+      const int prev = i == 0 ? carry : shifted;
+      ok = ok && (!in_row || (cur > prev && cur < k));
+      const unsigned lower = static_cast<unsigned>(
+          __builtin_amdgcn_ballot_w64(in_row && cur < boundary) >> (g * 16)) & 0xffffu;
+      below += __popc(lower);
+      carry = row_bcast_i<15>(cur);
+    }
+    cut[t] = below;
+  }
+  return __builtin_amdgcn_ballot_w64(!ok) == 0;
 }
 
 __device__ __forceinline__ void store_rows(const float (&acc)[kPQuads][4], const Rows& r,
@@ -342,7 +390,9 @@ __global__ __launch_bounds__(kPThreads) void spmm_panel64_kernel(
     int64_t values_stride, const int* __restrict__ row_offsets,
     const int* __restrict__ column_indices, const int* __restrict__ value_permutation,
     const float* __restrict__ dense, int64_t dense_stride, float* __restrict__ out,
-    int64_t out_stride, Epilogue epi, int block_rows, int mask_heads, int first_replica) {
+    int64_t out_stride, Epilogue epi, int block_rows, int mask_heads, int first_replica,
+    int debug /* bit 4: rows are never cut (the masked walk for every order); bit 5 (timing
+                 experiment, wrong results): no panel copies */) {
   extern __shared__ float panel[];   // [min(k, 512)][64]
 
   const int lane = threadIdx.x % kWave;
@@ -380,9 +430,41 @@ __global__ __launch_bounds__(kPThreads) void spmm_panel64_kernel(
     fetch_first_windows<PERM>(rows, first_col, first_val, column_indices, values,
                               value_permutation, last, i);
 
+  // MULTI with exactly two panels: rows cut at the panel boundary (scan_cuts), found while
+  // the first panel is on its way; `sorted` is wave-uniform, the waves of a workgroup
+  // choose for themselves (only the panel copies are a workgroup matter)
+  bool sorted = false, first_issued = false;
+  int cut[kPQuads] = {};
+  if constexpr (MULTI) {
+    if (k <= 2 * kPMaxK && !(debug & 16)) {
+      // (the copies first: the scan's loads wait behind them in the memory pipeline either way)
+      copy_panel_issue(panel, dense, k, n, 0, col, wave, g, debug & 32);
+      first_issued = true;
+      sorted = scan_cuts(rows, cut, kPMaxK, k, column_indices, last, g, i);
+    }
+  }
   for (int kbase = 0; kbase < k; kbase += kPMaxK) {
     if (MULTI && kbase > 0) __syncthreads();   // every wave is done with the previous panel
-    copy_panel(panel, dense, k, n, kbase, col, wave, g);
+    if (MULTI && sorted) {
+      // this pass's part of every row, as a row of its own
+      Rows part;
+#pragma unroll
+      for (int t = 0; t < kPQuads; ++t) {
+        part.row[t] = rows.row[t];
+        part.p0[t] = rows.p0[t] + (kbase > 0 ? cut[t] : 0);
+        part.cnt[t] = kbase > 0 ? rows.cnt[t] - cut[t] : cut[t];
+      }
+      fetch_first_windows<PERM>(part, first_col, first_val, column_indices, values,
+                                value_permutation, last, i);   // (in flight while the panel is copied)
+      if (kbase > 0) copy_panel_issue(panel, dense, k, n, kbase, col, wave, g, debug & 32);
+      wait_vm<0>();
+      __syncthreads();
+      stream_pairs<PERM>(acc, part, first_col, first_val, column_indices, values,
+                         value_permutation, last, i, lane_base, kbase);
+      continue;
+    }
+    if (!(kbase == 0 && first_issued)) copy_panel_issue(panel, dense, k, n, kbase, col, wave, g, debug & 32);
+    wait_vm<0>();
     __syncthreads();
     if constexpr (!MULTI)
       stream_pairs<PERM>(acc, rows, first_col, first_val, column_indices, values,
@@ -641,7 +723,8 @@ int spmm_panel_launch(int m, int k, int n, int nonzeros, int replicas, const int
                        stream, m, k, n, nonzeros, slots, n_tiles, row_indices,
                        values + r0 * values_stride, values_stride, row_offsets, column_indices,
                        value_permutation, dense + r0 * dense_stride, dense_stride,
-                       out + r0 * out_stride, out_stride, epi, block_rows, mask_heads, r0);
+                       out + r0 * out_stride, out_stride, epi, block_rows, mask_heads, r0,
+                       options().spmm_debug);
     const int st = launch_status();
     if (st != 0) return st;
   }
