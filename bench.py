@@ -585,10 +585,12 @@ def other_ops(dev):
                                               "projection_density": 0.1}
         # forward + backward of the whole module (gradients to the inputs and to every
         # projection's values), through the one-kernel attention forward with the
-        # recomputing backward (fused_training) and through the separate operators
-        for key, flags in (("sparse_attention_fwd_bwd_c3_fused_training", {"fused_training": True}),
+        # recomputing backward (low_memory_training: keeps no [B*H, nnz] tensor between the
+        # passes -- a memory option, named `fused_training` in rounds 1-3) and through the
+        # separate operators
+        for key, flags in (("sparse_attention_fwd_bwd_c3_low_memory_training", {"low_memory_training": True}),
                            ("sparse_attention_fwd_bwd_c3_separate_ops", {"differentiable_softmax": True})):
-            for name, value in {"fused_training": False, "differentiable_softmax": False, **flags}.items():
+            for name, value in {"low_memory_training": False, "differentiable_softmax": False, **flags}.items():
                 setattr(attn, name, value)
             xg = x.clone().requires_grad_(True)
             gout = torch.randn(batch, s, emb, device=dev)

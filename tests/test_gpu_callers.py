@@ -231,15 +231,15 @@ def test_sparse_attention_module_forward_vs_dense(tsa, dev, heads, embed, seq, b
 @pytest.mark.parametrize("geometry", [(4, 256, 256, 2), (8, 512, 1024, 2)],
                          ids=["h4_e256_s256_b2", "c3_geometry_b2"])
 @pytest.mark.parametrize("shared_input", [False, True])
-@pytest.mark.parametrize("fused_training", [False, True])
-def test_sparse_attention_module_backward_vs_dense(tsa, dev, fused_training, shared_input, geometry):
+@pytest.mark.parametrize("low_memory_training", [False, True])
+def test_sparse_attention_module_backward_vs_dense(tsa, dev, low_memory_training, shared_input, geometry):
     """Gradients of the whole module w.r.t. the inputs and every projection's
     values, against dense float64 autograd.  (The reference's module calls the
     raw softmax op and so cuts the gradient to Q/K, modules/sparse_attention.py:76;
-    `differentiable_softmax` / `fused_training` give the true gradient.)"""
+    `differentiable_softmax` / `low_memory_training` give the true gradient.)"""
     heads, embed, seq, batch = geometry   # (config 3's geometry: S 1024, 8 heads of 64, batch 2)
     module = build_attention(tsa, dev, heads, embed, seq, seed=11, differentiable_softmax=True,
-                             fused_training=fused_training)
+                             low_memory_training=low_memory_training)
     rng = np.random.default_rng(8)
     q, k, v = (T(rng.uniform(-1, 1, (batch, seq, embed)).astype(np.float32), dev).requires_grad_(True)
                for _ in range(3))

@@ -498,6 +498,56 @@ def test_spmm_one_plan_serves_any_replica_count(capi, dev):
         assert rel_err(got, c_oracle.spmm(m, k, v, ro, ci, b)) < TOL, f"{replicas} replicas"
 
 
+@pytest.mark.parametrize("m,k,n,bias", [(1024, 4096, 72, False), (1000, 2100, 200, True),
+                                        (4096, 4096, 72, False)])
+def test_spmm_narrow_k_split(capi, dev, monkeypatch, m, k, n, bias):
+    """Round 4: one product against a narrow dense operand (the reference's own test
+    width n = 72, tests/test_spmm.py:13) gives the 64-column kernel few workgroups; the
+    K chunks are dealt to several workgroups per tile and the partial tiles added in
+    chunk order.  Against the oracle, with the epilogue behind the sum, with a row block
+    that takes the order-independent path, twice (deterministic), and identical to the
+    unsplit kernel up to the order of the partial sums."""
+    monkeypatch.setenv("SPUTNIK_HIP_SPMM_KERNEL", "narrow")
+    capi.reload_options()
+    try:
+        _, vals, ri, ro, ci = make_csr(m, k, 0.97, seed=m + n, round_to=1, empty_rows=(5,))
+        ci = ci.copy()
+        seg = ci[ro[9]:ro[10]]
+        seg[:] = seg[::-1]                       # one row with descending columns
+        rng = np.random.default_rng(n)
+        b = rng.uniform(-1, 1, size=(k, n)).astype(np.float32)
+        bias_v = rng.uniform(-1, 1, size=(m,)).astype(np.float32) if bias else None
+        want = c_oracle.spmm(m, k, vals, ro, ci, b)
+        if bias:
+            want = np.maximum(want + bias_v[:, None], 0)
+        topo = (T(ri, dev), T(ro, dev), T(ci, dev))
+        ws = torch.empty(capi.spmm_workspace_bytes(m, k, n, len(ci)) + 16, dtype=torch.uint8, device=dev)
+        assert ws.numel() > 4 * 2 * m * n, "no room for the partial tiles: the K split is not taken"
+        outs = []
+        for _ in range(2):
+            out = torch.full((m, n + 8), float("nan"), device=dev)[:, :n].contiguous()
+            if bias:
+                capi.spmm_bias_batched(m, k, n, 1, topo[0], T(vals, dev), 0, topo[1], topo[2], T(b, dev),
+                                       T(bias_v, dev), True, out, ws)
+            else:
+                capi.spmm_batched(m, k, n, 1, topo[0], T(vals, dev), 0, topo[1], topo[2], T(b, dev), out, ws)
+            outs.append(out)
+        got = outs[0].cpu().numpy()
+        assert not np.isnan(got).any()
+        assert rel_err(got, want) < TOL
+        assert torch.equal(outs[0], outs[1])
+        monkeypatch.setenv("SPUTNIK_HIP_SPMM_DEBUG", "64")   # the unsplit form
+        capi.reload_options()
+        if not bias:
+            one = torch.full((m, n), float("nan"), device=dev)
+            capi.spmm_batched(m, k, n, 1, topo[0], T(vals, dev), 0, topo[1], topo[2], T(b, dev), one, ws)
+            assert rel_err(one.cpu().numpy(), want) < TOL
+    finally:
+        monkeypatch.delenv("SPUTNIK_HIP_SPMM_KERNEL", raising=False)
+        monkeypatch.delenv("SPUTNIK_HIP_SPMM_DEBUG", raising=False)
+        capi.reload_options()
+
+
 def test_spmm_kernel_name_reports_the_dispatch(capi):
     assert capi.spmm_kernel_name(4096, 4096, 4096, 1677724, 1).startswith("spmm_flat_kernel")
     # config 5 at its stated size: 64 tiles per replica, the flat kernel from 3 replicas on

@@ -239,6 +239,14 @@ def test_sparse_attention_matches_dense(cpu_ops):
     q, k, v = (torch.randn(batch, seq, emb) for _ in range(3))
     out = attn(q, k, v, None)                       # [batch, seq, emb]
     assert tuple(out.shape) == (batch, seq, emb)
+    # `fused_training` (rounds 1-3) is an alias of `low_memory_training`
+    assert attn.low_memory_training is False and attn.fused_training is False
+    attn.fused_training = True
+    assert attn.low_memory_training is True
+    attn.low_memory_training = False
+    assert cpu_ops.SparseAttention(heads, emb, max_sequence_length=seq, device="cpu", sparsity=0.5,
+                                   mask_generator=np.random.default_rng(1),
+                                   fused_training=True).low_memory_training is True
 
     def proj(x, w):                                 # SparseLinear then the module's reshapes
         y = torch.matmul(x.double(), w.t())         # [b, s, e]

@@ -23,7 +23,7 @@ def main():
         w = torch.randn(emb, emb, device=dev) * (torch.rand(emb, emb, device=dev) < 0.1)
         lin.weight = torch.nn.Parameter(w)
         lin.setup_sparse_tensors()
-    attn.fused_training = fused
+    attn.low_memory_training = fused
     attn.differentiable_softmax = not fused
     x = torch.randn(batch, s, emb, device=dev).requires_grad_(True)
     gout = torch.randn(batch, s, emb, device=dev)

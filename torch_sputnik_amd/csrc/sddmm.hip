@@ -24,7 +24,8 @@ bool sddmm_tiled_applicable(int m, int k, int n, int nonzeros, const float* lhs,
 size_t sddmm_tiled_workspace_bytes(int m, int k, int n, int nonzeros, bool summed = false);
 int sddmm_tiled_plan(int m, int k, int n, int nonzeros, const int* row_indices,
                      const int* row_offsets, const int* column_indices, void* workspace,
-                     hipStream_t stream, bool summed = false, bool with_flat = false);
+                     hipStream_t stream, bool summed = false, bool with_flat = false, int masks = 1,
+                     int64_t mask_plan_ints = 0);
 int sddmm_tiled_launch(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
                        const int* row_offsets, const int* column_indices, const float* lhs,
                        int64_t lhs_stride, const float* rhs, int64_t rhs_stride, float* out,
@@ -308,15 +309,13 @@ int sddmm_exec(int m, int k, int n, int nonzeros, int replicas, const int* row_i
                   mask_heads > 0 ? workspace_bytes / masks : workspace_bytes) &&
       (mask_heads == 0 || plan_bytes * masks <= workspace_bytes)) {
     if (!planned) {
-      int64_t first = 0;
-      for (int i = 0; i < masks; ++i) {   // (one pre-pass per topology)
-        const int st = sddmm_tiled_plan(
-            m, k, n, mask_heads > 0 ? mask_nonzeros[i] : nonzeros, row_indices + static_cast<int64_t>(i) * m,
-            row_offsets + static_cast<int64_t>(i) * (m + 1), column_indices + first,
-            static_cast<char*>(workspace) + i * plan_bytes, stream);
-        if (st != 0) return st;
-        if (mask_heads > 0) first += mask_nonzeros[i];
-      }
+      // (many mask: the tables of all topologies in ONE launch, round 4; the masks share
+      // m, n and k, so they share the table's shape)
+      const int st = sddmm_tiled_plan(m, k, n, nonzeros, row_indices, row_offsets, column_indices,
+                                      workspace, stream, /*summed=*/false, /*with_flat=*/false,
+                                      mask_heads > 0 ? masks : 1,
+                                      static_cast<int64_t>(plan_bytes / sizeof(int)));
+      if (st != 0) return st;
     }
     // (a plan that was made ahead of the call carries the pair-flat kernel's lists too)
     return sddmm_tiled_launch(m, k, n, nonzeros, replicas, row_indices, row_offsets,

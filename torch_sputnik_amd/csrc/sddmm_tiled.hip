@@ -633,8 +633,16 @@ inline bool served(int k) { return panel_width(k) != 0 && k / panel_width(k) <= 
 // cut at slab boundaries.  Topology only: a caller with a static mask runs it once.
 template <int KV>
 int plan(int m, int n, int slots, const int* row_indices, const int* row_offsets,
-         const int* column_indices, int* table, int* row_ok, hipStream_t stream) {
+         const int* column_indices, int* table, int* row_ok, hipStream_t stream, int masks,
+         int64_t mask_plan_ints) {
   using S = Slab<KV>;
+  if (masks > 1) {   // concatenated topologies: all masks' tables in one launch
+    if (masks > kMaxGridYZ) return SPUTNIK_HIP_INVALID_ARGUMENT;
+    hipLaunchKernelGGL((spmm_chunk_table_masks_kernel<S::kRows>), dim3(ceil_div(slots, 4), masks),
+                       dim3(256), 0, stream, m, n, slots, kSGroups * kSRows, ceil_div(n, S::kRows),
+                       row_indices, row_offsets, column_indices, table, row_ok, mask_plan_ints);
+    return launch_status();
+  }
   hipLaunchKernelGGL((spmm_chunk_table_kernel<S::kRows>), dim3(ceil_div(slots, 4)),
                      dim3(256), 0, stream, m, n, slots, kSGroups * kSRows, ceil_div(n, S::kRows),
                      row_indices, row_offsets, column_indices, table, row_ok);
@@ -846,7 +854,8 @@ size_t sddmm_tiled_workspace_bytes(int m, int k, int n, int nonzeros, bool summe
 // plan away takes the tables only (one 5 us launch against a memset and four launches).
 int sddmm_tiled_plan(int m, int k, int n, int nonzeros, const int* row_indices,
                      const int* row_offsets, const int* column_indices, void* workspace,
-                     hipStream_t stream, bool summed, bool with_flat) {
+                     hipStream_t stream, bool summed, bool with_flat, int masks,
+                     int64_t mask_plan_ints) {
   if (with_flat && !summed && flat_shape(m, k, n, nonzeros)) {
     const int st = sddmm_flat_plan(m, n, nonzeros, row_indices, row_offsets, column_indices,
                                    static_cast<char*>(workspace) + flat_plan_offset(m, k, n, nonzeros),
@@ -857,10 +866,10 @@ int sddmm_tiled_plan(int m, int k, int n, int nonzeros, const int* row_indices,
   int* row_ok = static_cast<int*>(workspace);
   int* table = reinterpret_cast<int*>(static_cast<char*>(workspace) + row_ok_bytes(slots));
   switch (width_for(m, k, n, nonzeros, summed)) {
-    case 64: return plan<1>(m, n, slots, row_indices, row_offsets, column_indices, table, row_ok, stream);
-    case 128: return plan<2>(m, n, slots, row_indices, row_offsets, column_indices, table, row_ok, stream);
-    case 256: return plan<4>(m, n, slots, row_indices, row_offsets, column_indices, table, row_ok, stream);
-    case 512: return plan<8>(m, n, slots, row_indices, row_offsets, column_indices, table, row_ok, stream);
+    case 64: return plan<1>(m, n, slots, row_indices, row_offsets, column_indices, table, row_ok, stream, masks, mask_plan_ints);
+    case 128: return plan<2>(m, n, slots, row_indices, row_offsets, column_indices, table, row_ok, stream, masks, mask_plan_ints);
+    case 256: return plan<4>(m, n, slots, row_indices, row_offsets, column_indices, table, row_ok, stream, masks, mask_plan_ints);
+    case 512: return plan<8>(m, n, slots, row_indices, row_offsets, column_indices, table, row_ok, stream, masks, mask_plan_ints);
     default: return SPUTNIK_HIP_INVALID_ARGUMENT;
   }
 }

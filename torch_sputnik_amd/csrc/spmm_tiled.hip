@@ -50,7 +50,8 @@
 namespace sputnik_hip {
 
 bool spmm_tiled64_applicable(int m, int k, int n, int nonzeros);
-size_t spmm_tiled64_workspace_bytes(int m, int k);
+size_t spmm_tiled64_workspace_bytes(int m, int k, int n);
+int spmm_tiled64_ksplits(int m, int k, int n);
 int spmm_tiled64_plan(int m, int k, const int* row_indices, const int* row_offsets,
                       const int* column_indices, void* workspace, hipStream_t stream);
 int spmm_tiled64_exec(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
@@ -561,6 +562,14 @@ inline Kernel choose_kernel(int m, int k, int n, int nonzeros, int replicas /* <
   if (forced == 2) return Kernel::kNone;
   if (replicas >= 0 && forced == 0) {
     const int64_t work = static_cast<int64_t>(nonzeros) * n * replicas;
+    // (round 4) ONE product against a narrow operand over a long K: the 64-column kernel
+    // with its K chunks dealt to several workgroups per tile beats the row gather from
+    // about 1.7e7 multiply-adds (tools/narrow_n_bench.py: 2048^2 x 72 at density 0.1, 3e7:
+    // 24 against 40 us; 4096^2 x 72 40 against 75, x 200 59 against 88; 1024^2: a tie)
+    if (replicas == 1 && k >= 2048 && work >= (int64_t{1} << 24) && work < (int64_t{1} << 29) &&
+        spmm_tiled64_applicable(m, k, n, nonzeros) && spmm_tiled64_ksplits(m, k, n) >= 4 &&
+        !use_flat(m, k, n, nonzeros))
+      return Kernel::kNarrow;
     if (work < (int64_t{1} << 27) || (replicas < 8 && work < (int64_t{1} << 29)))
       return Kernel::kNone;
   }
@@ -597,8 +606,8 @@ size_t base_workspace_bytes(int m, int k, int n, int nonzeros) {
     case Kernel::kWide: return wide_workspace_bytes(m, k, n);
     case Kernel::kWide512: return wide512_workspace_bytes(m, k, n, nonzeros);
     case Kernel::kFlat: return spmm_flat_workspace_bytes(m, k, n, nonzeros);
-    case Kernel::kNarrow: return spmm_tiled64_workspace_bytes(m, k);
-    case Kernel::kEither: return wide_workspace_bytes(m, k, n) + spmm_tiled64_workspace_bytes(m, k);
+    case Kernel::kNarrow: return spmm_tiled64_workspace_bytes(m, k, n);
+    case Kernel::kEither: return wide_workspace_bytes(m, k, n) + spmm_tiled64_workspace_bytes(m, k, n);
     default: return 0;
   }
 }

@@ -23,6 +23,14 @@
 // costs nothing.  Rows with more than 32 entries in one chunk fetch the rest on
 // demand.  The four row groups of a wave run their own number of steps
 // (EXEC-masked), so no LDS traffic is spent on the shorter rows' padding.
+//
+// K SPLIT (round 4).  One product with a narrow dense operand gives few workgroups:
+// 4096 x 4096 against n = 72 columns is 32 row blocks x 2 column tiles = 64 workgroups
+// for 256 CUs that hold two each (3.3 TFLOP/s in rounds 2-3; the reference's own test
+// shape is n = 72, tests/test_spmm.py:13).  The K chunks are therefore dealt to up to 8
+// workgroups per tile, each writing its partial tile to the workspace, and a second
+// kernel adds the partial tiles in chunk order (fixed order: deterministic) and applies
+// the epilogue.  Only for a single replica (a batch fills the chip by itself).
 #include <type_traits>
 
 #include "options.h"
@@ -69,7 +77,8 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled64_kernel(
     int64_t values_stride, const int* __restrict__ column_indices,
     const int* __restrict__ table, const float* __restrict__ dense, int64_t dense_stride,
     float* __restrict__ out, int64_t out_stride, const int* __restrict__ row_ok,
-    const int* __restrict__ row_offsets, int debug, Epilogue epi) {
+    const int* __restrict__ row_offsets, int debug, Epilogue epi, int ksplits,
+    float* __restrict__ partials /* [ksplits][m][n] when ksplits > 1 */) {
   __shared__ float tile[2][kTileFloats];
   const bool dbg_no_compute = debug & 1, dbg_no_stage = debug & 2;
 
@@ -80,13 +89,22 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled64_kernel(
   // (row blocks that stage the same B tile -- same replica and column tile -- run
   // on one XCD: consecutive work indices, see xcd_local_index)
   const unsigned long long work = xcd_local_index();
-  const unsigned mblocks = gridDim.x / n_tiles;
+  const unsigned mblocks = gridDim.x / (n_tiles * ksplits);
   const int mblock = static_cast<int>(work % mblocks);
   const int ntile = static_cast<int>((work / mblocks) % n_tiles);
-  const int replica = static_cast<int>(work / (static_cast<unsigned long long>(mblocks) * n_tiles));
+  const unsigned long long rest = work / (static_cast<unsigned long long>(mblocks) * n_tiles);
+  const int split = static_cast<int>(rest % ksplits);     // (one replica when ksplits > 1)
+  const int replica = static_cast<int>(rest / ksplits);
   values += replica * values_stride;
   dense += replica * dense_stride;
   out += replica * out_stride;
+  // this workgroup's K chunks; with a split the tile goes to the partial buffer as it is
+  const int per_split = (nchunks + ksplits - 1) / ksplits;
+  const int c_begin = min(split * per_split, nchunks), c_end = min(c_begin + per_split, nchunks);
+  if (ksplits > 1) {
+    out = partials + static_cast<int64_t>(split) * m * n;
+    epi = Epilogue{};
+  }
   const int n0 = ntile * kBN;
   const int slot0 = mblock * kBM + wave * (kRQ * 4);  // this wave's first row slot
   const int last = nonzeros - 1;
@@ -99,8 +117,10 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled64_kernel(
       if (entry < m && n0 + i * 4 < n) {
         const int row = row_indices[entry];
         const int col = min(n0 + i * 4, n - 4);   // (any n: see the store phase below)
-        const float4 acc4 = gather_row_strip(values, column_indices, row_offsets[row],
-                                             row_offsets[row + 1], dense + col, n);
+        // (K split: the first split computes the whole row, the others contribute zeros)
+        const float4 acc4 = split == 0 ? gather_row_strip(values, column_indices, row_offsets[row],
+                                                          row_offsets[row + 1], dense + col, n)
+                                       : make_float4(0.f, 0.f, 0.f, 0.f);
         *reinterpret_cast<float4*>(out + static_cast<int64_t>(row) * n + col) =
             apply_epilogue(acc4, epi, row);
       }
@@ -165,9 +185,9 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled64_kernel(
   };
 
   int p0[kRQ], p1[kRQ], p2[kRQ], p3[kRQ];
-  load_positions(p0, 0);
-  load_positions(p1, 1);
-  load_positions(p2, 2);
+  load_positions(p0, c_begin);
+  load_positions(p1, c_begin + 1);
+  load_positions(p2, c_begin + 2);
   wait_vm<0>();
 #pragma unroll
   for (int t = 0; t < kRQ; ++t) {
@@ -175,7 +195,7 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled64_kernel(
     tie_reg(p1[t]);
     tie_reg(p2[t]);
   }
-  stage_chunk64(tile[0], dense, n, k, n0, 0, wave, lane);
+  stage_chunk64(tile[c_begin & 1], dense, n, k, n0, min(c_begin, nchunks - 1) * kBK, wave, lane);
   request(std::integral_constant<int, 0>{}, p0);
   request(std::integral_constant<int, 1>{}, p1);
   wait_vm<0>();
@@ -234,10 +254,10 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled64_kernel(
     }
     __syncthreads();  // the next tile is there for every wave, and the current buffer is free
   };
-  for (int c0 = 0; c0 < nchunks; c0 += 3) {
+  for (int c0 = c_begin; c0 < c_end; c0 += 3) {   // (register set of a chunk: (c - c_begin) % 3)
     chunk(std::integral_constant<int, 0>{}, c0);
-    if (c0 + 1 < nchunks) chunk(std::integral_constant<int, 1>{}, c0 + 1);
-    if (c0 + 2 < nchunks) chunk(std::integral_constant<int, 2>{}, c0 + 2);
+    if (c0 + 1 < c_end) chunk(std::integral_constant<int, 1>{}, c0 + 1);
+    if (c0 + 2 < c_end) chunk(std::integral_constant<int, 2>{}, c0 + 2);
   }
   wait_vm<0>();  // nothing may be in flight (LDS-DMA!) when the wave ends
   // the windows of the two chunks past the end were requested and never read:
@@ -265,7 +285,44 @@ __global__ __launch_bounds__(kThreads) void spmm_tiled64_kernel(
 inline int slots_of(int m) { return ceil_div(m, kBM) * kBM; }
 inline int chunks_of(int k) { return ceil_div(k, kBK); }
 
+// out[row][c] = epilogue(sum over the splits, in chunk order, of partials[s][row][c])
+__global__ __launch_bounds__(256) void spmm_tiled64_sum_kernel(int64_t quads /* m * n / 4 */, int n,
+                                                               int ksplits,
+                                                               const float* __restrict__ partials,
+                                                               float* __restrict__ out, Epilogue epi) {
+  const int64_t j = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (j >= quads) return;
+  float4 sum = reinterpret_cast<const float4*>(partials)[j];
+  for (int s = 1; s < ksplits; ++s) {
+    const float4 v = reinterpret_cast<const float4*>(partials)[static_cast<int64_t>(s) * quads + j];
+    sum.x += v.x;
+    sum.y += v.y;
+    sum.z += v.z;
+    sum.w += v.w;
+  }
+  reinterpret_cast<float4*>(out)[j] = apply_epilogue(sum, epi, static_cast<int>(j * 4 / n));
+}
+
+// Splits of the K walk for ONE replica: up to two workgroups per CU (512), at least two
+// chunks each, at most 8 (each split writes a partial tile); n a multiple of 4 (the
+// partial tiles are added in 16-byte pieces, a piece inside one row).  Measured
+// (tools/narrow_n_bench.py, density 0.1, us of the whole call, splits 1 / 2 / 4 / 8 / 16):
+//   4096^2 x 72   113 / 69 / 46 / 40 / 48      4096^2 x 200  114 / 74 / 59 / 66 / 78
+//   2048^2 x 72    59 / 38 / 28 / 24 / 28      2048^2 x 256   58 / 41 / 32 / 33 / 39
+inline int ksplits_of(int m, int k, int n) {
+  if (n % 4 != 0) return 1;
+  const int64_t groups = static_cast<int64_t>(slots_of(m) / kBM) * ceil_div(n, kBN);
+  const int forced = options().spmm_tile;   // (developer knob, 16 + s: s splits)
+  if (forced >= 16) return max(1, min(forced - 16, chunks_of(k)));
+  int splits = 1;
+  while (splits < 8 && groups * splits * 2 <= 512 && chunks_of(k) >= 4 * splits) splits *= 2;
+  return splits;
+}
+
 }  // namespace
+
+// (for the dispatcher: a single product that the K split spreads over the chip)
+int spmm_tiled64_ksplits(int m, int k, int n) { return ksplits_of(m, k, n); }
 
 bool spmm_tiled64_applicable(int m, int k, int n, int nonzeros) {
   // B rows are addressed with 32-bit byte offsets; enough work per staged tile.
@@ -273,9 +330,18 @@ bool spmm_tiled64_applicable(int m, int k, int n, int nonzeros) {
          static_cast<int64_t>(k) * n * 4 < (int64_t{1} << 32);
 }
 
-size_t spmm_tiled64_workspace_bytes(int m, int k) {
-  return row_ok_bytes(slots_of(m)) +
-         sizeof(int) * static_cast<size_t>(chunks_of(k) + 1) * slots_of(m);
+namespace {
+inline size_t tables_bytes(int m, int k) {
+  return (row_ok_bytes(slots_of(m)) + sizeof(int) * static_cast<size_t>(chunks_of(k) + 1) * slots_of(m) +
+          255) / 256 * 256;
+}
+}  // namespace
+
+// row order words + chunk table [+ the partial tiles of a K split]
+size_t spmm_tiled64_workspace_bytes(int m, int k, int n) {
+  const int splits = ksplits_of(m, k, n);
+  return tables_bytes(m, k) +
+         (splits > 1 ? sizeof(float) * static_cast<size_t>(splits) * m * n : size_t{0});
 }
 
 int spmm_tiled64_plan(int m, int k, const int* row_indices, const int* row_offsets,
@@ -300,10 +366,20 @@ int spmm_tiled64_exec(int m, int k, int n, int nonzeros, int replicas, const int
       reinterpret_cast<const int*>(static_cast<const char*>(workspace) + row_ok_bytes(slots));
   const int n_tiles = ceil_div(n, kBN);
   const int debug = options().spmm_debug;  // timing experiments only
-  hipLaunchKernelGGL(spmm_tiled64_kernel, dim3((slots / kBM) * n_tiles, replicas), dim3(kThreads),
-                     0, stream, m, k, n, nonzeros, slots, chunks_of(k), n_tiles, row_indices,
-                     values, values_stride, column_indices, table, dense, dense_stride, out,
-                     out_stride, row_ok, row_offsets, debug, epi);
+  // (debug bit 6: no K split -- the one-workgroup-per-tile form of rounds 1-3)
+  const int splits = replicas == 1 && !(debug & 64) && aligned_to(out, 16) ? ksplits_of(m, k, n) : 1;
+  float* partials = splits > 1 ? reinterpret_cast<float*>(const_cast<char*>(
+                                     static_cast<const char*>(workspace) + tables_bytes(m, k)))
+                               : nullptr;
+  hipLaunchKernelGGL(spmm_tiled64_kernel, dim3((slots / kBM) * n_tiles * splits, replicas),
+                     dim3(kThreads), 0, stream, m, k, n, nonzeros, slots, chunks_of(k), n_tiles,
+                     row_indices, values, values_stride, column_indices, table, dense, dense_stride,
+                     out, out_stride, row_ok, row_offsets, debug, epi, splits, partials);
+  int st = launch_status();
+  if (st != 0 || splits == 1) return st;
+  const int64_t quads = static_cast<int64_t>(m) * n / 4;
+  hipLaunchKernelGGL(spmm_tiled64_sum_kernel, dim3(static_cast<unsigned>(ceil_div64(quads, 256))),
+                     dim3(256), 0, stream, quads, n, splits, partials, out, epi);
   return launch_status();
 }
 

@@ -61,7 +61,7 @@ __device__ __forceinline__ int dealt_index(int slot, int slots, int per) {
 }
 
 template <int BK>  // rows of B per chunk (any positive number; a power of two divides by shifting)
-__global__ __launch_bounds__(256) void spmm_chunk_table_kernel(
+__device__ __forceinline__ void chunk_table_body(
     int m, int k, int slots, int per, int nchunks, const int* __restrict__ row_indices,
     const int* __restrict__ row_offsets, const int* __restrict__ column_indices,
     int* __restrict__ table, int* __restrict__ row_ok) {
@@ -103,6 +103,32 @@ __global__ __launch_bounds__(256) void spmm_chunk_table_kernel(
   // it); every slot writes its own word, so the array needs no initialisation.
   const bool wave_ok = __builtin_amdgcn_ballot_w64(!ok) == 0;
   if (lane == 0) row_ok[slot] = wave_ok ? 1 : 0;
+}
+
+template <int BK>
+__global__ __launch_bounds__(256) void spmm_chunk_table_kernel(
+    int m, int k, int slots, int per, int nchunks, const int* __restrict__ row_indices,
+    const int* __restrict__ row_offsets, const int* __restrict__ column_indices,
+    int* __restrict__ table, int* __restrict__ row_ok) {
+  chunk_table_body<BK>(m, k, slots, per, nchunks, row_indices, row_offsets, column_indices, table,
+                       row_ok);
+}
+
+// The same for the concatenated topologies of a "many mask" batch (common.h,
+// select_mask) in ONE launch: blockIdx.y = mask, every mask's table and order words
+// `mask_plan_ints` ints behind the previous mask's (round 4: one pre-pass launch per mask
+// was 8 launches in front of the many-mask SDDMM).
+template <int BK>
+__global__ __launch_bounds__(256) void spmm_chunk_table_masks_kernel(
+    int m, int k, int slots, int per, int nchunks, const int* __restrict__ row_indices,
+    const int* __restrict__ row_offsets, const int* __restrict__ column_indices,
+    int* __restrict__ table, int* __restrict__ row_ok, int64_t mask_plan_ints) {
+  const int mask = blockIdx.y;
+  int first = 0;   // entries of the masks before this one
+  for (int j = 0; j < mask; ++j) first += row_offsets[static_cast<int64_t>(j) * (m + 1) + m];
+  chunk_table_body<BK>(m, k, slots, per, nchunks, row_indices + static_cast<int64_t>(mask) * m,
+                       row_offsets + static_cast<int64_t>(mask) * (m + 1), column_indices + first,
+                       table + mask * mask_plan_ints, row_ok + mask * mask_plan_ints);
 }
 
 // Direct global->LDS copy of one 1 KiB row segment (64 lanes x 16 B):
