@@ -169,7 +169,16 @@ __device__ __forceinline__ void fetch_first_windows(const Rows& r, int (&ecol)[k
 // of B's rows: k <= 512), two row quads side by side.  Window w0 = entries w0 ..
 // w0+15 of a group's row, the next one requested before the current one is
 // worked on.  PERM: entry p takes values[value_permutation[p]].
-template <bool PERM, typename TV = float>
+// Round 4: the windows are requested kDepth + 1 = THREE ahead (a fourth set of registers spills).  With one window ahead a
+// request had the four bundles of one window -- 0.26 us -- to land in, a third of a
+// memory latency, and the waves of a workgroup, started together and joined by the panel's
+// rendezvous, wait and compute in phase: rocprofv3 on the attention P.V (tools/
+// spmm_c3_bench.py, SPUTNIK_HIP_SPMM_DEBUG=1): 25 us of the launch's 42 are there with the
+// arithmetic switched off, and the arithmetic's 17 us come ON TOP.
+// CHECK: every entry's column must lie in the panel, [kbase, kbase + kPMaxK) -- the rows
+// were cut by a search that trusts their order; an entry outside is skipped and reported
+// in `outside` (per lane; the caller votes and redoes the rows the slow way).
+template <bool PERM, typename TV = float, bool CHECK = false>
 __device__ __forceinline__ void stream_pairs(float (&acc)[kPQuads][4], const Rows& r,
                                              const int (&first_col)[kPQuads],
                                              const float (&first_val)[kPQuads],
@@ -177,7 +186,10 @@ __device__ __forceinline__ void stream_pairs(float (&acc)[kPQuads][4], const Row
                                              const TV* __restrict__ values,
                                              const int* __restrict__ value_permutation, int last,
                                              int i, const char* __restrict__ lane_base,
-                                             int kbase = 0 /* first row of B in the panel */) {
+                                             int kbase = 0 /* first row of B in the panel */,
+                                             int debug = 0 /* bit 0 (timing experiment): no arithmetic */,
+                                             bool* outside = nullptr) {
+  constexpr int kDepth = 1;
 #pragma unroll
   for (int t = 0; t < kPQuads; t += 2) {
     const int n_a = r.cnt[t], n_b = r.cnt[t + 1];
@@ -185,26 +197,51 @@ __device__ __forceinline__ void stream_pairs(float (&acc)[kPQuads][4], const Row
     const int longest =
         max(max(__builtin_amdgcn_readlane(n_max, 0), __builtin_amdgcn_readlane(n_max, 16)),
             max(__builtin_amdgcn_readlane(n_max, 32), __builtin_amdgcn_readlane(n_max, 48)));
-    int idx_a, idx_b;
-    int ecol_a = first_col[t], ecol_b = first_col[t + 1];
-    float eval_a = first_val[t], eval_b = first_val[t + 1];
+    // ring of the windows in flight: slot 0 = the window being worked on
+    int col_a[kDepth + 1], col_b[kDepth + 1];
+    float val_a[kDepth + 1], val_b[kDepth + 1];
+    auto request = [&](int slot, int w0) {
+      const int idx_a = max(min(r.p0[t] + w0 + i, last), 0);
+      const int idx_b = max(min(r.p0[t + 1] + w0 + i, last), 0);
+      col_a[slot] = at32(column_indices, idx_a);
+      col_b[slot] = at32(column_indices, idx_b);
+      val_a[slot] = static_cast<float>(at32(values, PERM ? at32(value_permutation, idx_a) : idx_a));
+      val_b[slot] = static_cast<float>(at32(values, PERM ? at32(value_permutation, idx_b) : idx_b));
+    };
+    col_a[0] = first_col[t];
+    col_b[0] = first_col[t + 1];
+    val_a[0] = first_val[t];
+    val_b[0] = first_val[t + 1];
+#pragma unroll
+    for (int d = 1; d <= kDepth; ++d) {
+      col_a[d] = col_b[d] = 0;
+      val_a[d] = val_b[d] = 0.f;
+      if (16 * d < longest) request(d, 16 * d);
+    }
     for (int w0 = 0; w0 < longest; w0 += 16) {
-      const int col_a = ecol_a, col_b = ecol_b;
-      const float val_a = eval_a, val_b = eval_b;
-      if (w0 + 16 < longest) {
-        idx_a = min(r.p0[t] + w0 + 16 + i, last);
-        idx_b = min(r.p0[t + 1] + w0 + 16 + i, last);
-        ecol_a = at32(column_indices, idx_a);
-        ecol_b = at32(column_indices, idx_b);
-        eval_a = static_cast<float>(at32(values, PERM ? at32(value_permutation, idx_a) : idx_a));
-        eval_b = static_cast<float>(at32(values, PERM ? at32(value_permutation, idx_b) : idx_b));
-      }
       const int left_a = n_a - w0, left_b = n_b - w0;
-      const int roff_a = i < left_a ? (col_a - kbase) * (kPBN * 4) : 0;
-      const int roff_b = i < left_b ? (col_b - kbase) * (kPBN * 4) : 0;
-      const float rval_a = i < left_a ? val_a : 0.f;
-      const float rval_b = i < left_b ? val_b : 0.f;
-      const int left = max(left_a, left_b);   // (entries past a row's end carry a zero value)
+      bool in_a = i < left_a, in_b = i < left_b;
+      if constexpr (CHECK) {
+        const bool ok_a = static_cast<unsigned>(col_a[0] - kbase) < static_cast<unsigned>(kPMaxK);
+        const bool ok_b = static_cast<unsigned>(col_b[0] - kbase) < static_cast<unsigned>(kPMaxK);
+        *outside = *outside || (in_a && !ok_a) || (in_b && !ok_b);
+        in_a = in_a && ok_a;
+        in_b = in_b && ok_b;
+      }
+      const int roff_a = in_a ? (col_a[0] - kbase) * (kPBN * 4) : 0;
+      const int roff_b = in_b ? (col_b[0] - kbase) * (kPBN * 4) : 0;
+      const float rval_a = in_a ? val_a[0] : 0.f;
+      const float rval_b = in_b ? val_b[0] : 0.f;
+      // the ring moves on; the window kDepth + 1 ahead is requested before this one's work
+#pragma unroll
+      for (int d = 0; d < kDepth; ++d) {
+        col_a[d] = col_a[d + 1];
+        col_b[d] = col_b[d + 1];
+        val_a[d] = val_a[d + 1];
+        val_b[d] = val_b[d + 1];
+      }
+      if (w0 + 16 * (kDepth + 1) < longest) request(kDepth, w0 + 16 * (kDepth + 1));
+      const int left = (debug & 1) ? 0 : max(left_a, left_b);   // (entries past a row's end carry a zero value)
       if (left > 0) dpp_group4_pair<0>(acc[t], acc[t + 1], roff_a, rval_a, roff_b, rval_b, lane_base);
       if (left > 4) dpp_group4_pair<4>(acc[t], acc[t + 1], roff_a, rval_a, roff_b, rval_b, lane_base);
       if (left > 8) dpp_group4_pair<8>(acc[t], acc[t + 1], roff_a, rval_a, roff_b, rval_b, lane_base);
@@ -274,39 +311,62 @@ __device__ __forceinline__ void stream_masked(float (&acc)[kPQuads][4], const Ro
 // (profiles/r3e_pmc_sq_attention_ops.json).  A row whose columns ascend is simply CUT at
 // the first entry of the second panel: pass 0 runs entries [0, cut), pass 1 [cut, end),
 // both as plain counted windows (stream_pairs: two row quads side by side, no mask).
-// The cut and the order are found by one scan of the row's columns WHILE THE FIRST PANEL
-// IS BEING COPIED (the same windows the passes read again, from cache): cut = number of
-// columns below the panel boundary, order = every column above the one before it.
-// Returns false (wave-uniform) if a row of the wave is not in ascending order or holds a
-// column outside [0, k): the wave then takes stream_masked.
-__device__ __forceinline__ bool scan_cuts(const Rows& r, int (&cut)[kPQuads], int boundary, int k,
-                                          const int* __restrict__ column_indices, int last, int g,
-                                          int i) {
-  bool ok = true;
+// The cut is found by a 16-ary SEARCH for the panel boundary in the row's columns, while
+// the first panel is being copied: two dependent requests per row (16 probes, then the 16
+// entries between two probes) for rows of up to 256 entries, the four quads of a wave side
+// by side.  (First form, measured: a scan of all of the row's windows that also checked
+// the order -- 6 us of the launch's 42 at the attention shape.)  The search TRUSTS the
+// order; what the passes need is only that every entry in front of the cut lies in the
+// first panel and every entry behind it in the second, and that they check themselves
+// (stream_pairs, CHECK): a workgroup in which any lane met an entry outside its panel
+// throws its sums away and runs the masked walk.
+__device__ __forceinline__ void search_cuts(const Rows& r, int (&cut)[kPQuads], int boundary,
+                                            const int* __restrict__ column_indices, int last, int g,
+                                            int i) {
+  // the group's 16-bit slice of a wave ballot
+  auto group_count = [&](bool flag) {
+    return __popc(static_cast<unsigned>(__builtin_amdgcn_ballot_w64(flag) >> (g * 16)) & 0xffffu);
+  };
+  int lo[kPQuads], hi[kPQuads];   // the cut lies in [lo, hi]
 #pragma unroll
   for (int t = 0; t < kPQuads; ++t) {
-    const int n_here = r.cnt[t];
-    const int longest =
-        max(max(__builtin_amdgcn_readlane(n_here, 0), __builtin_amdgcn_readlane(n_here, 16)),
-            max(__builtin_amdgcn_readlane(n_here, 32), __builtin_amdgcn_readlane(n_here, 48)));
-    int below = 0, carry = -1;   // entries in front of the boundary; the column before the window
-    int ecol = at32(column_indices, max(min(r.p0[t] + i, last), 0));
-    for (int w0 = 0; w0 < longest; w0 += 16) {
-      const int cur = ecol;
-      if (w0 + 16 < longest) ecol = at32(column_indices, min(r.p0[t] + w0 + 16 + i, last));
-      const bool in_row = i < n_here - w0;
-      // the column before: the lane below (row_shr:1; lane 0 of the group: the window before)
-      const int shifted = __builtin_amdgcn_update_dpp(0, cur, 0x111, 0xF, 0xF, false);
-      const int prev = i == 0 ? carry : shifted;
-      ok = ok && (!in_row || (cur > prev && cur < k));
-      const unsigned lower = static_cast<unsigned>(
-          __builtin_amdgcn_ballot_w64(in_row && cur < boundary) >> (g * 16)) & 0xffffu;
-      below += __popc(lower);
-      carry = row_bcast_i<15>(cur);
-    }
-    cut[t] = below;
+    lo[t] = 0;
+    hi[t] = r.cnt[t];
   }
-  return __builtin_amdgcn_ballot_w64(!ok) == 0;
+  // rounds: 16 probes spread over [lo, hi); rows of the wave differ in length, so every
+  // quad runs the rounds of the longest bracket (wave-uniform trip count)
+  for (;;) {
+    int span = 0;
+#pragma unroll
+    for (int t = 0; t < kPQuads; ++t) span = max(span, hi[t] - lo[t]);
+    const int widest =
+        max(max(__builtin_amdgcn_readlane(span, 0), __builtin_amdgcn_readlane(span, 16)),
+            max(__builtin_amdgcn_readlane(span, 32), __builtin_amdgcn_readlane(span, 48)));
+    if (widest <= 0) break;
+    int colv[kPQuads];
+#pragma unroll
+    for (int t = 0; t < kPQuads; ++t) {   // the four quads' requests together
+      // probe i at lo + floor(i * len / 16); a bracket of at most 16: its entries themselves
+      const int len = hi[t] - lo[t];
+      const int probe = len <= 16 ? lo[t] + i : lo[t] + ((i * len) >> 4);
+      colv[t] = at32(column_indices, max(min(r.p0[t] + probe, last), 0));
+    }
+#pragma unroll
+    for (int t = 0; t < kPQuads; ++t) {
+      const int len = hi[t] - lo[t];
+      const bool small = len <= 16;
+      // small: the entries in front of the boundary are counted and the cut is known.
+      // else f probes lie in front of the boundary: the cut is behind probe f - 1 and not
+      // behind probe f (the probes of a sorted row ascend; probe 0 is entry lo)
+      const int f = group_count(colv[t] < boundary && (!small || i < len));
+      const int new_lo = small ? lo[t] + f : (f > 0 ? lo[t] + (((f - 1) * len) >> 4) + 1 : lo[t]);
+      const int new_hi = small ? new_lo : (f < 16 ? lo[t] + ((f * len) >> 4) : hi[t]);
+      lo[t] = new_lo;
+      hi[t] = max(new_hi, new_lo);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < kPQuads; ++t) cut[t] = min(max(lo[t], 0), r.cnt[t]);
 }
 
 __device__ __forceinline__ void store_rows(const float (&acc)[kPQuads][4], const Rows& r,
@@ -430,48 +490,64 @@ __global__ __launch_bounds__(kPThreads) void spmm_panel64_kernel(
     fetch_first_windows<PERM>(rows, first_col, first_val, column_indices, values,
                               value_permutation, last, i);
 
-  // MULTI with exactly two panels: rows cut at the panel boundary (scan_cuts), found while
-  // the first panel is on its way; `sorted` is wave-uniform, the waves of a workgroup
-  // choose for themselves (only the panel copies are a workgroup matter)
-  bool sorted = false, first_issued = false;
+  // MULTI with exactly two panels: rows cut at the panel boundary (search_cuts), found
+  // while the first panel is on its way, the passes checking that the cut holds
+  bool cut_rows = false, first_issued = false, outside = false;
   int cut[kPQuads] = {};
   if constexpr (MULTI) {
     if (k <= 2 * kPMaxK && !(debug & 16)) {
-      // (the copies first: the scan's loads wait behind them in the memory pipeline either way)
+      // (the copies first: the search's loads wait behind them in the memory pipeline either way)
       copy_panel_issue(panel, dense, k, n, 0, col, wave, g, debug & 32);
       first_issued = true;
-      sorted = scan_cuts(rows, cut, kPMaxK, k, column_indices, last, g, i);
+      cut_rows = true;
+      if (!(debug & 256)) search_cuts(rows, cut, kPMaxK, column_indices, last, g, i);
     }
   }
-  for (int kbase = 0; kbase < k; kbase += kPMaxK) {
-    if (MULTI && kbase > 0) __syncthreads();   // every wave is done with the previous panel
-    if (MULTI && sorted) {
-      // this pass's part of every row, as a row of its own
-      Rows part;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    for (int kbase = 0; kbase < k; kbase += kPMaxK) {
+      if (MULTI && (kbase > 0 || attempt > 0)) __syncthreads();   // every wave is done with the previous panel
+      if (MULTI && cut_rows) {
+        // this pass's part of every row, as a row of its own
+        Rows part;
 #pragma unroll
-      for (int t = 0; t < kPQuads; ++t) {
-        part.row[t] = rows.row[t];
-        part.p0[t] = rows.p0[t] + (kbase > 0 ? cut[t] : 0);
-        part.cnt[t] = kbase > 0 ? rows.cnt[t] - cut[t] : cut[t];
+        for (int t = 0; t < kPQuads; ++t) {
+          part.row[t] = rows.row[t];
+          part.p0[t] = rows.p0[t] + (kbase > 0 ? cut[t] : 0);
+          part.cnt[t] = kbase > 0 ? rows.cnt[t] - cut[t] : cut[t];
+        }
+        fetch_first_windows<PERM>(part, first_col, first_val, column_indices, values,
+                                  value_permutation, last, i);   // (in flight while the panel is copied)
+        if (kbase > 0) copy_panel_issue(panel, dense, k, n, kbase, col, wave, g, debug & 32);
+        first_issued = false;
+        wait_vm<0>();
+        __syncthreads();
+        if (!(debug & 128))   // (timing experiment: no stream at all)
+          stream_pairs<PERM, float, true>(acc, part, first_col, first_val, column_indices, values,
+                                          value_permutation, last, i, lane_base, kbase, debug, &outside);
+        continue;
       }
-      fetch_first_windows<PERM>(part, first_col, first_val, column_indices, values,
-                                value_permutation, last, i);   // (in flight while the panel is copied)
-      if (kbase > 0) copy_panel_issue(panel, dense, k, n, kbase, col, wave, g, debug & 32);
+      if (!(kbase == 0 && first_issued)) copy_panel_issue(panel, dense, k, n, kbase, col, wave, g, debug & 32);
+      first_issued = false;
       wait_vm<0>();
       __syncthreads();
-      stream_pairs<PERM>(acc, part, first_col, first_val, column_indices, values,
-                         value_permutation, last, i, lane_base, kbase);
-      continue;
+      if constexpr (!MULTI)
+        stream_pairs<PERM>(acc, rows, first_col, first_val, column_indices, values,
+                           value_permutation, last, i, lane_base);
+      else
+        stream_masked<PERM>(acc, rows, kbase, start, column_indices, values, value_permutation,
+                            last, g, i, lane_base);
     }
-    if (!(kbase == 0 && first_issued)) copy_panel_issue(panel, dense, k, n, kbase, col, wave, g, debug & 32);
-    wait_vm<0>();
-    __syncthreads();
-    if constexpr (!MULTI)
-      stream_pairs<PERM>(acc, rows, first_col, first_val, column_indices, values,
-                         value_permutation, last, i, lane_base);
-    else
-      stream_masked<PERM>(acc, rows, kbase, start, column_indices, values, value_permutation,
-                          last, g, i, lane_base);
+    if constexpr (!MULTI) break;
+    if (!cut_rows) break;
+    // did every cut hold?  (one vote of the workgroup; an order the search cannot trust
+    // is rare: the reference's topologies come from to_sparse_csr, columns ascending)
+    if (!__syncthreads_or(outside ? 1 : 0)) break;
+    cut_rows = false;
+#pragma unroll
+    for (int t = 0; t < kPQuads; ++t) {
+      acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0.f;
+      start[t] = 0;
+    }
   }
   if constexpr (!TOUT)
     store_rows(acc, rows, out, n, n0, i, epi);
