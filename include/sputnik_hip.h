@@ -118,6 +118,10 @@ SPUTNIK_HIP_API int sputnik_hip_spmm_batched(int m, int k, int n, int nonzeros, 
  * three index arrays, m, k and n may not).  No counterpart in the reference,
  * which re-derives everything per call (src/spmm_cuda.cu:48-57).
  */
+/* (Round 4) A single product against a narrow dense operand (n < 512, k >= 2048, one
+ * replica) deals its K chunks to several workgroups per tile; their partial tiles live in
+ * the workspace (sputnik_hip_spmm_workspace_bytes counts them) and are scratch of the
+ * call: one workspace, planned or not, serves one stream at a time for such a shape. */
 SPUTNIK_HIP_API int sputnik_hip_spmm_plan(int m, int k, int n, int nonzeros,
                           const int* row_indices, const int* row_offsets,
                           const int* column_indices, void* workspace,
