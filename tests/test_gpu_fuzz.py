@@ -78,6 +78,54 @@ def test_fuzz_spmm(capi, dev, spmm_kernel):
         assert rel_err(got, want) < TOL, (it, m, k, n, sparsity, order, replicas)
 
 
+def test_fuzz_sddmm_planned_pair_flat(capi, dev, monkeypatch):
+    """The pair-flat SDDMM (csrc/sddmm_flat.hip, round 4: planned products with rows of 128
+    / 256 bytes) on random masks: any m, n >= 128, densities from one entry per row to
+    dense, columns ascending or shuffled inside rows, empty rows, float32 / float16 /
+    bfloat16 operands with k = 64 (and k = 128 in half), float32 output -- against the
+    oracle on the rounded operands, and the same bits from a second planned call."""
+    monkeypatch.setenv("SPUTNIK_HIP_SDDMM_KERNEL", "tiled")
+    capi.reload_options()
+    try:
+        rng = np.random.default_rng(177 + SEED_SHIFT)
+        for it in range(24 * SCALE):
+            m = int(rng.choice([128, 200, 256, 300, 513, 777, 1024]))
+            n = int(rng.choice([128, 130, 256, 500, 1024, 2048]))
+            sparsity = float(rng.choice([0.0, 0.5, 0.9, 0.97, 0.995]))
+            replicas = int(rng.integers(1, 4))
+            dtype = [torch.float32, torch.float16, torch.bfloat16][int(rng.integers(0, 3))]
+            k = 64 if dtype == torch.float32 else int(rng.choice([64, 128]))
+            empty = tuple(int(x) for x in rng.choice(m, size=int(rng.integers(0, 4)), replace=False))
+            _, _, ri, ro, ci = make_csr(m, n, sparsity, seed=300 + it, round_to=1, empty_rows=empty)
+            nnz = len(ci)
+            if nnz < 4 * m:
+                continue
+            if rng.random() < 0.5:   # shuffled columns: pairs are CSR neighbours wherever they lie
+                ci = ci.copy()
+                for r in range(0, m, 2):
+                    rng.shuffle(ci[ro[r]:ro[r + 1]])
+            assert capi.sddmm_kernel_name(m, k, n, nnz, replicas, 4 if dtype == torch.float32 else 2,
+                                          planned=True) == "sddmm_flat_kernel"
+            lhs = torch.from_numpy(rng.uniform(-1, 1, (replicas, m, k)).astype(np.float32)).to(dev).to(dtype)
+            rhs = torch.from_numpy(rng.uniform(-1, 1, (replicas, n, k)).astype(np.float32)).to(dev).to(dtype)
+            want = O.sddmm(m, n, ri, ro, ci, lhs.float().cpu().numpy(), rhs.float().cpu().numpy())
+            topo = (T(ri, dev), T(ro, dev), T(ci, dev))
+            ws = torch.empty(capi.sddmm_workspace_bytes(m, k, n, nnz) + 16, dtype=torch.uint8, device=dev)
+            capi.sddmm_plan(m, k, n, *topo, ws)
+            outs = []
+            for _ in range(2):
+                out = torch.full((replicas, nnz), float("nan"), device=dev)
+                capi.sddmm_typed(m, k, n, replicas, *topo, lhs, rhs, out, ws, planned=True)
+                outs.append(out)
+            got = outs[0].cpu().numpy()
+            assert not np.isnan(got).any(), (it, m, k, n, sparsity, dtype)
+            assert rel_err(got, want, ro) < TOL, (it, m, k, n, sparsity, dtype)
+            assert torch.equal(outs[0], outs[1]), (it, m, k, n)
+    finally:
+        monkeypatch.delenv("SPUTNIK_HIP_SDDMM_KERNEL", raising=False)
+        capi.reload_options()
+
+
 def test_fuzz_sddmm_softmax_transpose(capi, dev, sddmm_kernel):
     rng = np.random.default_rng(77 + SEED_SHIFT)
     for it in range(40 * SCALE):
