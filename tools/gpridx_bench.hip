@@ -244,6 +244,95 @@ DEF_STEP(k_colgroup_d50_ahead, V2_BODY_D50_AHEAD)
 //    v_pk_fma_f32 per entry, FMAs three pairs behind the reads.  8 entries per body.
 DEF_STEP(k_pair256, "s_mov_b32 s45, 0x7fffffff\n" V4_PAIR_BODY)
 
+// f) HALF dense operand kept as half in LDS (8 columns per lane = ONE ds_read_b128 per
+//    entry): fp16 through v_fma_mix_f32 (f32 value x f16 B + f32 sum, 8 per entry), and
+//    bf16 widened by a shift / a mask outside the index-mode region (8 VALU) in front of
+//    the four v_pk_fma_f32.  Same scalar work as c).
+#define NZH8(U, PAIR_LO, PAIR_HI, ADDR, B0, B3)                                                     \
+  "v_mov_b64_dpp v[" PAIR_LO ":" PAIR_HI "], v[6:7] row_newbcast:" U " row_mask:0xf bank_mask:0xf\n" \
+  "v_add_u32 " ADDR ", v" PAIR_LO ", v40\n"                                                         \
+  "ds_read_b128 v[" B0 ":" B3 "], " ADDR "\n"
+#define MIX8(AV, B0, B1, B2, B3)                                                      \
+  "v_fma_mix_f32 v64, v" AV ", v" B0 ", v64 op_sel:[0,0,0] op_sel_hi:[0,1,0]\n"       \
+  "v_fma_mix_f32 v65, v" AV ", v" B0 ", v65 op_sel:[0,1,0] op_sel_hi:[0,1,0]\n"       \
+  "v_fma_mix_f32 v66, v" AV ", v" B1 ", v66 op_sel:[0,0,0] op_sel_hi:[0,1,0]\n"       \
+  "v_fma_mix_f32 v67, v" AV ", v" B1 ", v67 op_sel:[0,1,0] op_sel_hi:[0,1,0]\n"       \
+  "v_fma_mix_f32 v68, v" AV ", v" B2 ", v68 op_sel:[0,0,0] op_sel_hi:[0,1,0]\n"       \
+  "v_fma_mix_f32 v69, v" AV ", v" B2 ", v69 op_sel:[0,1,0] op_sel_hi:[0,1,0]\n"       \
+  "v_fma_mix_f32 v70, v" AV ", v" B3 ", v70 op_sel:[0,0,0] op_sel_hi:[0,1,0]\n"       \
+  "v_fma_mix_f32 v71, v" AV ", v" B3 ", v71 op_sel:[0,1,0] op_sel_hi:[0,1,0]\n"
+// bf16 -> f32: odd columns keep the high half (mask), even columns shift up; W0..W7 = 8
+// consecutive registers taking the widened strip, written from the top so the strip may
+// start in the same registers
+#define WIDEN8(B0, B1, B2, B3, W0, W1, W2, W3, W4, W5, W6, W7)                        \
+  "v_and_b32 v" W7 ", 0xffff0000, v" B3 "\nv_lshlrev_b32 v" W6 ", 16, v" B3 "\n"      \
+  "v_and_b32 v" W5 ", 0xffff0000, v" B2 "\nv_lshlrev_b32 v" W4 ", 16, v" B2 "\n"      \
+  "v_and_b32 v" W3 ", 0xffff0000, v" B1 "\nv_lshlrev_b32 v" W2 ", 16, v" B1 "\n"      \
+  "v_and_b32 v" W1 ", 0xffff0000, v" B0 "\nv_lshlrev_b32 v" W0 ", 16, v" B0 "\n"
+
+DEF_STEP(k_half_mix,
+         NZH8("2", "34", "35", "v46", "48", "51") NZH8("3", "36", "37", "v47", "56", "59")
+         "s_bfe_u32 s40, s44, 0x80000\ns_bfe_u32 s41, s44, 0x80008\n"
+         "s_waitcnt lgkmcnt(3)\ns_set_gpr_idx_on s40, 0xc\n" MIX8("31", "10", "11", "12", "13")
+         "s_waitcnt lgkmcnt(2)\ns_set_gpr_idx_idx s41\n" MIX8("33", "18", "19", "20", "21")
+         "s_set_gpr_idx_off\ns_cmp_eq_u32 s20, 0\ns_cbranch_scc1 2f\n"
+         NZH8("0", "30", "31", "v44", "10", "13") NZH8("1", "32", "33", "v45", "18", "21")
+         "s_bfe_u32 s42, s44, 0x80010\ns_bfe_u32 s43, s44, 0x80018\n"
+         "s_waitcnt lgkmcnt(3)\ns_set_gpr_idx_on s42, 0xc\n" MIX8("35", "48", "49", "50", "51")
+         "s_waitcnt lgkmcnt(2)\ns_set_gpr_idx_idx s43\n" MIX8("37", "56", "57", "58", "59")
+         "s_set_gpr_idx_off\ns_cmp_eq_u32 s20, 0\ns_cbranch_scc1 2f\n2:\n")
+
+DEF_STEP(k_half_widen,
+         NZH8("2", "34", "35", "v46", "48", "51") NZH8("3", "36", "37", "v47", "56", "59")
+         "s_bfe_u32 s40, s44, 0x80000\ns_bfe_u32 s41, s44, 0x80008\n"
+         "s_waitcnt lgkmcnt(3)\n" WIDEN8("10", "11", "12", "13", "10", "11", "12", "13", "14", "15", "16", "17")
+         "s_waitcnt lgkmcnt(2)\n" WIDEN8("18", "19", "20", "21", "18", "19", "20", "21", "22", "23", "24", "25")
+         "s_set_gpr_idx_on s40, 0xc\n" PK8("30:31", "10:11", "12:13", "14:15", "16:17")
+         "s_set_gpr_idx_idx s41\n" PK8("32:33", "18:19", "20:21", "22:23", "24:25")
+         "s_set_gpr_idx_off\ns_cmp_eq_u32 s20, 0\ns_cbranch_scc1 2f\n"
+         NZH8("0", "30", "31", "v44", "10", "13") NZH8("1", "32", "33", "v45", "18", "21")
+         "s_bfe_u32 s42, s44, 0x80010\ns_bfe_u32 s43, s44, 0x80018\n"
+         "s_waitcnt lgkmcnt(3)\n" WIDEN8("48", "49", "50", "51", "48", "49", "50", "51", "52", "53", "54", "55")
+         "s_waitcnt lgkmcnt(2)\n" WIDEN8("56", "57", "58", "59", "56", "57", "58", "59", "60", "61", "62", "63")
+         "s_set_gpr_idx_on s42, 0xc\n" PK8("34:35", "48:49", "50:51", "52:53", "54:55")
+         "s_set_gpr_idx_idx s43\n" PK8("36:37", "56:57", "58:59", "60:61", "62:63")
+         "s_set_gpr_idx_off\ns_cmp_eq_u32 s20, 0\ns_cbranch_scc1 2f\n2:\n")
+
+// v_fma_mix_f32 under DST|SRC2 index mode: acc[idx] += (idx+1) * half(1.0), both halves
+// of the B register in turn -> acc[idx] = 2*(idx+1) if dst and src2 both follow M0.
+__global__ void k_correct_mix(float* out) {
+  float r[16];
+  asm volatile(
+      "v_mov_b32 v64, 0\nv_mov_b32 v65, 0\nv_mov_b32 v66, 0\nv_mov_b32 v67, 0\n"
+      "v_mov_b32 v68, 0\nv_mov_b32 v69, 0\nv_mov_b32 v70, 0\nv_mov_b32 v71, 0\n"
+      "v_mov_b32 v72, 0\nv_mov_b32 v73, 0\nv_mov_b32 v74, 0\nv_mov_b32 v75, 0\n"
+      "v_mov_b32 v76, 0\nv_mov_b32 v77, 0\nv_mov_b32 v78, 0\nv_mov_b32 v79, 0\n"
+      "v_mov_b32 v4, 0x3c003c00\n"
+      "s_mov_b32 s20, 0\n"
+      "1:\n"
+      "s_add_u32 s21, s20, 1\n"
+      "v_cvt_f32_u32 v2, s21\n"
+      "s_set_gpr_idx_on s20, 0xc\n"
+      "v_fma_mix_f32 v64, v2, v4, v64 op_sel:[0,0,0] op_sel_hi:[0,1,0]\n"
+      "v_fma_mix_f32 v64, v2, v4, v64 op_sel:[0,1,0] op_sel_hi:[0,1,0]\n"
+      "s_set_gpr_idx_off\n"
+      "s_add_u32 s20, s20, 1\n"
+      "s_cmp_lt_u32 s20, 16\n"
+      "s_cbranch_scc1 1b\n"
+      "v_mov_b32 %0, v64\nv_mov_b32 %1, v65\nv_mov_b32 %2, v66\nv_mov_b32 %3, v67\n"
+      "v_mov_b32 %4, v68\nv_mov_b32 %5, v69\nv_mov_b32 %6, v70\nv_mov_b32 %7, v71\n"
+      "v_mov_b32 %8, v72\nv_mov_b32 %9, v73\nv_mov_b32 %10, v74\nv_mov_b32 %11, v75\n"
+      "v_mov_b32 %12, v76\nv_mov_b32 %13, v77\nv_mov_b32 %14, v78\nv_mov_b32 %15, v79\n"
+      : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]), "=v"(r[4]), "=v"(r[5]), "=v"(r[6]),
+        "=v"(r[7]), "=v"(r[8]), "=v"(r[9]), "=v"(r[10]), "=v"(r[11]), "=v"(r[12]), "=v"(r[13]),
+        "=v"(r[14]), "=v"(r[15])
+      :
+      : "memory", "s20", "s21", "m0", "v2", "v3", "v4", "v5", "v64", "v65", "v66", "v67", "v68",
+        "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79");
+  if (threadIdx.x == 0)
+    for (int i = 0; i < 16; ++i) out[i] = r[i];
+}
+
 typedef void (*kern_t)(unsigned long long*, int, int);
 
 static void run(const char* name, kern_t k, int rnd, int per_iter = 16) {
@@ -289,7 +378,14 @@ int main() {
   printf("mode on, index 2: mov_b64_dpp->v64 add->v68 mov->v72 ds_read->v76:");
   for (float v : h) printf(" %g", v);
   printf("\n");
+  hipLaunchKernelGGL(k_correct_mix, dim3(1), dim3(64), 0, 0, d);
+  CHECK(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+  printf("fma_mix dst|src2 relative, both halves (want 2 4 6 ...):");
+  for (float v : h) printf(" %g", v);
+  printf("\n");
   for (int rnd = 0; rnd < 2; ++rnd) {
+    run("half_mix(fp16 B)", k_half_mix, rnd);
+    run("half_widen(bf16 B)", k_half_widen, rnd);
     run("pipe_plain", k_pipe_plain, rnd);
     run("pipe_idx", k_pipe_idx, rnd);
     run("pipe_idx_salu", k_pipe_idx_salu, rnd);
