@@ -540,9 +540,22 @@ def other_ops(dev):
         t = event_time_ms(lambda: capi.spmm_many_mask(b_mm, s, s, d, nn, r_mm, mri, mprobs, mro, mci,
                                                       v, ctx, mws), 20)
         res["many_mask_spmm"] = {"ms": t, "gflops": 2.0 * total * d / t / 1e6}
+        # the transposes of the backward pass: all masks in the same three launches against
+        # mask after mask (the single-mask workspace)
+        mvt = torch.zeros_like(mprobs)
+        mrot = torch.empty(b_mm, s + 1, dtype=torch.int32, device=dev)
+        mcit = torch.empty_like(mci)
+        tws = {name: torch.empty(nbytes, dtype=torch.uint8, device=dev) for name, nbytes in (
+            ("ms", capi.csr_transpose_many_mask_workspace_bytes(b_mm, s, s, width)),
+            ("mask_after_mask_ms", capi.csr_transpose_workspace_bytes(s, s, width)))}
+        res["many_mask_transpose"] = {
+            name: event_time_ms(lambda w=w: capi.csr_transpose_many_mask(
+                b_mm, s, s, nn, r_mm, mprobs, mro, mci, mvt, mrot, mcit, None, w), 20)
+            for name, w in tws.items()}
         res["many_mask_note"] = ("b 8 x 8 heads, S 1024, head_dim 64, mask densities 0.1/0.2/0.05/0.5 "
-                                 "repeated: one launch per operator for all masks")
-        del mscores, mprobs, mws
+                                 "repeated: one launch per operator (per phase of the transpose) "
+                                 "for all masks")
+        del mscores, mprobs, mws, mvt, tws
     except Exception as e3:  # noqa: BLE001 - extra metric, best effort
         res["many_mask_sddmm"] = {"error": str(e3)[:200]}
     # the same chain as ONE kernel (online softmax; scores / weights never reach HBM)

@@ -593,7 +593,14 @@ SPUTNIK_HIP_API int sputnik_hip_sparse_softmax_backward_many_mask(int masks, int
                              sputnik_hip_stream_t stream);
 
 /* out_row_offsets [masks][n + 1], out_column_indices / out_permutation
- * (may be NULL) laid out like column_indices. */
+ * (may be NULL) laid out like column_indices.  With a workspace of
+ * sputnik_hip_csr_transpose_many_mask_workspace_bytes (a region of tables and
+ * room for the permutation per mask) all masks are transposed by the same three
+ * launches, plus one gather for the values of all replicas when a mask has
+ * several heads; with less, but at least
+ * sputnik_hip_csr_transpose_workspace_bytes(m, n, largest), mask after mask. */
+SPUTNIK_HIP_API size_t sputnik_hip_csr_transpose_many_mask_workspace_bytes(int masks, int m, int n,
+                             int largest_nonzeros);
 SPUTNIK_HIP_API int sputnik_hip_csr_transpose_many_mask(int masks, int m, int n,
                              const int* nonzeros, int replicas, const float* values,
                              int64_t values_stride, const int* row_offsets,

@@ -238,6 +238,55 @@ def test_many_mask_chain_capi_vs_oracle(capi, dev, b, heads, s, hn, sparsities, 
     assert rel_err(dx.cpu().numpy(), want_dx) < TOL
 
 
+@pytest.mark.parametrize("b,heads,s,sparsities", [
+    (3, 1, 96, (0.5, 0.8)),                    # one replica per mask: values staged with the entries
+    (4, 2, 160, (0.7, 1.0, 0.9)),              # an EMPTY mask inside the batch
+    (8, 8, 1024, (0.9, 0.8, 0.95, 0.5)),       # attention size
+    (5, 2, 300, (0.6, 0.9)),                   # rows not a multiple of the 32-row chunks
+])
+@pytest.mark.parametrize("regions", [True, False], ids=["one_launch_per_phase", "mask_after_mask"])
+def test_csr_transpose_many_mask_capi_vs_oracle(capi, dev, b, heads, s, sparsities, regions):
+    """All masks in the same three launches (a region of tables per mask in the workspace)
+    against the mask-after-mask form (the single-mask workspace) and the oracle: bit-exact
+    values, offsets, indices and permutation; padding behind a mask's entries untouched."""
+    rng = np.random.default_rng(s + b)
+    masks = np.stack([O.random_mask(s, s, sparsities[i % len(sparsities)], round_to=4, rng=rng)
+                      for i in range(b)])
+    ri, ro, ci, nn = O.dense_to_csr_many_mask(masks)
+    r, width = b * heads, int(nn.max())
+    values = rng.uniform(-1, 1, (r, width)).astype(np.float32)
+    ws_bytes = (capi.csr_transpose_many_mask_workspace_bytes(b, s, s, width) if regions
+                else capi.csr_transpose_workspace_bytes(s, s, width))
+    assert capi.csr_transpose_many_mask_workspace_bytes(b, s, s, width) > \
+        capi.csr_transpose_workspace_bytes(s, s, width)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    d_ro, d_ci, d_values = T(ro, dev), T(ci, dev), T(values, dev)
+    vt = torch.full((r, width), -7.0, device=dev)
+    rot = torch.empty(b, s + 1, dtype=torch.int32, device=dev)
+    cit = torch.full((len(ci),), -1, dtype=torch.int32, device=dev)
+    perm = torch.full((len(ci),), -1, dtype=torch.int32, device=dev)
+    capi.csr_transpose_many_mask(b, s, s, nn, r, d_values, d_ro, d_ci, vt, rot, cit, perm, ws)
+    w_vt, w_rot, w_cit = O.csr_transpose_many_mask(b, s, s, nn, values, ro, ci)
+    assert np.array_equal(rot.cpu().numpy(), w_rot)
+    assert np.array_equal(cit.cpu().numpy(), w_cit)
+    got = vt.cpu().numpy()
+    first = 0
+    for i in range(b):
+        n_i = int(nn[i])
+        rows = slice(i * heads, (i + 1) * heads)
+        assert np.array_equal(got[rows, :n_i], w_vt[rows, :n_i])
+        assert (got[rows, n_i:] == -7.0).all()
+        # the permutation is relative to the mask's own entries
+        p_i = perm[first:first + n_i].cpu().numpy()
+        assert np.array_equal(values[rows][:, p_i], w_vt[rows, :n_i])
+        first += n_i
+    # topology only (no values), as the planning callers use it
+    rot2 = torch.empty_like(rot)
+    cit2 = torch.empty_like(cit)
+    capi.csr_transpose_many_mask(b, s, s, nn, 0, None, d_ro, d_ci, None, rot2, cit2, None, ws)
+    assert torch.equal(rot2, rot) and torch.equal(cit2, cit)
+
+
 def test_many_mask_ops_golden_and_autograd(ts, dev, golden):
     from torch_sputnik_amd.functional import CsrSoftmaxManyMask, SddmmManyMask, SpmmManyMask
     g = golden("many_mask_b3_h2_s24")

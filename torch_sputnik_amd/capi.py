@@ -38,6 +38,7 @@ SIGNATURES = {
     "sputnik_hip_sddmm": (_c_int, [_c_int] * 4 + [_c_ptr] * 7),
     "sputnik_hip_sddmm_workspace_bytes": (_c_size, [_c_int] * 4),
     "sputnik_hip_sddmm_many_mask_workspace_bytes": (_c_size, [_c_int] * 5),
+    "sputnik_hip_csr_transpose_many_mask_workspace_bytes": (_c_size, [_c_int] * 4),
     "sputnik_hip_sddmm_batched": (_c_int, [_c_int] * 5 + [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64,
                                                          _c_ptr, _c_i64, _c_ptr, _c_i64, _c_ptr,
                                                          _c_size, _c_ptr]),
@@ -505,6 +506,11 @@ def sparse_softmax_backward_many_mask(masks, m, nonzeros, replicas, softmax_out,
         grad_values.shape[-1], _stream(grad_values)),
         "sputnik_hip_sparse_softmax_backward_many_mask")
     return grad_values
+
+
+def csr_transpose_many_mask_workspace_bytes(masks, m, n, largest_nonzeros):
+    """A region of tables per mask: with it all masks are transposed by the same three launches."""
+    return lib().sputnik_hip_csr_transpose_many_mask_workspace_bytes(masks, m, n, largest_nonzeros)
 
 
 def csr_transpose_many_mask(masks, m, n, nonzeros, replicas, values, row_offsets, column_indices,

@@ -9,9 +9,10 @@
 // from the concatenated row offsets -- no device table to build, no host
 // synchronisation): the softmax pair always, SpMM on the panel-resident kernel
 // (attention: n = head_dim), SDDMM on both of its kernels (the stationary one
-// with one pre-pass per mask in front).  Other SpMM shapes, and the transpose,
-// take one batched launch per mask over its heads, ordered on the stream and
-// sharing the workspace.
+// with one pre-pass for all masks in front), the transpose in its three phases
+// (round 4: the grid's last dimension is the mask; a region of tables per mask in
+// the workspace).  Other SpMM shapes take one batched launch per mask over its
+// heads, ordered on the stream and sharing the workspace.
 #include <algorithm>
 
 #include "common.h"
@@ -29,6 +30,13 @@ int spmm_panel_launch(int m, int k, int n, int nonzeros, int replicas, const int
                       const int* column_indices, const float* dense, int64_t dense_stride,
                       float* out, int64_t out_stride, hipStream_t stream, Epilogue epi,
                       const int* value_permutation, int block_rows, int mask_heads);
+size_t csr_transpose_many_bytes(int masks, int m, int n, int largest_nonzeros);
+int csr_transpose_many_launch(int masks, int m, int n, int largest_nonzeros, int64_t total_nonzeros,
+                              int heads, const float* values, int64_t values_stride,
+                              const int* row_offsets, const int* column_indices, float* out_values,
+                              int64_t out_values_stride, int* out_row_offsets,
+                              int* out_column_indices, int* out_permutation, void* workspace,
+                              size_t workspace_bytes, hipStream_t stream);
 }  // namespace sputnik_hip
 
 extern "C" int sputnik_hip_internal_sddmm_many_mask(
@@ -74,6 +82,13 @@ size_t sputnik_hip_sddmm_many_mask_workspace_bytes(int masks, int m, int k, int 
   if (masks <= 0 || m <= 0 || k <= 0 || n <= 0 || largest_nonzeros <= 0) return 0;
   const size_t one = (sddmm_tiled_workspace_bytes(m, k, n, largest_nonzeros, false) + 255) / 256 * 256;
   return one * static_cast<size_t>(masks);
+}
+
+size_t sputnik_hip_csr_transpose_many_mask_workspace_bytes(int masks, int m, int n,
+                                                           int largest_nonzeros) {
+  if (masks <= 0 || m <= 0 || n <= 0 || largest_nonzeros <= 0) return 0;
+  return std::max(csr_transpose_many_bytes(masks, m, n, largest_nonzeros),
+                  sputnik_hip_csr_transpose_workspace_bytes(m, n, largest_nonzeros));
 }
 
 int sputnik_hip_spmm_many_mask(int masks, int m, int k, int n, const int* nonzeros, int replicas,
@@ -173,6 +188,20 @@ int sputnik_hip_csr_transpose_many_mask(int masks, int m, int n, const int* nonz
                                         sputnik_hip_stream_t stream) {
   const MaskWalk w = check(masks, m, n, nonzeros, replicas);
   if (!w.ok) return SPUTNIK_HIP_INVALID_ARGUMENT;
+  if (masks > 1 && m > 0 && n > 0) {
+    const bool with_values = values != nullptr && out_values != nullptr;
+    const int largest = largest_of(masks, nonzeros);
+    if (!with_values || (values_stride >= largest && out_values_stride >= largest)) {
+      int64_t total = 0;
+      for (int i = 0; i < masks; ++i) total += nonzeros[i];
+      const int st = csr_transpose_many_launch(
+          masks, m, n, largest, total, with_values ? w.heads : 0, with_values ? values : nullptr,
+          values_stride, row_offsets, column_indices, with_values ? out_values : nullptr,
+          out_values_stride, out_row_offsets, out_column_indices, out_permutation, workspace,
+          workspace_bytes, stream);
+      if (st >= 0) return st;
+    }
+  }
   int64_t first = 0;
   for (int i = 0; i < masks; ++i) {
     const int64_t r0 = static_cast<int64_t>(i) * w.heads;

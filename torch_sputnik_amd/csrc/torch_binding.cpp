@@ -1164,7 +1164,7 @@ std::vector<Tensor> csr_transpose_many_mask(int64_t b, int64_t m64, int64_t n64,
   // [b, n + 1]: tests/transformer/utils.py:51-62 (diffsort_many_mask) indexes it per mask
   Tensor out_row_offsets = at::empty({mm.masks, n + 1}, index_options);
   Tensor out_column_indices = at::empty({mm.column_indices.numel()}, index_options);
-  const size_t ws_bytes = sputnik_hip_csr_transpose_workspace_bytes(mm.m, n, mm.width);
+  const size_t ws_bytes = sputnik_hip_csr_transpose_many_mask_workspace_bytes(mm.masks, mm.m, n, mm.width);
   Tensor workspace =
       at::empty({static_cast<int64_t>(ws_bytes)}, values.options().dtype(at::kByte));
   check_status(sputnik_hip_csr_transpose_many_mask(

@@ -65,6 +65,21 @@ constexpr int kLongColumn = 2048; // O(n + nnz) path: output rows beyond this ar
 
 typedef unsigned int mask_t;
 
+// "Many mask" batches in ONE launch per phase (round 4): the grid's last dimension is
+// the mask.  Mask i reads the i-th topology of the concatenated arrays (common.h:
+// row_offsets [masks][m + 1], column_indices back to back), moves the values of its
+// `heads` replicas, and keeps its tables `region` ints behind those of mask i - 1.
+// mask 0 -- and every single-topology call -- moves nothing.
+struct ManyPlace {
+  int64_t offsets;   // ints to add to row_offsets
+  int first;         // entries in front of this mask's in column_indices / the outputs
+};
+__device__ __forceinline__ ManyPlace many_place(int mask, int m, const int* __restrict__ row_offsets) {
+  int first = 0;
+  for (int j = 0; j < mask; ++j) first += row_offsets[static_cast<int64_t>(j) * (m + 1) + m];
+  return ManyPlace{static_cast<int64_t>(mask) * (m + 1), first};
+}
+
 // Column groups of a matrix with n <= kColsPerRange columns: a multiple of 8, so
 // that group g of every chunk has the same `workgroup id % 8` (see the scatter).
 inline int column_groups(int n) { return ceil_div(ceil_div(n, kGroupCols), 8) * 8; }
@@ -82,8 +97,15 @@ constexpr int kMaskBlock = 1024;
 constexpr int kRowsPerWave = kRowsPerChunk / (kMaskBlock / kWave);  // 2
 __global__ __launch_bounds__(kMaskBlock) void transpose_mask_kernel(
     int m, int n, const int* __restrict__ row_offsets, const int* __restrict__ column_indices,
-    mask_t* __restrict__ gmask, int* __restrict__ balances) {
+    mask_t* __restrict__ gmask, int* __restrict__ balances, int64_t region) {
   extern __shared__ mask_t masks[];
+  if (blockIdx.z > 0) {
+    const ManyPlace place = many_place(blockIdx.z, m, row_offsets);
+    row_offsets += place.offsets;
+    column_indices += place.first;
+    gmask += blockIdx.z * region;
+    balances += blockIdx.z * region;
+  }
   __shared__ int balance;   // entries seen minus bits found set: 0 unless a row repeats a column or holds one outside [0, n)
   if (threadIdx.x == 0) balance = 0;
   int entries = 0;
@@ -317,13 +339,58 @@ __global__ __launch_bounds__(kBlock) void transpose_sparse_values_kernel(
     out_values[r * out_values_stride + i] = static_cast<float>(values[r * values_stride + p]);
 }
 
+// The same for a "many mask" batch: grid (pieces of 4 x kBlock entries, heads, masks);
+// replica mask * heads + head reads its row through the mask's part of the permutation.
+constexpr int kManyValuesUnroll = 4;
+__global__ __launch_bounds__(kBlock) void transpose_many_values_kernel(
+    int m, int heads, const float* __restrict__ values, int64_t values_stride,
+    const int* __restrict__ row_offsets, const int* __restrict__ permutation,
+    float* __restrict__ out_values, int64_t out_values_stride) {
+  // Workgroups are dealt to the 8 XCDs round-robin in launch order and every XCD has its
+  // own L2: the pieces of one replica's row -- 4-byte reads all over up to 2 MiB -- go to
+  // ONE XCD.  In launch order
+  // every XCD fetched every row for itself: 88 us for 57 MB at 8 masks x 8 heads of 1024^2.
+  const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+  const unsigned launch = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  const unsigned work = total % 8 == 0 ? (launch % 8) * (total / 8) + launch / 8 : launch;
+  // (masks before heads: the masks differ in size, an XCD that took whole masks would take
+  // 10 x the work of another -- 142 us)
+  const int piece = work % gridDim.x;
+  const int mask = (work / gridDim.x) % gridDim.z;
+  const int head = work / (gridDim.x * gridDim.z);
+  const ManyPlace place = many_place(mask, m, row_offsets);
+  const int count = row_offsets[place.offsets + m];
+  const int64_t replica = static_cast<int64_t>(mask) * heads + head;
+  values += replica * values_stride;
+  out_values += replica * out_values_stride;
+  permutation += place.first;
+  const int i0 = piece * (kBlock * kManyValuesUnroll) + threadIdx.x;
+  int p[kManyValuesUnroll];
+#pragma unroll
+  for (int u = 0; u < kManyValuesUnroll; ++u) p[u] = i0 + u * kBlock < count ? permutation[i0 + u * kBlock] : 0;
+  float v[kManyValuesUnroll];
+#pragma unroll
+  for (int u = 0; u < kManyValuesUnroll; ++u) v[u] = i0 + u * kBlock < count ? values[p[u]] : 0.f;
+#pragma unroll
+  for (int u = 0; u < kManyValuesUnroll; ++u)
+    if (i0 + u * kBlock < count) out_values[i0 + u * kBlock] = v[u];
+}
+
 // table[chunk][c] = sum of popc(gmask[chunk'][c]) over chunk' < chunk;
 // totals[c] = column count.  Block = 64 columns x kScanGroups chunk groups.
 __global__ __launch_bounds__(kWave* kScanGroups) void transpose_scan_table_kernel(
     int n, int chunks, const mask_t* __restrict__ gmask, int* __restrict__ table,
     int* __restrict__ totals, const int* __restrict__ balances, int nbalances,
-    int* __restrict__ status) {
+    int* __restrict__ status, int64_t region) {
   __shared__ int group_sum[kScanGroups][kWave];
+  if (blockIdx.y > 0) {
+    const int64_t move = blockIdx.y * region;
+    gmask += move;
+    table += move;
+    totals += move;
+    balances += move;
+    status += move;
+  }
   if (blockIdx.x == 0) {   // status word: a non-zero balance = a row holds a column twice
     int bad = 0;
     for (int i = threadIdx.x; i < nbalances; i += kWave * kScanGroups) bad |= balances[i] != 0;
@@ -516,7 +583,21 @@ __global__ __launch_bounds__(kGroupBlock) void transpose_scatter_grouped_kernel(
     const int* __restrict__ table, const int* __restrict__ totals,
     int* __restrict__ out_row_offsets, float* __restrict__ out_values,
     int64_t out_values_stride, int* __restrict__ out_column_indices,
-    int* __restrict__ out_permutation) {
+    int* __restrict__ out_permutation, int64_t region) {
+  if (blockIdx.y > 0) {   // (many masks: `replicas` is the heads of one mask)
+    const ManyPlace place = many_place(blockIdx.y, m, row_offsets);
+    const int64_t move = blockIdx.y * region;
+    row_offsets += place.offsets;
+    column_indices += place.first;
+    gmask += move;
+    table += move;
+    totals += move;
+    out_row_offsets += static_cast<int64_t>(blockIdx.y) * (n + 1);
+    out_column_indices += place.first;
+    if (out_permutation != nullptr) out_permutation += place.first;
+    if (values != nullptr) values += static_cast<int64_t>(blockIdx.y) * replicas * values_stride;
+    if (out_values != nullptr) out_values += static_cast<int64_t>(blockIdx.y) * replicas * out_values_stride;
+  }
   __shared__ mask_t masks[kGroupCols];
   __shared__ int base[kGroupCols];       // global slot of the first entry (this chunk, column)
   __shared__ int lbase[kGroupCols];      // the same in the staging area
@@ -612,13 +693,28 @@ __global__ __launch_bounds__(kGroupBlock) void transpose_scatter_grouped_kernel(
     const int pos = st_pos[i];
     out_column_indices[pos] = row0 + st_row[i];
     if (out_permutation != nullptr) out_permutation[pos] = st_src[i];
-    if (stage_values) {
-      out_values[pos] = st_val[i];
-    } else {
-      const int p = st_src[i];
-      for (int r = 0; r < replicas; ++r)
-        out_values[r * out_values_stride + pos] = values[r * values_stride + p];
-    }
+    if (stage_values) out_values[pos] = st_val[i];
+  }
+  if (stage_values || replicas == 0) return;
+  // the values of several replicas: a thread's (up to) 8 entries per replica in flight
+  // together -- the loads of a replica do not wait for the stores of the one before
+  constexpr int kPer = kStageCap / kGroupBlock;
+  int pos[kPer], src[kPer];
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) {
+    const int i = t + u * kGroupBlock;
+    pos[u] = i < staged ? st_pos[i] : -1;
+    src[u] = i < staged ? st_src[i] : 0;
+  }
+  for (int r = 0; r < replicas; ++r) {
+    const float* __restrict__ in = values + r * values_stride;
+    float* __restrict__ out = out_values + r * out_values_stride;
+    float v[kPer];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) v[u] = pos[u] >= 0 ? in[src[u]] : 0.f;
+#pragma unroll
+    for (int u = 0; u < kPer; ++u)
+      if (pos[u] >= 0) out[pos[u]] = v[u];
   }
 }
 
@@ -643,6 +739,73 @@ inline size_t status_offset(int m, int n, int nonzeros) {
 }
 
 }  // namespace
+
+// All masks of a "many mask" batch in three launches (many_mask.hip).  Taken when the
+// LARGEST mask is a table-path matrix of one column range (every attention mask is) and
+// the workspace holds one region of tables per mask; returns -1 otherwise (the caller
+// then transposes mask after mask).  With several heads per mask the scatter moves the
+// topology and the permutation only and ONE gather moves the values of all replicas: the
+// permutation then needs room behind the regions if the caller takes none.  Measured at 8
+// masks x 8 heads of 1024^2 (densities 0.05 .. 0.5, 14.2 M values): 238 us mask after mask,
+// 127 us here = masks 7 + scan 5 + scatter 38 + gather 77; with the values in the scatter
+// (eight replicas per staged entry, loads of a replica batched) 133.  Either way a value
+// costs one 4-byte request to L2 on one side -- the gather's reads, the scatter's runs of
+// 32 x density entries per column and chunk -- and 14.2 M of them take 77 us; full lines on
+// both sides need chunks of 32 / density rows (not built).
+size_t csr_transpose_many_region_bytes(int m, int n, int largest_nonzeros) {
+  return (status_offset(m, n, largest_nonzeros) + 16 + 255) / 256 * 256;
+}
+size_t csr_transpose_many_bytes(int masks, int m, int n, int largest_nonzeros) {
+  return static_cast<size_t>(masks) * (csr_transpose_many_region_bytes(m, n, largest_nonzeros) +
+                                       sizeof(int) * static_cast<size_t>(largest_nonzeros));
+}
+int csr_transpose_many_launch(int masks, int m, int n, int largest_nonzeros, int64_t total_nonzeros,
+                              int heads, const float* values, int64_t values_stride,
+                              const int* row_offsets, const int* column_indices, float* out_values,
+                              int64_t out_values_stride, int* out_row_offsets,
+                              int* out_column_indices, int* out_permutation, void* workspace,
+                              size_t workspace_bytes, hipStream_t stream) {
+  const int chunks = chunks_of(m);
+  const int groups = column_groups(n);
+  const size_t region_bytes = csr_transpose_many_region_bytes(m, n, largest_nonzeros);
+  const bool gather = heads > 1;
+  const size_t tables_bytes = region_bytes * static_cast<size_t>(masks);
+  const size_t need = tables_bytes + (gather && out_permutation == nullptr
+                                          ? sizeof(int) * static_cast<size_t>(total_nonzeros) : 0);
+  if (masks < 2 || masks > kMaxGridYZ || heads > kMaxGridYZ || largest_nonzeros <= 0 ||
+      static_cast<int64_t>(ceil_div(largest_nonzeros, kBlock * kManyValuesUnroll)) * max(heads, 1) * masks >=
+          (int64_t{1} << 32) ||
+      n > kColsPerRange || sparse_path(m, n, largest_nonzeros) || chunks > 0x7fffffff / groups ||
+      workspace == nullptr || workspace_bytes < need)
+    return -1;
+  const int64_t region = static_cast<int64_t>(region_bytes / sizeof(int));
+  mask_t* gmask = static_cast<mask_t*>(workspace);
+  int* table = reinterpret_cast<int*>(gmask + static_cast<size_t>(chunks) * n);
+  int* totals = table + static_cast<size_t>(chunks) * n;
+  int* balances = totals + n;
+  int* status = reinterpret_cast<int*>(static_cast<char*>(workspace) + status_offset(m, n, largest_nonzeros));
+  int* permutation = out_permutation;
+  if (gather && permutation == nullptr)
+    permutation = reinterpret_cast<int*>(static_cast<char*>(workspace) + tables_bytes);
+  hipLaunchKernelGGL(transpose_mask_kernel, dim3(chunks, 1, masks), dim3(kMaskBlock),
+                     sizeof(mask_t) * static_cast<size_t>(n), stream, m, n, row_offsets,
+                     column_indices, gmask, balances, region);
+  hipLaunchKernelGGL(transpose_scan_table_kernel, dim3(ceil_div(n, kWave), masks),
+                     dim3(kWave * kScanGroups), 0, stream, n, chunks, gmask, table, totals, balances,
+                     chunks, status, region);
+  hipLaunchKernelGGL(transpose_scatter_grouped_kernel, dim3(chunks * groups, masks),
+                     dim3(kGroupBlock), 0, stream, m, n, groups, gather ? 0 : heads,
+                     gather ? nullptr : values, values_stride, row_offsets, column_indices, gmask,
+                     table, totals, out_row_offsets, gather ? nullptr : out_values,
+                     out_values_stride, out_column_indices, permutation, region);
+  if (gather)
+    hipLaunchKernelGGL(transpose_many_values_kernel,
+                       dim3(ceil_div(largest_nonzeros, kBlock * kManyValuesUnroll), heads, masks),
+                       dim3(kBlock), 0, stream, m, heads, values, values_stride, row_offsets,
+                       permutation, out_values, out_values_stride);
+  return launch_status();
+}
+
 }  // namespace sputnik_hip
 
 using namespace sputnik_hip;
@@ -716,19 +879,20 @@ int sputnik_hip_csr_transpose(int m, int n, int nonzeros, int replicas, const fl
   const bool grouped = ranges == 1 && chunks <= 0x7fffffff / groups;
 
   hipLaunchKernelGGL(transpose_mask_kernel, dim3(chunks, ranges), dim3(kMaskBlock), lds_bytes,
-                     stream, m, n, row_offsets, column_indices, gmask, balances);
+                     stream, m, n, row_offsets, column_indices, gmask, balances, int64_t{0});
   int st = launch_status();
   if (st != 0) return st;
   hipLaunchKernelGGL(transpose_scan_table_kernel, dim3(ceil_div(n, kWave)),
                      dim3(kWave * kScanGroups), 0, stream, n, chunks, gmask, table, totals, balances,
-                     chunks * ranges, status);
+                     chunks * ranges, status, int64_t{0});
   st = launch_status();
   if (st != 0) return st;
   if (grouped) {
     hipLaunchKernelGGL(transpose_scatter_grouped_kernel, dim3(chunks * groups), dim3(kGroupBlock),
                        0, stream, m, n, groups, replicas, values, values_stride, row_offsets,
                        column_indices, gmask, table, totals, out_row_offsets,
-                       out_values, out_values_stride, out_column_indices, out_permutation);
+                       out_values, out_values_stride, out_column_indices, out_permutation,
+                       int64_t{0});
     return launch_status();
   }
   hipLaunchKernelGGL(transpose_scan_totals_kernel, dim3(1), dim3(kScanBlock), 0, stream, n,
