@@ -81,6 +81,20 @@ def spmm_kernel(request, monkeypatch):
     _reload_library_options()
 
 
+@pytest.fixture(params=["plan_slabs_auto", "plan_slabs_80_rows"])
+def sddmm_sum_slab(request, monkeypatch):
+    """Slab rows of the summed SDDMM's 256-wide panels: large masks take 80-row slabs (two
+    workgroups per CU) on their own; the knob puts the small test shapes on them too."""
+    if request.param == "plan_slabs_80_rows":
+        monkeypatch.setenv("SPUTNIK_HIP_SDDMM_SLAB", "80")
+    else:
+        monkeypatch.delenv("SPUTNIK_HIP_SDDMM_SLAB", raising=False)
+    _reload_library_options()
+    yield request.param
+    monkeypatch.delenv("SPUTNIK_HIP_SDDMM_SLAB", raising=False)
+    _reload_library_options()
+
+
 @pytest.fixture(params=["auto", "tiled", "wave"])
 def sddmm_kernel(request, monkeypatch):
     """As spmm_kernel, for the SDDMM dispatch (LDS-tiled / row-wave)."""

@@ -268,7 +268,8 @@ def test_sddmm_half_output_needs_one_pass(capi, dev):
     (512, 1024, 512, 0.9, 8), (512, 512, 512, 0.8, 3), (256, 1024, 96, 0.7, 1),
     (200, 768, 130, 0.8, 2), (100, 40, 60, 0.5, 5), (128, 384, 200, 0.8, 3),
     (2048, 512, 2048, 0.8, 2)])
-def test_sddmm_sum_half_capi_vs_oracle(capi, dev, dtype, planned, m, k, n, sparsity, replicas):
+def test_sddmm_sum_half_capi_vs_oracle(capi, dev, sddmm_sum_slab, dtype, planned, m, k, n, sparsity,
+                                       replicas):
     _, _, ri, ro, ci = make_csr(m, n, sparsity, seed=m + k + n, empty_rows=(m // 2,))
     rng = np.random.default_rng(k + 1)
     lhs, lhs32 = rounded(rng.uniform(-1, 1, size=(replicas, m, k)), dtype, dev)

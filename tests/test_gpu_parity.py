@@ -707,7 +707,8 @@ SDDMM_SUM_SHAPES = [
 
 @pytest.mark.parametrize("planned", [False, True])
 @pytest.mark.parametrize("m,k,n,sparsity,replicas", SDDMM_SUM_SHAPES)
-def test_sddmm_sum_capi_vs_oracle(capi, dev, sddmm_kernel, m, k, n, sparsity, replicas, planned):
+def test_sddmm_sum_capi_vs_oracle(capi, dev, sddmm_kernel, sddmm_sum_slab, m, k, n, sparsity, replicas,
+                                  planned):
     round_to = 1 if m == 33 else 4
     _, _, ri, ro, ci = make_csr(m, n, sparsity, seed=m + k + n, round_to=round_to,
                                 empty_rows=(m // 2,))

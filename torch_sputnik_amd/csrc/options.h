@@ -13,6 +13,7 @@ struct Options {
   int sddmm_kernel = 0;   // SPUTNIK_HIP_SDDMM_KERNEL: 0 auto, 1 "tiled", 2 "wave"
   int sddmm_panel = 0;    // SPUTNIK_HIP_SDDMM_PANEL (developer): forces the k-panel width of the tiled SDDMM
   int sddmm_debug = 0;    // SPUTNIK_HIP_SDDMM_DEBUG: timing experiments only (bits 8.. : the pair-flat kernel's)
+  int sddmm_slab = 0;     // SPUTNIK_HIP_SDDMM_SLAB: 80 / 128 forces the slab rows of the summed product's 256-wide panels
   int sddmm_flat = 1;     // SPUTNIK_HIP_SDDMM_FLAT: 0 = planned products keep the rhs-stationary kernels
   int softmax_rpg = 0;    // SPUTNIK_HIP_SOFTMAX_RPG: rows per group (0 = automatic)
   int softmax_nt = -1;    // SPUTNIK_HIP_SOFTMAX_NT (developer): nontemporal 0 none, 1 loads, 2 stores, 3 both; -1 default

@@ -52,11 +52,18 @@ constexpr int kSGroups = kSWaves * 4;  // 16-lane row groups per workgroup
 constexpr int kSRows = 8;              // mask rows per group: a workgroup owns 256 rows
 constexpr int kWin = 2;                // 16-entry column windows fetched ahead per row
 
-template <int KV>
+constexpr int default_slab_rows(int kv) { return (kv <= 2 ? 64 * 1024 : 128 * 1024) / (64 * kv * 4); }
+
+// ROWS: rows of the slab.  The default is the 64 / 128 KiB slab; the SUMMED product's
+// 256-wide panels also come with 80 rows (80 KiB, 8 waves): two workgroups per CU, so
+// that one's prologue -- two dependent hops of row bookkeeping and the slab itself, 5 us
+// during which a lone workgroup's CU computes nothing -- runs under the other's
+// arithmetic (sum_slab_rows below says when).
+template <int KV, int ROWS = default_slab_rows(KV)>
 struct Slab {
   static constexpr int kdim = 64 * KV;
-  static constexpr int kBytes = KV <= 2 ? 64 * 1024 : 128 * 1024;
-  static constexpr int kRows = kBytes / (kdim * 4);
+  static constexpr int kRows = ROWS;
+  static constexpr int kBytes = kRows * kdim * 4;
   // lhs fragments in flight (KV float4 each): fetched 2 rows / 1 row ahead
   static constexpr int kRing = KV <= 2 ? 3 : 2;
   // Waves per workgroup.  A 128 KiB slab admits one workgroup per CU; with 8
@@ -65,7 +72,7 @@ struct Slab {
   // few enough registers (<= 128) for four waves per SIMD, so its workgroup has
   // 16 waves that share the slab, each group walking 4 mask rows instead of 8
   // (the workgroup still owns 256 rows: plans and tables are unchanged).
-  static constexpr int kWaves = KV == 4 ? 2 * kSWaves : kSWaves;
+  static constexpr int kWaves = (KV == 4 && kBytes > 80 * 1024) ? 2 * kSWaves : kSWaves;
   static constexpr int kThreads = kWaves * kWave;
   static constexpr int kGroups = kWaves * 4;            // 16-lane row groups per workgroup
   static constexpr int kGroupRows = kSGroups * kSRows / kGroups;   // mask rows per group
@@ -79,8 +86,8 @@ struct Slab {
 // run-time one the conditional load of the previous value made the compiler put
 // `s_waitcnt vmcnt(0)` in front of EVERY result store, i.e. every window waited for
 // all rows fetched ahead and all earlier stores (10 us of 52 at config 3).
-template <int KV, bool ACC>
-__global__ __launch_bounds__(Slab<KV>::kThreads)
+template <int KV, bool ACC, int ROWS = default_slab_rows(KV)>
+__global__ __launch_bounds__((Slab<KV, ROWS>::kThreads))
 __attribute__((amdgpu_waves_per_eu(2, (KV <= 2 || KV == 4 ? 4 : 2))))
 void sddmm_stationary_kernel(
     int m, int n, int nonzeros, int slots, const int* __restrict__ row_indices,
@@ -90,7 +97,7 @@ void sddmm_stationary_kernel(
     int64_t rhs_stride, int ld /* floats between rows of lhs / rhs */,
     float* __restrict__ out, int64_t out_stride, int panels /* of one replica along grid z */,
     int debug, int mask_heads, int64_t mask_plan_ints, int first_replica) {
-  using S = Slab<KV>;
+  using S = Slab<KV, ROWS>;
   constexpr int kdim = S::kdim;  // panel width; lhs / rhs point at the panel's first column
   constexpr int kRowBytes = kdim * 4;
   __shared__ float tile[S::kBytes / 4];
@@ -127,6 +134,7 @@ void sddmm_stationary_kernel(
 
   if (!(debug & 2)) {  // stage the slab in 1 KiB pieces (64 lanes x 16 B, lane-linear in LDS)
     constexpr int kPieces = S::kBytes / 1024;
+    static_assert(kPieces % S::kWaves == 0, "whole pieces per wave");
 #pragma unroll
     for (int j = 0; j < kPieces / S::kWaves; ++j) {
       const int piece = wave + j * S::kWaves;
@@ -624,6 +632,31 @@ inline int sum_panel_width(int m, int k, int n, int nonzeros) {
   if (per_visit >= 10.0) return w;
   return k / 128 <= 16 ? 128 : w;
 }
+// Slab rows of the summed product's plan: 80-row slabs for 256-wide panels of LARGE masks.
+// What the second workgroup of a CU hides are the prologues of the many workgroups a CU
+// works through one after the other; a grid of a round or two has none to hide and pays
+// for the shorter visits (a mask row brings 80 / 128 of the entries to a window).  Measured,
+// 8 replicas, 128 / 80 rows (tools/sddmm_panel_bench.py under SPUTNIK_HIP_SDDMM_SLAB):
+//   2048^2 x 512,  density 0.2  (config 5's weight gradient, 2048 workgroups):  226 / 215 us
+//   4096^2 x 512,  density 0.05 (8192):                                         504 / 474
+//   4096^2 x 512,  density 0.1, 4 replicas (4096):                              312 / 285
+//   1024^2 x 1024, density 0.3  (1024):                                         156 / 154
+//   512^2  x 1024, density 0.1  (256: the attention projections):                27 /  34
+//   512^2  x 1024, density 0.5  (256):                                           62 /  74
+// The plan does not know the batch: the rule counts the workgroups of ONE replica (256 of
+// them = 2048 at a batch of 8).
+inline int sum_slab_rows(int m, int k, int n, int nonzeros) {
+  const int w = sum_panel_width(m, k, n, nonzeros);
+  // (one panel and one replica: the call is the plain product, on the plain geometry)
+  if (w != 256 || k / 256 < 2 || m <= 0 || n <= 0) return slab_rows_of_width(w);
+  const int forced = options().sddmm_slab;
+  if (forced == 80 || forced == 128) return forced;
+  const int64_t per_replica = static_cast<int64_t>(ceil_div(n, 128)) * ceil_div(m, kSGroups * kSRows) * (k / 256);
+  return per_replica >= 256 ? 80 : 128;
+}
+inline int rows_for(int m, int k, int n, int nonzeros, bool summed) {
+  return summed ? sum_slab_rows(m, k, n, nonzeros) : slab_rows_of_width(panel_width(k));
+}
 inline int width_for(int m, int k, int n, int nonzeros, bool summed) {
   return summed ? sum_panel_width(m, k, n, nonzeros) : panel_width(k);
 }
@@ -631,11 +664,11 @@ inline bool served(int k) { return panel_width(k) != 0 && k / panel_width(k) <= 
 
 // The chunk table is the SpMM one with the mask's columns (n) in the role of k,
 // cut at slab boundaries.  Topology only: a caller with a static mask runs it once.
-template <int KV>
+template <int KV, int ROWS = default_slab_rows(KV)>
 int plan(int m, int n, int slots, const int* row_indices, const int* row_offsets,
          const int* column_indices, int* table, int* row_ok, hipStream_t stream, int masks,
          int64_t mask_plan_ints) {
-  using S = Slab<KV>;
+  using S = Slab<KV, ROWS>;
   if (masks > 1) {   // concatenated topologies: all masks' tables in one launch
     if (masks > kMaxGridYZ) return SPUTNIK_HIP_INVALID_ARGUMENT;
     hipLaunchKernelGGL((spmm_chunk_table_masks_kernel<S::kRows>), dim3(ceil_div(slots, 4), masks),
@@ -737,7 +770,7 @@ int launch_half(int m, int k, int n, int nonzeros, int replicas, int slots, cons
 }
 
 template <typename T, typename TO>
-int launch_half_width(int width, int m, int k, int n, int nonzeros, int replicas, int slots,
+int launch_half_width(int width, int rows /* of the plan's slabs */, int m, int k, int n, int nonzeros, int replicas, int slots,
                       const int* row_indices, const int* row_offsets, const int* column_indices,
                       const int* table, const int* row_ok, const void* lhs, int64_t lhs_stride,
                       const void* rhs, int64_t rhs_stride, void* out, int64_t out_stride,
@@ -752,7 +785,9 @@ int launch_half_width(int width, int m, int k, int n, int nonzeros, int replicas
   switch (width) {
     case 64: SPUTNIK_HIP_SDH(1, 256);
     case 128: SPUTNIK_HIP_SDH(2, 128);
-    case 256: SPUTNIK_HIP_SDH(4, 128);
+    case 256:
+      if (rows == 80) SPUTNIK_HIP_SDH(4, 80);
+      SPUTNIK_HIP_SDH(4, 128);
     case 512: SPUTNIK_HIP_SDH(4, 64);   // the plan's slabs (64 rows), panels of 256
     default: return SPUTNIK_HIP_INVALID_ARGUMENT;
   }
@@ -763,19 +798,19 @@ int launch_half_width(int width, int m, int k, int n, int nonzeros, int replicas
 // vector of `partials` (z = replica * panels + panel): for callers that sum the
 // replicas anyway (the gradient of a weight shared by a batch), so that the
 // panels need not run one after the other.
-template <int KV>
+template <int KV, int ROWS = default_slab_rows(KV)>
 int launch_partials(int m, int k, int n, int nonzeros, int replicas, int slots,
                     const int* row_indices, const int* row_offsets, const int* column_indices,
                     const int* table, const int* row_ok, const float* lhs, int64_t lhs_stride,
                     const float* rhs, int64_t rhs_stride, float* partials, int debug,
                     hipStream_t stream) {
-  using S = Slab<KV>;
+  using S = Slab<KV, ROWS>;
   const int slabs = ceil_div(n, S::kRows);
   const int row_blocks = slots / (kSGroups * kSRows);
   const int panels = k / S::kdim;
   if (row_blocks > kMaxGridYZ || static_cast<int64_t>(replicas) * panels > kMaxGridYZ)
     return SPUTNIK_HIP_INVALID_ARGUMENT;
-  hipLaunchKernelGGL((sddmm_stationary_kernel<KV, false>), dim3(slabs, row_blocks, replicas * panels),
+  hipLaunchKernelGGL((sddmm_stationary_kernel<KV, false, ROWS>), dim3(slabs, row_blocks, replicas * panels),
                      dim3(S::kThreads), 0, stream, m, n, nonzeros, slots, row_indices, row_offsets,
                      column_indices, table, row_ok, lhs, lhs_stride, rhs, rhs_stride, k,
                      partials, static_cast<int64_t>(nonzeros), panels, debug, 0, int64_t{0}, 0);
@@ -807,7 +842,12 @@ int sddmm_tiled_launch_partials(int m, int k, int n, int nonzeros, int replicas,
   switch (sum_panel_width(m, k, n, nonzeros)) {
     case 64: SPUTNIK_HIP_SD(1);
     case 128: SPUTNIK_HIP_SD(2);
-    case 256: SPUTNIK_HIP_SD(4);
+    case 256:
+      if (sum_slab_rows(m, k, n, nonzeros) == 80)
+        return launch_partials<4, 80>(m, k, n, nonzeros, replicas, slots, row_indices, row_offsets,
+                                      column_indices, table, row_ok, lhs, lhs_stride, rhs,
+                                      rhs_stride, partials, debug, stream);
+      SPUTNIK_HIP_SD(4);
     case 512: SPUTNIK_HIP_SD(8);
     default: return SPUTNIK_HIP_INVALID_ARGUMENT;
   }
@@ -828,7 +868,7 @@ namespace {
 // Tables of the rhs-stationary kernels alone.
 size_t table_bytes(int m, int k, int n, int nonzeros, bool summed) {
   if (!served(k) || n < 16 || m < 16 || nonzeros < 4 * static_cast<int64_t>(m)) return 0;
-  const int rows = slab_rows_of_width(width_for(m, k, n, nonzeros, summed));
+  const int rows = rows_for(m, k, n, nonzeros, summed);
   return row_ok_bytes(slots_of(m)) +
          sizeof(int) * static_cast<size_t>(ceil_div(n, rows) + 1) * slots_of(m);
 }
@@ -868,7 +908,10 @@ int sddmm_tiled_plan(int m, int k, int n, int nonzeros, const int* row_indices,
   switch (width_for(m, k, n, nonzeros, summed)) {
     case 64: return plan<1>(m, n, slots, row_indices, row_offsets, column_indices, table, row_ok, stream, masks, mask_plan_ints);
     case 128: return plan<2>(m, n, slots, row_indices, row_offsets, column_indices, table, row_ok, stream, masks, mask_plan_ints);
-    case 256: return plan<4>(m, n, slots, row_indices, row_offsets, column_indices, table, row_ok, stream, masks, mask_plan_ints);
+    case 256:
+      if (rows_for(m, k, n, nonzeros, summed) == 80)
+        return plan<4, 80>(m, n, slots, row_indices, row_offsets, column_indices, table, row_ok, stream, masks, mask_plan_ints);
+      return plan<4>(m, n, slots, row_indices, row_offsets, column_indices, table, row_ok, stream, masks, mask_plan_ints);
     case 512: return plan<8>(m, n, slots, row_indices, row_offsets, column_indices, table, row_ok, stream, masks, mask_plan_ints);
     default: return SPUTNIK_HIP_INVALID_ARGUMENT;
   }
@@ -934,7 +977,7 @@ int sddmm_tiled_launch_half(int m, int k, int n, int nonzeros, int replicas, con
       reinterpret_cast<const int*>(static_cast<const char*>(workspace) + row_ok_bytes(slots));
   const int width = panel_width(k);
 #define SPUTNIK_HIP_SDT(T, TO)                                                                    \
-  return launch_half_width<T, TO>(width, m, k, n, nonzeros, replicas, slots, row_indices,         \
+  return launch_half_width<T, TO>(width, slab_rows_of_width(width), m, k, n, nonzeros, replicas, slots, row_indices, \
                                   row_offsets, column_indices, table, row_ok, lhs, lhs_stride,    \
                                   rhs, rhs_stride, out, out_stride, 1, debug, stream, mask_heads, \
                                   mask_plan_ints)
@@ -966,13 +1009,13 @@ int sddmm_tiled_launch_partials_half(int m, int k, int n, int nonzeros, int repl
   if (width > 256) return SPUTNIK_HIP_UNSUPPORTED;
   const int panels = k / width;
   if (in_type == SPUTNIK_HIP_F16)
-    return launch_half_width<_Float16, float>(width, m, k, n, nonzeros, replicas, slots, row_indices,
+    return launch_half_width<_Float16, float>(width, sum_slab_rows(m, k, n, nonzeros), m, k, n, nonzeros, replicas, slots, row_indices,
                                               row_offsets, column_indices, table, row_ok, lhs,
                                               lhs_stride, rhs, rhs_stride, partials,
                                               static_cast<int64_t>(nonzeros), panels, debug, stream,
                                               0, int64_t{0});
   if (in_type == SPUTNIK_HIP_BF16)
-    return launch_half_width<__bf16, float>(width, m, k, n, nonzeros, replicas, slots, row_indices,
+    return launch_half_width<__bf16, float>(width, sum_slab_rows(m, k, n, nonzeros), m, k, n, nonzeros, replicas, slots, row_indices,
                                             row_offsets, column_indices, table, row_ok, lhs,
                                             lhs_stride, rhs, rhs_stride, partials,
                                             static_cast<int64_t>(nonzeros), panels, debug, stream,

@@ -26,6 +26,7 @@ Options read_options() {
   o.spmm_tile = num("SPUTNIK_HIP_SPMM_MEDIUM", 0);
   o.sddmm_debug = num("SPUTNIK_HIP_SDDMM_DEBUG", 0);
   o.sddmm_flat = num("SPUTNIK_HIP_SDDMM_FLAT", 1);
+  o.sddmm_slab = num("SPUTNIK_HIP_SDDMM_SLAB", 0);
   o.sddmm_panel = num("SPUTNIK_HIP_SDDMM_PANEL", 0);
   o.softmax_rpg = num("SPUTNIK_HIP_SOFTMAX_RPG", 0);
   o.softmax_depth = num("SPUTNIK_HIP_SOFTMAX_DEPTH", 1);
