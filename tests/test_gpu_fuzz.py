@@ -164,6 +164,49 @@ def test_fuzz_sddmm_softmax_transpose(capi, dev, sddmm_kernel):
         assert np.array_equal(probs.cpu().numpy()[:, perm.cpu().numpy()], w_vt)
 
 
+def test_fuzz_csr_transpose_many_mask(capi, dev):
+    """Batches of masks of mixed density (some empty, some dense) with 1..4 heads, on the
+    region workspace (all masks in one launch per phase) and on the single-mask one: values,
+    offsets, indices and permutation against the oracle, bit for bit."""
+    rng = np.random.default_rng(20261005 + SEED_SHIFT)
+    for it in range(24 * SCALE):
+        m = max(2, _dims(rng, [16, 33, 64, 100, 256]))
+        n = max(2, _dims(rng, [16, 40, 128, 300, 512]))
+        b = int(rng.integers(2, 7))
+        heads = int(rng.integers(1, 5))
+        masks = np.stack([O.random_mask(m, n, float(rng.choice([0.0, 0.5, 0.9, 0.97, 1.0])),
+                                        round_to=1, rng=rng) for _ in range(b)])
+        ri, ro, ci, nn = O.dense_to_csr_many_mask(masks)
+        width = int(nn.max())
+        if width == 0:
+            continue
+        r = b * heads
+        values = rng.uniform(-1, 1, (r, width + int(rng.integers(0, 5)))).astype(np.float32)
+        regions = bool(rng.integers(0, 2))
+        nbytes = (capi.csr_transpose_many_mask_workspace_bytes(b, m, n, width) if regions
+                  else capi.csr_transpose_workspace_bytes(m, n, width))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        vt = torch.full(values.shape, -7.0, device=dev)
+        rot = torch.empty(b, n + 1, dtype=torch.int32, device=dev)
+        cit = torch.full((max(len(ci), 1),), -1, dtype=torch.int32, device=dev)
+        perm = torch.full((max(len(ci), 1),), -1, dtype=torch.int32, device=dev)
+        capi.csr_transpose_many_mask(b, m, n, nn, r, T(values, dev), T(ro, dev), T(ci, dev), vt, rot,
+                                     cit, perm, ws)
+        w_vt, w_rot, w_cit = O.csr_transpose_many_mask(b, m, n, nn, values[:, :width], ro, ci)
+        tag = f"case {it}: b={b} heads={heads} m={m} n={n} nnz={list(nn)} regions={regions}"
+        assert np.array_equal(rot.cpu().numpy(), w_rot), tag
+        assert np.array_equal(cit.cpu().numpy()[:len(ci)], w_cit), tag
+        got, first = vt.cpu().numpy(), 0
+        for i in range(b):
+            n_i = int(nn[i])
+            rows = slice(i * heads, (i + 1) * heads)
+            assert np.array_equal(got[rows, :n_i], w_vt[rows, :n_i]), tag
+            assert (got[rows, n_i:] == -7.0).all(), tag
+            p_i = perm[first:first + n_i].cpu().numpy()
+            assert np.array_equal(values[rows][:, p_i], w_vt[rows, :n_i]), tag
+            first += n_i
+
+
 def test_fuzz_sparse_attention(capi, dev):
     rng = np.random.default_rng(5150 + SEED_SHIFT)
     for it in range(25 * SCALE):
