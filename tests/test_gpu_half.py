@@ -288,6 +288,114 @@ def test_sddmm_sum_half_capi_vs_oracle(capi, dev, sddmm_sum_slab, dtype, planned
     assert rel_err(got[None, :], want[None, :].astype(np.float32), ro) < TOL
 
 
+@pytest.fixture
+def sddmm_mfma(monkeypatch):
+    """SPUTNIK_HIP_SDDMM_KERNEL=mfma: the summed product of half operands takes the
+    matrix-core kernel (csrc/sddmm_mfma.hip) for every shape it serves -- small test
+    shapes included, which the dispatcher leaves on the vector kernels."""
+    from torch_sputnik_amd import capi
+    monkeypatch.setenv("SPUTNIK_HIP_SDDMM_KERNEL", "mfma")
+    capi.reload_options()
+    yield
+    monkeypatch.delenv("SPUTNIK_HIP_SDDMM_KERNEL", raising=False)
+    capi.reload_options()
+
+
+def _sddmm_sum_typed(capi, dev, m, k, n, replicas, topo, lhs, rhs, with_scratch=True, planned=False,
+                     with_workspace=True):
+    nnz = topo[2].numel()
+    out = torch.full((nnz,), float("nan"), device=dev)
+    ws = torch.empty((capi.sddmm_sum_workspace_bytes(m, k, n, nnz) if with_workspace else 0) + 16,
+                     dtype=torch.uint8, device=dev)
+    scratch = torch.empty((capi.sddmm_sum_scratch_bytes(m, k, n, nnz, replicas) if with_scratch else 0)
+                          + 16, dtype=torch.uint8, device=dev)
+    if planned:
+        capi.sddmm_sum_plan(m, k, n, *topo, ws)
+    capi.sddmm_sum_typed(m, k, n, replicas, *topo, lhs, rhs, out, ws, scratch, planned=planned)
+    return out
+
+
+@pytest.mark.parametrize("dtype", HALF_TYPES)
+@pytest.mark.parametrize("m,k,n,sparsity,replicas,round_to", [
+    (256, 512, 256, 0.8, 2, 4),      # four tiles, two workgroups per tile
+    (128, 64, 128, 0.5, 1, 4),       # one tile, ONE step
+    (200, 192, 130, 0.8, 3, 1),      # ragged tiles (rows and columns clamped), nnz % 4 != 0
+    (72, 128, 40, 0.5, 5, 1),        # a mask smaller than a tile
+    (513, 64, 129, 0.9, 16, 1),      # one-row / one-column last tiles, 16 replicas
+    (384, 1024, 640, 0.95, 2, 4),    # very sparse: most rows have no entry in a tile
+    (300, 256, 300, 0.0, 2, 4),      # a dense mask: every tile element is sampled
+])
+def test_sddmm_sum_mfma_vs_oracle(capi, dev, sddmm_mfma, dtype, m, k, n, sparsity, replicas, round_to):
+    """The matrix-core route of the summed SDDMM (the weight gradient of
+    modules/sparse_linear.py:44-49 on half storage) against the C oracle on the
+    rounded operands: products exact, float32 sums."""
+    _, _, ri, ro, ci = make_csr(m, n, sparsity, seed=m + k + n, empty_rows=(m // 2, m - 1),
+                                round_to=round_to)
+    rng = np.random.default_rng(k + 7)
+    lhs, lhs32 = rounded(rng.uniform(-1, 1, size=(replicas, m, k)), dtype, dev)
+    rhs, rhs32 = rounded(rng.uniform(-1, 1, size=(replicas, n, k)), dtype, dev)
+    want = c_oracle.sddmm(m, n, ro, ci, lhs32, rhs32).astype(np.float64).sum(axis=0)
+    topo = (T(ri, dev), T(ro, dev), T(ci, dev))
+    out = _sddmm_sum_typed(capi, dev, m, k, n, replicas, topo, lhs, rhs)
+    got = out.cpu().numpy()
+    assert not np.isnan(got).any()
+    assert rel_err(got[None, :], want[None, :].astype(np.float32), ro) < TOL
+    # reproducible; the same bits on a kept plan and without any (the tile's entries are
+    # found by a walk then: a different epilogue, the same sums); and the same bound without
+    # the partial vectors' room (one workgroup per tile reduces everything: another order)
+    assert torch.equal(_sddmm_sum_typed(capi, dev, m, k, n, replicas, topo, lhs, rhs), out)
+    assert torch.equal(_sddmm_sum_typed(capi, dev, m, k, n, replicas, topo, lhs, rhs, planned=True), out)
+    assert torch.equal(_sddmm_sum_typed(capi, dev, m, k, n, replicas, topo, lhs, rhs,
+                                        with_workspace=False), out)
+    alone = _sddmm_sum_typed(capi, dev, m, k, n, replicas, topo, lhs, rhs, with_scratch=False)
+    assert rel_err(alone.cpu().numpy()[None, :], want[None, :].astype(np.float32), ro) < TOL
+
+
+@pytest.mark.parametrize("dtype", HALF_TYPES)
+@pytest.mark.parametrize("shuffled", ["every_row", "one_row"])
+def test_sddmm_sum_mfma_unsorted_columns_and_views(capi, dev, sddmm_mfma, dtype, shuffled):
+    """Rows whose columns do not ascend (the plan marks them; a tile that holds one finds
+    its entries by a flat walk over its rows' entries, the other tiles by the plan), an
+    unaligned column_indices pointer (entry-wise index loads in the walk), and exact
+    integer data (every element must be the exact integer)."""
+    m, k, n, replicas = 260, 128, 200, 3
+    _, _, ri, ro, ci = make_csr(m, n, 0.7, seed=11, round_to=1)
+    rng = np.random.default_rng(5)
+    ci = ci.copy()
+    for r in (range(m) if shuffled == "every_row" else (140,)):
+        rng.shuffle(ci[ro[r]:ro[r + 1]])
+    assert not np.all(np.diff(ci[ro[140]:ro[141]]) > 0)
+    lhs32 = rng.integers(-3, 4, size=(replicas, m, k)).astype(np.float32)
+    rhs32 = rng.integers(-3, 4, size=(replicas, n, k)).astype(np.float32)
+    lhs, rhs = T(lhs32, dev).to(dtype), T(rhs32, dev).to(dtype)
+    want = c_oracle.sddmm(m, n, ro, ci, lhs32, rhs32).astype(np.float64).sum(axis=0)
+    padded = torch.zeros(len(ci) + 1, dtype=torch.int32, device=dev)
+    padded[1:] = T(ci, dev)
+    topo = (T(ri, dev), T(ro, dev), padded[1:])            # 4 bytes off a 16-byte boundary
+    for planned in (False, True):
+        got = _sddmm_sum_typed(capi, dev, m, k, n, replicas, topo, lhs, rhs, planned=planned).cpu().numpy()
+        assert np.array_equal(got, want.astype(np.float32))
+
+
+@pytest.mark.parametrize("dtype,seq", [(torch.float16, 512), (torch.bfloat16, 512), (torch.float16, 2048)])
+def test_sddmm_sum_mfma_config5(capi, dev, dtype, seq):
+    """BASELINE config 5's weight gradient at full size -- 2048 x 2048 mask at density
+    0.2, batch 8, reduction over seq 512 and over the stated 2048 -- on the route the
+    dispatcher picks by itself (no knob), every entry against the C oracle."""
+    m = n = 2048
+    replicas = 8
+    _, _, ri, ro, ci = make_csr(m, n, 0.8, seed=seq)
+    rng = np.random.default_rng(seq)
+    lhs, lhs32 = rounded(rng.uniform(-1, 1, size=(replicas, m, seq)), dtype, dev)
+    rhs, rhs32 = rounded(rng.uniform(-1, 1, size=(replicas, n, seq)), dtype, dev)
+    want = np.zeros(len(ci), np.float64)
+    for r in range(replicas):
+        want += c_oracle.sddmm(m, n, ro, ci, lhs32[r:r + 1], rhs32[r:r + 1])[0]
+    topo = (T(ri, dev), T(ro, dev), T(ci, dev))
+    got = _sddmm_sum_typed(capi, dev, m, seq, n, replicas, topo, lhs, rhs).cpu().numpy()
+    assert rel_err(got[None, :], want[None, :].astype(np.float32), ro) < TOL
+
+
 @pytest.mark.parametrize("dtype", HALF_TYPES)
 def test_sddmm_half_ops(ts, dev, dtype):
     """torch ops: half operands go to the kernel as they are; `sddmm` returns float32

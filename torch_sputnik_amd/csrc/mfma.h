@@ -1,0 +1,37 @@
+// Matrix-core (MFMA) routes of the HALF-storage extension (gfx950).
+//
+// The reference's five operators are float32 (data_ptr<float>(), src/sddmm_cuda.cu:48-53)
+// and stay on the vector kernels.  float16 / bfloat16 operands are this library's
+// extension (include/sputnik_hip.h, *_typed): their products are exact in float32, so a
+// product with a long reduction over a mask that occupies every tile -- the gradient of
+// sparse weights shared by a batch, modules/sparse_linear.py:44-49 -- is a sampled DENSE
+// contraction and runs on v_mfma_f32_32x32x16_{f16,bf16}.
+#pragma once
+
+#include "common.h"
+
+namespace sputnik_hip {
+
+// out[p] = sum_r < lhs_r[i_p, 0:k], rhs_r[j_p, 0:k] >, operands stored as `in_type`
+// (SPUTNIK_HIP_F16 / BF16), float32 sums.  `shape_only`: the answer for a workspace /
+// scratch query, which has no pointers to look at.
+bool sddmm_mfma_applicable(int m, int k, int n, int nonzeros, int replicas, const void* lhs,
+                           int64_t lhs_stride, const void* rhs, int64_t rhs_stride);
+bool sddmm_mfma_shape(int m, int k, int n, int nonzeros, int replicas);
+// Workgroups that share one output tile (each reduces a contiguous range of the
+// (replica, k-step) pairs and writes its own partial vector); 1: straight into `out`.
+int sddmm_mfma_splits(int m, int k, int n, int replicas);
+// The plan (topology only, one small launch): per row, where its entries cross the tile
+// columns, and whether its columns ascend.  Optional: without it (plan == nullptr), and for
+// every tile with a row whose columns do not ascend, the kernel finds a tile's entries by
+// walking its rows' entries.
+size_t sddmm_mfma_plan_bytes(int m, int n);
+int sddmm_mfma_plan(int m, int n, const int* row_offsets, const int* column_indices, void* plan,
+                    hipStream_t stream);
+// partials: [splits][nonzeros] float32 (== out when splits is 1).
+int sddmm_mfma_launch(int m, int k, int n, int nonzeros, int replicas, const int* row_offsets,
+                      const int* column_indices, const void* lhs, int64_t lhs_stride,
+                      const void* rhs, int64_t rhs_stride, int in_type, float* partials,
+                      int splits, const void* plan, hipStream_t stream);
+
+}  // namespace sputnik_hip

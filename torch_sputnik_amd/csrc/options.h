@@ -10,7 +10,7 @@ struct Options {
   int spmm_sparse = -1;   // SPUTNIK_HIP_SPMM_SPARSE: 0 / 1 forces the long- / short-segment variant (spmm_tiled); 2 / 3 / 4 the entry / group-straight / group-diagonal loop (spmm_flat)
   int spmm_debug = 0;     // SPUTNIK_HIP_SPMM_DEBUG: timing experiments only (wrong results)
   int spmm_tile = 0;      // SPUTNIK_HIP_SPMM_MEDIUM: 1 = medium, 2 = small tile
-  int sddmm_kernel = 0;   // SPUTNIK_HIP_SDDMM_KERNEL: 0 auto, 1 "tiled", 2 "wave"
+  int sddmm_kernel = 0;   // SPUTNIK_HIP_SDDMM_KERNEL: 0 auto, 1 "tiled", 2 "wave", 3 "mfma" (summed product on half operands: every shape the matrix-core kernel serves)
   int sddmm_panel = 0;    // SPUTNIK_HIP_SDDMM_PANEL (developer): forces the k-panel width of the tiled SDDMM
   int sddmm_debug = 0;    // SPUTNIK_HIP_SDDMM_DEBUG: timing experiments only (bits 8.. : the pair-flat kernel's)
   int sddmm_slab = 0;     // SPUTNIK_HIP_SDDMM_SLAB: 80 / 128 forces the slab rows of the summed product's 256-wide panels

@@ -14,6 +14,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "mfma.h"
 #include "options.h"
 #include "wave_utils.h"
 
@@ -425,6 +426,21 @@ int sputnik_hip_sddmm_batched(int m, int k, int n, int nonzeros, int replicas,
 
 namespace {
 
+// The summed form's workspace: the vector kernels' tables, then (256-byte aligned) the plan
+// of the matrix-core route when SOME call on this shape could take it (the queries know
+// neither the operands' storage type nor the replica count).
+bool mfma_for_some_call(int m, int k, int n, int nonzeros) {
+  return sddmm_mfma_shape(m, k, n, nonzeros, /*replicas=*/1 << 20);
+}
+size_t mfma_plan_offset(int m, int k, int n, int nonzeros) {
+  return (sddmm_tiled_workspace_bytes(m, k, n, nonzeros, /*summed=*/true) + 255) / 256 * 256;
+}
+size_t sum_workspace_bytes(int m, int k, int n, int nonzeros) {
+  if (!mfma_for_some_call(m, k, n, nonzeros))
+    return sddmm_tiled_workspace_bytes(m, k, n, nonzeros, /*summed=*/true);
+  return mfma_plan_offset(m, k, n, nonzeros) + sddmm_mfma_plan_bytes(m, n);
+}
+
 // Partial vectors a summed call needs: one per (replica, panel) on the tiled path.
 int64_t sum_parts(int m, int k, int n, int nonzeros, int replicas) {
   const bool tiled_shape = sddmm_tiled_workspace_bytes(m, k, n, nonzeros) != 0;
@@ -501,6 +517,39 @@ int sddmm_sum_exec_half(int m, int k, int n, int nonzeros, int replicas, const i
     const hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * static_cast<size_t>(nonzeros), stream);
     return static_cast<int>(e);
   }
+  // Long reductions over a mask that occupies every tile: the dense tiles on the matrix
+  // cores, sampled at the mask (sddmm_mfma.hip; half operands only).  No workspace; the
+  // partial vectors of the workgroups that share a tile go to `scratch`, without which
+  // (or with too little of it) one workgroup per tile writes straight into `out`.
+  if (sddmm_mfma_applicable(m, k, n, nonzeros, replicas, lhs, lhs_stride, rhs, rhs_stride)) {
+    int splits = sddmm_mfma_splits(m, k, n, replicas);
+    if (splits > 1 && (scratch == nullptr || !aligned_to(scratch, 16) ||
+                       scratch_bytes < sizeof(float) * static_cast<size_t>(splits) * nonzeros))
+      splits = 1;
+    // its plan sits behind the vector kernels' tables in the summed form's workspace
+    void* plan = nullptr;
+    const size_t plan_at = mfma_plan_offset(m, k, n, nonzeros);
+    if (workspace != nullptr && aligned_to(workspace, 16) &&
+        workspace_bytes >= plan_at + sddmm_mfma_plan_bytes(m, n)) {
+      plan = static_cast<char*>(workspace) + plan_at;
+      if (!planned) {
+        const int st = sddmm_mfma_plan(m, n, row_offsets, column_indices, plan, stream);
+        if (st != 0) return st;
+      }
+    }
+    float* dst = splits == 1 ? out : static_cast<float*>(scratch);
+    const int st = sddmm_mfma_launch(m, k, n, nonzeros, replicas, row_offsets, column_indices, lhs,
+                                     lhs_stride, rhs, rhs_stride, in_type, dst, splits, plan, stream);
+    if (st != 0 || splits == 1) return st;
+    if (nonzeros % 4 == 0 && aligned_to(out, 16)) {
+      hipLaunchKernelGGL(sum_partials_kernel<4>, dim3(ceil_div(nonzeros / 4, kBlock)), dim3(kBlock),
+                         0, stream, nonzeros / 4, splits, static_cast<int64_t>(nonzeros), dst, out);
+    } else {
+      hipLaunchKernelGGL(sum_partials_kernel<1>, dim3(ceil_div(nonzeros, kBlock)), dim3(kBlock), 0,
+                         stream, nonzeros, splits, static_cast<int64_t>(nonzeros), dst, out);
+    }
+    return launch_status();
+  }
   const bool force_tiled = options().sddmm_kernel == 1;
   const bool force_wave = options().sddmm_kernel == 2;
   const bool small = static_cast<double>(nonzeros) * k * k * replicas < 17179869184.0;  // 2^34
@@ -553,7 +602,7 @@ int sddmm_sum_exec_half(int m, int k, int n, int nonzeros, int replicas, const i
 
 size_t sputnik_hip_sddmm_sum_workspace_bytes(int m, int k, int n, int nonzeros) {
   if (m <= 0 || k <= 0 || n <= 0 || nonzeros <= 0) return 0;
-  return sddmm_tiled_workspace_bytes(m, k, n, nonzeros, /*summed=*/true);
+  return sum_workspace_bytes(m, k, n, nonzeros);
 }
 
 int sputnik_hip_sddmm_sum_plan(int m, int k, int n, int nonzeros, const int* row_indices,
@@ -562,16 +611,27 @@ int sputnik_hip_sddmm_sum_plan(int m, int k, int n, int nonzeros, const int* row
                                sputnik_hip_stream_t stream) {
   if (m < 0 || k < 0 || n < 0 || nonzeros < 0) return SPUTNIK_HIP_INVALID_ARGUMENT;
   if (m == 0 || nonzeros == 0 || k == 0) return 0;
+  if (workspace == nullptr || !aligned_to(workspace, 16)) return 0;
+  if (mfma_for_some_call(m, k, n, nonzeros) &&
+      workspace_bytes >= mfma_plan_offset(m, k, n, nonzeros) + sddmm_mfma_plan_bytes(m, n)) {
+    const int st = sddmm_mfma_plan(m, n, row_offsets, column_indices,
+                                   static_cast<char*>(workspace) + mfma_plan_offset(m, k, n, nonzeros),
+                                   stream);
+    if (st != 0) return st;
+  }
   const size_t need = sddmm_tiled_workspace_bytes(m, k, n, nonzeros, /*summed=*/true);
-  if (workspace == nullptr || !aligned_to(workspace, 16) || need == 0 || workspace_bytes < need)
-    return 0;  // nothing to plan: the row-wave kernel needs no workspace
+  if (need == 0 || workspace_bytes < need)
+    return 0;  // nothing (else) to plan: the row-wave kernel needs no workspace
   return sddmm_tiled_plan(m, k, n, nonzeros, row_indices, row_offsets, column_indices, workspace,
                           stream, /*summed=*/true);
 }
 
 size_t sputnik_hip_sddmm_sum_scratch_bytes(int m, int k, int n, int nonzeros, int replicas) {
   if (m <= 0 || k <= 0 || n <= 0 || nonzeros <= 0 || replicas <= 0) return 0;
-  const int64_t parts = sum_parts(m, k, n, nonzeros, replicas);
+  int64_t parts = sum_parts(m, k, n, nonzeros, replicas);
+  // (the query knows no storage type: room for the matrix-core route of half operands too)
+  if (sddmm_mfma_shape(m, k, n, nonzeros, replicas))
+    parts = max(parts, static_cast<int64_t>(sddmm_mfma_splits(m, k, n, replicas)));
   return parts <= 1 ? 0 : sizeof(float) * static_cast<size_t>(parts) * nonzeros;
 }
 

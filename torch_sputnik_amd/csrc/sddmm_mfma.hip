@@ -1,0 +1,366 @@
+// Summed SDDMM on HALF-storage operands through the matrix cores (round 5).
+//
+//   out[p] = sum_r < lhs_r[i_p, 0:k], rhs_r[j_p, 0:k] >        for every stored (i_p, j_p)
+//
+// i.e. the gradient of sparse weights shared by a batch: the reference computes the
+// [R, nnz] products with sputnik::CudaSddmm in a host loop (src/sddmm_cuda.cu:45-54, called
+// from modules/sparse_linear.py:44-49) and lets autograd add them up.  For float32
+// operands that is the vector kernel of sddmm_tiled.hip (the north star: no MFMA for the
+// five float32 operators).  float16 / bfloat16 operands are this library's extension, their
+// products are exact in float32, and with a reduction of R * k elements over a mask that
+// occupies every 128 x 128 tile (density 0.2 at config 5) the product is a sampled DENSE
+// contraction: the dense tile on v_mfma_f32_32x32x16_{f16,bf16} costs 1 / density times the
+// sparse flops on a unit sixteen times faster than the packed-float32 vector pipe.
+//
+// One workgroup (4 waves) = one 128 x 128 tile of lhs * rhs^T over a contiguous range of
+// the (replica, 64-element k step) pairs:
+//   * both operands are k-contiguous, so a step's 128 x 64 tiles go to LDS by direct
+//     global->LDS copies (1 KiB = 8 rows x 128 B per wave instruction), double buffered,
+//     one rendezvous per step: the copies of step s + 1 fly under the MFMAs of step s;
+//   * the LDS image is lane-linear (the copy's rule), the XOR swizzle that keeps the
+//     fragment reads off each other's banks sits in the per-lane SOURCE address: 16-byte
+//     slot g of row r lands in slot g ^ ((r >> 1) & 7) (ds_read_b128 serves 16 lanes at a
+//     time -- rows {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31} of a fragment -- and with
+//     128-byte rows two rows share a bank row: the 16 lanes hit 16 different slots);
+//   * a wave owns a 64 x 64 quarter as 2 x 2 accumulators of 32 x 32 (64 registers);
+//     per step 16 ds_read_b128 and 16 MFMAs;
+//   * epilogue: the float tile goes to LDS (it reuses the stages), and the workgroup walks
+//     the CSR entries of its 128 rows FLAT -- they are contiguous in column_indices --
+//     sixteen bytes per lane, storing those whose column lies in the tile.  No table, no
+//     pre-pass, no assumption on the order of a row's columns.
+// `splits` workgroups share a tile (each writes its own partial vector, added in index
+// order by sum_partials_kernel of sddmm.hip: deterministic), so that a 2048 x 2048 mask
+// -- 256 tiles -- puts two workgroups on every CU.
+//
+// Bytes and flops per launch (config 5: 2048^2 mask at density 0.2, k = 512, 8 replicas):
+// dense 2 * 2048^2 * 4096 = 34.4 GFLOP for 6.9 GFLOP of sampled products; operands
+// 2 * 16.8 MB once from memory, 2048 / 128 = 16 times through L2 (one 128-row panel per
+// tile row / tile column).
+#include "mfma.h"
+#include "options.h"
+#include "spmm_tiled_common.h"
+
+namespace sputnik_hip {
+namespace {
+
+using tiled::xcd_local_index32;
+using f32x16 = float __attribute__((ext_vector_type(16)));
+
+template <typename T>
+struct Half8;
+template <>
+struct Half8<_Float16> {
+  using type = _Float16 __attribute__((ext_vector_type(8)));
+  static __device__ __forceinline__ f32x16 mfma(type a, type b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+template <>
+struct Half8<__bf16> {
+  using type = __bf16 __attribute__((ext_vector_type(8)));
+  static __device__ __forceinline__ f32x16 mfma(type a, type b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+constexpr int kTile = 128;                       // rows and columns of an output tile
+constexpr int kStep = 64;                        // k elements per step (128 bytes per row)
+constexpr int kOperandBytes = kTile * kStep * 2; // 16 KiB: one operand's tile of a step
+constexpr int kStageBytes = 2 * kOperandBytes;   // lhs tile, rhs tile
+constexpr int kPitch = kTile + 4;                // floats per row of the epilogue's tile
+constexpr int kTileBytes = kTile * kPitch * 4;   // 67 584
+constexpr int kLdsBytes = kTileBytes + 4 * (kTile + 4);   // + the tile rows' CSR bounds
+static_assert(kTileBytes >= 2 * kStageBytes, "the float tile reuses the stages");
+
+// ints of the plan's row_ok part (the table sits behind it)
+__host__ __device__ inline int64_t plan_rows(int m) { return (static_cast<int64_t>(m) + 3) / 4 * 4; }
+
+// direct global->LDS copy of 64 x 16 bytes: LDS destination M0 + lane * 16, per-lane source
+__device__ __forceinline__ void copy_piece(const void* base /* wave-uniform */,
+                                           unsigned lane_byte_offset, const char* lds_dst) {
+  const unsigned lds_addr =
+      static_cast<unsigned>(reinterpret_cast<uintptr_t>(AS_LDS(const_cast<char*>(lds_dst))));
+  asm volatile(
+      "s_mov_b32 m0, %0\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2"
+      :
+      : "s"(lds_addr), "v"(lane_byte_offset), "s"(base)
+      : "memory", "m0");
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sddmm_mfma_kernel(
+    int m, int n, int k, int nonzeros, int steps_per_replica, int total_steps, int splits,
+    int tiles_m, const int* __restrict__ row_offsets, const int* __restrict__ column_indices,
+    const T* __restrict__ lhs, int64_t lhs_stride, const T* __restrict__ rhs, int64_t rhs_stride,
+    float* __restrict__ partials, int vector_columns, const int* __restrict__ plan, int tiles_n) {
+  using H = Half8<T>;
+  using frag = typename H::type;
+  __shared__ __attribute__((aligned(16))) char smem[kLdsBytes];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (an SGPR: M0 takes it)
+  const int wr = wave >> 1, wc = wave & 1;
+  // consecutive work indices run behind one L2: the splits of a tile, then the row tiles
+  // of one tile column (they stage the same rhs panel)
+  const int work = xcd_local_index32();
+  const int split = work % splits;
+  const int tile = work / splits;
+  const int rt = tile % tiles_m, ct = tile / tiles_m;
+  const int r0 = rt * kTile, c0 = ct * kTile;
+  const int s_begin = static_cast<int>(static_cast<int64_t>(total_steps) * split / splits);
+  const int s_end = static_cast<int>(static_cast<int64_t>(total_steps) * (split + 1) / splits);
+
+  // per-lane source offsets of this wave's four pieces of each operand (rows beyond the
+  // matrix are clamped onto its last row: their products are never sampled)
+  unsigned a_off[4], b_off[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = 8 * wave + 32 * j + (lane >> 3);
+    const unsigned slot = static_cast<unsigned>((lane & 7) ^ ((row >> 1) & 7)) * 16u;
+    a_off[j] = static_cast<unsigned>(min(r0 + row, m - 1) - r0) * static_cast<unsigned>(k) * 2u + slot;
+    b_off[j] = static_cast<unsigned>(min(c0 + row, n - 1) - c0) * static_cast<unsigned>(k) * 2u + slot;
+  }
+  auto stage = [&](int s, int buffer) {
+    const int replica = s / steps_per_replica;
+    const int k0 = (s - replica * steps_per_replica) * kStep;
+    const T* a = lhs + replica * lhs_stride + static_cast<int64_t>(r0) * k + k0;
+    const T* b = rhs + replica * rhs_stride + static_cast<int64_t>(c0) * k + k0;
+    const char* dst = smem + buffer * kStageBytes + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) copy_piece(a, a_off[j], dst + j * 4096);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) copy_piece(b, b_off[j], dst + kOperandBytes + j * 4096);
+  };
+
+  // fragment addresses (k slot 0; slot 2 * ks + (lane >> 5) is an XOR with ks * 32)
+  unsigned fa[2], fb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ra = wr * 64 + i * 32 + (lane & 31);
+    const int rb = wc * 64 + i * 32 + (lane & 31);
+    fa[i] = static_cast<unsigned>(ra * 128 + (((lane >> 5) ^ ((ra >> 1) & 7)) * 16));
+    fb[i] = static_cast<unsigned>(kOperandBytes + rb * 128 + (((lane >> 5) ^ ((rb >> 1) & 7)) * 16));
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{};
+
+  if (s_begin < s_end) {
+    stage(s_begin, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  unsigned stage_base = 0;
+  for (int s = s_begin; s < s_end; ++s) {
+    if (s + 1 < s_end) stage(s + 1, stage_base == 0 ? 1 : 0);
+    frag a[2][4], b[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        a[i][ks] = *reinterpret_cast<const frag*>(smem + ((fa[i] ^ (ks * 32u)) + stage_base));
+        b[i][ks] = *reinterpret_cast<const frag*>(smem + ((fb[i] ^ (ks * 32u)) + stage_base));
+      }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = H::mfma(a[i][ks], b[j][ks], acc[i][j]);
+    // the next step's tiles have landed (this wave's copies), and every wave is done
+    // with this step's
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    stage_base ^= static_cast<unsigned>(kStageBytes);
+  }
+
+  // ---- epilogue: the tile to LDS, then the rows' entries that fall into it ----
+  float* tile_lds = reinterpret_cast<float*>(smem);
+  int* bounds = reinterpret_cast<int*>(smem + kTileBytes);   // [kTile + 1]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = wr * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        const int col = wc * 64 + j * 32 + (lane & 31);
+        tile_lds[row * kPitch + col] = acc[i][j][reg];
+      }
+  float* __restrict__ o = partials + static_cast<int64_t>(split) * nonzeros;
+  // With a plan (sddmm_mfma_plan: where every row's entries cross the tile columns) whose
+  // rows all have ascending columns, a row's entries inside this tile are one known run.
+  bool by_table = plan != nullptr;
+  if (by_table) {
+    const int ok = threadIdx.x < kTile ? plan[min(r0 + static_cast<int>(threadIdx.x), m - 1)] : 1;
+    by_table = __syncthreads_and(ok) != 0;
+  } else {
+    __syncthreads();
+  }
+  if (by_table) {
+    const int* table = plan + plan_rows(m);
+    const int group = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+    int from[8], to[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {   // (all bounds requested before the first is used)
+      const int row = r0 + group + 16 * j;
+      const int* run = table + static_cast<int64_t>(min(row, m - 1)) * (tiles_n + 1) + ct;
+      from[j] = run[0];
+      to[j] = row < m ? run[1] : run[0];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float* tile_row = tile_lds + (group + 16 * j) * kPitch - c0;
+      for (int p = from[j] + l16; p < to[j]; p += 16) o[p] = tile_row[column_indices[p]];
+    }
+    return;
+  }
+
+  // No plan, or a row whose columns do not ascend: the workgroup walks the CSR entries of
+  // its 128 rows FLAT (they are contiguous in column_indices), sixteen bytes per lane,
+  // and stores those whose column lies in the tile.
+  if (threadIdx.x <= kTile) bounds[threadIdx.x] = row_offsets[min(r0 + static_cast<int>(threadIdx.x), m)];
+  __syncthreads();
+  const int first = bounds[0], last = bounds[kTile];
+  // a lane takes four consecutive entries per round; its row moves forward only
+  int row = 0;
+  const int start = (first & ~3) + 4 * static_cast<int>(threadIdx.x);
+  {  // first row whose end lies behind `start` (binary search over the 128 bounds)
+    int lo = 0, hi = kTile;   // answer in [lo, hi]
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (bounds[mid + 1] > start) hi = mid; else lo = mid + 1;
+    }
+    row = lo;
+  }
+  for (int p = start; p < last; p += 4 * 256) {
+    int cols[4];
+    if (vector_columns && p + 3 < nonzeros) {
+      const int4 v = *reinterpret_cast<const int4*>(column_indices + p);
+      cols[0] = v.x; cols[1] = v.y; cols[2] = v.z; cols[3] = v.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cols[e] = p + e < nonzeros ? column_indices[p + e] : -1;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int q = p + e;
+      while (row < kTile && bounds[row + 1] <= q) ++row;
+      const unsigned c = static_cast<unsigned>(cols[e] - c0);
+      if (q >= first && q < last && c < static_cast<unsigned>(kTile)) o[q] = tile_lds[row * kPitch + c];
+    }
+  }
+}
+
+// The plan: per row, where its entry stream crosses the boundaries of the 128-column
+// tiles -- table[row][c] = first entry with column >= 128 c, c = 0 .. tiles_n: a tile's run
+// of the row is [table[row][ct], table[row][ct + 1]) -- and whether the row's
+// columns ascend (row_ok; every row writes its own word, nothing is initialised).  One
+// wave per row, topology only.
+__global__ __launch_bounds__(256) void sddmm_mfma_plan_kernel(int m, int n, int tiles_n,
+                                                              const int* __restrict__ row_offsets,
+                                                              const int* __restrict__ column_indices,
+                                                              int* __restrict__ plan) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= m) return;
+  int* table = plan + plan_rows(m) + static_cast<int64_t>(row) * (tiles_n + 1);
+  const int p0 = row_offsets[row], p1 = row_offsets[row + 1];
+  bool ok = true;
+  for (int base = p0; base < p1; base += 64) {
+    const int p = base + lane;
+    if (p < p1) {
+      const int cur = column_indices[p];
+      const int prev = p > p0 ? column_indices[p - 1] : -1;
+      if (cur <= prev || cur >= n) {
+        ok = false;
+      } else {
+        const int tc = cur / kTile, tp = prev < 0 ? -1 : prev / kTile;
+        for (int c = tp + 1; c <= tc; ++c) table[c] = p;
+      }
+    }
+  }
+  // the tile columns behind the row's last entry (all of them for an empty row)
+  const int last_tile = p1 > p0 ? min(max(column_indices[p1 - 1], 0), n - 1) / kTile : -1;
+  for (int c = last_tile + 1 + lane; c <= tiles_n; c += 64) table[c] = p1;
+  const bool wave_ok = __builtin_amdgcn_ballot_w64(!ok) == 0;
+  if (lane == 0) plan[row] = wave_ok ? 1 : 0;
+}
+
+}  // namespace
+
+bool sddmm_mfma_shape(int m, int k, int n, int nonzeros, int replicas) {
+  const int forced = options().sddmm_kernel;
+  if (forced == 1 || forced == 2) return false;   // "tiled" / "wave": the vector kernels
+  if (k <= 0 || k % kStep != 0 || m <= 0 || n <= 0 || nonzeros <= 0 || replicas <= 0) return false;
+  if (static_cast<int64_t>(k) * 2 * kTile >= (int64_t{1} << 31)) return false;
+  const int64_t tiles = static_cast<int64_t>(ceil_div(m, kTile)) * ceil_div(n, kTile);
+  if (tiles * 64 > (int64_t{1} << 30)) return false;
+  if (forced == 3) return true;                   // "mfma": every shape the kernel serves
+  // The dense tiles cost 1 / density times the sampled flops; the vector kernels run the
+  // sampled flops at 25-27 TFLOP/s on half operands, the tiles at several hundred.
+  const double density = static_cast<double>(nonzeros) / (static_cast<double>(m) * n);
+  const int64_t reduction = static_cast<int64_t>(replicas) * k;
+  return m >= kTile && n >= kTile && density >= 0.05 && reduction >= 1024;
+}
+
+bool sddmm_mfma_applicable(int m, int k, int n, int nonzeros, int replicas, const void* lhs,
+                           int64_t lhs_stride, const void* rhs, int64_t rhs_stride) {
+  return sddmm_mfma_shape(m, k, n, nonzeros, replicas) && aligned_to(lhs, 16) &&
+         aligned_to(rhs, 16) && lhs_stride % 8 == 0 && rhs_stride % 8 == 0;
+}
+
+int sddmm_mfma_splits(int m, int k, int n, int replicas) {
+  const int64_t tiles = static_cast<int64_t>(ceil_div(m, kTile)) * ceil_div(n, kTile);
+  const int64_t steps = static_cast<int64_t>(replicas) * (k / kStep);
+  // two workgroups per CU (68 KiB of LDS each), at least eight steps per workgroup
+  int64_t splits = ceil_div64(512, tiles);
+  if (splits > steps / 8) splits = steps / 8;
+  if (splits > 8) splits = 8;
+  return splits < 1 ? 1 : static_cast<int>(splits);
+}
+
+size_t sddmm_mfma_plan_bytes(int m, int n) {
+  return sizeof(int) * static_cast<size_t>(plan_rows(m) + static_cast<int64_t>(m) * (ceil_div(n, kTile) + 1));
+}
+
+int sddmm_mfma_plan(int m, int n, const int* row_offsets, const int* column_indices, void* plan,
+                    hipStream_t stream) {
+  hipLaunchKernelGGL(sddmm_mfma_plan_kernel, dim3(ceil_div(m, 4)), dim3(256), 0, stream, m, n,
+                     ceil_div(n, kTile), row_offsets, column_indices, static_cast<int*>(plan));
+  return launch_status();
+}
+
+int sddmm_mfma_launch(int m, int k, int n, int nonzeros, int replicas, const int* row_offsets,
+                      const int* column_indices, const void* lhs, int64_t lhs_stride,
+                      const void* rhs, int64_t rhs_stride, int in_type, float* partials,
+                      int splits, const void* plan, hipStream_t stream) {
+  const int tiles_m = ceil_div(m, kTile), tiles_n = ceil_div(n, kTile);
+  const int steps_per_replica = k / kStep;
+  const int64_t total_steps = static_cast<int64_t>(replicas) * steps_per_replica;
+  if (total_steps >= (int64_t{1} << 31) || splits < 1) return SPUTNIK_HIP_INVALID_ARGUMENT;
+  const dim3 grid(static_cast<unsigned>(static_cast<int64_t>(tiles_m) * tiles_n * splits));
+  const int vector_columns = aligned_to(column_indices, 16) ? 1 : 0;
+#define SPUTNIK_HIP_MF(T)                                                                      \
+  hipLaunchKernelGGL(sddmm_mfma_kernel<T>, grid, dim3(256), 0, stream, m, n, k, nonzeros,       \
+                     steps_per_replica, static_cast<int>(total_steps), splits, tiles_m,        \
+                     row_offsets, column_indices, static_cast<const T*>(lhs), lhs_stride,      \
+                     static_cast<const T*>(rhs), rhs_stride, partials, vector_columns,          \
+                     static_cast<const int*>(plan), tiles_n)
+  if (in_type == SPUTNIK_HIP_F16) {
+    SPUTNIK_HIP_MF(_Float16);
+  } else if (in_type == SPUTNIK_HIP_BF16) {
+    SPUTNIK_HIP_MF(__bf16);
+  } else {
+    return SPUTNIK_HIP_INVALID_ARGUMENT;
+  }
+#undef SPUTNIK_HIP_MF
+  return launch_status();
+}
+
+}  // namespace sputnik_hip

@@ -20,7 +20,7 @@ Options read_options() {
     else o.spmm_kernel = e[0] == 'n' ? 1 : e[0] == 'g' ? 2 : e[0] == 'p' ? 3 : e[0] == 'f' ? -3 : 0;
   }
   if (const char* e = getenv("SPUTNIK_HIP_SDDMM_KERNEL"))
-    o.sddmm_kernel = e[0] == 't' ? 1 : e[0] == 'w' ? 2 : 0;
+    o.sddmm_kernel = e[0] == 't' ? 1 : e[0] == 'w' ? 2 : e[0] == 'm' ? 3 : 0;
   o.spmm_sparse = num("SPUTNIK_HIP_SPMM_SPARSE", -1);
   o.spmm_debug = num("SPUTNIK_HIP_SPMM_DEBUG", 0);
   o.spmm_tile = num("SPUTNIK_HIP_SPMM_MEDIUM", 0);
