@@ -211,13 +211,40 @@ SPUTNIK_HIP_API int sputnik_hip_spmm_typed(int m, int k, int n, int nonzeros, in
 
 /* sum over the replicas (sputnik_hip_sddmm_sum_batched{,_planned}) on operands stored as
  * `in_type`; the partial vectors and the result are float32.  Workspace / scratch sizes as
- * the float form's (sputnik_hip_sddmm_sum_workspace_bytes / _scratch_bytes). */
+ * the float form's (sputnik_hip_sddmm_sum_workspace_bytes / _scratch_bytes).
+ * Round 5: half operands with a long reduction (replicas * k >= 1024) over a mask of
+ * density >= 0.05 (m, n >= 128, k a multiple of 64) take the MATRIX CORES
+ * (csrc/sddmm_mfma.hip): the product is then a sampled dense contraction -- every 128 x 128
+ * tile of the mask is occupied -- and the half products are exact in float32 either way.
+ * The float32 form stays on the vector kernels. */
 SPUTNIK_HIP_API int sputnik_hip_sddmm_sum_typed(int m, int k, int n, int nonzeros, int replicas,
                               const int* row_indices, const int* row_offsets,
                               const int* column_indices, const void* lhs, int64_t lhs_stride,
                               const void* rhs, int64_t rhs_stride, int in_type, float* out,
                               void* workspace, size_t workspace_bytes, int planned,
                               void* scratch, size_t scratch_bytes, sputnik_hip_stream_t stream);
+
+/* The same for a (float32, half) pair of operands -- the weight gradient of a layer whose
+ * activations are stored in half precision while the incoming gradient is float32
+ * (modules/sparse_linear.py:44-49 with the extension's storage types).  Where the
+ * matrix-core route serves the shape (long reduction, mask density from 0.05: the dense
+ * 128 x 128 tiles on v_mfma_f32_32x32x16_{f16,bf16}, sampled at the mask) the float32
+ * operand is NOT rounded to the storage type: one pass splits it into two half planes,
+ * v = hi + lo, and the tiles accumulate hi * x + lo * x (exact products, float32 sums).
+ * `scratch` holds sputnik_hip_sddmm_sum_mixed_scratch_bytes(...) bytes (the planes, then the
+ * partial vectors); workspace / planned as sputnik_hip_sddmm_sum_typed.  Returns
+ * SPUTNIK_HIP_UNSUPPORTED for every other shape and for a float32 operand whose replicas do
+ * not lie back to back: widen the half operand and take sputnik_hip_sddmm_sum_typed then.
+ * lhs_type == rhs_type is sputnik_hip_sddmm_sum_typed itself. */
+SPUTNIK_HIP_API size_t sputnik_hip_sddmm_sum_mixed_scratch_bytes(int m, int k, int n, int nonzeros,
+                              int replicas, int lhs_type, int rhs_type);
+SPUTNIK_HIP_API int sputnik_hip_sddmm_sum_mixed(int m, int k, int n, int nonzeros, int replicas,
+                              const int* row_indices, const int* row_offsets,
+                              const int* column_indices, const void* lhs, int lhs_type,
+                              int64_t lhs_stride, const void* rhs, int rhs_type,
+                              int64_t rhs_stride, float* out, void* workspace,
+                              size_t workspace_bytes, int planned, void* scratch,
+                              size_t scratch_bytes, sputnik_hip_stream_t stream);
 
 SPUTNIK_HIP_API int sputnik_hip_sddmm_typed(int m, int k, int n, int nonzeros, int replicas,
                               const int* row_indices, const int* row_offsets,

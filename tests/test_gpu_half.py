@@ -377,6 +377,67 @@ def test_sddmm_sum_mfma_unsorted_columns_and_views(capi, dev, sddmm_mfma, dtype,
         assert np.array_equal(got, want.astype(np.float32))
 
 
+def _sddmm_sum_mixed(capi, dev, m, k, n, replicas, topo, lhs, rhs, planned=False):
+    nnz = topo[2].numel()
+    out = torch.full((nnz,), float("nan"), device=dev)
+    ws = torch.empty(capi.sddmm_sum_workspace_bytes(m, k, n, nnz) + 16, dtype=torch.uint8, device=dev)
+    scratch = torch.empty(capi.sddmm_sum_mixed_scratch_bytes(m, k, n, nnz, replicas, lhs, rhs) + 16,
+                          dtype=torch.uint8, device=dev)
+    if planned:
+        capi.sddmm_sum_plan(m, k, n, *topo, ws)
+    capi.sddmm_sum_mixed(m, k, n, replicas, *topo, lhs, rhs, out, ws, scratch, planned=planned)
+    return out
+
+
+@pytest.mark.parametrize("dtype", HALF_TYPES)
+@pytest.mark.parametrize("wide", ["lhs", "rhs"])
+@pytest.mark.parametrize("m,k,n,sparsity,replicas,magnitude", [
+    (256, 512, 256, 0.8, 2, 1.0),
+    (200, 192, 130, 0.8, 3, 1.0),      # ragged tiles
+    (128, 64, 384, 0.5, 1, 1e-3),      # small gradients: float16's low plane is kept out of
+    (300, 256, 300, 0.7, 4, 3e-4),     # the subnormals by its 2^11 scale (values 3e-7 .. 3e-4)
+    (256, 128, 256, 0.7, 2, 900.0),
+])
+def test_sddmm_sum_mixed_mfma_vs_oracle(capi, dev, sddmm_mfma, dtype, wide, m, k, n, sparsity, replicas,
+                                        magnitude):
+    """A (float32, half) pair: the float32 operand -- the incoming gradient of
+    modules/sparse_linear.py:44-49 when only the activations are stored in half precision --
+    enters the matrix-core product as half planes whose sum is the value, NOT rounded to
+    the storage type: held to the float32 bound against float64 on (float32 operand, rounded
+    half operand)."""
+    _, _, ri, ro, ci = make_csr(m, n, sparsity, seed=m + k + n + 1, empty_rows=(3,), round_to=1)
+    rng = np.random.default_rng(k + 17)
+    # full float32 mantissas, magnitudes spread over three decades
+    wide32 = (rng.uniform(-1, 1, size=(replicas, m if wide == "lhs" else n, k)) *
+              magnitude * 10.0 ** rng.uniform(-3, 0, size=(replicas, 1, k))).astype(np.float32)
+    half_t, half32 = rounded(rng.uniform(-1, 1, size=(replicas, n if wide == "lhs" else m, k)), dtype, dev)
+    lhs32, rhs32 = (wide32, half32) if wide == "lhs" else (half32, wide32)
+    lhs, rhs = (T(wide32, dev), half_t) if wide == "lhs" else (half_t, T(wide32, dev))
+    want = c_oracle.sddmm(m, n, ro, ci, lhs32, rhs32).astype(np.float64).sum(axis=0)
+    topo = (T(ri, dev), T(ro, dev), T(ci, dev))
+    got = _sddmm_sum_mixed(capi, dev, m, k, n, replicas, topo, lhs, rhs)
+    assert rel_err(got.cpu().numpy()[None, :], want[None, :].astype(np.float32), ro) < TOL
+    assert torch.equal(_sddmm_sum_mixed(capi, dev, m, k, n, replicas, topo, lhs, rhs, planned=True), got)
+
+
+def test_sddmm_sum_mixed_op_takes_the_route_or_widens(ts, dev):
+    """torch op: sddmm_sum of (float32, half) operands -- matrix cores where the shape is
+    served, the half operand widened everywhere else; both against the oracle."""
+    import torch_sputnik_amd as tsa
+    for m, k, n, replicas in ((256, 512, 384, 4), (96, 40, 60, 3)):
+        _, _, ri, ro, ci = make_csr(m, n, 0.8, seed=k, round_to=1)
+        topo = (T(ri, dev), T(ro, dev), T(ci, dev))
+        rng = np.random.default_rng(k)
+        lhs32 = rng.uniform(-1, 1, size=(replicas, m, k)).astype(np.float32)
+        rhs, rhs32 = rounded(rng.uniform(-1, 1, size=(replicas, n, k)), torch.float16, dev)
+        want = c_oracle.sddmm(m, n, ro, ci, lhs32, rhs32).astype(np.float64).sum(0)
+        total = tsa.ops.sddmm_sum(m, n, *topo, T(lhs32, dev), rhs)
+        assert total.dtype == torch.float32
+        assert rel_err(total.cpu().numpy()[None], want[None], ro) < TOL
+        plan = ts.sddmm_sum_plan(m, n, k, *topo)
+        assert torch.equal(ts.sddmm_sum_planned(m, n, *topo, T(lhs32, dev), rhs, plan), total)
+
+
 @pytest.mark.parametrize("dtype,seq", [(torch.float16, 512), (torch.bfloat16, 512), (torch.float16, 2048)])
 def test_sddmm_sum_mfma_config5(capi, dev, dtype, seq):
     """BASELINE config 5's weight gradient at full size -- 2048 x 2048 mask at density

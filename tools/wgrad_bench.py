@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--seqs", default="512,2048")
     ap.add_argument("--densities", default="0.2")
     ap.add_argument("--replicas", type=int, default=8)
-    ap.add_argument("--types", default="f16,bf16,f32")
+    ap.add_argument("--types", default="f16,bf16,f32,f32xf16,f32xbf16")
     ap.add_argument("--routes", default="auto,tiled")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -39,12 +39,14 @@ def main():
         for seq in (int(s) for s in args.seqs.split(",")):
             gy = uniform((reps, m, seq), dev, 22) - 0.5
             x = uniform((reps, n, seq), dev, 21) - 0.5
-            for name, dt in (("f16", torch.float16), ("bf16", torch.bfloat16), ("f32", torch.float32)):
+            for name, dt in (("f16", torch.float16), ("bf16", torch.bfloat16), ("f32", torch.float32),
+                             ("f32xf16", torch.float16), ("f32xbf16", torch.bfloat16)):
                 if name not in args.types.split(","):
                     continue
-                a, b = gy.to(dt), x.to(dt)
+                mixed = name.startswith("f32x")
+                a, b = (gy if mixed else gy.to(dt)), x.to(dt)
                 out = torch.empty(nnz, device=dev)
-                for route in args.routes.split(","):
+                for route in (["auto"] if mixed else args.routes.split(",")):
                     if route == "auto":
                         os.environ.pop("SPUTNIK_HIP_SDDMM_KERNEL", None)
                     else:
@@ -52,11 +54,13 @@ def main():
                     capi.reload_options()
                     ws = torch.empty(capi.sddmm_sum_workspace_bytes(m, seq, n, nnz) + 16, dtype=torch.uint8,
                                      device=dev)
-                    scratch = torch.empty(capi.sddmm_sum_scratch_bytes(m, seq, n, nnz, reps) + 16,
+                    scratch = torch.empty((capi.sddmm_sum_mixed_scratch_bytes(m, seq, n, nnz, reps, a, b)
+                                           if mixed else capi.sddmm_sum_scratch_bytes(m, seq, n, nnz, reps)) + 16,
                                           dtype=torch.uint8, device=dev)
                     capi.sddmm_sum_plan(m, seq, n, ri, ro, ci, ws)
-                    t = timeit(lambda: capi.sddmm_sum_typed(m, seq, n, reps, ri, ro, ci, a, b, out, ws, scratch,
-                                                            planned=True), iters=30, warmup=5)
+                    call = capi.sddmm_sum_mixed if mixed else capi.sddmm_sum_typed
+                    t = timeit(lambda: call(m, seq, n, reps, ri, ro, ci, a, b, out, ws, scratch,
+                                            planned=True), iters=30, warmup=5)
                     print(json.dumps(dict(m=m, density=density, seq=seq, replicas=reps, type=name, route=route,
                                           us=round(1000 * t, 1),
                                           sampled_tflops=round(2.0 * nnz * seq * reps / t / 1e9, 1),

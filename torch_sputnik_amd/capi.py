@@ -102,6 +102,11 @@ SIGNATURES = {
     "sputnik_hip_sddmm_sum_typed": (_c_int, [_c_int] * 5 + [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64,
                                                            _c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr,
                                                            _c_size, _c_int, _c_ptr, _c_size, _c_ptr]),
+    "sputnik_hip_sddmm_sum_mixed_scratch_bytes": (_c_size, [_c_int] * 7),
+    "sputnik_hip_sddmm_sum_mixed": (_c_int, [_c_int] * 5 + [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int,
+                                                           _c_i64, _c_ptr, _c_int, _c_i64, _c_ptr,
+                                                           _c_ptr, _c_size, _c_int, _c_ptr, _c_size,
+                                                           _c_ptr]),
     "sputnik_hip_sparse_softmax_typed": (_c_int, [_c_int] * 4 + [
         _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_float, _c_ptr, _c_i64, _c_int, _c_ptr]),
     "sputnik_hip_sparse_softmax_backward_typed": (_c_int, [_c_int] * 3 + [
@@ -655,6 +660,26 @@ def sddmm_sum_typed(m, k, n, replicas, row_indices, row_offsets, column_indices,
         _ptr(lhs), m * k, _ptr(rhs), n * k, _type_code(lhs, rhs), _ptr(out), _ptr(workspace),
         _ws_bytes(workspace), int(bool(planned)), _ptr(scratch), _ws_bytes(scratch), _stream(out)),
         "sputnik_hip_sddmm_sum_typed")
+    return out
+
+
+def sddmm_sum_mixed_scratch_bytes(m, k, n, nonzeros, replicas, lhs, rhs):
+    return lib().sputnik_hip_sddmm_sum_mixed_scratch_bytes(m, k, n, nonzeros, replicas,
+                                                           _type_code(lhs), _type_code(rhs))
+
+
+def sddmm_sum_mixed(m, k, n, replicas, row_indices, row_offsets, column_indices, lhs, rhs, out,
+                    workspace, scratch, planned=False):
+    """The summed SDDMM on a (float32, half) pair of operands: the float32 one enters the
+    matrix-core product as two half planes (not rounded).  Raises (status -2) where that
+    route does not serve the shape."""
+    nonzeros = column_indices.numel()
+    _require(out, torch.float32, "out")
+    _check(lib().sputnik_hip_sddmm_sum_mixed(
+        m, k, n, nonzeros, replicas, _ptr(row_indices), _ptr(row_offsets), _ptr(column_indices),
+        _ptr(lhs), _type_code(lhs), m * k, _ptr(rhs), _type_code(rhs), n * k, _ptr(out),
+        _ptr(workspace), _ws_bytes(workspace), int(bool(planned)), _ptr(scratch), _ws_bytes(scratch),
+        _stream(out)), "sputnik_hip_sddmm_sum_mixed")
     return out
 
 

@@ -20,7 +20,7 @@ bool sddmm_mfma_applicable(int m, int k, int n, int nonzeros, int replicas, cons
 bool sddmm_mfma_shape(int m, int k, int n, int nonzeros, int replicas);
 // Workgroups that share one output tile (each reduces a contiguous range of the
 // (replica, k-step) pairs and writes its own partial vector); 1: straight into `out`.
-int sddmm_mfma_splits(int m, int k, int n, int replicas);
+int sddmm_mfma_splits(int m, int k, int n, int replicas, int planes = 1);
 // The plan (topology only, one small launch): per row, where its entries cross the tile
 // columns, and whether its columns ascend.  Optional: without it (plan == nullptr), and for
 // every tile with a row whose columns do not ascend, the kernel finds a tile's entries by
@@ -32,6 +32,14 @@ int sddmm_mfma_plan(int m, int n, const int* row_offsets, const int* column_indi
 int sddmm_mfma_launch(int m, int k, int n, int nonzeros, int replicas, const int* row_offsets,
                       const int* column_indices, const void* lhs, int64_t lhs_stride,
                       const void* rhs, int64_t rhs_stride, int in_type, float* partials,
-                      int splits, const void* plan, hipStream_t stream);
+                      int splits, const void* plan, hipStream_t stream, int planes = 1,
+                      int64_t lhs_plane_stride = 0, int64_t rhs_plane_stride = 0);
+// `count` float32 values (a multiple of 4) as sddmm_mfma_planes_of(half_type) planes of
+// `half_type`, `count` elements apart, whose (scaled) sum is the value: how an operand that
+// arrives as float32 enters the half-operand product without being rounded to the storage
+// type (planes = that number above, the operand's plane stride = count).
+int sddmm_mfma_planes_of(int half_type);
+int sddmm_mfma_split_planes(int64_t count, const float* in, int half_type, void* planes,
+                            hipStream_t stream);
 
 }  // namespace sputnik_hip

@@ -503,6 +503,47 @@ int sddmm_sum_exec(int m, int k, int n, int nonzeros, int replicas, const int* r
   return launch_status();
 }
 
+// Long reductions over a mask that occupies every tile: the dense tiles on the matrix
+// cores, sampled at the mask (sddmm_mfma.hip; half operands only).  Its plan sits behind
+// the vector kernels' tables in the summed form's workspace (made here when the call is
+// not planned; without the room the kernel finds a tile's entries by a walk); the partial
+// vectors of the workgroups that share a tile go to `scratch`, without which (or with too
+// little of it) one workgroup per tile writes straight into `out`.
+int sum_on_matrix_cores(int m, int k, int n, int nonzeros, int replicas, const int* row_offsets,
+                        const int* column_indices, const void* lhs, int64_t lhs_stride,
+                        const void* rhs, int64_t rhs_stride, int in_type, float* out,
+                        void* workspace, size_t workspace_bytes, bool planned, void* scratch,
+                        size_t scratch_bytes, hipStream_t stream, int planes,
+                        int64_t lhs_plane_stride, int64_t rhs_plane_stride) {
+  int splits = sddmm_mfma_splits(m, k, n, replicas, planes);
+  if (splits > 1 && (scratch == nullptr || !aligned_to(scratch, 16) ||
+                     scratch_bytes < sizeof(float) * static_cast<size_t>(splits) * nonzeros))
+    splits = 1;
+  void* plan = nullptr;
+  const size_t plan_at = mfma_plan_offset(m, k, n, nonzeros);
+  if (workspace != nullptr && aligned_to(workspace, 16) &&
+      workspace_bytes >= plan_at + sddmm_mfma_plan_bytes(m, n)) {
+    plan = static_cast<char*>(workspace) + plan_at;
+    if (!planned) {
+      const int st = sddmm_mfma_plan(m, n, row_offsets, column_indices, plan, stream);
+      if (st != 0) return st;
+    }
+  }
+  float* dst = splits == 1 ? out : static_cast<float*>(scratch);
+  const int st = sddmm_mfma_launch(m, k, n, nonzeros, replicas, row_offsets, column_indices, lhs,
+                                   lhs_stride, rhs, rhs_stride, in_type, dst, splits, plan, stream,
+                                   planes, lhs_plane_stride, rhs_plane_stride);
+  if (st != 0 || splits == 1) return st;
+  if (nonzeros % 4 == 0 && aligned_to(out, 16)) {
+    hipLaunchKernelGGL(sum_partials_kernel<4>, dim3(ceil_div(nonzeros / 4, kBlock)), dim3(kBlock),
+                       0, stream, nonzeros / 4, splits, static_cast<int64_t>(nonzeros), dst, out);
+  } else {
+    hipLaunchKernelGGL(sum_partials_kernel<1>, dim3(ceil_div(nonzeros, kBlock)), dim3(kBlock), 0,
+                       stream, nonzeros, splits, static_cast<int64_t>(nonzeros), dst, out);
+  }
+  return launch_status();
+}
+
 // The same on float16 / bfloat16 operands read as they are; partial vectors and the
 // sum are float32.
 int sddmm_sum_exec_half(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
@@ -517,39 +558,10 @@ int sddmm_sum_exec_half(int m, int k, int n, int nonzeros, int replicas, const i
     const hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * static_cast<size_t>(nonzeros), stream);
     return static_cast<int>(e);
   }
-  // Long reductions over a mask that occupies every tile: the dense tiles on the matrix
-  // cores, sampled at the mask (sddmm_mfma.hip; half operands only).  No workspace; the
-  // partial vectors of the workgroups that share a tile go to `scratch`, without which
-  // (or with too little of it) one workgroup per tile writes straight into `out`.
-  if (sddmm_mfma_applicable(m, k, n, nonzeros, replicas, lhs, lhs_stride, rhs, rhs_stride)) {
-    int splits = sddmm_mfma_splits(m, k, n, replicas);
-    if (splits > 1 && (scratch == nullptr || !aligned_to(scratch, 16) ||
-                       scratch_bytes < sizeof(float) * static_cast<size_t>(splits) * nonzeros))
-      splits = 1;
-    // its plan sits behind the vector kernels' tables in the summed form's workspace
-    void* plan = nullptr;
-    const size_t plan_at = mfma_plan_offset(m, k, n, nonzeros);
-    if (workspace != nullptr && aligned_to(workspace, 16) &&
-        workspace_bytes >= plan_at + sddmm_mfma_plan_bytes(m, n)) {
-      plan = static_cast<char*>(workspace) + plan_at;
-      if (!planned) {
-        const int st = sddmm_mfma_plan(m, n, row_offsets, column_indices, plan, stream);
-        if (st != 0) return st;
-      }
-    }
-    float* dst = splits == 1 ? out : static_cast<float*>(scratch);
-    const int st = sddmm_mfma_launch(m, k, n, nonzeros, replicas, row_offsets, column_indices, lhs,
-                                     lhs_stride, rhs, rhs_stride, in_type, dst, splits, plan, stream);
-    if (st != 0 || splits == 1) return st;
-    if (nonzeros % 4 == 0 && aligned_to(out, 16)) {
-      hipLaunchKernelGGL(sum_partials_kernel<4>, dim3(ceil_div(nonzeros / 4, kBlock)), dim3(kBlock),
-                         0, stream, nonzeros / 4, splits, static_cast<int64_t>(nonzeros), dst, out);
-    } else {
-      hipLaunchKernelGGL(sum_partials_kernel<1>, dim3(ceil_div(nonzeros, kBlock)), dim3(kBlock), 0,
-                         stream, nonzeros, splits, static_cast<int64_t>(nonzeros), dst, out);
-    }
-    return launch_status();
-  }
+  if (sddmm_mfma_applicable(m, k, n, nonzeros, replicas, lhs, lhs_stride, rhs, rhs_stride))
+    return sum_on_matrix_cores(m, k, n, nonzeros, replicas, row_offsets, column_indices, lhs,
+                               lhs_stride, rhs, rhs_stride, in_type, out, workspace, workspace_bytes,
+                               planned, scratch, scratch_bytes, stream, 1, 0, 0);
   const bool force_tiled = options().sddmm_kernel == 1;
   const bool force_wave = options().sddmm_kernel == 2;
   const bool small = static_cast<double>(nonzeros) * k * k * replicas < 17179869184.0;  // 2^34
@@ -673,6 +685,75 @@ int sputnik_hip_sddmm_sum_typed(int m, int k, int n, int nonzeros, int replicas,
   return sddmm_sum_exec_half(m, k, n, nonzeros, replicas, row_indices, row_offsets, column_indices,
                              lhs, lhs_stride, rhs, rhs_stride, in_type, out, workspace,
                              workspace_bytes, planned != 0, scratch, scratch_bytes, stream);
+}
+
+namespace {
+// (float32, half) operand pairs of the summed product: bytes of the float32 operand's two
+// half planes in front of the partial vectors in `scratch`
+size_t mixed_planes_bytes(int rows, int k, int replicas, int half_type) {
+  return (static_cast<size_t>(sddmm_mfma_planes_of(half_type)) * replicas * rows * k * 2 + 255) / 256 * 256;
+}
+bool mixed_pair(int lhs_type, int rhs_type) {
+  const bool lhs_half = lhs_type == SPUTNIK_HIP_F16 || lhs_type == SPUTNIK_HIP_BF16;
+  const bool rhs_half = rhs_type == SPUTNIK_HIP_F16 || rhs_type == SPUTNIK_HIP_BF16;
+  return (lhs_type == SPUTNIK_HIP_F32 && rhs_half) || (rhs_type == SPUTNIK_HIP_F32 && lhs_half);
+}
+}  // namespace
+
+size_t sputnik_hip_sddmm_sum_mixed_scratch_bytes(int m, int k, int n, int nonzeros, int replicas,
+                                                 int lhs_type, int rhs_type) {
+  if (lhs_type == rhs_type) return sputnik_hip_sddmm_sum_scratch_bytes(m, k, n, nonzeros, replicas);
+  if (m <= 0 || k <= 0 || n <= 0 || nonzeros <= 0 || replicas <= 0) return 0;
+  if (!mixed_pair(lhs_type, rhs_type) || !sddmm_mfma_shape(m, k, n, nonzeros, replicas)) return 0;
+  const int rows = lhs_type == SPUTNIK_HIP_F32 ? m : n;
+  const int half_type = lhs_type == SPUTNIK_HIP_F32 ? rhs_type : lhs_type;
+  return mixed_planes_bytes(rows, k, replicas, half_type) +
+         sizeof(float) * static_cast<size_t>(sddmm_mfma_splits(m, k, n, replicas,
+                                                               sddmm_mfma_planes_of(half_type))) * nonzeros;
+}
+
+int sputnik_hip_sddmm_sum_mixed(int m, int k, int n, int nonzeros, int replicas,
+                                const int* row_indices, const int* row_offsets,
+                                const int* column_indices, const void* lhs, int lhs_type,
+                                int64_t lhs_stride, const void* rhs, int rhs_type,
+                                int64_t rhs_stride, float* out, void* workspace,
+                                size_t workspace_bytes, int planned, void* scratch,
+                                size_t scratch_bytes, sputnik_hip_stream_t stream) {
+  if (lhs_type == rhs_type)
+    return sputnik_hip_sddmm_sum_typed(m, k, n, nonzeros, replicas, row_indices, row_offsets,
+                                       column_indices, lhs, lhs_stride, rhs, rhs_stride, lhs_type,
+                                       out, workspace, workspace_bytes, planned, scratch,
+                                       scratch_bytes, stream);
+  if (m < 0 || k < 0 || n < 0 || nonzeros < 0 || replicas < 0) return SPUTNIK_HIP_INVALID_ARGUMENT;
+  if (!mixed_pair(lhs_type, rhs_type)) return SPUTNIK_HIP_INVALID_ARGUMENT;
+  if (m == 0 || nonzeros == 0 || k == 0 || replicas == 0) return SPUTNIK_HIP_UNSUPPORTED;
+  const bool lhs_float = lhs_type == SPUTNIK_HIP_F32;
+  const int half_type = lhs_float ? rhs_type : lhs_type;
+  const int rows = lhs_float ? m : n;
+  const void* wide = lhs_float ? lhs : rhs;
+  const int64_t wide_stride = lhs_float ? lhs_stride : rhs_stride;
+  // the float32 operand is split in one flat pass: its replicas must lie back to back
+  if (replicas > 1 && wide_stride != static_cast<int64_t>(rows) * k) return SPUTNIK_HIP_UNSUPPORTED;
+  const size_t planes_bytes = mixed_planes_bytes(rows, k, replicas, half_type);
+  if (scratch == nullptr || !aligned_to(scratch, 16) || scratch_bytes < planes_bytes ||
+      !aligned_to(wide, 16))
+    return SPUTNIK_HIP_UNSUPPORTED;
+  const int64_t plane_elems = static_cast<int64_t>(replicas) * rows * k;
+  char* hi = static_cast<char*>(scratch);
+  const void* a = lhs_float ? static_cast<const void*>(hi) : lhs;
+  const void* b = lhs_float ? rhs : static_cast<const void*>(hi);
+  const int64_t a_stride = lhs_float ? static_cast<int64_t>(rows) * k : lhs_stride;
+  const int64_t b_stride = lhs_float ? rhs_stride : static_cast<int64_t>(rows) * k;
+  if (!sddmm_mfma_applicable(m, k, n, nonzeros, replicas, a, a_stride, b, b_stride))
+    return SPUTNIK_HIP_UNSUPPORTED;
+  const int st = sddmm_mfma_split_planes(plane_elems, static_cast<const float*>(wide), half_type, hi,
+                                         stream);
+  if (st != 0) return st;
+  return sum_on_matrix_cores(m, k, n, nonzeros, replicas, row_offsets, column_indices, a, a_stride, b,
+                             b_stride, half_type, out, workspace, workspace_bytes, planned != 0,
+                             static_cast<char*>(scratch) + planes_bytes, scratch_bytes - planes_bytes,
+                             stream, sddmm_mfma_planes_of(half_type), lhs_float ? plane_elems : 0,
+                             lhs_float ? 0 : plane_elems);
 }
 
 int sputnik_hip_sddmm_plan(int m, int k, int n, int nonzeros, const int* row_indices,

@@ -72,6 +72,8 @@ constexpr int kTileBytes = kTile * kPitch * 4;   // 67 584
 constexpr int kLdsBytes = kTileBytes + 4 * (kTile + 4);   // + the tile rows' CSR bounds
 static_assert(kTileBytes >= 2 * kStageBytes, "the float tile reuses the stages");
 
+constexpr float kLowPlaneScale = 2048.f;   // 2^11: the float16 split's low plane (see split_planes_kernel)
+
 // ints of the plan's row_ok part (the table sits behind it)
 __host__ __device__ inline int64_t plan_rows(int m) { return (static_cast<int64_t>(m) + 3) / 4 * 4; }
 
@@ -89,12 +91,16 @@ __device__ __forceinline__ void copy_piece(const void* base /* wave-uniform */,
       : "memory", "m0");
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void sddmm_mfma_kernel(
+// ACCS = 2: the second plane of a split float32 operand accumulates in a tile of its own
+// and enters the result times `low_scale` (the float16 split keeps its low plane scaled
+// up by 2^11, out of the subnormals: split_planes_kernel).
+template <typename T, int PLANES, int ACCS>
+__global__ __launch_bounds__(256, 2) void sddmm_mfma_kernel(
     int m, int n, int k, int nonzeros, int steps_per_replica, int total_steps, int splits,
     int tiles_m, const int* __restrict__ row_offsets, const int* __restrict__ column_indices,
     const T* __restrict__ lhs, int64_t lhs_stride, const T* __restrict__ rhs, int64_t rhs_stride,
-    float* __restrict__ partials, int vector_columns, const int* __restrict__ plan, int tiles_n) {
+    float* __restrict__ partials, int vector_columns, const int* __restrict__ plan, int tiles_n,
+    int64_t lhs_plane_stride, int64_t rhs_plane_stride, float low_scale) {
   using H = Half8<T>;
   using frag = typename H::type;
   __shared__ __attribute__((aligned(16))) char smem[kLdsBytes];
@@ -122,11 +128,14 @@ __global__ __launch_bounds__(256) void sddmm_mfma_kernel(
     a_off[j] = static_cast<unsigned>(min(r0 + row, m - 1) - r0) * static_cast<unsigned>(k) * 2u + slot;
     b_off[j] = static_cast<unsigned>(min(c0 + row, n - 1) - c0) * static_cast<unsigned>(k) * 2u + slot;
   }
-  auto stage = [&](int s, int buffer) {
+  // a step = (replica, 64 elements of k), PLANES tile products each.  PLANES > 1: an
+  // operand that arrived as float32 is given as half planes (split_planes_kernel; the other
+  // operand's plane stride is 0) and the tile accumulates every plane's product
+  auto stage = [&](int s, int plane, int buffer) {
     const int replica = s / steps_per_replica;
     const int k0 = (s - replica * steps_per_replica) * kStep;
-    const T* a = lhs + replica * lhs_stride + static_cast<int64_t>(r0) * k + k0;
-    const T* b = rhs + replica * rhs_stride + static_cast<int64_t>(c0) * k + k0;
+    const T* a = lhs + replica * lhs_stride + plane * lhs_plane_stride + static_cast<int64_t>(r0) * k + k0;
+    const T* b = rhs + replica * rhs_stride + plane * rhs_plane_stride + static_cast<int64_t>(c0) * k + k0;
     const char* dst = smem + buffer * kStageBytes + wave * 1024;
 #pragma unroll
     for (int j = 0; j < 4; ++j) copy_piece(a, a_off[j], dst + j * 4096);
@@ -144,39 +153,52 @@ __global__ __launch_bounds__(256) void sddmm_mfma_kernel(
     fb[i] = static_cast<unsigned>(kOperandBytes + rb * 128 + (((lane >> 5) ^ ((rb >> 1) & 7)) * 16));
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[ACCS][2][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int z = 0; z < ACCS; ++z)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{};
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[z][i][j] = f32x16{};
 
   if (s_begin < s_end) {
-    stage(s_begin, 0);
+    stage(s_begin, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
   unsigned stage_base = 0;
   for (int s = s_begin; s < s_end; ++s) {
-    if (s + 1 < s_end) stage(s + 1, stage_base == 0 ? 1 : 0);
-    frag a[2][4], b[2][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        a[i][ks] = *reinterpret_cast<const frag*>(smem + ((fa[i] ^ (ks * 32u)) + stage_base));
-        b[i][ks] = *reinterpret_cast<const frag*>(smem + ((fb[i] ^ (ks * 32u)) + stage_base));
+    for (int plane = 0; plane < PLANES; ++plane) {
+      const int other = stage_base == 0 ? 1 : 0;
+      if (plane + 1 < PLANES) {
+        stage(s, plane + 1, other);
+      } else if (s + 1 < s_end) {
+        stage(s + 1, 0, other);
       }
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+      frag a[2][4], b[2][4];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = H::mfma(a[i][ks], b[j][ks], acc[i][j]);
-    // the next step's tiles have landed (this wave's copies), and every wave is done
-    // with this step's
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    stage_base ^= static_cast<unsigned>(kStageBytes);
+        for (int ks = 0; ks < 4; ++ks) {
+          a[i][ks] = *reinterpret_cast<const frag*>(smem + ((fa[i] ^ (ks * 32u)) + stage_base));
+          b[i][ks] = *reinterpret_cast<const frag*>(smem + ((fb[i] ^ (ks * 32u)) + stage_base));
+        }
+      constexpr int z = ACCS == 2 ? 1 : 0;   // (ACCS == 2 has PLANES == 2: plane 1's own tile)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            if (plane == 0) acc[0][i][j] = H::mfma(a[i][ks], b[j][ks], acc[0][i][j]);
+            else acc[z][i][j] = H::mfma(a[i][ks], b[j][ks], acc[z][i][j]);
+          }
+      // the next tiles have landed (this wave's copies), and every wave is done with these
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      stage_base ^= static_cast<unsigned>(kStageBytes);
+    }
   }
 
   // ---- epilogue: the tile to LDS, then the rows' entries that fall into it ----
@@ -190,7 +212,8 @@ __global__ __launch_bounds__(256) void sddmm_mfma_kernel(
       for (int reg = 0; reg < 16; ++reg) {
         const int row = wr * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
         const int col = wc * 64 + j * 32 + (lane & 31);
-        tile_lds[row * kPitch + col] = acc[i][j][reg];
+        tile_lds[row * kPitch + col] =
+            ACCS == 2 ? fmaf(acc[ACCS - 1][i][j][reg], low_scale, acc[0][i][j][reg]) : acc[0][i][j][reg];
       }
   float* __restrict__ o = partials + static_cast<int64_t>(split) * nonzeros;
   // With a plan (sddmm_mfma_plan: where every row's entries cross the tile columns) whose
@@ -257,6 +280,38 @@ __global__ __launch_bounds__(256) void sddmm_mfma_kernel(
   }
 }
 
+// float32 -> PLANES planes of the half type T whose sum is the value: p0 = round(v), p1 =
+// round((v - p0) * scale1), p2 = round(v - p0 - p1) -- the products p * x are exact in
+// float32, so a float32 operand (the incoming gradient of modules/sparse_linear.py:44-49,
+// which no storage type rounds) keeps its bits on the matrix cores at PLANES times the tiles.
+//   float16: 2 planes, the low one scaled by 2^11 (scale1; the kernel accumulates it in a
+//     tile of its own and adds it times 2^-11): 22 bits of every value down to ~1e-6 --
+//     unscaled, the low plane of a value below 0.1 would sit in float16's subnormals;
+//   bfloat16: 3 planes as they are (float32's exponent range): 24 bits.
+template <typename T, int PLANES>
+__global__ __launch_bounds__(256) void split_planes_kernel(int64_t quads /* of 4 elements */,
+                                                           const float* __restrict__ in,
+                                                           T* __restrict__ out, int64_t plane_stride,
+                                                           float scale1) {
+  using T4 = T __attribute__((ext_vector_type(4)));
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < quads;
+       i += static_cast<int64_t>(gridDim.x) * 256) {
+    const float4 v4 = reinterpret_cast<const float4*>(in)[i];
+    float rest[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+    for (int p = 0; p < PLANES; ++p) {
+      T4 h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float scaled = p == 1 ? rest[e] * scale1 : rest[e];
+        h[e] = static_cast<T>(scaled);
+        rest[e] -= p == 1 ? static_cast<float>(h[e]) / scale1 : static_cast<float>(h[e]);
+      }
+      reinterpret_cast<T4*>(out + p * plane_stride)[i] = h;
+    }
+  }
+}
+
 // The plan: per row, where its entry stream crosses the boundaries of the 128-column
 // tiles -- table[row][c] = first entry with column >= 128 c, c = 0 .. tiles_n: a tile's run
 // of the row is [table[row][ct], table[row][ct + 1]) -- and whether the row's
@@ -315,12 +370,13 @@ bool sddmm_mfma_applicable(int m, int k, int n, int nonzeros, int replicas, cons
          aligned_to(rhs, 16) && lhs_stride % 8 == 0 && rhs_stride % 8 == 0;
 }
 
-int sddmm_mfma_splits(int m, int k, int n, int replicas) {
+int sddmm_mfma_splits(int m, int k, int n, int replicas, int planes) {
   const int64_t tiles = static_cast<int64_t>(ceil_div(m, kTile)) * ceil_div(n, kTile);
   const int64_t steps = static_cast<int64_t>(replicas) * (k / kStep);
-  // two workgroups per CU (68 KiB of LDS each), at least eight steps per workgroup
+  // two workgroups per CU (68 KiB of LDS each), at least eight tile products per workgroup
   int64_t splits = ceil_div64(512, tiles);
-  if (splits > steps / 8) splits = steps / 8;
+  if (splits > steps * planes / 8) splits = steps * planes / 8;
+  if (splits > steps) splits = steps;
   if (splits > 8) splits = 8;
   return splits < 1 ? 1 : static_cast<int>(splits);
 }
@@ -339,27 +395,59 @@ int sddmm_mfma_plan(int m, int n, const int* row_offsets, const int* column_indi
 int sddmm_mfma_launch(int m, int k, int n, int nonzeros, int replicas, const int* row_offsets,
                       const int* column_indices, const void* lhs, int64_t lhs_stride,
                       const void* rhs, int64_t rhs_stride, int in_type, float* partials,
-                      int splits, const void* plan, hipStream_t stream) {
+                      int splits, const void* plan, hipStream_t stream, int planes,
+                      int64_t lhs_plane_stride, int64_t rhs_plane_stride) {
   const int tiles_m = ceil_div(m, kTile), tiles_n = ceil_div(n, kTile);
   const int steps_per_replica = k / kStep;
   const int64_t total_steps = static_cast<int64_t>(replicas) * steps_per_replica;
+  if (planes < 1 || planes > 3) return SPUTNIK_HIP_INVALID_ARGUMENT;
   if (total_steps >= (int64_t{1} << 31) || splits < 1) return SPUTNIK_HIP_INVALID_ARGUMENT;
   const dim3 grid(static_cast<unsigned>(static_cast<int64_t>(tiles_m) * tiles_n * splits));
   const int vector_columns = aligned_to(column_indices, 16) ? 1 : 0;
-#define SPUTNIK_HIP_MF(T)                                                                      \
-  hipLaunchKernelGGL(sddmm_mfma_kernel<T>, grid, dim3(256), 0, stream, m, n, k, nonzeros,       \
-                     steps_per_replica, static_cast<int>(total_steps), splits, tiles_m,        \
+  // (a float16 pair of planes keeps the low one scaled: sddmm_mfma_split_planes)
+  const bool two_tiles = planes == 2 && in_type == SPUTNIK_HIP_F16;
+  const float low_scale = two_tiles ? 1.f / kLowPlaneScale : 1.f;
+#define SPUTNIK_HIP_MF(T, PLANES, ACCS)                                                        \
+  hipLaunchKernelGGL((sddmm_mfma_kernel<T, PLANES, ACCS>), grid, dim3(256), 0, stream, m, n, k,  \
+                     nonzeros, steps_per_replica, static_cast<int>(total_steps), splits, tiles_m, \
                      row_offsets, column_indices, static_cast<const T*>(lhs), lhs_stride,      \
                      static_cast<const T*>(rhs), rhs_stride, partials, vector_columns,          \
-                     static_cast<const int*>(plan), tiles_n)
-  if (in_type == SPUTNIK_HIP_F16) {
-    SPUTNIK_HIP_MF(_Float16);
-  } else if (in_type == SPUTNIK_HIP_BF16) {
-    SPUTNIK_HIP_MF(__bf16);
+                     static_cast<const int*>(plan), tiles_n, lhs_plane_stride, rhs_plane_stride, \
+                     low_scale)
+  if (in_type == SPUTNIK_HIP_F16 && planes == 2) {
+    SPUTNIK_HIP_MF(_Float16, 2, 2);
+  } else if (in_type == SPUTNIK_HIP_F16 && planes == 1) {
+    SPUTNIK_HIP_MF(_Float16, 1, 1);
+  } else if (in_type == SPUTNIK_HIP_BF16 && planes == 3) {
+    SPUTNIK_HIP_MF(__bf16, 3, 1);
+  } else if (in_type == SPUTNIK_HIP_BF16 && planes == 1) {
+    SPUTNIK_HIP_MF(__bf16, 1, 1);
   } else {
     return SPUTNIK_HIP_INVALID_ARGUMENT;
   }
 #undef SPUTNIK_HIP_MF
+  return launch_status();
+}
+
+int sddmm_mfma_planes_of(int half_type) { return half_type == SPUTNIK_HIP_BF16 ? 3 : 2; }
+
+int sddmm_mfma_split_planes(int64_t count, const float* in, int half_type, void* planes,
+                            hipStream_t stream) {
+  if (count % 4 != 0 || !aligned_to(in, 16) || !aligned_to(planes, 8))
+    return SPUTNIK_HIP_INVALID_ARGUMENT;
+  if (count == 0) return 0;
+  const int64_t quads = count / 4;
+  const int64_t want = ceil_div64(quads, 256);
+  const unsigned blocks = static_cast<unsigned>(want < 8192 ? want : 8192);
+  if (half_type == SPUTNIK_HIP_F16) {
+    hipLaunchKernelGGL((split_planes_kernel<_Float16, 2>), dim3(blocks), dim3(256), 0, stream, quads,
+                       in, static_cast<_Float16*>(planes), count, kLowPlaneScale);
+  } else if (half_type == SPUTNIK_HIP_BF16) {
+    hipLaunchKernelGGL((split_planes_kernel<__bf16, 3>), dim3(blocks), dim3(256), 0, stream, quads, in,
+                       static_cast<__bf16*>(planes), count, 1.f);
+  } else {
+    return SPUTNIK_HIP_INVALID_ARGUMENT;
+  }
   return launch_status();
 }
 

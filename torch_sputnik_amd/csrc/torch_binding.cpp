@@ -497,6 +497,53 @@ Tensor left_spmm(int64_t m, int64_t k, const Tensor& values, const Tensor& row_i
                    "left_spmm");
 }
 
+// sddmm_sum on one float32 and one half operand (3-D, contiguous).  False: the library
+// does not serve the pair on this shape -- the caller widens the half operand.
+bool sddmm_sum_mixed(int m, int n, const Tensor& row_indices, const Tensor& row_offsets,
+                     const Tensor& column_indices, const Tensor& lhs_in, const Tensor& rhs_in,
+                     const c10::optional<Tensor>& plan, Tensor* result) {
+  const auto is_half = [](const Tensor& t) {
+    return t.scalar_type() == at::kHalf || t.scalar_type() == at::kBFloat16;
+  };
+  if (!((lhs_in.scalar_type() == at::kFloat && is_half(rhs_in)) ||
+        (rhs_in.scalar_type() == at::kFloat && is_half(lhs_in))))
+    return false;
+  if (!lhs_in.is_cuda() || lhs_in.dim() != 3 || rhs_in.dim() != 3 ||
+      lhs_in.device() != rhs_in.device() || lhs_in.size(0) != rhs_in.size(0) ||
+      lhs_in.size(-1) != rhs_in.size(-1) || lhs_in.size(1) != m || rhs_in.size(1) != n)
+    return false;   // (the plain path reports what is wrong with the shapes)
+  const Tensor lhs = lhs_in.contiguous(), rhs = rhs_in.contiguous();
+  const c10::DeviceGuard guard(lhs.device());
+  const Topology topo = check_topology(m, row_indices, row_offsets, column_indices, lhs);
+  const int replicas = to_int(lhs.size(0), "replicas"), k = to_int(lhs.size(2), "k");
+  const int lhs_code = type_code(lhs.scalar_type()), rhs_code = type_code(rhs.scalar_type());
+  const size_t scratch_bytes = sputnik_hip_sddmm_sum_mixed_scratch_bytes(
+      m, k, n, topo.nonzeros, replicas, lhs_code, rhs_code);
+  if (scratch_bytes == 0) return false;
+  const size_t ws_bytes = sputnik_hip_sddmm_sum_workspace_bytes(m, k, n, topo.nonzeros);
+  Tensor workspace;
+  void* ws = nullptr;
+  if (plan.has_value()) {
+    check_plan(*plan, ws_bytes, lhs);
+    ws = ws_bytes ? plan->data_ptr() : nullptr;
+  } else if (ws_bytes > 0) {
+    workspace = at::empty({static_cast<int64_t>(ws_bytes)}, lhs.options().dtype(at::kByte));
+    ws = workspace.data_ptr();
+  }
+  Tensor scratch = at::empty({static_cast<int64_t>(scratch_bytes)}, lhs.options().dtype(at::kByte));
+  Tensor out = at::empty({topo.nonzeros}, lhs.options().dtype(at::kFloat));
+  const int status = sputnik_hip_sddmm_sum_mixed(
+      m, k, n, topo.nonzeros, replicas, topo.row_indices.data_ptr<int>(),
+      topo.row_offsets.data_ptr<int>(), topo.column_indices.data_ptr<int>(), lhs.data_ptr(), lhs_code,
+      static_cast<int64_t>(m) * k, rhs.data_ptr(), rhs_code, static_cast<int64_t>(n) * k,
+      out.data_ptr<float>(), ws, ws_bytes, plan.has_value() ? 1 : 0, scratch.data_ptr(),
+      scratch_bytes, current_stream(lhs));
+  if (status == SPUTNIK_HIP_UNSUPPORTED) return false;
+  check_status(status, "sddmm_sum (float32 x half)");
+  *result = out;
+  return true;
+}
+
 // lhs / rhs float32, float16 or bfloat16 (handed to the kernels as they are; operands
 // of different types take the wider one).  out_type: -1 / SPUTNIK_HIP_F32 = float32 --
 // the reference's output type (src/sddmm_cuda.cu:43) --, or the operands' half type.
@@ -505,6 +552,13 @@ Tensor sddmm_impl(int64_t m64, int64_t n64, const Tensor& row_indices, const Ten
                   const c10::optional<Tensor>& plan, bool sum_replicas = false,
                   int64_t out_type = -1) {
   const int m = to_int(m64, "m"), n = to_int(n64, "n");
+  if (sum_replicas && lhs_in.scalar_type() != rhs_in.scalar_type()) {
+    // a (float32, half) pair: the matrix-core route takes the float32 operand as two half
+    // planes instead of widening the half one (sputnik_hip.h: sddmm_sum_mixed)
+    Tensor mixed;
+    if (sddmm_sum_mixed(m, n, row_indices, row_offsets, column_indices, lhs_in, rhs_in, plan, &mixed))
+      return mixed;
+  }
   const auto st = at::promote_types(lhs_in.scalar_type(), rhs_in.scalar_type());
   const Tensor lhs = as_storage(lhs_in, "lhs_matrix").to(st);
   const Tensor rhs = as_storage(rhs_in, "rhs_matrix").to(st);

@@ -583,6 +583,47 @@ class SparseLinearFunction(torch.autograd.Function):
         return None, None, grad_values, None, None, None, grad_dense, None, None
 
 
+class HalfSparseLinearFunction(torch.autograd.Function):
+    """``SparseLinear.forward`` for activations stored in float16 / bfloat16 (BASELINE
+    config 5; the reference knows float32 only, src/left_replicated_spmm.cu:34-38):
+    ``apply(m, k, values, row_indices, row_offsets, column_indices, x)`` with x [B, S, in]
+    -> [B, out, S] float32 -- the layout passes of modules/sparse_linear.py:89 sit INSIDE
+    the Function so that the half operand is what is kept for the backward pass:
+
+      forward   xT = transpose(x) stays in half (one tiled pass, no widening);
+                y = left_spmm(W, xT), float32
+      backward  dW = sddmm_sum(dy, xT): the float32 gradient and the half activations go to
+                the kernels as they are -- where the matrix-core route serves the shape the
+                float32 operand enters as half planes, not rounded (sputnik_hip.h:
+                sddmm_sum_mixed); dx = transpose(W^T dy), narrowed to x's type in that pass.
+    """
+
+    @staticmethod
+    def forward(ctx, m, k, values, row_indices, row_offsets, column_indices, x):
+        ctx.shape = (m, k)
+        ctx.topology = (row_indices, row_offsets, column_indices)
+        ctx.in_dtype = x.dtype
+        dense = ops.transpose_last2(x)
+        ctx.save_for_backward(values, dense)
+        return _linear(m, k, values, row_indices, row_offsets, column_indices, dense)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        m, k = ctx.shape
+        row_indices, row_offsets, column_indices = ctx.topology
+        values, dense = ctx.saved_tensors
+        grad_output = _contiguous(grad_output)
+        grad_values = grad_x = None
+        if ctx.needs_input_grad[2]:
+            grad_values = _sddmm(m, k, row_indices, row_offsets, column_indices, grad_output, dense,
+                                 sum_replicas=True)
+        if ctx.needs_input_grad[6]:
+            grad_dense = _spmm_transposed(m, k, values, row_offsets, column_indices, grad_output,
+                                          left=True)
+            grad_x = ops.transpose_last2(grad_dense, ctx.in_dtype)
+        return None, None, grad_values, None, None, None, grad_x
+
+
 class GroupProjectionFunction(torch.autograd.Function):
     """Several SparseLinear weights of one shape applied to ONE input in one launch
     (ops.left_spmm_group): the q, k and v projections of a self-attention block,

@@ -19,8 +19,8 @@ import torch
 import torch.nn as nn
 
 from . import functional, ops
-from .functional import (GroupProjectionFunction, SparseAttentionFunction, Sddmm,
-                         SparseLinearFunction, SparseSoftmax, Spmm)
+from .functional import (GroupProjectionFunction, HalfSparseLinearFunction, SparseAttentionFunction,
+                         Sddmm, SparseLinearFunction, SparseSoftmax, Spmm)
 from .topology import dense_to_sparse, generate_mask
 
 
@@ -50,6 +50,12 @@ class SparseLinear(nn.Module):
         # [B, S, in] -> the k-major operand [B, in, S] of left_spmm: the reference's
         # `x.transpose(1, 2).contiguous()` (modules/sparse_linear.py:89) as one tiled
         # kernel (same values, same layout)
+        if x.dtype in (torch.float16, torch.bfloat16) and x.dim() == 3 and torch.is_grad_enabled() \
+                and (x.requires_grad or self.values.requires_grad):
+            # half-precision activations under autograd: kept in half for the backward pass
+            return HalfSparseLinearFunction.apply(
+                self.output_features, self.input_features, self.values, self.row_indices,
+                self.row_offsets, self.column_indices, x)
         return self.project(functional._to_operand(x))
 
     def project(self, dense, split_rows=0, dense_blocks=0):
