@@ -209,6 +209,36 @@ SPUTNIK_HIP_API int sputnik_hip_spmm_typed(int m, int k, int n, int nonzeros, in
                               int64_t out_stride, void* workspace, size_t workspace_bytes,
                               sputnik_hip_stream_t stream);
 
+/*
+ * left_spmm (values shared by the replicas: src/left_replicated_spmm.cu:32-41) as a DENSE
+ * contraction on the matrix cores, for the half-storage extension (round 5,
+ * csrc/spmm_mfma.hip): the CSR values are scattered into a zeroed [m, k] image of
+ * `tile_type` (SPUTNIK_HIP_F16 / BF16) and multiplied against the dense operand
+ * [replicas][k][n] on v_mfma_f32_32x32x16 tiles, float32 sums, float32 product with the
+ * bias / ReLU epilogue of sputnik_hip_spmm_bias_batched.  At layer densities every tile of
+ * the weight is occupied, and the tiles cost 1 / density times the sparse flops on a unit
+ * sixteen times faster than the vector pipe.  An operand given as float32 (values_type /
+ * dense_type = SPUTNIK_HIP_F32; the other, if half, has type tile_type) is NOT rounded to the
+ * tile type: it enters as half planes whose sum is the value (float16: 22 bits, bfloat16:
+ * 24), at one more tile product per plane pair.  sputnik_hip_spmm_typed takes this route by
+ * itself for a half dense operand; this entry adds the float32 dense operand (the incoming
+ * gradient of modules/sparse_linear.py:60-65 in a half-storage layer).
+ * Returns SPUTNIK_HIP_UNSUPPORTED where the route does not serve the call (k not a
+ * multiple of 64, n not of 8, a grid under 192 tiles, density under 0.06 per tile
+ * product, too little workspace, ...): take sputnik_hip_spmm_typed / _batched then.
+ * The float32 operators never come here.
+ */
+SPUTNIK_HIP_API size_t sputnik_hip_left_spmm_half_tiles_workspace_bytes(int m, int k, int n,
+                              int nonzeros, int replicas, int values_type, int dense_type,
+                              int tile_type);
+SPUTNIK_HIP_API int sputnik_hip_left_spmm_half_tiles(int m, int k, int n, int nonzeros, int replicas,
+                              const int* row_offsets, const int* column_indices,
+                              const void* values, int values_type, const void* dense,
+                              int dense_type, int64_t dense_stride, int tile_type,
+                              const float* bias, int relu, float* out, int64_t out_stride,
+                              void* workspace, size_t workspace_bytes,
+                              sputnik_hip_stream_t stream);
+
 /* sum over the replicas (sputnik_hip_sddmm_sum_batched{,_planned}) on operands stored as
  * `in_type`; the partial vectors and the result are float32.  Workspace / scratch sizes as
  * the float form's (sputnik_hip_sddmm_sum_workspace_bytes / _scratch_bytes).

@@ -536,6 +536,112 @@ def test_spmm_half_capi_vs_oracle(capi, dev, half_spmm_kernel, tv, tb, m, k, n, 
     assert rel_err(out.cpu().numpy(), want0) < TOL
 
 
+@pytest.fixture
+def spmm_mfma(monkeypatch):
+    """SPUTNIK_HIP_SPMM_KERNEL=mfma: left_spmm with a half dense operand takes the
+    matrix-core kernel (csrc/spmm_mfma.hip) for every shape it serves -- small test shapes
+    included, which the dispatcher leaves on the vector kernels."""
+    from torch_sputnik_amd import capi
+    monkeypatch.setenv("SPUTNIK_HIP_SPMM_KERNEL", "mfma")
+    capi.reload_options()
+    yield
+    monkeypatch.delenv("SPUTNIK_HIP_SPMM_KERNEL", raising=False)
+    capi.reload_options()
+
+
+def _operand(x, kind, tile, dev):
+    """(device tensor, the values it holds as float32 numpy): stored in the tile type
+    (rounded) or in float32 with full mantissas."""
+    if kind == "half":
+        return rounded(x, tile, dev)
+    x32 = np.asarray(x, np.float32)
+    return T(x32, dev), x32
+
+
+@pytest.mark.parametrize("tile", HALF_TYPES)
+@pytest.mark.parametrize("values_kind,dense_kind", [("half", "half"), ("float", "half"), ("half", "float"),
+                                                    ("float", "float")])
+@pytest.mark.parametrize("m,k,n,sparsity,replicas", [
+    (256, 128, 256, 0.8, 2),     # four tiles per replica
+    (128, 64, 128, 0.5, 1),      # one tile, ONE step
+    (200, 192, 136, 0.8, 3),     # ragged: the last row tile and the last column tile are partial
+    (130, 256, 72, 0.7, 2),      # the reference's test width (tests/test_spmm.py:13): one partial tile
+    (384, 512, 264, 0.95, 2),    # very sparse
+])
+def test_left_spmm_half_tiles_vs_oracle(capi, dev, spmm_mfma, tile, values_kind, dense_kind, m, k, n,
+                                        sparsity, replicas):
+    """left_spmm as a dense contraction on the matrix cores: the densified weight against
+    [R, k, n], every pairing of (float32 | half) values and dense operand -- a float32
+    operand enters as half planes, not rounded: the float32 bound against the oracle on
+    the operands as stored."""
+    _, vals, ri, ro, ci = make_csr(m, k, sparsity, seed=m + k + n + 3, round_to=1, empty_rows=(m // 3,))
+    rng = np.random.default_rng(n + 5)
+    # (full float32 mantissas; magnitudes over two decades so that the planes have work)
+    v, v32 = _operand(vals * 10.0 ** rng.uniform(-2, 0, size=len(vals)) * rng.choice([-1, 1], size=len(vals)),
+                      values_kind, tile, dev)
+    b, b32 = _operand(rng.uniform(-1, 1, size=(replicas, k, n)) * 10.0 ** rng.uniform(-2, 0, size=(replicas, k, 1)),
+                      dense_kind, tile, dev)
+    want = O.left_spmm(m, k, v32, ri, ro, ci, b32)
+    ws_bytes = capi.left_spmm_half_tiles_workspace_bytes(m, k, n, len(ci), replicas, v, b, tile)
+    if tile == torch.bfloat16 and values_kind == dense_kind == "float":
+        assert ws_bytes == 0      # six tile products per step: not served (the vector kernels win)
+        return
+    assert ws_bytes > 0
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    out = torch.full((replicas, m, n + 8), float("nan"), device=dev)[:, :, :n].contiguous()
+    capi.left_spmm_half_tiles(m, k, n, replicas, T(ro, dev), T(ci, dev), v, b, tile, out, ws)
+    got = out.cpu().numpy()
+    assert not np.isnan(got).any()
+    assert rel_err(got, want) < TOL
+    # bias + ReLU epilogue, and reproducible
+    bias = T(rng.uniform(-1, 1, size=(m,)).astype(np.float32), dev)
+    fused = torch.empty_like(out)
+    capi.left_spmm_half_tiles(m, k, n, replicas, T(ro, dev), T(ci, dev), v, b, tile, fused, ws,
+                              bias=bias, relu=True)
+    want_f = np.maximum(want.astype(np.float64) + bias.cpu().numpy()[None, :, None], 0.0)
+    assert np.max(np.abs(fused.cpu().numpy() - want_f)) < 1e-4 * max(1.0, np.abs(want_f).max())
+    again = torch.empty_like(out)
+    capi.left_spmm_half_tiles(m, k, n, replicas, T(ro, dev), T(ci, dev), v, b, tile, again, ws)
+    assert torch.equal(again, out)
+
+
+def test_left_spmm_half_tiles_exact_integers_and_guard(capi, dev, spmm_mfma):
+    """Small integers (every product and sum exact): the tile kernel's fragment maps --
+    rows against columns, the transposing reads of the [k][n] operand -- must give the
+    exact matrix; nothing outside [R, m, n] is written (ragged tiles)."""
+    m, k, n, replicas = 200, 128, 136, 2
+    _, _, ri, ro, ci = make_csr(m, k, 0.6, seed=19, round_to=1)
+    rng = np.random.default_rng(20)
+    v32 = rng.integers(-4, 5, size=len(ci)).astype(np.float32)
+    b32 = rng.integers(-4, 5, size=(replicas, k, n)).astype(np.float32)
+    want = O.left_spmm(m, k, v32, ri, ro, ci, b32)
+    v, b = T(v32, dev).half(), T(b32, dev).half()
+    ws = torch.empty(capi.left_spmm_half_tiles_workspace_bytes(m, k, n, len(ci), replicas, v, b, torch.float16),
+                     dtype=torch.uint8, device=dev)
+    guard = torch.full((replicas * m * n + 4096,), 777.0, device=dev)
+    out = guard[:replicas * m * n].view(replicas, m, n)
+    capi.left_spmm_half_tiles(m, k, n, replicas, T(ro, dev), T(ci, dev), v, b, torch.float16, out, ws)
+    assert np.array_equal(out.cpu().numpy(), want.astype(np.float32))
+    assert bool((guard[replicas * m * n:] == 777.0).all())
+
+
+@pytest.mark.parametrize("dtype", HALF_TYPES)
+def test_left_spmm_typed_takes_the_tiles_at_layer_density(ts, capi, dev, dtype):
+    """The op level: left_spmm with a half dense operand at a layer's density and size goes
+    to the matrix cores by itself (no knob) -- float32 and half weights -- and agrees
+    with the oracle; the float32 op never does."""
+    m, k, n, r = 1024, 1024, 512, 8      # 256 tiles: a tile per CU
+    _, vals, ri, ro, ci = make_csr(m, k, 0.8, seed=91)
+    topo = (T(ri, dev), T(ro, dev), T(ci, dev))
+    rng = np.random.default_rng(92)
+    b, b32 = rounded(rng.uniform(-1, 1, size=(r, k, n)), dtype, dev)
+    assert capi.left_spmm_half_tiles_workspace_bytes(m, k, n, len(ci), r, T(vals, dev), b, dtype) > 0
+    for v, v32 in ((T(vals, dev), vals), rounded(vals, dtype, dev)):
+        out = ts.left_spmm(m, k, v, *topo, b)
+        assert out.dtype == torch.float32 and tuple(out.shape) == (r, m, n)
+        assert rel_err(out.cpu().numpy(), O.left_spmm(m, k, v32, ri, ro, ci, b32)) < TOL
+
+
 @pytest.mark.parametrize("dtype", HALF_TYPES)
 def test_spmm_half_ops(ts, dev, dtype):
     """The torch ops hand half operands to the kernels as they are; the product is

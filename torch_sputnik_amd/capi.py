@@ -102,6 +102,10 @@ SIGNATURES = {
     "sputnik_hip_sddmm_sum_typed": (_c_int, [_c_int] * 5 + [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64,
                                                            _c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr,
                                                            _c_size, _c_int, _c_ptr, _c_size, _c_ptr]),
+    "sputnik_hip_left_spmm_half_tiles_workspace_bytes": (_c_size, [_c_int] * 8),
+    "sputnik_hip_left_spmm_half_tiles": (_c_int, [_c_int] * 5 + [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr,
+                                                                _c_int, _c_i64, _c_int, _c_ptr, _c_int,
+                                                                _c_ptr, _c_i64, _c_ptr, _c_size, _c_ptr]),
     "sputnik_hip_sddmm_sum_mixed_scratch_bytes": (_c_size, [_c_int] * 7),
     "sputnik_hip_sddmm_sum_mixed": (_c_int, [_c_int] * 5 + [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int,
                                                            _c_i64, _c_ptr, _c_int, _c_i64, _c_ptr,
@@ -660,6 +664,25 @@ def sddmm_sum_typed(m, k, n, replicas, row_indices, row_offsets, column_indices,
         _ptr(lhs), m * k, _ptr(rhs), n * k, _type_code(lhs, rhs), _ptr(out), _ptr(workspace),
         _ws_bytes(workspace), int(bool(planned)), _ptr(scratch), _ws_bytes(scratch), _stream(out)),
         "sputnik_hip_sddmm_sum_typed")
+    return out
+
+
+def left_spmm_half_tiles_workspace_bytes(m, k, n, nonzeros, replicas, values, dense, tile_dtype):
+    return lib().sputnik_hip_left_spmm_half_tiles_workspace_bytes(
+        m, k, n, nonzeros, replicas, _type_code(values), _type_code(dense),
+        TYPE_CODES[tile_dtype])
+
+
+def left_spmm_half_tiles(m, k, n, replicas, row_offsets, column_indices, values, dense, tile_dtype, out,
+                         workspace, bias=None, relu=False):
+    """left_spmm on the matrix cores (values shared, dense [R, k, n], out [R, m, n] float32);
+    raises (status -2) where the route does not serve the call."""
+    _require(out, torch.float32, "out")
+    _check(lib().sputnik_hip_left_spmm_half_tiles(
+        m, k, n, column_indices.numel(), replicas, _ptr(row_offsets), _ptr(column_indices),
+        _ptr(values), _type_code(values), _ptr(dense), _type_code(dense), k * n,
+        TYPE_CODES[tile_dtype], _ptr(bias), int(bool(relu)), _ptr(out), m * n,
+        _ptr(workspace), _ws_bytes(workspace), _stream(out)), "sputnik_hip_left_spmm_half_tiles")
     return out
 
 

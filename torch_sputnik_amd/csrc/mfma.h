@@ -42,4 +42,18 @@ int sddmm_mfma_planes_of(int half_type);
 int sddmm_mfma_split_planes(int64_t count, const float* in, int half_type, void* planes,
                             hipStream_t stream);
 
+// left_spmm (values shared by the replicas) as a dense contraction: the densified weight
+// against the dense operand [replicas][k][n] on half tiles of `tile_type` (spmm_mfma.hip).
+// A float32 operand enters as half planes (not rounded).  Workspace: the densified
+// weight's planes, then a float32 dense operand's.
+bool spmm_mfma_shape(int m, int k, int n, int nonzeros, int replicas, int values_type,
+                     int dense_type, int tile_type);
+size_t spmm_mfma_workspace_bytes(int m, int k, int n, int replicas, int values_type, int dense_type,
+                                 int tile_type);
+int spmm_mfma_launch(int m, int k, int n, int nonzeros, int replicas, const int* row_offsets,
+                     const int* column_indices, const void* values, int values_type,
+                     const void* dense, int dense_type, int64_t dense_stride, int tile_type,
+                     const float* bias, int relu, float* out, int64_t out_stride, void* workspace,
+                     hipStream_t stream);
+
 }  // namespace sputnik_hip

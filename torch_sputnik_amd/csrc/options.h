@@ -6,7 +6,7 @@
 namespace sputnik_hip {
 
 struct Options {
-  int spmm_kernel = 0;    // SPUTNIK_HIP_SPMM_KERNEL: 0 auto, -1 "wide", -2 "wide512", -3 "flat", 1 "narrow", 2 "gather", 3 "panel"
+  int spmm_kernel = 0;    // SPUTNIK_HIP_SPMM_KERNEL: 0 auto, -1 "wide", -2 "wide512", -3 "flat", 1 "narrow", 2 "gather", 3 "panel", 4 "mfma" (half dense operand, shared values: every shape the matrix-core kernel serves)
   int spmm_sparse = -1;   // SPUTNIK_HIP_SPMM_SPARSE: 0 / 1 forces the long- / short-segment variant (spmm_tiled); 2 / 3 / 4 the entry / group-straight / group-diagonal loop (spmm_flat)
   int spmm_debug = 0;     // SPUTNIK_HIP_SPMM_DEBUG: timing experiments only (wrong results)
   int spmm_tile = 0;      // SPUTNIK_HIP_SPMM_MEDIUM: 1 = medium, 2 = small tile

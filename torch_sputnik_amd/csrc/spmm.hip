@@ -15,6 +15,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "mfma.h"
 #include "options.h"
 #include "wave_utils.h"
 
@@ -490,6 +491,33 @@ int sputnik_hip_spmm_group_batched(int m, int k, int n, int replicas, int count,
                                  dense_stride, out_stride, block_rows, accumulate != 0, stream);
 }
 
+size_t sputnik_hip_left_spmm_half_tiles_workspace_bytes(int m, int k, int n, int nonzeros,
+                                                        int replicas, int values_type,
+                                                        int dense_type, int tile_type) {
+  if (!spmm_mfma_shape(m, k, n, nonzeros, replicas, values_type, dense_type, tile_type)) return 0;
+  return spmm_mfma_workspace_bytes(m, k, n, replicas, values_type, dense_type, tile_type);
+}
+
+int sputnik_hip_left_spmm_half_tiles(int m, int k, int n, int nonzeros, int replicas,
+                                     const int* row_offsets, const int* column_indices,
+                                     const void* values, int values_type, const void* dense,
+                                     int dense_type, int64_t dense_stride, int tile_type,
+                                     const float* bias, int relu, float* out, int64_t out_stride,
+                                     void* workspace, size_t workspace_bytes,
+                                     sputnik_hip_stream_t stream) {
+  if (m < 0 || k < 0 || n < 0 || nonzeros < 0 || replicas < 0) return SPUTNIK_HIP_INVALID_ARGUMENT;
+  if (!spmm_mfma_shape(m, k, n, nonzeros, replicas, values_type, dense_type, tile_type))
+    return SPUTNIK_HIP_UNSUPPORTED;
+  const size_t need = spmm_mfma_workspace_bytes(m, k, n, replicas, values_type, dense_type, tile_type);
+  if (workspace == nullptr || !aligned_to(workspace, 256) || workspace_bytes < need ||
+      !aligned_to(dense, 16) || !aligned_to(out, 4) || dense_stride % 8 != 0 ||
+      !aligned_to(values, values_type == SPUTNIK_HIP_F32 ? 4 : 2))
+    return SPUTNIK_HIP_UNSUPPORTED;
+  return spmm_mfma_launch(m, k, n, nonzeros, replicas, row_offsets, column_indices, values,
+                          values_type, dense, dense_type, dense_stride, tile_type, bias, relu, out,
+                          out_stride, workspace, stream);
+}
+
 // Workspace of sputnik_hip_spmm_typed: the float form's, plus room for float copies of
 // the half operands for the shapes the half-reading kernels do not serve well.
 size_t sputnik_hip_spmm_typed_workspace_bytes(int m, int k, int n, int nonzeros, int replicas,
@@ -500,8 +528,13 @@ size_t sputnik_hip_spmm_typed_workspace_bytes(int m, int k, int n, int nonzeros,
   const bool panel_shape = n % 4 == 0 && n >= 64 && m >= 16 &&
                            (k <= 512 || (k <= 1024 && nonzeros <= 320 * static_cast<int64_t>(m)));
   const bool big = static_cast<int64_t>(nonzeros) * n * replicas >= (int64_t{1} << 28);
+  // (the matrix-core route of a half dense operand against shared values: spmm_mfma.hip)
+  const size_t tiles_bytes =
+      values_stride == 0 && spmm_mfma_shape(m, k, n, nonzeros, replicas, values_type, dense_type, dense_type)
+          ? spmm_mfma_workspace_bytes(m, k, n, replicas, values_type, dense_type, dense_type) : 0;
   if (panel_shape || !big || (values_type == SPUTNIK_HIP_F32 && dense_type == SPUTNIK_HIP_F32))
-    return 0;
+    return tiles_bytes;
+  if (tiles_bytes != 0) return tiles_bytes;
   size_t bytes = align256(spmm_tiled_workspace_bytes(m, k, n, nonzeros));
   if (dense_type != SPUTNIK_HIP_F32)
     bytes += align256(sizeof(float) * static_cast<size_t>(replicas) * k * n);
@@ -534,6 +567,15 @@ int sputnik_hip_spmm_typed(int m, int k, int n, int nonzeros, int replicas,
   if (!aligned_to(values, values_type == SPUTNIK_HIP_F32 ? 4 : 2) ||
       !aligned_to(dense, dense_type == SPUTNIK_HIP_F32 ? 4 : 2) || !aligned_to(out, 4))
     return SPUTNIK_HIP_INVALID_ARGUMENT;
+  // Shared values at layer density against a half dense operand: a dense contraction on
+  // the matrix cores (spmm_mfma.hip) where the shape is served and the workspace is there.
+  if (values_stride == 0 && dense_type != SPUTNIK_HIP_F32) {
+    const int st = sputnik_hip_left_spmm_half_tiles(
+        m, k, n, nonzeros, replicas, row_offsets, column_indices, values, values_type, dense,
+        dense_type, dense_stride, dense_type, bias, relu, out, out_stride, workspace, workspace_bytes,
+        stream);
+    if (st != SPUTNIK_HIP_UNSUPPORTED) return st;
+  }
   Epilogue epi;
   epi.bias = bias;
   epi.relu = relu != 0;

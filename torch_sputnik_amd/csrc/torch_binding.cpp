@@ -497,6 +497,42 @@ Tensor left_spmm(int64_t m, int64_t k, const Tensor& values, const Tensor& row_i
                    "left_spmm");
 }
 
+// left_spmm as a dense contraction on half tiles (sputnik_hip.h: left_spmm_half_tiles):
+// values [nnz] and dense [R, k, n] float32 or of the tile type (1 float16 / 2 bfloat16).
+// An EMPTY tensor says the route does not serve the call: take left_spmm then.
+Tensor left_spmm_half_tiles(int64_t m64, int64_t k64, const Tensor& values_in,
+                            const Tensor& row_offsets, const Tensor& column_indices,
+                            const Tensor& dense_in, int64_t tile_type) {
+  const int m = to_int(m64, "m"), k = to_int(k64, "k");
+  const Tensor values = as_storage(values_in, "values");
+  const Tensor dense = as_storage(dense_in, "dense");
+  TORCH_CHECK(values.dim() == 1, "left_spmm_half_tiles: values should have 1 dimension");
+  TORCH_CHECK(dense.dim() == 3 && dense.size(1) == k, "left_spmm_half_tiles: dense must be [R, k, n]");
+  TORCH_CHECK(dense.device() == values.device(), "values and dense must be on one device");
+  const c10::DeviceGuard guard(values.device());
+  const Tensor ro = as_index(row_offsets, "row_offsets", values);
+  const Tensor ci = as_index(column_indices, "column_indices", values);
+  TORCH_CHECK(ro.size(0) == m + 1, "row_offsets should have m + 1 entries");
+  TORCH_CHECK(values.size(0) == ci.size(0), "number of values and column_indices must match");
+  const int nonzeros = to_int(ci.size(0), "nonzeros");
+  const int replicas = to_int(dense.size(0), "replicas"), n = to_int(dense.size(2), "n");
+  const int vt = type_code(values.scalar_type()), dt = type_code(dense.scalar_type());
+  const size_t ws_bytes = sputnik_hip_left_spmm_half_tiles_workspace_bytes(
+      m, k, n, nonzeros, replicas, vt, dt, static_cast<int>(tile_type));
+  const auto options = values.options().dtype(at::kFloat);
+  if (ws_bytes == 0) return at::empty({0}, options);
+  Tensor workspace = at::empty({static_cast<int64_t>(ws_bytes)}, values.options().dtype(at::kByte));
+  Tensor out = at::empty({replicas, m, n}, options);
+  const int st = sputnik_hip_left_spmm_half_tiles(
+      m, k, n, nonzeros, replicas, ro.data_ptr<int>(), ci.data_ptr<int>(), values.data_ptr(), vt,
+      dense.data_ptr(), dt, static_cast<int64_t>(k) * n, static_cast<int>(tile_type), nullptr, 0,
+      out.data_ptr<float>(), static_cast<int64_t>(m) * n, workspace.data_ptr(), ws_bytes,
+      current_stream(values));
+  if (st == SPUTNIK_HIP_UNSUPPORTED) return at::empty({0}, options);
+  check_status(st, "left_spmm_half_tiles");
+  return out;
+}
+
 // sddmm_sum on one float32 and one half operand (3-D, contiguous).  False: the library
 // does not serve the pair on this shape -- the caller widens the half operand.
 bool sddmm_sum_mixed(int m, int n, const Tensor& row_indices, const Tensor& row_offsets,
@@ -1326,6 +1362,9 @@ TORCH_LIBRARY(torch_sputnik, m) {
       "left_spmm(int m, int k, Tensor values, Tensor row_indices, Tensor row_offsets, "
       "Tensor column_indices, Tensor dense_matrix) -> Tensor");
   m.def(
+      "left_spmm_half_tiles(int m, int k, Tensor values, Tensor row_offsets, Tensor column_indices, "
+      "Tensor dense_matrix, int tile_type) -> Tensor");
+  m.def(
       "sddmm(int m, int n, Tensor row_indices, Tensor row_offsets, Tensor column_indices, "
       "Tensor lhs_matrix, Tensor rhs_matrix) -> Tensor");
   m.def(
@@ -1451,6 +1490,7 @@ TORCH_LIBRARY_IMPL(torch_sputnik, CUDA, m) {
   m.impl("left_spmm_planned", &left_spmm_planned);
   m.impl("sddmm_plan", &sddmm_plan);
   m.impl("sddmm_planned", &sddmm_planned);
+  m.impl("left_spmm_half_tiles", &left_spmm_half_tiles);
   m.impl("sddmm_sum", &sddmm_sum);
   m.impl("sddmm_sum_plan", &sddmm_sum_plan);
   m.impl("sddmm_sum_planned", &sddmm_sum_planned);

@@ -17,7 +17,7 @@ Options read_options() {
   };
   if (const char* e = getenv("SPUTNIK_HIP_SPMM_KERNEL")) {
     if (e[0] == 'w') o.spmm_kernel = (e[1] && e[2] && e[3] && e[4] == '5') ? -2 : -1;
-    else o.spmm_kernel = e[0] == 'n' ? 1 : e[0] == 'g' ? 2 : e[0] == 'p' ? 3 : e[0] == 'f' ? -3 : 0;
+    else o.spmm_kernel = e[0] == 'n' ? 1 : e[0] == 'g' ? 2 : e[0] == 'p' ? 3 : e[0] == 'f' ? -3 : e[0] == 'm' ? 4 : 0;
   }
   if (const char* e = getenv("SPUTNIK_HIP_SDDMM_KERNEL"))
     o.sddmm_kernel = e[0] == 't' ? 1 : e[0] == 'w' ? 2 : e[0] == 'm' ? 3 : 0;

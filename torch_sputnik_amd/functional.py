@@ -618,8 +618,17 @@ class HalfSparseLinearFunction(torch.autograd.Function):
             grad_values = _sddmm(m, k, row_indices, row_offsets, column_indices, grad_output, dense,
                                  sum_replicas=True)
         if ctx.needs_input_grad[6]:
-            grad_dense = _spmm_transposed(m, k, values, row_offsets, column_indices, grad_output,
-                                          left=True)
+            grad_dense = None
+            if grad_output.dim() == 3:
+                # W^T dy as a dense contraction on half tiles where that route serves the
+                # shape (the float32 gradient enters as half planes, not rounded)
+                values_t, _, row_offsets_t, column_indices_t = _transpose(
+                    m, k, values, row_offsets, column_indices)
+                grad_dense = ops.left_spmm_half_tiles(k, m, values_t, row_offsets_t, column_indices_t,
+                                                      grad_output, ctx.in_dtype)
+            if grad_dense is None:
+                grad_dense = _spmm_transposed(m, k, values, row_offsets, column_indices, grad_output,
+                                              left=True)
             grad_x = ops.transpose_last2(grad_dense, ctx.in_dtype)
         return None, None, grad_values, None, None, None, grad_x
 

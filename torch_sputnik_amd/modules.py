@@ -50,12 +50,18 @@ class SparseLinear(nn.Module):
         # [B, S, in] -> the k-major operand [B, in, S] of left_spmm: the reference's
         # `x.transpose(1, 2).contiguous()` (modules/sparse_linear.py:89) as one tiled
         # kernel (same values, same layout)
-        if x.dtype in (torch.float16, torch.bfloat16) and x.dim() == 3 and torch.is_grad_enabled() \
-                and (x.requires_grad or self.values.requires_grad):
-            # half-precision activations under autograd: kept in half for the backward pass
-            return HalfSparseLinearFunction.apply(
-                self.output_features, self.input_features, self.values, self.row_indices,
-                self.row_offsets, self.column_indices, x)
+        if x.dtype in (torch.float16, torch.bfloat16) and x.dim() == 3:
+            # half-precision activations stay in half: the k-major operand is one tiled
+            # pass without widening, the product reads it as it is (at layer densities on
+            # the matrix cores, csrc/spmm_mfma.hip), and under autograd it is what the
+            # backward pass keeps
+            if torch.is_grad_enabled() and (x.requires_grad or self.values.requires_grad):
+                return HalfSparseLinearFunction.apply(
+                    self.output_features, self.input_features, self.values, self.row_indices,
+                    self.row_offsets, self.column_indices, x)
+            return functional._linear(self.output_features, self.input_features, self.values.detach(),
+                                      self.row_indices, self.row_offsets, self.column_indices,
+                                      ops.transpose_last2(x))
         return self.project(functional._to_operand(x))
 
     def project(self, dense, split_rows=0, dense_blocks=0):

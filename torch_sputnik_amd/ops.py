@@ -30,6 +30,19 @@ def left_spmm(m, k, values, row_indices, row_offsets, column_indices, dense_matr
                           dense_matrix)
 
 
+def left_spmm_half_tiles(m, k, values, row_offsets, column_indices, dense_matrix, tile_dtype):
+    """left_spmm as a dense contraction on the matrix cores (the half-storage extension,
+    csrc/spmm_mfma.hip): the densified weight against dense [R, k, n] on tiles of
+    ``tile_dtype`` (float16 / bfloat16); `values` and `dense_matrix` float32 or of that
+    type -- a float32 operand enters as half planes, not rounded.  -> [R, m, n] float32,
+    or None where the route does not serve the call (take left_spmm then)."""
+    import torch
+    code = {torch.float16: 1, torch.bfloat16: 2}[tile_dtype]
+    out = _ops.left_spmm_half_tiles(int(m), int(k), values, row_offsets, column_indices,
+                                    dense_matrix, code)
+    return out if out.numel() else None
+
+
 # BASELINE.json names this op left_replicated_spmm; the binding exports left_spmm.
 left_replicated_spmm = left_spmm
 
