@@ -112,88 +112,25 @@ class SpmmProblem:
                                        self.dense, self.out, self.ws)
 
 
-class Exchange:
-    """The all-gather of C for the replica-sharded product, on
-    preallocated buffers: every rank ends with all `world * replicas` output
-    matrices.  Two transports -- RCCL's all_gather_into_tensor, and direct
-    grouped send/recv to every peer (xGMI is a full mesh: all 7 links carry one
-    block each, no ring) -- each either after the launch or chunk by chunk on a
-    side stream while the next chunk is being computed."""
+def _exchange_base():
+    from torch_sputnik_amd.sharding import ReplicaExchange
+    return ReplicaExchange
+
+
+class Exchange(_exchange_base()):
+    """The all-gather of C for the replica-sharded product: the PRODUCT's
+    exchange -- torch_sputnik_amd/sharding.py, `ReplicaExchange`: preallocated buffers,
+    RCCL's all_gather_into_tensor or direct grouped send / recv to every peer, after the
+    launch or chunk by chunk on a side stream -- bound to the benchmark's problem (the
+    kernels write straight into its local block).  What this class adds is bookkeeping:
+    the poison / verify pair around every timed schedule and the report."""
 
     def __init__(self, problem, world, rank, dev, chunks):
-        import torch.distributed as dist
-        self.dist, self.problem, self.world, self.rank, self.dev = dist, problem, world, rank, dev
         r = problem.replicas
         m, n = problem.out.shape[-2:]            # (4096 x 4096 in the benchmark)
-        self.m, self.n = m, n
-        self.local = problem.out.reshape(r, m, n)
-        self.flat = torch.empty(world * r * m * n, device=dev)
-        self.rank_major = self.flat.view(world, r, m, n)          # = global replica order
-        self.set_chunks(chunks)
-        # (tests/test_bench_exchange.py drives this class on CPU tensors over gloo)
-        self.side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
-        self.bytes_per_peer = r * m * n * 4.0
-
-    def set_chunks(self, chunks):
-        """The overlapped schedules exchange the local block in `chunks` pieces (at
-        most one replica each): chunk i travels while chunk i + 1 is computed."""
-        r, m, n, world = self.problem.replicas, self.m, self.n, self.world
-        chunks = max(1, min(chunks, r))
-        per = (r + chunks - 1) // chunks
-        self.bounds = [(a, min(a + per, r)) for a in range(0, r, per)]
-        # collective chunks land chunk-major ([chunk][rank][replicas of the chunk]):
-        # one contiguous all_gather_into_tensor each, in the same storage
-        self.chunk_major, off = [], 0
-        for a, b in self.bounds:
-            size = world * (b - a) * m * n
-            self.chunk_major.append(self.flat[off:off + size].view(world * (b - a), m, n))
-            off += size
-        return len(self.bounds)
-
-    def collective(self):
-        self.dist.all_gather_into_tensor(self.rank_major.view(-1, self.m, self.n), self.local)
-
-    def collective_chunk(self, c):
-        a, b = self.bounds[c]
-        self.dist.all_gather_into_tensor(self.chunk_major[c], self.local[a:b])
-
-    def p2p_chunk(self, c):
-        a, b = self.bounds[c]
-        self.p2p(a, b)
-
-    def p2p(self, a=0, b=None):
-        dist = self.dist
-        b = self.problem.replicas if b is None else b
-        send = self.local[a:b]
-        ops = []
-        if self.world == 1:   # BENCH_FORCE_DIST: the block to itself, through RCCL
-            ops = [dist.P2POp(dist.isend, send, 0), dist.P2POp(dist.irecv, self.rank_major[0, a:b], 0)]
-        else:
-            self.rank_major[self.rank, a:b].copy_(send)
-            for step in range(1, self.world):
-                dst, src = (self.rank + step) % self.world, (self.rank - step) % self.world
-                ops.append(dist.P2POp(dist.isend, send, dst))
-                ops.append(dist.P2POp(dist.irecv, self.rank_major[src, a:b], src))
-        for work in dist.batch_isend_irecv(ops):
-            work.wait()
-
-    def overlapped(self, exchange_chunk):
-        """compute chunk i on the main stream; its exchange runs on the side stream
-        behind an event while the main stream computes chunk i + 1."""
-        if self.side is None:          # CPU (tests): the same order, no streams
-            for c, (a, b) in enumerate(self.bounds):
-                self.problem.step_range(a, b)
-                exchange_chunk(c)
-            return
-        main = torch.cuda.current_stream(self.dev)
-        for c, (a, b) in enumerate(self.bounds):
-            self.problem.step_range(a, b)
-            done = torch.cuda.Event()
-            done.record(main)
-            with torch.cuda.stream(self.side):
-                self.side.wait_event(done)
-                exchange_chunk(c)
-        main.wait_stream(self.side)
+        self.problem, self.m, self.n = problem, m, n
+        super().__init__(problem.out.reshape(r, m, n), world, rank, chunks,
+                         compute_range=problem.step_range)
 
     def poison(self):
         """Before a schedule runs: the first row of every block of the gathered buffer
@@ -324,6 +261,41 @@ class Watchdog:
                         os.write(fd, line)
                 finally:
                     os._exit(WATCHDOG_EXIT_CODE)
+
+
+def dense_gpu_ms(problem):
+    """The reference's README table sets Sputnik beside cuSPARSE and cuBLAS
+    (/root/reference README.md:46-55); this is the cuBLAS column on THIS GPU: the
+    densified A against B with torch.matmul in float32 (the vendor library, used as a
+    yardstick only -- the product never calls it)."""
+    try:
+        rows = torch.repeat_interleave(torch.arange(M, device=problem.ro.device),
+                                       (problem.ro[1:] - problem.ro[:-1]).long())
+        a = torch.zeros(M, K, device=problem.ro.device)
+        a[rows, problem.ci.long()] = problem.values.reshape(-1)[:problem.nnz]
+        b = problem.dense.reshape(-1, K, N)[0]
+        return event_time_ms(lambda: torch.matmul(a, b), 20, warmup=5)
+    except Exception:  # noqa: BLE001 - an extra column, best effort
+        return None
+
+
+def dense_crossover(sweep):
+    """Density at which the sparse kernel and the dense float32 GEMM of the same GPU take
+    the same time (linear between the two sweep points around it)."""
+    pts = sorted((e["density"], e["ms"], e["dense_gpu_ms"]) for e in sweep if e.get("dense_gpu_ms"))
+    if not pts:
+        return None
+    out = {"dense_fp32_matmul_ms": sorted(p[2] for p in pts)[len(pts) // 2],
+           "library": "torch.matmul float32 (hipBLASLt / rocBLAS): yardstick only",
+           "crossover_density": None}
+    for (d0, s0, g0), (d1, s1, g1) in zip(pts, pts[1:]):
+        if (s0 - g0) <= 0 <= (s1 - g1):
+            t = (g0 - s0) / ((s1 - g1) - (s0 - g0)) if (s1 - g1) != (s0 - g0) else 0.0
+            out["crossover_density"] = d0 + t * (d1 - d0)
+    if out["crossover_density"] is None:
+        out["note"] = ("sparse faster at every density of the sweep" if pts[-1][1] < pts[-1][2]
+                       else "dense faster at every density of the sweep")
+    return out
 
 
 def cpu_baseline(problem):
@@ -656,6 +628,37 @@ def other_ops(dev):
     sws = torch.empty(capi.sddmm_workspace_bytes(m, seq, n, nnz) + 16, dtype=torch.uint8, device=dev)
     t = event_time_ms(lambda: capi.sddmm_batched(m, seq, n, batch, ri, ro, ci, gy, x, gw, sws), 10)
     res["sddmm_grad_values_c5"] = {"ms": t, "gflops": 2.0 * nnz * seq * batch / t / 1e6}
+    # the two products on half-stored operands (BASELINE config 5 says fp16): the matrix-core
+    # routes of round 5 (csrc/spmm_mfma.hip, csrc/sddmm_mfma.hip).  `float32_*`: that operand
+    # is handed over as float32 and enters the tiles as half planes, not rounded.
+    try:
+        half = {}
+        xh, gyh, vh = x.half(), gy.half(), vals.half()
+        for key, v, d in (("half_values_half_dense", vh, xh), ("float32_values_half_dense", vals, xh),
+                          ("half_values_float32_dense", vh, x), ("float32_values_float32_dense", vals, x)):
+            need = capi.left_spmm_half_tiles_workspace_bytes(m, n, seq, nnz, batch, v, d, torch.float16)
+            wst = torch.empty(need, dtype=torch.uint8, device=dev)
+            t = event_time_ms(lambda: capi.left_spmm_half_tiles(m, n, seq, batch, ro, ci, v, d, torch.float16,
+                                                                y, wst), 10)
+            half[key] = {"ms": t, "gflops": 2.0 * nnz * seq * batch / t / 1e6}
+        res["left_spmm_c5_f16_tiles"] = half
+        grads = {}
+        gsum = torch.empty(nnz, device=dev)
+        wsum = torch.empty(capi.sddmm_sum_workspace_bytes(m, seq, n, nnz) + 16, dtype=torch.uint8, device=dev)
+        capi.sddmm_sum_plan(m, seq, n, ri, ro, ci, wsum)
+        for key, a, b in (("half_half", gyh, xh), ("float32_gradient_half_activations", gy, xh),
+                          ("float32_float32_vector_kernels", gy, x)):
+            mixed = a.dtype != b.dtype
+            sc = torch.empty((capi.sddmm_sum_mixed_scratch_bytes(m, seq, n, nnz, batch, a, b) if mixed
+                              else capi.sddmm_sum_scratch_bytes(m, seq, n, nnz, batch)) + 16,
+                             dtype=torch.uint8, device=dev)
+            call = capi.sddmm_sum_mixed if mixed else capi.sddmm_sum_typed
+            t = event_time_ms(lambda: call(m, seq, n, batch, ri, ro, ci, a, b, gsum, wsum, sc, planned=True), 10)
+            grads[key] = {"ms": t, "gflops": 2.0 * nnz * seq * batch / t / 1e6}
+        res["sddmm_sum_grad_values_c5"] = grads
+        del xh, gyh, vh
+    except Exception as e:  # noqa: BLE001 - extra metric, best effort
+        res["left_spmm_c5_f16_tiles"] = {"error": str(e)[:200]}
     # the same operators at config 5's STATED size M = N = K = 2048 (N of left_spmm is the
     # sequence length, modules/sparse_linear.py:28,89): batch 8 x seq 2048
     try:
@@ -686,8 +689,14 @@ def other_ops(dev):
         w = torch.randn(m, n, device=dev) * (torch.rand(m, n, device=dev) < 0.2)
         layer.weight = torch.nn.Parameter(w)
         layer.setup_sparse_tensors()
+        values32 = layer.values
         for name, dt, sq in (("fp32", torch.float32, seq), ("fp16_storage", torch.float16, seq),
-                             ("n2048_fp32", torch.float32, 2048), ("n2048_fp16_storage", torch.float16, 2048)):
+                             ("fp16_storage_and_weights", torch.float16, seq),
+                             ("n2048_fp32", torch.float32, 2048), ("n2048_fp16_storage", torch.float16, 2048),
+                             ("n2048_fp16_storage_and_weights", torch.float16, 2048)):
+            # (`_and_weights`: the layer's values are stored in half precision too)
+            layer.values = (torch.nn.Parameter(values32.detach().to(dt)) if name.endswith("and_weights")
+                            else values32)
             xin = torch.randn(batch, sq, n, device=dev).to(dt).requires_grad_(True)
             gout = torch.randn(batch, m, sq, device=dev)
 
@@ -972,10 +981,12 @@ def main():
                               "kernel_ms": ms_kern,
                               "gflops": p.flops / ms_full / 1e6, "alg_gbs": p.bytes / ms_full / 1e6,
                               "hbm_frac": p.bytes / ms_kern / 1e6 / HBM_PEAK_GBS,
-                              "valu_frac": p.flops / ms_kern / 1e9 / VALU_PEAK_TFLOPS})
+                              "valu_frac": p.flops / ms_kern / 1e9 / VALU_PEAK_TFLOPS,
+                              "dense_gpu_ms": dense_gpu_ms(p)})
                 if p is not problem:
                     del p
             result["sweep"] = sweep
+            result["dense_gpu"] = dense_crossover(sweep)
             result["other_ops"] = other_ops(dev)
             # the same headline call WITH output / workspace allocation, i.e.
             # through the reference-compatible torch op (src/spmm_cuda.cu:9-60 semantics)

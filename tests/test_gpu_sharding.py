@@ -68,6 +68,35 @@ def test_gather_modes_through_rccl(one_rank_rccl, mode, chunks):
                                      b[..., :64].contiguous()))
 
 
+def test_kept_exchange_writes_in_place_through_rccl(one_rank_rccl):
+    """A kept `ReplicaExchange` (what bench.py --gpus N runs on): the kernels write straight
+    into its local block through the C ABI -- no output tensor, no copy -- and every
+    schedule gathers on the same buffers, step after step."""
+    from torch_sputnik_amd import ops, sharding
+    dev = one_rank_rccl
+    m, k, n, replicas = 256, 192, 128, 4
+    _, vals, ri, ro, ci = make_csr(m, k, 0.8, seed=7)
+    rng = np.random.default_rng(8)
+    v = torch.from_numpy(rng.uniform(-1, 1, (replicas, len(vals))).astype(np.float32)).to(dev)
+    b = torch.from_numpy(rng.uniform(-1, 1, (replicas, k, n)).astype(np.float32)).to(dev)
+    topo = [torch.from_numpy(x).to(dev) for x in (ri, ro, ci)]
+    ex = sharding.make_exchange(replicas, (m, n), b)
+    flat_ptr = ex.flat.data_ptr()
+    for step in range(2):
+        scale = float(step + 1)
+        want = ops.spmm(m, k, v * scale, *topo, b)
+        for mode, chunks in (("collective", 1), ("p2p", 1), ("p2p", 4), ("collective", 2)):
+            before = torch.cuda.memory_allocated(dev)
+            got = sharding.spmm(m, k, v * scale, *topo, b, gather_mode=mode, overlap_chunks=chunks,
+                                local_operands=True, exchange=ex)
+            torch.cuda.synchronize()
+            assert torch.equal(got, want), (mode, chunks)
+            if not (mode == "collective" and chunks > 1):   # (that layout is re-ordered by one copy)
+                assert got.data_ptr() == flat_ptr
+            del got
+    assert ex.flat.data_ptr() == flat_ptr
+
+
 def test_bench_line_carries_the_three_multi_gpu_figures():
     env = dict(os.environ, BENCH_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
                MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),

@@ -128,10 +128,21 @@ def _worker_c4_shape(rank, world, port, replicas, results):
             got = sharding.spmm(m, k, mine_v, *topo, mine_b, gather_mode=mode, local_operands=True)
             ok = ok and torch.equal(got, full)
         for chunks in (8, 16):
-            for mode in ("collective", "p2p"):   # (the chunked exchange is peer to peer in both)
+            for mode in ("collective", "p2p"):
                 got = sharding.spmm(m, k, mine_v, *topo, mine_b, gather_mode=mode,
                                     overlap_chunks=chunks, local_operands=True)
                 ok = ok and torch.equal(got, full)
+        # a KEPT exchange (what bench.py --gpus N runs on): the same buffers step after step,
+        # every schedule, other operands in between
+        ex = sharding.make_exchange(z - a, (m, n), mine_b)
+        flat_ptr = ex.flat.data_ptr()
+        for step in range(3):
+            scale = float(step + 1)
+            for mode, chunks in (("collective", 1), ("p2p", 1), ("p2p", 8), ("collective", 16)):
+                got = sharding.spmm(m, k, mine_v * scale, *topo, mine_b, gather_mode=mode,
+                                    overlap_chunks=chunks, local_operands=True, exchange=ex)
+                ok = ok and torch.equal(got, ops.spmm(m, k, v * scale, *topo, b).reshape(replicas, m, n))
+        ok = ok and ex.flat.data_ptr() == flat_ptr
         results[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
