@@ -377,7 +377,14 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_flat_kernel(
   const int bid = blockIdx.x;
   int ntile, mblock;
   int replica = blockIdx.y;
-  if (n_tiles % 8 == 0) {
+  const int xcd_cols = 1 << ((debug >> 13) & 3);   // column tiles per XCD (xcd_columns below)
+  if (xcd_cols > 1 && n_tiles == 8 && (gridDim.x / 8) % xcd_cols == 0) {
+    // `xcd_cols` column tiles and 1 / xcd_cols of the row blocks per XCD: a row block's
+    // entry stream is read behind 8 / xcd_cols L2s, a column tile of B behind xcd_cols
+    const int xcd = bid % 8, i = bid / 8, col_groups = 8 / xcd_cols;
+    ntile = (xcd % col_groups) * xcd_cols + i % xcd_cols;
+    mblock = (xcd / col_groups) * ((gridDim.x / 8) / xcd_cols) + i / xcd_cols;
+  } else if (n_tiles % 8 == 0) {
     const int per_xcd = n_tiles / 8;
     const int xcd = bid % 8, i = bid / 8;
     ntile = xcd * per_xcd + i % per_xcd;
@@ -575,6 +582,33 @@ int spmm_flat_plan(int m, int k, int n, int nonzeros, const int* row_indices,
   return launch_status();
 }
 
+// Which workgroups share an XCD (an L2) in the 8-column-tile shape (n = 4096).  Every XCD
+// that holds a row block reads its entry stream (13 bytes per entry with the gathered
+// value), every XCD that holds a column tile reads that tile's part of B (k x 512 floats):
+// with c column tiles per XCD the launch fetches  stream * 8 / c  +  B * c  bytes.  One
+// column tile per XCD (rounds 1-4) is the minimum only below density ~0.07; at 0.1 two are
+// (measured: 270 -> 240 MB fetched per launch, time unchanged within 0.5 %), at 0.5 four.
+// Code in bits 13-14 of the kernel's debug word (bit 15 of SPUTNIK_HIP_SPMM_DEBUG: take
+// bits 13-14 of the knob instead -- measurements).
+int xcd_columns_code(int k, int n, int nonzeros, int row_blocks) {
+  const int forced = options().spmm_debug;
+  if (forced & 0x8000) return (forced >> 13) & 3;
+  if (ceil_div(n, kBN) != 8) return 0;
+  const double stream = 13.0 * nonzeros, b = 4.0 * k * n;
+  int best = 0;
+  double best_bytes = stream * 8 + b;
+  for (int code = 1; code <= 3; ++code) {
+    const int c = 1 << code;
+    if (row_blocks % c != 0) break;
+    const double bytes = stream * 8 / c + b * c;
+    if (bytes < 0.97 * best_bytes) {
+      best = code;
+      best_bytes = bytes;
+    }
+  }
+  return best;
+}
+
 int spmm_flat_exec(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
                    const float* values, int64_t values_stride, const int* row_offsets,
                    const int* column_indices, const float* dense, int64_t dense_stride, float* out,
@@ -590,7 +624,9 @@ int spmm_flat_exec(int m, int k, int n, int nonzeros, int replicas, const int* r
                      reinterpret_cast<const unsigned char*>(base + p.stream_off), dense,           \
                      dense_stride, out, out_stride,                                                \
                      reinterpret_cast<const int*>(base + p.row_ok_off), row_offsets,               \
-                     column_indices, options().spmm_debug, epi)
+                     column_indices, debug_word, epi)
+  const int debug_word = (options().spmm_debug & ~0xe000) |
+                         (xcd_columns_code(k, n, nonzeros, p.slots / kBM) << 13);
   switch (flat_mode(m, k, nonzeros)) {
     case 0: SPUTNIK_HIP_LAUNCH_FLAT(0); break;
     case 1: SPUTNIK_HIP_LAUNCH_FLAT(1); break;
