@@ -587,6 +587,20 @@ def other_ops(dev):
                 attn(xg, xg, xg, None).backward(gout)
 
             res[key] = {"ms": event_time_ms(fwd_bwd, 10)}
+            if key.endswith("separate_ops"):
+                # the same step replayed from ONE hipGraph (torch_sputnik_amd/graphs.py): no
+                # Python, no autograd walk, no launch gaps between its ~27 kernels --
+                # `in_place_ms`: the caller wrote the static input / gradient buffers itself
+                try:
+                    from torch_sputnik_amd.graphs import capture_training_step
+                    step = capture_training_step(attn, xg, xg, xg, grad_output=gout)
+                    sx, sg = step.static_inputs[0], step.static_grad_output
+                    res[key + "_graph"] = {
+                        "ms": event_time_ms(lambda: step(xg, xg, xg, grad_output=gout), 10),
+                        "in_place_ms": event_time_ms(lambda: step(sx, sx, sx, grad_output=sg), 10)}
+                    del step
+                except Exception as e:  # noqa: BLE001
+                    res[key + "_graph"] = {"error": str(e)[:200]}
     except Exception as e:  # noqa: BLE001 - extra metric, best effort
         res["sparse_attention_forward_c3"] = {"error": str(e)[:200]}
     # dense widths that are no multiple of a tile width (the reference takes any n,

@@ -827,6 +827,50 @@ def test_hip_graph_replay_of_a_module_forward(dev):
         fast(x2[:1], x2[:1], x2[:1])
 
 
+def test_hip_graph_replay_of_a_training_step(dev):
+    """Forward + backward of the whole SparseAttention module as ONE hipGraph: output,
+    input gradient and every projection's value gradient bit-identical to the eager step
+    (the library keeps no floating-point atomics), also for new inputs and a new incoming
+    gradient, replay after replay."""
+    from torch_sputnik_amd.graphs import capture_training_step
+    from torch_sputnik_amd.modules import SparseAttention
+    torch.manual_seed(2)
+    layer = SparseAttention(num_heads=2, embedding_size=128, max_sequence_length=256, device=dev,
+                            sparsity=0.9, mask_generator=np.random.default_rng(7),
+                            differentiable_softmax=True)
+    for lin in layer.linears:
+        lin.weight = torch.nn.Parameter(torch.randn(128, 128, device=dev) *
+                                        (torch.rand(128, 128, device=dev) < 0.3))
+        lin.setup_sparse_tensors()
+
+    def eager(x, g):
+        xg = x.clone().requires_grad_(True)
+        for lin in layer.linears:
+            lin.values.grad = None
+        out = layer(xg, xg, xg)
+        out.backward(g)
+        return out.detach().clone(), xg.grad.clone(), [lin.values.grad.clone() for lin in layer.linears]
+
+    x, g = torch.randn(2, 256, 128, device=dev), torch.randn(2, 256, 128, device=dev)
+    want = eager(x, g)
+    step = capture_training_step(layer, x, x, x, grad_output=g)
+    static = {id(p): gp for p, gp in zip(step.params, step.param_grads)}
+    assert all(lin.values.grad is static[id(lin.values)] for lin in layer.linears)   # (for an optimizer)
+    for xi, gi, wi in ((x, g, want), (x * 0.5 + 1.0, g * 2.0, None), (x, g, want)):
+        wi = wi or eager(xi, gi)
+        out = step(xi, xi, xi, grad_output=gi)
+        torch.cuda.synchronize()
+        assert torch.equal(out, wi[0])
+        assert len(step.input_grads) == 1 and torch.equal(step.input_grads[0], wi[1])
+        grads = {id(p): gp for p, gp in zip(step.params, step.param_grads)}
+        for lin, gv in zip(layer.linears, wi[2]):
+            assert torch.equal(grads[id(lin.values)], gv)
+            assert grads[id(lin.weight)] is None      # (the reference's unused dense weight)
+        wi = None
+    with pytest.raises(ValueError):
+        step(x[:1], x[:1], x[:1])
+
+
 # ----------------------------------------------------------------------------
 # layout pass: batched 2-D transpose (modules/sparse_linear.py:89,
 # modules/sparse_attention.py:108-126)
