@@ -239,6 +239,62 @@ SPUTNIK_HIP_API int sputnik_hip_left_spmm_half_tiles(int m, int k, int n, int no
                               void* workspace, size_t workspace_bytes,
                               sputnik_hip_stream_t stream);
 
+/*
+ * A sparse layer on half-stored activations, all three products on the matrix cores with NO
+ * layout pass (round 5, csrc/sparse_linear_half.hip, csrc/mfma_gemm.h).  The reference's
+ * SparseLinear runs x.transpose(1, 2).contiguous() in front of left_spmm and the
+ * transposes back behind it (modules/sparse_linear.py:28,44-65,89); the tile kernel reads
+ * every operand in the layout the caller has it:
+ *   forward          y[b][o][s]  = sum_i W[o][i] x[b][s][i]            y float32 [batch, out, seq]
+ *   weight gradient  dW[p]       = sum_b sum_s dy[b][o_p][s] x[b][s][i_p]   float32 [nonzeros]
+ *   input gradient   dx[b][s][i] = sum_o dy[b][o][s] W[o][i]           [batch, seq, in], float32 or tile type
+ * x [batch, seq, in] in `tile_type` (SPUTNIK_HIP_F16 / BF16).  W is given as its IMAGE: the
+ * CSR values (float32 or tile_type) scattered into a zeroed [planes][out][in] array of the
+ * tile type -- sputnik_hip_sparse_linear_half_image, one memset + one launch per step, shared
+ * by the forward pass and the input gradient.  dy [batch, out, seq] is given either in the
+ * tile type (grad_type = tile_type) or as the PLANES of the float32 tensor
+ * (sputnik_hip_half_planes, grad_type = SPUTNIK_HIP_F32): float32 operands are never rounded
+ * to the storage type -- they enter as half planes whose sum is the value (float16: two
+ * planes, 22 bits; bfloat16: three, 24 bits).  The weight gradient takes a plan
+ * (sputnik_hip_sparse_linear_half_plan, topology only, may be NULL) and scratch for the
+ * partial vectors of the workgroups that share a tile.
+ * sputnik_hip_sparse_linear_half_supported: 1 where the three products take this route
+ * (out, in, seq multiples of 64, a grid of at least 192 tiles, density from 0.06 per plane of
+ * the values); an entry point returns SPUTNIK_HIP_UNSUPPORTED for a call it does not serve
+ * (bfloat16 tiles with BOTH float32 values and a float32 dy in the input gradient: nine
+ * plane pairs) -- use the typed operators then.  The float32 operators never come here.
+ */
+SPUTNIK_HIP_API int sputnik_hip_sparse_linear_half_supported(int out_features, int in_features, int seq,
+                              int batch, int nonzeros, int values_type, int tile_type);
+SPUTNIK_HIP_API size_t sputnik_hip_sparse_linear_half_image_bytes(int out_features, int in_features,
+                              int values_type, int tile_type);
+SPUTNIK_HIP_API int sputnik_hip_sparse_linear_half_image(int out_features, int in_features, int nonzeros,
+                              const int* row_offsets, const int* column_indices, const void* values,
+                              int values_type, int tile_type, void* image, size_t image_bytes,
+                              sputnik_hip_stream_t stream);
+SPUTNIK_HIP_API size_t sputnik_hip_half_planes_bytes(int64_t count, int tile_type);
+SPUTNIK_HIP_API int sputnik_hip_half_planes(int64_t count, const float* in, int tile_type, void* planes,
+                              sputnik_hip_stream_t stream);
+SPUTNIK_HIP_API int sputnik_hip_sparse_linear_half_forward(int out_features, int in_features, int seq,
+                              int batch, const void* image, int values_type, const void* x,
+                              int tile_type, const float* bias, int relu, float* y,
+                              sputnik_hip_stream_t stream);
+SPUTNIK_HIP_API size_t sputnik_hip_sparse_linear_half_plan_bytes(int out_features, int in_features);
+SPUTNIK_HIP_API int sputnik_hip_sparse_linear_half_plan(int out_features, int in_features,
+                              const int* row_offsets, const int* column_indices, void* plan,
+                              sputnik_hip_stream_t stream);
+SPUTNIK_HIP_API size_t sputnik_hip_sparse_linear_half_scratch_bytes(int out_features, int in_features,
+                              int seq, int batch, int nonzeros, int grad_type, int tile_type);
+SPUTNIK_HIP_API int sputnik_hip_sparse_linear_half_weight_gradient(int out_features, int in_features,
+                              int seq, int batch, int nonzeros, const int* row_offsets,
+                              const int* column_indices, const void* grad_output, int grad_type,
+                              const void* x, int tile_type, float* grad_values, const void* plan,
+                              void* scratch, size_t scratch_bytes, sputnik_hip_stream_t stream);
+SPUTNIK_HIP_API int sputnik_hip_sparse_linear_half_input_gradient(int out_features, int in_features,
+                              int seq, int batch, const void* grad_output, int grad_type,
+                              const void* image, int values_type, int tile_type, void* grad_input,
+                              int grad_input_type, sputnik_hip_stream_t stream);
+
 /* sum over the replicas (sputnik_hip_sddmm_sum_batched{,_planned}) on operands stored as
  * `in_type`; the partial vectors and the result are float32.  Workspace / scratch sizes as
  * the float form's (sputnik_hip_sddmm_sum_workspace_bytes / _scratch_bytes).

@@ -625,6 +625,81 @@ def test_left_spmm_half_tiles_exact_integers_and_guard(capi, dev, spmm_mfma):
     assert bool((guard[replicas * m * n:] == 777.0).all())
 
 
+@pytest.mark.parametrize("tile", HALF_TYPES)
+@pytest.mark.parametrize("values_kind,grad_kind", [("half", "half"), ("float", "half"), ("half", "float"),
+                                                   ("float", "float")])
+@pytest.mark.parametrize("out_f,in_f,seq,batch,sparsity", [
+    (256, 128, 128, 2, 0.8),
+    (128, 64, 64, 1, 0.5),       # one tile, one step, in every product
+    (192, 320, 192, 3, 0.8),     # ragged tiles in every product (192 = 128 + 64, 320 = 2 x 128 + 64)
+    (384, 256, 448, 2, 0.95),    # very sparse
+])
+def test_half_linear_three_products_vs_oracle(spmm_mfma, dev, tile, values_kind, grad_kind, out_f, in_f, seq,
+                                              batch, sparsity):
+    """A sparse layer on half-stored activations (csrc/sparse_linear_half.hip): forward,
+    weight gradient and input gradient on the matrix cores, every operand read in the
+    layout the caller has it (x [B, S, in], dy [B, out, S], one image of the weight) --
+    against float64 on the operands as stored (float32 operands enter as half planes, not
+    rounded: the float32 bound; dx is returned in x's type: one unit in its last place)."""
+    from torch_sputnik_amd import ops
+    _, vals, ri, ro, ci = make_csr(out_f, in_f, sparsity, seed=out_f + in_f + seq, round_to=1,
+                                   empty_rows=(out_f // 3,))
+    rng = np.random.default_rng(seq + 1)
+    v, v32 = _operand(vals * 10.0 ** rng.uniform(-2, 0, size=len(vals)) * rng.choice([-1, 1], size=len(vals)),
+                      values_kind, tile, dev)
+    x, x32 = rounded(rng.uniform(-1, 1, size=(batch, seq, in_f)), tile, dev)
+    g, g32 = _operand(rng.uniform(-1, 1, size=(batch, out_f, seq)) * 10.0 ** rng.uniform(-2, 0, size=(batch, out_f, 1)),
+                      grad_kind, tile, dev)
+    w = np.zeros((out_f, in_f), np.float64)
+    rows = np.repeat(np.arange(out_f), np.diff(ro))
+    w[rows, ci] = v32
+    x64, g64 = x32.astype(np.float64), g32.astype(np.float64)
+    want_y = np.einsum("oi,bsi->bos", w, x64)
+    want_dw = np.einsum("bos,bsi->oi", g64, x64)[rows, ci]
+    want_dx = np.einsum("bos,oi->bsi", g64, w)
+    rod, cid = T(ro, dev), T(ci, dev)
+    assert ops.half_linear_supported(out_f, in_f, seq, batch, len(ci), v.dtype, tile)   # (the knob)
+    image = ops.half_linear_image(out_f, in_f, v, rod, cid, tile)
+    y = ops.half_linear_forward(out_f, image, v.dtype, x)
+    assert y.dtype == torch.float32 and tuple(y.shape) == (batch, out_f, seq)
+    assert rel_err(y.cpu().numpy(), want_y) < TOL
+    planes = grad_kind == "float"
+    grad = ops.half_planes(g, tile) if planes else g
+    for plan in (None, ops.half_linear_plan(out_f, in_f, rod, cid)):
+        dw = ops.half_linear_weight_gradient(out_f, rod, cid, grad, planes, x, plan)
+        assert rel_err(dw.cpu().numpy()[None, :], want_dw[None, :], ro) < TOL
+    dx = ops.half_linear_input_gradient(out_f, in_f, grad, planes, image, v.dtype, x, batch, seq)
+    if tile == torch.bfloat16 and values_kind == grad_kind == "float":
+        assert dx is None       # nine plane pairs: not built, the caller takes the typed operators
+        return
+    assert dx.dtype == tile and tuple(dx.shape) == (batch, seq, in_f)
+    assert half_err(dx.float().cpu().numpy(), want_dx, tile) < TOL
+
+
+def test_half_linear_exact_integers(spmm_mfma, dev):
+    """Small integers (every product and sum exact): the four operand layouts' fragment
+    maps must give the exact matrices."""
+    from torch_sputnik_amd import ops
+    out_f, in_f, seq, batch = 192, 128, 192, 2
+    _, _, ri, ro, ci = make_csr(out_f, in_f, 0.6, seed=23, round_to=1)
+    rng = np.random.default_rng(24)
+    v32 = rng.integers(-4, 5, size=len(ci)).astype(np.float32)
+    x32 = rng.integers(-4, 5, size=(batch, seq, in_f)).astype(np.float32)
+    g32 = rng.integers(-4, 5, size=(batch, out_f, seq)).astype(np.float32)
+    rows = np.repeat(np.arange(out_f), np.diff(ro))
+    w = np.zeros((out_f, in_f), np.float32)
+    w[rows, ci] = v32
+    v, x, g = T(v32, dev).half(), T(x32, dev).half(), T(g32, dev).half()
+    rod, cid = T(ro, dev), T(ci, dev)
+    image = ops.half_linear_image(out_f, in_f, v, rod, cid, torch.float16)
+    assert np.array_equal(ops.half_linear_forward(out_f, image, v.dtype, x).cpu().numpy(),
+                          np.einsum("oi,bsi->bos", w, x32))
+    assert np.array_equal(ops.half_linear_weight_gradient(out_f, rod, cid, g, False, x).cpu().numpy(),
+                          np.einsum("bos,bsi->oi", g32, x32)[rows, ci])
+    dx = ops.half_linear_input_gradient(out_f, in_f, g, False, image, v.dtype, x, batch, seq)
+    assert np.array_equal(dx.float().cpu().numpy(), np.einsum("bos,oi->bsi", g32, w))
+
+
 @pytest.mark.parametrize("dtype", HALF_TYPES)
 def test_left_spmm_typed_takes_the_tiles_at_layer_density(ts, capi, dev, dtype):
     """The op level: left_spmm with a half dense operand at a layer's density and size goes

@@ -106,6 +106,22 @@ SIGNATURES = {
     "sputnik_hip_left_spmm_half_tiles": (_c_int, [_c_int] * 5 + [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr,
                                                                 _c_int, _c_i64, _c_int, _c_ptr, _c_int,
                                                                 _c_ptr, _c_i64, _c_ptr, _c_size, _c_ptr]),
+    "sputnik_hip_sparse_linear_half_supported": (_c_int, [_c_int] * 7),
+    "sputnik_hip_sparse_linear_half_image_bytes": (_c_size, [_c_int] * 4),
+    "sputnik_hip_sparse_linear_half_image": (_c_int, [_c_int] * 3 + [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int,
+                                                                    _c_ptr, _c_size, _c_ptr]),
+    "sputnik_hip_half_planes_bytes": (_c_size, [_c_i64, _c_int]),
+    "sputnik_hip_half_planes": (_c_int, [_c_i64, _c_ptr, _c_int, _c_ptr, _c_ptr]),
+    "sputnik_hip_sparse_linear_half_forward": (_c_int, [_c_int] * 4 + [_c_ptr, _c_int, _c_ptr, _c_int,
+                                                                      _c_ptr, _c_int, _c_ptr, _c_ptr]),
+    "sputnik_hip_sparse_linear_half_plan_bytes": (_c_size, [_c_int] * 2),
+    "sputnik_hip_sparse_linear_half_plan": (_c_int, [_c_int] * 2 + [_c_ptr, _c_ptr, _c_ptr, _c_ptr]),
+    "sputnik_hip_sparse_linear_half_scratch_bytes": (_c_size, [_c_int] * 7),
+    "sputnik_hip_sparse_linear_half_weight_gradient": (_c_int, [_c_int] * 5 + [_c_ptr, _c_ptr, _c_ptr, _c_int,
+                                                                              _c_ptr, _c_int, _c_ptr, _c_ptr,
+                                                                              _c_ptr, _c_size, _c_ptr]),
+    "sputnik_hip_sparse_linear_half_input_gradient": (_c_int, [_c_int] * 4 + [_c_ptr, _c_int, _c_ptr, _c_int,
+                                                                             _c_int, _c_ptr, _c_int, _c_ptr]),
     "sputnik_hip_sddmm_sum_mixed_scratch_bytes": (_c_size, [_c_int] * 7),
     "sputnik_hip_sddmm_sum_mixed": (_c_int, [_c_int] * 5 + [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int,
                                                            _c_i64, _c_ptr, _c_int, _c_i64, _c_ptr,

@@ -42,6 +42,9 @@ int sddmm_mfma_planes_of(int half_type);
 int sddmm_mfma_split_planes(int64_t count, const float* in, int half_type, void* planes,
                             hipStream_t stream);
 
+// out[i] = partials[0][i] + ... + partials[parts - 1][i], index order (sddmm.hip)
+int sum_partial_vectors(int nonzeros, int parts, const float* partials, float* out, hipStream_t stream);
+
 // left_spmm (values shared by the replicas) as a dense contraction: the densified weight
 // against the dense operand [replicas][k][n] on half tiles of `tile_type` (spmm_mfma.hip).
 // A float32 operand enters as half planes (not rounded).  Workspace: the densified

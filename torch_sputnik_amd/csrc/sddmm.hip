@@ -225,6 +225,18 @@ __global__ __launch_bounds__(kBlock) void sum_partials_kernel(int count /* of VE
   for (int e = 0; e < VEC; ++e) out[static_cast<int64_t>(i) * VEC + e] = acc[e];
 }
 
+// out[i] = partials[0][i] + ... + partials[parts - 1][i]  (one launch, index order)
+int sum_partials_launch(int nonzeros, int parts, const float* partials, float* out, hipStream_t stream) {
+  if (nonzeros % 4 == 0 && aligned_to(out, 16) && aligned_to(partials, 16)) {
+    hipLaunchKernelGGL(sum_partials_kernel<4>, dim3(ceil_div(nonzeros / 4, kBlock)), dim3(kBlock), 0,
+                       stream, nonzeros / 4, parts, static_cast<int64_t>(nonzeros), partials, out);
+  } else {
+    hipLaunchKernelGGL(sum_partials_kernel<1>, dim3(ceil_div(nonzeros, kBlock)), dim3(kBlock), 0, stream,
+                       nonzeros, parts, static_cast<int64_t>(nonzeros), partials, out);
+  }
+  return launch_status();
+}
+
 // Widest vector (4, 2 or 1 ELEMENTS of `elem` bytes) every row start supports.
 int vector_width_of(const void* p, int64_t width, int64_t stride, size_t elem) {
   if (width % 4 == 0 && stride % 4 == 0 && aligned_to(p, 4 * elem)) return 4;
@@ -253,6 +265,11 @@ int rowwave_half(int m, int k, int replicas, const int* row_indices, const int* 
 }
 
 }  // namespace
+
+int sum_partial_vectors(int nonzeros, int parts, const float* partials, float* out, hipStream_t stream) {
+  return sum_partials_launch(nonzeros, parts, partials, out, stream);
+}
+
 }  // namespace sputnik_hip
 
 using namespace sputnik_hip;

@@ -37,202 +37,13 @@
 // 2 * 16.8 MB once from memory, 2048 / 128 = 16 times through L2 (one 128-row panel per
 // tile row / tile column).
 #include "mfma.h"
-#include "mfma_tiles.h"
+#include "mfma_gemm.h"
 #include "options.h"
 
 namespace sputnik_hip {
 namespace {
 
 using namespace mfma_tiles;
-
-// ACCS = 2: the second plane of a split float32 operand accumulates in a tile of its own
-// and enters the result times `low_scale` (the float16 split keeps its low plane scaled
-// up by 2^11, out of the subnormals: split_planes_kernel).
-template <typename T, int PLANES, int ACCS>
-__global__ __launch_bounds__(256, 2) void sddmm_mfma_kernel(
-    int m, int n, int k, int nonzeros, int steps_per_replica, int total_steps, int splits,
-    int tiles_m, const int* __restrict__ row_offsets, const int* __restrict__ column_indices,
-    const T* __restrict__ lhs, int64_t lhs_stride, const T* __restrict__ rhs, int64_t rhs_stride,
-    float* __restrict__ partials, int vector_columns, const int* __restrict__ plan, int tiles_n,
-    int64_t lhs_plane_stride, int64_t rhs_plane_stride, float low_scale) {
-  using H = Half8<T>;
-  using frag = typename H::type;
-  __shared__ __attribute__((aligned(16))) char smem[kLdsBytes];
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (an SGPR: M0 takes it)
-  const int wr = wave >> 1, wc = wave & 1;
-  // consecutive work indices run behind one L2: the splits of a tile, then the row tiles
-  // of one tile column (they stage the same rhs panel)
-  const int work = xcd_local_index32();
-  const int split = work % splits;
-  const int tile = work / splits;
-  const int rt = tile % tiles_m, ct = tile / tiles_m;
-  const int r0 = rt * kTile, c0 = ct * kTile;
-  const int s_begin = static_cast<int>(static_cast<int64_t>(total_steps) * split / splits);
-  const int s_end = static_cast<int>(static_cast<int64_t>(total_steps) * (split + 1) / splits);
-
-  // per-lane source offsets of this wave's four pieces of each operand (rows beyond the
-  // matrix are clamped onto its last row: their products are never sampled)
-  unsigned a_off[4], b_off[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = 8 * wave + 32 * j + (lane >> 3);
-    const unsigned slot = static_cast<unsigned>((lane & 7) ^ ((row >> 1) & 7)) * 16u;
-    a_off[j] = static_cast<unsigned>(min(r0 + row, m - 1) - r0) * static_cast<unsigned>(k) * 2u + slot;
-    b_off[j] = static_cast<unsigned>(min(c0 + row, n - 1) - c0) * static_cast<unsigned>(k) * 2u + slot;
-  }
-  // a step = (replica, 64 elements of k), PLANES tile products each.  PLANES > 1: an
-  // operand that arrived as float32 is given as half planes (split_planes_kernel; the other
-  // operand's plane stride is 0) and the tile accumulates every plane's product
-  auto stage = [&](int s, int plane, int buffer) {
-    const int replica = s / steps_per_replica;
-    const int k0 = (s - replica * steps_per_replica) * kStep;
-    const T* a = lhs + replica * lhs_stride + plane * lhs_plane_stride + static_cast<int64_t>(r0) * k + k0;
-    const T* b = rhs + replica * rhs_stride + plane * rhs_plane_stride + static_cast<int64_t>(c0) * k + k0;
-    const char* dst = smem + buffer * kStageBytes + wave * 1024;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) copy_piece(a, a_off[j], dst + j * 4096);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) copy_piece(b, b_off[j], dst + kOperandBytes + j * 4096);
-  };
-
-  // fragment addresses (k slot 0; slot 2 * ks + (lane >> 5) is an XOR with ks * 32)
-  unsigned fa[2], fb[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int ra = wr * 64 + i * 32 + (lane & 31);
-    const int rb = wc * 64 + i * 32 + (lane & 31);
-    fa[i] = static_cast<unsigned>(ra * 128 + (((lane >> 5) ^ ((ra >> 1) & 7)) * 16));
-    fb[i] = static_cast<unsigned>(kOperandBytes + rb * 128 + (((lane >> 5) ^ ((rb >> 1) & 7)) * 16));
-  }
-
-  f32x16 acc[ACCS][2][2];
-#pragma unroll
-  for (int z = 0; z < ACCS; ++z)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[z][i][j] = f32x16{};
-
-  if (s_begin < s_end) {
-    stage(s_begin, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-  unsigned stage_base = 0;
-  for (int s = s_begin; s < s_end; ++s) {
-#pragma unroll
-    for (int plane = 0; plane < PLANES; ++plane) {
-      const int other = stage_base == 0 ? 1 : 0;
-      if (plane + 1 < PLANES) {
-        stage(s, plane + 1, other);
-      } else if (s + 1 < s_end) {
-        stage(s + 1, 0, other);
-      }
-      frag a[2][4], b[2][4];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          a[i][ks] = *reinterpret_cast<const frag*>(smem + ((fa[i] ^ (ks * 32u)) + stage_base));
-          b[i][ks] = *reinterpret_cast<const frag*>(smem + ((fb[i] ^ (ks * 32u)) + stage_base));
-        }
-      constexpr int z = ACCS == 2 ? 1 : 0;   // (ACCS == 2 has PLANES == 2: plane 1's own tile)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            if (plane == 0) acc[0][i][j] = H::mfma(a[i][ks], b[j][ks], acc[0][i][j]);
-            else acc[z][i][j] = H::mfma(a[i][ks], b[j][ks], acc[z][i][j]);
-          }
-      // the next tiles have landed (this wave's copies), and every wave is done with these
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      stage_base ^= static_cast<unsigned>(kStageBytes);
-    }
-  }
-
-  // ---- epilogue: the tile to LDS, then the rows' entries that fall into it ----
-  float* tile_lds = reinterpret_cast<float*>(smem);
-  int* bounds = reinterpret_cast<int*>(smem + kTileBytes);   // [kTile + 1]
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int row = wr * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-        const int col = wc * 64 + j * 32 + (lane & 31);
-        tile_lds[row * kPitch + col] =
-            ACCS == 2 ? fmaf(acc[ACCS - 1][i][j][reg], low_scale, acc[0][i][j][reg]) : acc[0][i][j][reg];
-      }
-  float* __restrict__ o = partials + static_cast<int64_t>(split) * nonzeros;
-  // With a plan (sddmm_mfma_plan: where every row's entries cross the tile columns) whose
-  // rows all have ascending columns, a row's entries inside this tile are one known run.
-  bool by_table = plan != nullptr;
-  if (by_table) {
-    const int ok = threadIdx.x < kTile ? plan[min(r0 + static_cast<int>(threadIdx.x), m - 1)] : 1;
-    by_table = __syncthreads_and(ok) != 0;
-  } else {
-    __syncthreads();
-  }
-  if (by_table) {
-    const int* table = plan + plan_rows(m);
-    const int group = threadIdx.x >> 4, l16 = threadIdx.x & 15;
-    int from[8], to[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {   // (all bounds requested before the first is used)
-      const int row = r0 + group + 16 * j;
-      const int* run = table + static_cast<int64_t>(min(row, m - 1)) * (tiles_n + 1) + ct;
-      from[j] = run[0];
-      to[j] = row < m ? run[1] : run[0];
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float* tile_row = tile_lds + (group + 16 * j) * kPitch - c0;
-      for (int p = from[j] + l16; p < to[j]; p += 16) o[p] = tile_row[column_indices[p]];
-    }
-    return;
-  }
-
-  // No plan, or a row whose columns do not ascend: the workgroup walks the CSR entries of
-  // its 128 rows FLAT (they are contiguous in column_indices), sixteen bytes per lane,
-  // and stores those whose column lies in the tile.
-  if (threadIdx.x <= kTile) bounds[threadIdx.x] = row_offsets[min(r0 + static_cast<int>(threadIdx.x), m)];
-  __syncthreads();
-  const int first = bounds[0], last = bounds[kTile];
-  // a lane takes four consecutive entries per round; its row moves forward only
-  int row = 0;
-  const int start = (first & ~3) + 4 * static_cast<int>(threadIdx.x);
-  {  // first row whose end lies behind `start` (binary search over the 128 bounds)
-    int lo = 0, hi = kTile;   // answer in [lo, hi]
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (bounds[mid + 1] > start) hi = mid; else lo = mid + 1;
-    }
-    row = lo;
-  }
-  for (int p = start; p < last; p += 4 * 256) {
-    int cols[4];
-    if (vector_columns && p + 3 < nonzeros) {
-      const int4 v = *reinterpret_cast<const int4*>(column_indices + p);
-      cols[0] = v.x; cols[1] = v.y; cols[2] = v.z; cols[3] = v.w;
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) cols[e] = p + e < nonzeros ? column_indices[p + e] : -1;
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int q = p + e;
-      while (row < kTile && bounds[row + 1] <= q) ++row;
-      const unsigned c = static_cast<unsigned>(cols[e] - c0);
-      if (q >= first && q < last && c < static_cast<unsigned>(kTile)) o[q] = tile_lds[row * kPitch + c];
-    }
-  }
-}
 
 // float32 -> PLANES planes of the half type T whose sum is the value: p0 = round(v), p1 =
 // round((v - p0) * scale1), p2 = round(v - p0 - p1) -- the products p * x are exact in
@@ -351,36 +162,21 @@ int sddmm_mfma_launch(int m, int k, int n, int nonzeros, int replicas, const int
                       const void* rhs, int64_t rhs_stride, int in_type, float* partials,
                       int splits, const void* plan, hipStream_t stream, int planes,
                       int64_t lhs_plane_stride, int64_t rhs_plane_stride) {
-  const int tiles_m = ceil_div(m, kTile), tiles_n = ceil_div(n, kTile);
-  const int steps_per_replica = k / kStep;
-  const int64_t total_steps = static_cast<int64_t>(replicas) * steps_per_replica;
-  if (planes < 1 || planes > 3) return SPUTNIK_HIP_INVALID_ARGUMENT;
-  if (total_steps >= (int64_t{1} << 31) || splits < 1) return SPUTNIK_HIP_INVALID_ARGUMENT;
-  const dim3 grid(static_cast<unsigned>(static_cast<int64_t>(tiles_m) * tiles_n * splits));
-  const int vector_columns = aligned_to(column_indices, 16) ? 1 : 0;
-  // (a float16 pair of planes keeps the low one scaled: sddmm_mfma_split_planes)
-  const bool two_tiles = planes == 2 && in_type == SPUTNIK_HIP_F16;
-  const float low_scale = two_tiles ? 1.f / kLowPlaneScale : 1.f;
-#define SPUTNIK_HIP_MF(T, PLANES, ACCS)                                                        \
-  hipLaunchKernelGGL((sddmm_mfma_kernel<T, PLANES, ACCS>), grid, dim3(256), 0, stream, m, n, k,  \
-                     nonzeros, steps_per_replica, static_cast<int>(total_steps), splits, tiles_m, \
-                     row_offsets, column_indices, static_cast<const T*>(lhs), lhs_stride,      \
-                     static_cast<const T*>(rhs), rhs_stride, partials, vector_columns,          \
-                     static_cast<const int*>(plan), tiles_n, lhs_plane_stride, rhs_plane_stride, \
-                     low_scale)
-  if (in_type == SPUTNIK_HIP_F16 && planes == 2) {
-    SPUTNIK_HIP_MF(_Float16, 2, 2);
-  } else if (in_type == SPUTNIK_HIP_F16 && planes == 1) {
-    SPUTNIK_HIP_MF(_Float16, 1, 1);
-  } else if (in_type == SPUTNIK_HIP_BF16 && planes == 3) {
-    SPUTNIK_HIP_MF(__bf16, 3, 1);
-  } else if (in_type == SPUTNIK_HIP_BF16 && planes == 1) {
-    SPUTNIK_HIP_MF(__bf16, 1, 1);
-  } else {
-    return SPUTNIK_HIP_INVALID_ARGUMENT;
-  }
-#undef SPUTNIK_HIP_MF
-  return launch_status();
+  if (planes < 1 || planes > 3 || splits < 1) return SPUTNIK_HIP_INVALID_ARGUMENT;
+  // (the planes belong to the operand whose plane stride is given)
+  const int pa = rhs_plane_stride == 0 ? planes : 1, pb = rhs_plane_stride == 0 ? 1 : planes;
+  const GemmOperand a{lhs, k, lhs_stride, lhs_plane_stride};
+  const GemmOperand b{rhs, k, rhs_stride, rhs_plane_stride};
+  GemmOut out{};
+  out.sampled = partials;
+  out.row_offsets = row_offsets;
+  out.column_indices = column_indices;
+  out.plan = static_cast<const int*>(plan);
+  out.nonzeros = nonzeros;
+  out.vector_columns = aligned_to(column_indices, 16) ? 1 : 0;
+  // lhs [m, k] and rhs [n, k] are both k-contiguous (src/sddmm_cuda.cu:48-53's layout)
+  return launch_mfma_gemm_typed<false, false, kSampled>(in_type, pa, pb, m, n, k, replicas, splits,
+                                                        /*outer_is_split=*/true, a, b, out, stream);
 }
 
 int sddmm_mfma_planes_of(int half_type) { return half_type == SPUTNIK_HIP_BF16 ? 3 : 2; }

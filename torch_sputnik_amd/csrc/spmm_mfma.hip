@@ -33,196 +33,13 @@
 //      rendezvous per tile product.  The float32 tile leaves from the accumulators with
 //      the bias / ReLU epilogue of sputnik_hip_spmm_bias_batched.
 #include "mfma.h"
-#include "mfma_tiles.h"
+#include "mfma_gemm.h"
 #include "options.h"
 
 namespace sputnik_hip {
 namespace {
 
 using namespace mfma_tiles;
-
-typedef short s4v __attribute__((__vector_size__(8)));
-typedef short s8v __attribute__((__vector_size__(16)));
-
-// The (A plane, B plane) pairs a step multiplies: every pair whose order a + b stays
-// below the longer operand's plane count (one plane each: the one product).
-template <int PA, int PB>
-struct Passes {
-  static constexpr int kLimit = (PA > PB ? PA : PB) - 1;
-  static constexpr int count() {
-    int c = 0;
-    for (int a = 0; a < PA; ++a)
-      for (int b = 0; b < PB; ++b) c += a + b <= kLimit ? 1 : 0;
-    return c;
-  }
-  static constexpr int a_of(int i) {
-    int c = 0;
-    for (int a = 0; a < PA; ++a)
-      for (int b = 0; b < PB; ++b)
-        if (a + b <= kLimit && c++ == i) return a;
-    return 0;
-  }
-  static constexpr int b_of(int i) {
-    int c = 0;
-    for (int a = 0; a < PA; ++a)
-      for (int b = 0; b < PB; ++b)
-        if (a + b <= kLimit && c++ == i) return b;
-    return 0;
-  }
-};
-
-// ACCS = 2 (float16 planes): products of order 1 (one low plane, kept scaled by 2^11)
-// accumulate in a second tile that enters the result times low_scale = 2^-11.
-template <typename T, int PA, int PB, int ACCS>
-__global__ __launch_bounds__(256, 2) void spmm_mfma_kernel(
-    int m, int n, int k, int steps, int tiles_m, int tiles_n, const T* __restrict__ a_planes,
-    int64_t a_plane_stride, const T* __restrict__ dense, int64_t dense_stride,
-    int64_t dense_plane_stride, const float* __restrict__ bias, int relu, float* __restrict__ out,
-    int64_t out_stride, float low_scale) {
-  using H = Half8<T>;
-  using frag = typename H::type;
-  using P = Passes<PA, PB>;
-  constexpr int NP = P::count();
-  __shared__ __attribute__((aligned(16))) char smem[2 * kStageBytes];
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (an SGPR: M0 takes it)
-  const int wr = wave >> 1, wc = wave & 1;
-  // consecutive work indices run behind one L2: the row tiles of one column tile (they
-  // stage the same B panel), then the column tiles of one replica
-  const int work = xcd_local_index32();
-  const int rt = work % tiles_m;
-  const int ct = (work / tiles_m) % tiles_n;
-  const int replica = work / (tiles_m * tiles_n);
-  const int r0 = rt * kTile, c0 = ct * kTile;
-
-  // per-lane source offsets: A's four pieces (8 rows x 128 B each; the image has whole
-  // tiles of rows), B's four pieces (4 rows x 256 B each; chunks beyond the matrix's last
-  // column are clamped onto its last chunk: their products are never stored)
-  unsigned a_off[4], b_off[4];
-  const int last_chunk = (n - c0) / 8 - 1;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int arow = 8 * wave + 32 * j + (lane >> 3);
-    a_off[j] = static_cast<unsigned>(arow) * static_cast<unsigned>(k) * 2u +
-               static_cast<unsigned>((lane & 7) ^ ((arow >> 1) & 7)) * 16u;
-    const int brow = 4 * (wave + 4 * j) + (lane >> 4);
-    const int chunk = (lane & 15) ^ ((((lane >> 4) & 3) << 2) | wave);
-    b_off[j] = static_cast<unsigned>(brow) * static_cast<unsigned>(n) * 2u +
-               static_cast<unsigned>(min(chunk, last_chunk)) * 16u;
-  }
-  const T* a_tile = uniform_ptr(a_planes + static_cast<int64_t>(r0) * k);
-  const T* b_tile = uniform_ptr(dense + replica * dense_stride + c0);
-  auto stage = [&](int s, int pass, int buffer) {
-    const T* a = a_tile + P::a_of(pass) * a_plane_stride + s * kStep;
-    const T* b = b_tile + P::b_of(pass) * dense_plane_stride + static_cast<int64_t>(s) * kStep * n;
-    const char* dst = smem + buffer * kStageBytes + wave * 1024;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) copy_piece(a, a_off[j], dst + j * 4096);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) copy_piece(b, b_off[j], dst + kOperandBytes + j * 4096);
-  };
-
-  // A fragment addresses (k slot 0; slot 2 * ks + (lane >> 5) is an XOR with ks * 32)
-  unsigned fa[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int ra = wr * 64 + i * 32 + (lane & 31);
-    fa[i] = static_cast<unsigned>(ra * 128 + (((lane >> 5) ^ ((ra >> 1) & 7)) * 16));
-  }
-  // B: transposing reads.  Lane 4q + p of a 16-lane group supplies row q, columns 4p .. 4p + 3
-  // of a 4 x 16 block and receives column (lane & 15) of its four rows; block rows
-  // 16 ks + 8 (lane >> 5) + 4 t + q (t = 0, 1: the fragment's k 0-3 and 4-7), block columns
-  // wc * 64 + 32 j + 16 ((lane >> 4) & 1) + ...: fb[t][j] at ks = 0, + ks * 4096
-  unsigned fb[2][2];
-  {
-    const int q = (lane & 15) >> 2, p = lane & 3, h = lane >> 5, g1 = (lane >> 4) & 1;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int row = 8 * h + 4 * t + q;
-        const int chunk = wc * 8 + j * 4 + 2 * g1 + (p >> 1);
-        const int swz = ((row & 3) << 2) | ((row >> 2) & 3);
-        fb[t][j] = static_cast<unsigned>(kOperandBytes + row * 256 + ((chunk ^ swz) * 16) + 8 * (p & 1));
-      }
-  }
-
-  f32x16 acc[ACCS][2][2];
-#pragma unroll
-  for (int z = 0; z < ACCS; ++z)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[z][i][j] = f32x16{};
-
-  stage(0, 0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  unsigned stage_base = 0;
-  for (int s = 0; s < steps; ++s) {
-#pragma unroll
-    for (int pass = 0; pass < NP; ++pass) {
-      const int other = stage_base == 0 ? 1 : 0;
-      if (pass + 1 < NP) {
-        stage(s, pass + 1, other);
-      } else if (s + 1 < steps) {
-        stage(s + 1, 0, other);
-      }
-      frag a[2][4], b[2][4];
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-          a[i][ks] = *reinterpret_cast<const frag*>(smem + ((fa[i] ^ (ks * 32u)) + stage_base));
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s4v*)(smem + (fb[0][j] + ks * 4096u + stage_base)));
-          const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s4v*)(smem + (fb[1][j] + ks * 4096u + stage_base)));
-          b[j][ks] = __builtin_bit_cast(frag, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-        }
-      }
-      constexpr int kOne = ACCS == 2 ? 1 : 0;
-      const bool low = P::a_of(pass) + P::b_of(pass) > 0;   // (a compile-time constant once unrolled)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            if (low) acc[kOne][i][j] = H::mfma(a[i][ks], b[j][ks], acc[kOne][i][j]);
-            else acc[0][i][j] = H::mfma(a[i][ks], b[j][ks], acc[0][i][j]);
-          }
-      // the next tiles have landed (this wave's copies), and every wave is done with these
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      stage_base ^= static_cast<unsigned>(kStageBytes);
-    }
-  }
-
-  // ---- epilogue: the accumulators' 32 x 32 blocks (column = lane & 31: 128-byte runs) ----
-  float* __restrict__ o = out + replica * out_stride;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int row = r0 + wr * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-      if (row < m) {
-        const float bv = bias != nullptr ? bias[row] : 0.f;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int col = c0 + wc * 64 + j * 32 + (lane & 31);
-          float v = ACCS == 2 ? fmaf(acc[ACCS - 1][i][j][reg], low_scale, acc[0][i][j][reg])
-                              : acc[0][i][j][reg];
-          v += bv;
-          if (relu) v = fmaxf(v, 0.f);
-          if (col < n) o[static_cast<int64_t>(row) * n + col] = v;
-        }
-      }
-    }
-}
 
 // The CSR values scattered into the zeroed dense image(s) [PLANES][rows][k]: one wave per
 // row.  TV = float: split into planes as split_planes_kernel does (sddmm_mfma.hip); TV = T:
@@ -267,6 +84,30 @@ int passes_of(int pa, int pb) {
 
 }  // namespace
 
+// A zeroed image [planes][rows_padded][k] of the tile type with the CSR values scattered in
+// (memset + one launch).
+int densify_into(int m, int k, const int* row_offsets, const int* column_indices, const void* values,
+                 int values_type, int tile_type, void* image, int64_t rows_padded, hipStream_t stream) {
+  const int pa = planes_of(values_type, tile_type);
+  const int64_t a_plane = rows_padded * k;
+  hipError_t e = hipMemsetAsync(image, 0, static_cast<size_t>(pa) * a_plane * 2, stream);
+  if (e != hipSuccess) return static_cast<int>(e);
+  const dim3 rows_grid(ceil_div(m, 4));
+#define SPUTNIK_HIP_DENSIFY(T, TV, PLANES, SCALE)                                                  \
+  hipLaunchKernelGGL((densify_kernel<T, TV, PLANES>), rows_grid, dim3(256), 0, stream, m, k,       \
+                     row_offsets, column_indices, static_cast<const TV*>(values),                  \
+                     static_cast<T*>(image), a_plane, SCALE)
+  if (tile_type == SPUTNIK_HIP_F16) {
+    if (values_type == SPUTNIK_HIP_F32) SPUTNIK_HIP_DENSIFY(_Float16, float, 2, kLowPlaneScale);
+    else SPUTNIK_HIP_DENSIFY(_Float16, _Float16, 1, 1.f);
+  } else {
+    if (values_type == SPUTNIK_HIP_F32) SPUTNIK_HIP_DENSIFY(__bf16, float, 3, 1.f);
+    else SPUTNIK_HIP_DENSIFY(__bf16, __bf16, 1, 1.f);
+  }
+#undef SPUTNIK_HIP_DENSIFY
+  return launch_status();
+}
+
 // tile_type: the half type of the tiles (a half operand's own type).
 bool spmm_mfma_shape(int m, int k, int n, int nonzeros, int replicas, int values_type,
                      int dense_type, int tile_type) {
@@ -308,22 +149,8 @@ int spmm_mfma_launch(int m, int k, int n, int nonzeros, int replicas, const int*
   const int pa = planes_of(values_type, tile_type), pb = planes_of(dense_type, tile_type);
   const int64_t a_plane = padded_rows(m) * k;
   const size_t a_bytes = (static_cast<size_t>(pa) * a_plane * 2 + 255) / 256 * 256;
-  hipError_t e = hipMemsetAsync(workspace, 0, static_cast<size_t>(pa) * a_plane * 2, stream);
-  if (e != hipSuccess) return static_cast<int>(e);
-  const dim3 rows_grid(ceil_div(m, 4));
-#define SPUTNIK_HIP_DENSIFY(T, TV, PLANES, SCALE)                                                  \
-  hipLaunchKernelGGL((densify_kernel<T, TV, PLANES>), rows_grid, dim3(256), 0, stream, m, k,       \
-                     row_offsets, column_indices, static_cast<const TV*>(values),                  \
-                     static_cast<T*>(workspace), a_plane, SCALE)
-  if (tile_type == SPUTNIK_HIP_F16) {
-    if (values_type == SPUTNIK_HIP_F32) SPUTNIK_HIP_DENSIFY(_Float16, float, 2, kLowPlaneScale);
-    else SPUTNIK_HIP_DENSIFY(_Float16, _Float16, 1, 1.f);
-  } else {
-    if (values_type == SPUTNIK_HIP_F32) SPUTNIK_HIP_DENSIFY(__bf16, float, 3, 1.f);
-    else SPUTNIK_HIP_DENSIFY(__bf16, __bf16, 1, 1.f);
-  }
-#undef SPUTNIK_HIP_DENSIFY
-  int st = launch_status();
+  int st = densify_into(m, k, row_offsets, column_indices, values, values_type, tile_type, workspace,
+                        padded_rows(m), stream);
   if (st != 0) return st;
   const void* b = dense;
   int64_t b_stride = dense_stride, b_plane = 0;
@@ -337,28 +164,18 @@ int spmm_mfma_launch(int m, int k, int n, int nonzeros, int replicas, const int*
     b = planes;
     b_stride = static_cast<int64_t>(k) * n;
   }
-  const int tiles_m = ceil_div(m, kTile), tiles_n = ceil_div(n, kTile);
-  const dim3 grid(static_cast<unsigned>(static_cast<int64_t>(tiles_m) * tiles_n * replicas));
-  const bool two_tiles = tile_type == SPUTNIK_HIP_F16 && (pa > 1 || pb > 1);
-  const float low_scale = two_tiles ? 1.f / kLowPlaneScale : 1.f;
-#define SPUTNIK_HIP_MF(T, PA, PB, ACCS)                                                            \
-  hipLaunchKernelGGL((spmm_mfma_kernel<T, PA, PB, ACCS>), grid, dim3(256), 0, stream, m, n, k,     \
-                     k / kStep, tiles_m, tiles_n, static_cast<const T*>(workspace), a_plane,       \
-                     static_cast<const T*>(b), b_stride, b_plane, bias, relu, out, out_stride,     \
-                     low_scale)
-  if (tile_type == SPUTNIK_HIP_F16) {
-    if (pa == 1 && pb == 1) SPUTNIK_HIP_MF(_Float16, 1, 1, 1);
-    else if (pa == 2 && pb == 1) SPUTNIK_HIP_MF(_Float16, 2, 1, 2);
-    else if (pa == 1 && pb == 2) SPUTNIK_HIP_MF(_Float16, 1, 2, 2);
-    else SPUTNIK_HIP_MF(_Float16, 2, 2, 2);
-  } else {
-    if (pa == 1 && pb == 1) SPUTNIK_HIP_MF(__bf16, 1, 1, 1);
-    else if (pa == 3 && pb == 1) SPUTNIK_HIP_MF(__bf16, 3, 1, 1);
-    else if (pa == 1 && pb == 3) SPUTNIK_HIP_MF(__bf16, 1, 3, 1);
-    else return SPUTNIK_HIP_UNSUPPORTED;
-  }
-#undef SPUTNIK_HIP_MF
-  return launch_status();
+  const GemmOperand a{workspace, k, 0, a_plane};
+  const GemmOperand bop{b, n, b_stride, b_plane};
+  GemmOut o{};
+  o.dense = out;
+  o.ld = n;
+  o.outer_stride = out_stride;
+  o.bias = bias;
+  o.relu = relu;
+  // the densified weight is k-contiguous, the dense operand [k][n] k-major (the layout
+  // src/left_replicated_spmm.cu:36 takes): its fragments are transposing reads
+  return launch_mfma_gemm_typed<false, true, kDense>(tile_type, pa, pb, m, n, k, replicas, replicas,
+                                                     /*outer_is_split=*/false, a, bop, o, stream);
 }
 
 }  // namespace sputnik_hip

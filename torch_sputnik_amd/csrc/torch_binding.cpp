@@ -533,6 +533,135 @@ Tensor left_spmm_half_tiles(int64_t m64, int64_t k64, const Tensor& values_in,
   return out;
 }
 
+// ---- a sparse layer on half-stored activations: the three products on the matrix cores,
+// no layout pass (sputnik_hip.h: sparse_linear_half_*) ----
+int tile_code_of(const Tensor& x) {
+  const int code = type_code(x.scalar_type());
+  TORCH_CHECK(code == SPUTNIK_HIP_F16 || code == SPUTNIK_HIP_BF16,
+              "expected float16 / bfloat16 activations, got ", x.scalar_type());
+  return code;
+}
+
+// The weight's image [planes][out][in] in the tile type (uint8 tensor).
+Tensor half_linear_image(int64_t out64, int64_t in64, const Tensor& values_in, const Tensor& row_offsets,
+                         const Tensor& column_indices, int64_t tile_type) {
+  const int out_f = to_int(out64, "out"), in_f = to_int(in64, "in");
+  const Tensor values = as_storage(values_in, "values");
+  const c10::DeviceGuard guard(values.device());
+  const Tensor ro = as_index(row_offsets, "row_offsets", values);
+  const Tensor ci = as_index(column_indices, "column_indices", values);
+  TORCH_CHECK(ro.size(0) == out_f + 1 && values.dim() == 1 && values.size(0) == ci.size(0),
+              "half_linear_image: CSR arrays do not match");
+  const int vt = type_code(values.scalar_type());
+  const size_t bytes = sputnik_hip_sparse_linear_half_image_bytes(out_f, in_f, vt, static_cast<int>(tile_type));
+  Tensor image = at::empty({static_cast<int64_t>(bytes)}, values.options().dtype(at::kByte));
+  check_status(sputnik_hip_sparse_linear_half_image(out_f, in_f, to_int(ci.size(0), "nonzeros"),
+                                                    ro.data_ptr<int>(), ci.data_ptr<int>(),
+                                                    values.data_ptr(), vt, static_cast<int>(tile_type),
+                                                    image.data_ptr(), bytes, current_stream(values)),
+               "half_linear_image");
+  return image;
+}
+
+// float32 tensor -> its half planes (uint8 tensor, planes x numel x 2 bytes).
+Tensor half_planes(const Tensor& t_in, int64_t tile_type) {
+  TORCH_CHECK(t_in.is_cuda() && t_in.scalar_type() == at::kFloat, "half_planes: expected a float32 GPU tensor");
+  const Tensor t = t_in.contiguous();
+  TORCH_CHECK(t.numel() % 4 == 0, "half_planes: element count must be a multiple of 4");
+  const c10::DeviceGuard guard(t.device());
+  const size_t bytes = sputnik_hip_half_planes_bytes(t.numel(), static_cast<int>(tile_type));
+  Tensor planes = at::empty({static_cast<int64_t>(bytes)}, t.options().dtype(at::kByte));
+  check_status(sputnik_hip_half_planes(t.numel(), t.data_ptr<float>(), static_cast<int>(tile_type),
+                                       planes.data_ptr(), current_stream(t)),
+               "half_planes");
+  return planes;
+}
+
+// y [batch, out, seq] float32 = W x^T per batch element, x [batch, seq, in] half.
+Tensor half_linear_forward(int64_t out64, const Tensor& image, int64_t values_type, const Tensor& x_in) {
+  const Tensor x = x_in.contiguous();
+  TORCH_CHECK(x.is_cuda() && x.dim() == 3, "half_linear_forward: x must be a GPU tensor [batch, seq, in]");
+  const int tile = tile_code_of(x);
+  const c10::DeviceGuard guard(x.device());
+  const int out_f = to_int(out64, "out"), batch = to_int(x.size(0), "batch"), seq = to_int(x.size(1), "seq"),
+            in_f = to_int(x.size(2), "in");
+  TORCH_CHECK(static_cast<size_t>(image.numel()) >=
+                  sputnik_hip_sparse_linear_half_image_bytes(out_f, in_f, static_cast<int>(values_type), tile),
+              "half_linear_forward: the image was made for another shape");
+  Tensor y = at::empty({batch, out_f, seq}, x.options().dtype(at::kFloat));
+  check_status(sputnik_hip_sparse_linear_half_forward(out_f, in_f, seq, batch, image.data_ptr(),
+                                                      static_cast<int>(values_type), x.data_ptr(), tile,
+                                                      nullptr, 0, y.data_ptr<float>(), current_stream(x)),
+               "half_linear_forward");
+  return y;
+}
+
+Tensor half_linear_plan(int64_t out64, int64_t in64, const Tensor& row_offsets, const Tensor& column_indices) {
+  const int out_f = to_int(out64, "out"), in_f = to_int(in64, "in");
+  TORCH_CHECK(row_offsets.is_cuda(), "half_linear_plan: expected GPU index tensors");
+  const c10::DeviceGuard guard(row_offsets.device());
+  const Tensor ro = as_index(row_offsets, "row_offsets", row_offsets);
+  const Tensor ci = as_index(column_indices, "column_indices", row_offsets);
+  const size_t bytes = sputnik_hip_sparse_linear_half_plan_bytes(out_f, in_f);
+  Tensor plan = at::empty({static_cast<int64_t>(bytes)}, row_offsets.options().dtype(at::kByte));
+  check_status(sputnik_hip_sparse_linear_half_plan(out_f, in_f, ro.data_ptr<int>(), ci.data_ptr<int>(),
+                                                   plan.data_ptr(), current_stream(row_offsets)),
+               "half_linear_plan");
+  return plan;
+}
+
+// grad: the planes of the float32 dy (half_planes; grad_is_planes) or dy in x's type.
+Tensor half_linear_weight_gradient(int64_t out64, const Tensor& row_offsets, const Tensor& column_indices,
+                                   const Tensor& grad, bool grad_is_planes, const Tensor& x_in,
+                                   const c10::optional<Tensor>& plan) {
+  const Tensor x = x_in.contiguous();
+  const int tile = tile_code_of(x);
+  const c10::DeviceGuard guard(x.device());
+  const int out_f = to_int(out64, "out"), batch = to_int(x.size(0), "batch"), seq = to_int(x.size(1), "seq"),
+            in_f = to_int(x.size(2), "in");
+  const Tensor ro = as_index(row_offsets, "row_offsets", x);
+  const Tensor ci = as_index(column_indices, "column_indices", x);
+  const int nonzeros = to_int(ci.size(0), "nonzeros");
+  const int grad_type = grad_is_planes ? SPUTNIK_HIP_F32 : tile;
+  const Tensor g = grad.contiguous();
+  const size_t want = grad_is_planes
+                          ? sputnik_hip_half_planes_bytes(static_cast<int64_t>(batch) * out_f * seq, tile)
+                          : static_cast<size_t>(batch) * out_f * seq * 2;
+  TORCH_CHECK(static_cast<size_t>(g.numel()) * g.element_size() >= want,
+              "half_linear_weight_gradient: grad does not hold [batch, out, seq]");
+  const size_t scratch_bytes = sputnik_hip_sparse_linear_half_scratch_bytes(out_f, in_f, seq, batch,
+                                                                            nonzeros, grad_type, tile);
+  Tensor scratch;
+  if (scratch_bytes) scratch = at::empty({static_cast<int64_t>(scratch_bytes)}, x.options().dtype(at::kByte));
+  Tensor out = at::empty({nonzeros}, x.options().dtype(at::kFloat));
+  check_status(sputnik_hip_sparse_linear_half_weight_gradient(
+                   out_f, in_f, seq, batch, nonzeros, ro.data_ptr<int>(), ci.data_ptr<int>(), g.data_ptr(),
+                   grad_type, x.data_ptr(), tile, out.data_ptr<float>(),
+                   plan.has_value() ? plan->data_ptr() : nullptr,
+                   scratch_bytes ? scratch.data_ptr() : nullptr, scratch_bytes, current_stream(x)),
+               "half_linear_weight_gradient");
+  return out;
+}
+
+// dx [batch, seq, in] in `like`'s type (the activations'), or an EMPTY tensor where the
+// route does not serve the call.
+Tensor half_linear_input_gradient(int64_t out64, int64_t in64, const Tensor& grad, bool grad_is_planes,
+                                  const Tensor& image, int64_t values_type, const Tensor& like,
+                                  int64_t batch64, int64_t seq64) {
+  const int tile = tile_code_of(like);
+  const c10::DeviceGuard guard(like.device());
+  const int out_f = to_int(out64, "out"), in_f = to_int(in64, "in"), batch = to_int(batch64, "batch"),
+            seq = to_int(seq64, "seq");
+  const Tensor g = grad.contiguous();
+  Tensor dx = at::empty({batch, seq, in_f}, like.options());
+  const int st = sputnik_hip_sparse_linear_half_input_gradient(
+      out_f, in_f, seq, batch, g.data_ptr(), grad_is_planes ? SPUTNIK_HIP_F32 : tile, image.data_ptr(),
+      static_cast<int>(values_type), tile, dx.data_ptr(), tile, current_stream(like));
+  if (st == SPUTNIK_HIP_UNSUPPORTED) return at::empty({0}, like.options());
+  check_status(st, "half_linear_input_gradient");
+  return dx;
+}
+
 // sddmm_sum on one float32 and one half operand (3-D, contiguous).  False: the library
 // does not serve the pair on this shape -- the caller widens the half operand.
 bool sddmm_sum_mixed(int m, int n, const Tensor& row_indices, const Tensor& row_offsets,
@@ -1364,6 +1493,16 @@ TORCH_LIBRARY(torch_sputnik, m) {
   m.def(
       "left_spmm_half_tiles(int m, int k, Tensor values, Tensor row_offsets, Tensor column_indices, "
       "Tensor dense_matrix, int tile_type) -> Tensor");
+  m.def("half_linear_image(int out_features, int in_features, Tensor values, Tensor row_offsets, "
+        "Tensor column_indices, int tile_type) -> Tensor");
+  m.def("half_planes(Tensor t, int tile_type) -> Tensor");
+  m.def("half_linear_forward(int out_features, Tensor image, int values_type, Tensor x) -> Tensor");
+  m.def("half_linear_plan(int out_features, int in_features, Tensor row_offsets, Tensor column_indices) "
+        "-> Tensor");
+  m.def("half_linear_weight_gradient(int out_features, Tensor row_offsets, Tensor column_indices, "
+        "Tensor grad, bool grad_is_planes, Tensor x, Tensor? plan) -> Tensor");
+  m.def("half_linear_input_gradient(int out_features, int in_features, Tensor grad, bool grad_is_planes, "
+        "Tensor image, int values_type, Tensor like, int batch, int seq) -> Tensor");
   m.def(
       "sddmm(int m, int n, Tensor row_indices, Tensor row_offsets, Tensor column_indices, "
       "Tensor lhs_matrix, Tensor rhs_matrix) -> Tensor");
@@ -1491,6 +1630,12 @@ TORCH_LIBRARY_IMPL(torch_sputnik, CUDA, m) {
   m.impl("sddmm_plan", &sddmm_plan);
   m.impl("sddmm_planned", &sddmm_planned);
   m.impl("left_spmm_half_tiles", &left_spmm_half_tiles);
+  m.impl("half_linear_image", &half_linear_image);
+  m.impl("half_planes", &half_planes);
+  m.impl("half_linear_forward", &half_linear_forward);
+  m.impl("half_linear_plan", &half_linear_plan);
+  m.impl("half_linear_weight_gradient", &half_linear_weight_gradient);
+  m.impl("half_linear_input_gradient", &half_linear_input_gradient);
   m.impl("sddmm_sum", &sddmm_sum);
   m.impl("sddmm_sum_plan", &sddmm_sum_plan);
   m.impl("sddmm_sum_planned", &sddmm_sum_planned);

@@ -227,6 +227,12 @@ class PlanCache(_TopologyCache):
                               m, n, k, row_indices, row_offsets, column_indices),
                           row_indices, row_offsets, column_indices)
 
+    def half_linear(self, m, k, row_offsets, column_indices):
+        """Plan of the half-storage layer's weight gradient (ops.half_linear_plan)."""
+        return self._plan("half_linear", (m, k),
+                          lambda: ops.half_linear_plan(m, k, row_offsets, column_indices),
+                          row_offsets, column_indices)
+
     def attention(self, m, n, d, row_indices, row_offsets, column_indices):
         return self._plan("attention", (m, n, d),
                           lambda: ops.sparse_attention_plan(m, n, d, row_indices, row_offsets,
@@ -587,22 +593,28 @@ class HalfSparseLinearFunction(torch.autograd.Function):
     """``SparseLinear.forward`` for activations stored in float16 / bfloat16 (BASELINE
     config 5; the reference knows float32 only, src/left_replicated_spmm.cu:34-38):
     ``apply(m, k, values, row_indices, row_offsets, column_indices, x)`` with x [B, S, in]
-    -> [B, out, S] float32 -- the layout passes of modules/sparse_linear.py:89 sit INSIDE
-    the Function so that the half operand is what is kept for the backward pass:
+    -> [B, out, S] float32.
 
-      forward   xT = transpose(x) stays in half (one tiled pass, no widening);
-                y = left_spmm(W, xT), float32
-      backward  dW = sddmm_sum(dy, xT): the float32 gradient and the half activations go to
-                the kernels as they are -- where the matrix-core route serves the shape the
-                float32 operand enters as half planes, not rounded (sputnik_hip.h:
-                sddmm_sum_mixed); dx = transpose(W^T dy), narrowed to x's type in that pass.
-    """
+    At a layer's density and size all three products run on the matrix cores and read
+    their operands as the caller has them -- NO layout pass (csrc/sparse_linear_half.hip):
+    the weight as one densified image (made in the forward pass, kept for the backward),
+    x [B, S, in], dy [B, out, S]; float32 values and the float32 dy enter as half planes,
+    not rounded.  Elsewhere the typed operators with the layout passes of
+    modules/sparse_linear.py:89 inside the Function (the half operand is what is kept)."""
 
     @staticmethod
     def forward(ctx, m, k, values, row_indices, row_offsets, column_indices, x):
         ctx.shape = (m, k)
         ctx.topology = (row_indices, row_offsets, column_indices)
         ctx.in_dtype = x.dtype
+        batch, seq = x.size(0), x.size(1)
+        ctx.tiles = x.is_cuda and ops.half_linear_supported(m, k, seq, batch, column_indices.numel(),
+                                                            values.dtype, x.dtype)
+        if ctx.tiles:
+            x = x.contiguous()
+            image = ops.half_linear_image(m, k, values, row_offsets, column_indices, x.dtype)
+            ctx.save_for_backward(values, x, image)
+            return ops.half_linear_forward(m, image, values.dtype, x)
         dense = ops.transpose_last2(x)
         ctx.save_for_backward(values, dense)
         return _linear(m, k, values, row_indices, row_offsets, column_indices, dense)
@@ -611,9 +623,26 @@ class HalfSparseLinearFunction(torch.autograd.Function):
     def backward(ctx, grad_output):
         m, k = ctx.shape
         row_indices, row_offsets, column_indices = ctx.topology
-        values, dense = ctx.saved_tensors
         grad_output = _contiguous(grad_output)
         grad_values = grad_x = None
+        if ctx.tiles:
+            values, x, image = ctx.saved_tensors
+            batch, seq = x.size(0), x.size(1)
+            # dy as planes, once for both gradients (float32 dy), or as it is (dy in x's type)
+            planes = grad_output.dtype == torch.float32
+            grad = ops.half_planes(grad_output, x.dtype) if planes else grad_output.to(x.dtype)
+            if ctx.needs_input_grad[2]:
+                plan = None if _plans is None else _plans.half_linear(m, k, row_offsets, column_indices)
+                grad_values = ops.half_linear_weight_gradient(m, row_offsets, column_indices, grad, planes,
+                                                              x, plan)
+            if ctx.needs_input_grad[6]:
+                grad_x = ops.half_linear_input_gradient(m, k, grad, planes, image, values.dtype, x, batch, seq)
+                if grad_x is None:   # (bfloat16 tiles with float32 values AND a float32 dy)
+                    grad_dense = _spmm_transposed(m, k, values, row_offsets, column_indices, grad_output,
+                                                  left=True)
+                    grad_x = ops.transpose_last2(grad_dense, ctx.in_dtype)
+            return None, None, grad_values, None, None, None, grad_x
+        values, dense = ctx.saved_tensors
         if ctx.needs_input_grad[2]:
             grad_values = _sddmm(m, k, row_indices, row_offsets, column_indices, grad_output, dense,
                                  sum_replicas=True)

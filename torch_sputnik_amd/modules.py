@@ -59,7 +59,14 @@ class SparseLinear(nn.Module):
                 return HalfSparseLinearFunction.apply(
                     self.output_features, self.input_features, self.values, self.row_indices,
                     self.row_offsets, self.column_indices, x)
-            return functional._linear(self.output_features, self.input_features, self.values.detach(),
+            values = self.values.detach()
+            if x.is_cuda and ops.half_linear_supported(self.output_features, self.input_features, x.size(1),
+                                                       x.size(0), self.column_indices.numel(), values.dtype,
+                                                       x.dtype):
+                image = ops.half_linear_image(self.output_features, self.input_features, values,
+                                              self.row_offsets, self.column_indices, x.dtype)
+                return ops.half_linear_forward(self.output_features, image, values.dtype, x)
+            return functional._linear(self.output_features, self.input_features, values,
                                       self.row_indices, self.row_offsets, self.column_indices,
                                       ops.transpose_last2(x))
         return self.project(functional._to_operand(x))

@@ -43,6 +43,70 @@ def left_spmm_half_tiles(m, k, values, row_offsets, column_indices, dense_matrix
     return out if out.numel() else None
 
 
+# ---- a sparse layer on half-stored activations: the three products on the matrix cores with
+# no layout pass (csrc/sparse_linear_half.hip; include/sputnik_hip.h: sparse_linear_half_*) ----
+_HALF_CODES = None
+
+
+def _half_code(dtype):
+    global _HALF_CODES
+    if _HALF_CODES is None:
+        import torch
+        _HALF_CODES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+    return _HALF_CODES[dtype]
+
+
+def half_linear_supported(out_features, in_features, seq, batch, nonzeros, values_dtype, tile_dtype):
+    """Whether forward, weight gradient and input gradient of a sparse layer with these
+    sizes take the matrix-core route (they share the weight's image and dy's planes)."""
+    from . import capi
+    try:
+        vt, tt = _half_code(values_dtype), _half_code(tile_dtype)
+    except KeyError:
+        return False
+    if tt == 0:
+        return False
+    return bool(capi.lib().sputnik_hip_sparse_linear_half_supported(
+        int(out_features), int(in_features), int(seq), int(batch), int(nonzeros), vt, tt))
+
+
+def half_linear_image(out_features, in_features, values, row_offsets, column_indices, tile_dtype):
+    """The weight as a zeroed [planes, out, in] image of `tile_dtype` with the CSR values
+    scattered in (float32 values: half planes whose sum is the value)."""
+    return _ops.half_linear_image(int(out_features), int(in_features), values, row_offsets,
+                                  column_indices, _half_code(tile_dtype))
+
+
+def half_planes(t, tile_dtype):
+    """A float32 tensor as half planes whose (scaled) sum is the value."""
+    return _ops.half_planes(t, _half_code(tile_dtype))
+
+
+def half_linear_forward(out_features, image, values_dtype, x):
+    """y [batch, out, seq] float32 from x [batch, seq, in] (float16 / bfloat16), no layout pass."""
+    return _ops.half_linear_forward(int(out_features), image, _half_code(values_dtype), x)
+
+
+def half_linear_plan(out_features, in_features, row_offsets, column_indices):
+    return _ops.half_linear_plan(int(out_features), int(in_features), row_offsets, column_indices)
+
+
+def half_linear_weight_gradient(out_features, row_offsets, column_indices, grad, grad_is_planes, x,
+                                plan=None):
+    """dW [nnz] float32 = sum over the batch of dy x, sampled at the weight's mask; `grad` is
+    dy [batch, out, seq] in x's type, or the planes of the float32 dy (`half_planes`)."""
+    return _ops.half_linear_weight_gradient(int(out_features), row_offsets, column_indices, grad,
+                                            bool(grad_is_planes), x, plan)
+
+
+def half_linear_input_gradient(out_features, in_features, grad, grad_is_planes, image, values_dtype,
+                               like, batch, seq):
+    """dx [batch, seq, in] in `like`'s type, or None where the route does not serve the call."""
+    out = _ops.half_linear_input_gradient(int(out_features), int(in_features), grad, bool(grad_is_planes),
+                                          image, _half_code(values_dtype), like, int(batch), int(seq))
+    return out if out.numel() else None
+
+
 # BASELINE.json names this op left_replicated_spmm; the binding exports left_spmm.
 left_replicated_spmm = left_spmm
 
