@@ -288,6 +288,19 @@ def test_sddmm_sum_half_capi_vs_oracle(capi, dev, sddmm_sum_slab, dtype, planned
     assert rel_err(got[None, :], want[None, :].astype(np.float32), ro) < TOL
 
 
+@pytest.fixture(params=["tile_rows_128", "tile_rows_256"])
+def mfma_tile(request, monkeypatch):
+    """SPUTNIK_HIP_MFMA_TILE: the matrix-core kernels' tile has 128 rows (four waves, two LDS
+    stages, two workgroups per CU) or, where the output has 256 rows or more, 256 (eight
+    waves, three stages); by itself the library picks by shape."""
+    from torch_sputnik_amd import capi
+    monkeypatch.setenv("SPUTNIK_HIP_MFMA_TILE", request.param.rsplit("_", 1)[1])
+    capi.reload_options()
+    yield request.param
+    monkeypatch.delenv("SPUTNIK_HIP_MFMA_TILE", raising=False)
+    capi.reload_options()
+
+
 @pytest.fixture
 def sddmm_mfma(monkeypatch):
     """SPUTNIK_HIP_SDDMM_KERNEL=mfma: the summed product of half operands takes the
@@ -325,7 +338,7 @@ def _sddmm_sum_typed(capi, dev, m, k, n, replicas, topo, lhs, rhs, with_scratch=
     (384, 1024, 640, 0.95, 2, 4),    # very sparse: most rows have no entry in a tile
     (300, 256, 300, 0.0, 2, 4),      # a dense mask: every tile element is sampled
 ])
-def test_sddmm_sum_mfma_vs_oracle(capi, dev, sddmm_mfma, dtype, m, k, n, sparsity, replicas, round_to):
+def test_sddmm_sum_mfma_vs_oracle(capi, dev, sddmm_mfma, mfma_tile, dtype, m, k, n, sparsity, replicas, round_to):
     """The matrix-core route of the summed SDDMM (the weight gradient of
     modules/sparse_linear.py:44-49 on half storage) against the C oracle on the
     rounded operands: products exact, float32 sums."""
@@ -353,7 +366,7 @@ def test_sddmm_sum_mfma_vs_oracle(capi, dev, sddmm_mfma, dtype, m, k, n, sparsit
 
 @pytest.mark.parametrize("dtype", HALF_TYPES)
 @pytest.mark.parametrize("shuffled", ["every_row", "one_row"])
-def test_sddmm_sum_mfma_unsorted_columns_and_views(capi, dev, sddmm_mfma, dtype, shuffled):
+def test_sddmm_sum_mfma_unsorted_columns_and_views(capi, dev, sddmm_mfma, mfma_tile, dtype, shuffled):
     """Rows whose columns do not ascend (the plan marks them; a tile that holds one finds
     its entries by a flat walk over its rows' entries, the other tiles by the plan), an
     unaligned column_indices pointer (entry-wise index loads in the walk), and exact
@@ -398,8 +411,8 @@ def _sddmm_sum_mixed(capi, dev, m, k, n, replicas, topo, lhs, rhs, planned=False
     (300, 256, 300, 0.7, 4, 3e-4),     # the subnormals by its 2^11 scale (values 3e-7 .. 3e-4)
     (256, 128, 256, 0.7, 2, 900.0),
 ])
-def test_sddmm_sum_mixed_mfma_vs_oracle(capi, dev, sddmm_mfma, dtype, wide, m, k, n, sparsity, replicas,
-                                        magnitude):
+def test_sddmm_sum_mixed_mfma_vs_oracle(capi, dev, sddmm_mfma, mfma_tile, dtype, wide, m, k, n, sparsity,
+                                        replicas, magnitude):
     """A (float32, half) pair: the float32 operand -- the incoming gradient of
     modules/sparse_linear.py:44-49 when only the activations are stored in half precision --
     enters the matrix-core product as half planes whose sum is the value, NOT rounded to
@@ -568,7 +581,7 @@ def _operand(x, kind, tile, dev):
     (130, 256, 72, 0.7, 2),      # the reference's test width (tests/test_spmm.py:13): one partial tile
     (384, 512, 264, 0.95, 2),    # very sparse
 ])
-def test_left_spmm_half_tiles_vs_oracle(capi, dev, spmm_mfma, tile, values_kind, dense_kind, m, k, n,
+def test_left_spmm_half_tiles_vs_oracle(capi, dev, spmm_mfma, mfma_tile, tile, values_kind, dense_kind, m, k, n,
                                         sparsity, replicas):
     """left_spmm as a dense contraction on the matrix cores: the densified weight against
     [R, k, n], every pairing of (float32 | half) values and dense operand -- a float32
@@ -605,11 +618,11 @@ def test_left_spmm_half_tiles_vs_oracle(capi, dev, spmm_mfma, tile, values_kind,
     assert torch.equal(again, out)
 
 
-def test_left_spmm_half_tiles_exact_integers_and_guard(capi, dev, spmm_mfma):
+def test_left_spmm_half_tiles_exact_integers_and_guard(capi, dev, spmm_mfma, mfma_tile):
     """Small integers (every product and sum exact): the tile kernel's fragment maps --
     rows against columns, the transposing reads of the [k][n] operand -- must give the
     exact matrix; nothing outside [R, m, n] is written (ragged tiles)."""
-    m, k, n, replicas = 200, 128, 136, 2
+    m, k, n, replicas = 328, 128, 136, 2
     _, _, ri, ro, ci = make_csr(m, k, 0.6, seed=19, round_to=1)
     rng = np.random.default_rng(20)
     v32 = rng.integers(-4, 5, size=len(ci)).astype(np.float32)
@@ -634,8 +647,8 @@ def test_left_spmm_half_tiles_exact_integers_and_guard(capi, dev, spmm_mfma):
     (192, 320, 192, 3, 0.8),     # ragged tiles in every product (192 = 128 + 64, 320 = 2 x 128 + 64)
     (384, 256, 448, 2, 0.95),    # very sparse
 ])
-def test_half_linear_three_products_vs_oracle(spmm_mfma, dev, tile, values_kind, grad_kind, out_f, in_f, seq,
-                                              batch, sparsity):
+def test_half_linear_three_products_vs_oracle(spmm_mfma, mfma_tile, dev, tile, values_kind, grad_kind, out_f,
+                                              in_f, seq, batch, sparsity):
     """A sparse layer on half-stored activations (csrc/sparse_linear_half.hip): forward,
     weight gradient and input gradient on the matrix cores, every operand read in the
     layout the caller has it (x [B, S, in], dy [B, out, S], one image of the weight) --
@@ -676,11 +689,11 @@ def test_half_linear_three_products_vs_oracle(spmm_mfma, dev, tile, values_kind,
     assert half_err(dx.float().cpu().numpy(), want_dx, tile) < TOL
 
 
-def test_half_linear_exact_integers(spmm_mfma, dev):
+def test_half_linear_exact_integers(spmm_mfma, mfma_tile, dev):
     """Small integers (every product and sum exact): the four operand layouts' fragment
     maps must give the exact matrices."""
     from torch_sputnik_amd import ops
-    out_f, in_f, seq, batch = 192, 128, 192, 2
+    out_f, in_f, seq, batch = 320, 128, 384, 2     # (256-row tiles: one whole, one ragged)
     _, _, ri, ro, ci = make_csr(out_f, in_f, 0.6, seed=23, round_to=1)
     rng = np.random.default_rng(24)
     v32 = rng.integers(-4, 5, size=len(ci)).astype(np.float32)

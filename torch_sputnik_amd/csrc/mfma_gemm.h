@@ -29,14 +29,21 @@
 // Epilogues: kDense (float32 tile, bias / ReLU), kDenseHalf (rounded to T), kSampled (the
 // tile goes to LDS and the entries of a CSR mask that fall into it are stored: SDDMM).
 //
-// What bounds it: a 128 x 128 x 64 step moves 32 KiB from L2 to LDS for 2.1 MFLOP -- 64
-// flop per byte; the chip delivers ~18 TB/s into LDS (MI355X_MICROARCH.md, "Indexed rows"),
-// i.e. ~1.15 PFLOP/s for this tile whatever the MFMA peak.  Measured 0.87 (config 5).
+// Where the time of a launch goes (config 5's forward pass, one plane pair, 34.4 dense GFLOP;
+// SPUTNIK_HIP_MFMA_DEBUG switches parts off, tools/half_linear_bench.py): 40.4 us, of which
+// 19.6 us remain with copies, fragment reads and MFMAs all switched off -- launch, the first
+// tiles' latency, 32 rendezvous and 33.5 MB of output stores; the steps themselves take the
+// other ~21 us = 1.6 PFLOP/s (dense).  Two rules of the epilogues come from that accounting:
+// vmcnt retires in order, so NO load may sit between the stores (a per-row bias load in front
+// of every store pair made each store wait for all earlier ones: 28 us of skeleton instead of
+// 19.6), and the steps' tile origins advance by scalar additions (a division per step cost
+// as much as the step's arithmetic).
 #pragma once
 
 #include <type_traits>
 
 #include "mfma_tiles.h"
+#include "options.h"
 
 namespace sputnik_hip {
 namespace mfma_tiles {
@@ -92,29 +99,44 @@ struct GemmOut {
   const int* plan;         // sddmm_mfma_plan_kernel's table, or null
   int nonzeros;
   int vector_columns;
+  // SPUTNIK_HIP_MFMA_DEBUG (timing experiments, wrong results): 1 no MFMAs, 2 no copies after
+  // the prologue's, 4 no fragment reads
+  int debug;
 };
 
-// Per-lane source byte offsets of this wave's four copy pieces of one operand's tile, and
-// its fragment read addresses inside a stage (relative to the operand's 16 KiB).
-template <bool KM>
+// One operand's tile of a step: R rows (R = 128 or 256: the extent of m or n it covers) by 64
+// k, copied by W waves (W * PIECES pieces of 1 KiB).  Per-lane source byte offsets of this
+// wave's pieces, the pieces' LDS offsets, and the fragment read addresses of a wave's 64-row
+// block (all relative to the operand's place in a stage).
+template <bool KM, int R, int W>
 struct TileMap {
+  static constexpr int kBytes = R * kStep * 2;             // 16 / 32 KiB
+  static constexpr int kPieces = kBytes / 1024 / W;        // per wave
+  static constexpr int kRowBytes = KM ? R * 2 : kStep * 2; // 256 / 512 (k-major), 128 (k-contiguous)
+  // LDS offset of this wave's piece j
+  static __device__ __forceinline__ int piece_offset(int wave, int j) { return (wave + W * j) * 1024; }
   // rows: extent of the r dimension (m or n); r0: first r of the tile
-  static __device__ __forceinline__ void copy_offsets(unsigned (&off)[4], int wave, int lane, int r0,
+  static __device__ __forceinline__ void copy_offsets(unsigned (&off)[kPieces], int wave, int lane, int r0,
                                                       int rows, int64_t ld) {
     if constexpr (!KM) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row = 8 * wave + 32 * j + (lane >> 3);
+      for (int j = 0; j < kPieces; ++j) {
+        const int row = 8 * (wave + W * j) + (lane >> 3);
         const unsigned slot = static_cast<unsigned>((lane & 7) ^ ((row >> 1) & 7)) * 16u;
         // (rows beyond the matrix are clamped onto its last row: never stored / sampled)
         off[j] = static_cast<unsigned>(min(r0 + row, rows - 1) - r0) * static_cast<unsigned>(ld) * 2u + slot;
       }
     } else {
       const int last_chunk = (rows - r0) / 8 - 1;   // (rows is a multiple of 8)
+      constexpr int kPerRow = kRowBytes / 16;        // 16-byte chunks per k row: 16 / 32
+      constexpr int kRowsPerPiece = 64 / kPerRow;    // 4 / 2
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int krow = 4 * (wave + 4 * j) + (lane >> 4);
-        const int chunk = (lane & 15) ^ ((((lane >> 4) & 3) << 2) | wave);
+      for (int j = 0; j < kPieces; ++j) {
+        const int in_piece = lane / kPerRow;                       // k row inside the piece
+        const int krow = kRowsPerPiece * (wave + W * j) + in_piece;
+        const int at = lane % kPerRow;                             // LDS chunk inside the row
+        // (a 512-byte row is two 256-byte bank rows, swizzled each on its own)
+        const int chunk = (at & ~15) | ((at & 15) ^ (((krow & 3) << 2) | ((krow >> 2) & 3)));
         off[j] = static_cast<unsigned>(krow) * static_cast<unsigned>(ld) * 2u +
                  static_cast<unsigned>(min(chunk, last_chunk)) * 16u;
       }
@@ -124,9 +146,9 @@ struct TileMap {
   static __device__ __forceinline__ int64_t tile_origin(int r0, int64_t k0, int64_t ld) {
     return KM ? k0 * ld + r0 : static_cast<int64_t>(r0) * ld + k0;
   }
-  // fragment addresses of the wave's two 32-row blocks at `r_in_tile` = w * 64:
+  // fragment addresses of the wave's two 32-row blocks at rows w * 64 of the tile:
   //   k-contiguous: addr[i][0] (k slot 0; slot 2 ks + (lane >> 5) is an XOR with ks * 32)
-  //   k-major:      addr[i][t] for the two transposing reads (k 0-3, 4-7) at ks = 0; + ks * 4096
+  //   k-major:      addr[i][t] for the two transposing reads (k 0-3, 4-7) at ks = 0; + ks * 16 rows
   static __device__ __forceinline__ void fragment_addresses(unsigned (&addr)[2][2], int w, int lane) {
     if constexpr (!KM) {
 #pragma unroll
@@ -146,7 +168,8 @@ struct TileMap {
           const int row = 8 * h + 4 * t + q;
           const int chunk = w * 8 + i * 4 + 2 * g1 + (p >> 1);
           const int swz = ((row & 3) << 2) | ((row >> 2) & 3);
-          addr[i][t] = static_cast<unsigned>(row * 256 + ((chunk ^ swz) * 16) + 8 * (p & 1));
+          addr[i][t] = static_cast<unsigned>(row * kRowBytes + ((chunk & ~15) | ((chunk & 15) ^ swz)) * 16 +
+                                             8 * (p & 1));
         }
     }
   }
@@ -157,26 +180,44 @@ struct TileMap {
     } else {
       typedef short s8v __attribute__((__vector_size__(16)));
       const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-          (__attribute__((address_space(3))) s4v*)(stage_operand + (addr[0] + ks * 4096u)));
+          (__attribute__((address_space(3))) s4v*)(stage_operand + (addr[0] + ks * (16u * kRowBytes))));
       const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-          (__attribute__((address_space(3))) s4v*)(stage_operand + (addr[1] + ks * 4096u)));
+          (__attribute__((address_space(3))) s4v*)(stage_operand + (addr[1] + ks * (16u * kRowBytes))));
       const s8v both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
       return __builtin_bit_cast(frag, both);
     }
   }
 };
 
-template <typename T, bool AKM, bool BKM, int PA, int PB, int ACCS, int EPI>
-__global__ __launch_bounds__(256, 2) void mfma_gemm_kernel(
+// Geometry of a workgroup's tile: TM rows (128: four waves, two LDS stages, two workgroups
+// per CU; 256: eight waves, three stages -- the copies of two steps in flight -- one
+// workgroup per CU, 87 flop per staged byte instead of 64) by 128 columns.
+template <int TM, int EPI>
+struct TileGeometry {
+  static constexpr int kWaves = TM / 32;
+  static constexpr int kThreads = 64 * kWaves;
+  static constexpr int kStages = TM == 256 ? 3 : 2;
+  static constexpr int kABytes = TM * kStep * 2, kBBytes = kTile * kStep * 2;
+  static constexpr int kStage = kABytes + kBBytes;
+  static constexpr int kTileFloats = TM * kPitch;                 // the sampled epilogue's tile
+  static constexpr int kBounds = 4 * (TM + 4);
+  static constexpr int kSmem = EPI == kSampled && kTileFloats * 4 + kBounds > kStages * kStage
+                                   ? kTileFloats * 4 + kBounds : kStages * kStage;
+};
+
+template <typename T, int TM, bool AKM, bool BKM, int PA, int PB, int ACCS, int EPI>
+__global__ __launch_bounds__((TileGeometry<TM, EPI>::kThreads), (TM == 256 ? 1 : 2)) void mfma_gemm_kernel(
     int m, int n, int k, int tiles_m, int tiles_n, int steps_per_replica, int total_steps,
     int outers, int outer_is_split, GemmOperand a_op, GemmOperand b_op, GemmOut out,
     float low_scale) {
   using H = Half8<T>;
   using frag = typename H::type;
   using P = Passes<PA, PB>;
+  using G = TileGeometry<TM, EPI>;
+  using MapA = TileMap<AKM, TM, G::kWaves>;
+  using MapB = TileMap<BKM, kTile, G::kWaves>;
   constexpr int NP = P::count();
-  constexpr int kSmem = EPI == kSampled ? kLdsBytes : 2 * kStageBytes;
-  __shared__ __attribute__((aligned(16))) char smem[kSmem];
+  __shared__ __attribute__((aligned(16))) char smem[G::kSmem];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (an SGPR: M0 takes it)
@@ -197,35 +238,61 @@ __global__ __launch_bounds__(256, 2) void mfma_gemm_kernel(
     ct = (work / tiles_m) % tiles_n;
     outer = work / (tiles_m * tiles_n);
   }
-  const int r0 = rt * kTile, c0 = ct * kTile;
+  const int r0 = rt * TM, c0 = ct * kTile;
   // the (replica, k step) pairs this workgroup reduces
   const int s_begin = outer_is_split ? static_cast<int>(static_cast<int64_t>(total_steps) * outer / outers)
                                      : outer * steps_per_replica;
   const int s_end = outer_is_split ? static_cast<int>(static_cast<int64_t>(total_steps) * (outer + 1) / outers)
                                    : (outer + 1) * steps_per_replica;
 
-  unsigned a_off[4], b_off[4];
-  TileMap<AKM>::copy_offsets(a_off, wave, lane, r0, m, a_op.ld);
-  TileMap<BKM>::copy_offsets(b_off, wave, lane, c0, n, b_op.ld);
-  const T* a_base = static_cast<const T*>(a_op.base);
-  const T* b_base = static_cast<const T*>(b_op.base);
-  auto stage = [&](int s, int pass, int buffer) {
-    const int replica = s / steps_per_replica;
-    const int64_t k0 = static_cast<int64_t>(s - replica * steps_per_replica) * kStep;
-    const T* a = uniform_ptr(a_base + replica * a_op.replica_stride + P::a_of(pass) * a_op.plane_stride +
-                             TileMap<AKM>::tile_origin(r0, k0, a_op.ld));
-    const T* b = uniform_ptr(b_base + replica * b_op.replica_stride + P::b_of(pass) * b_op.plane_stride +
-                             TileMap<BKM>::tile_origin(c0, k0, b_op.ld));
-    const char* dst = smem + buffer * kStageBytes + wave * 1024;
+  unsigned a_off[MapA::kPieces], b_off[MapB::kPieces];
+  MapA::copy_offsets(a_off, wave, lane, r0, m, a_op.ld);
+  MapB::copy_offsets(b_off, wave, lane, c0, n, b_op.ld);
+  // The operands' tile origins step by step, advanced by scalar additions (a division per
+  // step -- which replica, which k -- cost as much as the step's arithmetic).
+  struct StepAt {
+    const T* a;
+    const T* b;
+    int kk;   // k step inside the replica
+  };
+  const int64_t a_step = AKM ? kStep * a_op.ld : kStep, b_step = BKM ? kStep * b_op.ld : kStep;
+  const int64_t a_jump = a_op.replica_stride - (steps_per_replica - 1) * a_step;
+  const int64_t b_jump = b_op.replica_stride - (steps_per_replica - 1) * b_step;
+  auto advanced = [&](StepAt at) {
+    if (++at.kk == steps_per_replica) {
+      at.kk = 0;
+      at.a += a_jump;
+      at.b += b_jump;
+    } else {
+      at.a += a_step;
+      at.b += b_step;
+    }
+    return at;
+  };
+  StepAt at0;
+  {
+    const int replica = s_begin / steps_per_replica;
+    at0.kk = s_begin - replica * steps_per_replica;
+    at0.a = uniform_ptr(static_cast<const T*>(a_op.base) + replica * a_op.replica_stride +
+                        MapA::tile_origin(r0, static_cast<int64_t>(at0.kk) * kStep, a_op.ld));
+    at0.b = uniform_ptr(static_cast<const T*>(b_op.base) + replica * b_op.replica_stride +
+                        MapB::tile_origin(c0, static_cast<int64_t>(at0.kk) * kStep, b_op.ld));
+  }
+  auto stage = [&](const StepAt& at, int pass, unsigned buffer_offset, bool first) {
+    if ((out.debug & 2) && !first) return;
+    const T* a = at.a + P::a_of(pass) * a_op.plane_stride;
+    const T* b = at.b + P::b_of(pass) * b_op.plane_stride;
+    const char* dst = smem + buffer_offset;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) copy_piece(a, a_off[j], dst + j * 4096);
+    for (int j = 0; j < MapA::kPieces; ++j) copy_piece(a, a_off[j], dst + MapA::piece_offset(wave, j));
 #pragma unroll
-    for (int j = 0; j < 4; ++j) copy_piece(b, b_off[j], dst + kOperandBytes + j * 4096);
+    for (int j = 0; j < MapB::kPieces; ++j)
+      copy_piece(b, b_off[j], dst + G::kABytes + MapB::piece_offset(wave, j));
   };
 
   unsigned fa[2][2], fb[2][2];
-  TileMap<AKM>::fragment_addresses(fa, wr, lane);
-  TileMap<BKM>::fragment_addresses(fb, wc, lane);
+  MapA::fragment_addresses(fa, wr, lane);
+  MapB::fragment_addresses(fb, wc, lane);
 
   f32x16 acc[ACCS][2][2];
 #pragma unroll
@@ -235,47 +302,112 @@ __global__ __launch_bounds__(256, 2) void mfma_gemm_kernel(
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[z][i][j] = f32x16{};
 
-  if (s_begin < s_end) {
-    stage(s_begin, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-  unsigned stage_base = 0;
-  for (int s = s_begin; s < s_end; ++s) {
-#pragma unroll
-    for (int pass = 0; pass < NP; ++pass) {
-      const int other = stage_base == 0 ? 1 : 0;
-      if (pass + 1 < NP) {
-        stage(s, pass + 1, other);
-      } else if (s + 1 < s_end) {
-        stage(s + 1, 0, other);
-      }
-      const char* sa = smem + stage_base;
-      const char* sb = sa + kOperandBytes;
-      frag a[2][4], b[2][4];
+  // one tile product: fragments from the stage at `offset`, 16 MFMAs
+  auto multiply = [&](unsigned offset, bool low) {
+    const char* sa = smem + offset;
+    const char* sb = sa + G::kABytes;
+    frag a[2][4], b[2][4];
+    if (out.debug & 4) {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          a[i][ks] = TileMap<AKM>::template read<frag>(sa, fa[i], ks);
-          b[i][ks] = TileMap<BKM>::template read<frag>(sb, fb[i], ks);
+          a[i][ks] = frag{};
+          b[i][ks] = frag{};
+          asm volatile("" : "+v"(a[i][ks]), "+v"(b[i][ks]));
         }
-      constexpr int kOne = ACCS == 2 ? 1 : 0;
-      const bool low = P::a_of(pass) + P::b_of(pass) > 0;   // (a compile-time constant once unrolled)
+    } else {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) {
+          a[i][ks] = MapA::template read<frag>(sa, fa[i], ks);
+          b[i][ks] = MapB::template read<frag>(sb, fb[i], ks);
+        }
+    }
+    if (out.debug & 1) {
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            if (low) acc[kOne][i][j] = H::mfma(a[i][ks], b[j][ks], acc[kOne][i][j]);
-            else acc[0][i][j] = H::mfma(a[i][ks], b[j][ks], acc[0][i][j]);
-          }
-      // the next tiles have landed (this wave's copies), and every wave is done with these
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(a[i][ks]), "v"(b[i][ks]));
+      return;
+    }
+    constexpr int kOne = ACCS == 2 ? 1 : 0;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (low) acc[kOne][i][j] = H::mfma(a[i][ks], b[j][ks], acc[kOne][i][j]);
+          else acc[0][i][j] = H::mfma(a[i][ks], b[j][ks], acc[0][i][j]);
+        }
+  };
+
+  if constexpr (G::kStages == 2) {
+    if (s_begin < s_end) {
+      stage(at0, 0, 0, true);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      stage_base ^= static_cast<unsigned>(kStageBytes);
     }
+    unsigned stage_base = 0;
+    StepAt at = at0;
+    for (int s = s_begin; s < s_end; ++s) {
+      const StepAt next = advanced(at);
+#pragma unroll
+      for (int pass = 0; pass < NP; ++pass) {
+        const unsigned other = stage_base == 0 ? G::kStage : 0;
+        if (pass + 1 < NP) {
+          stage(at, pass + 1, other, s == s_begin);
+        } else if (s + 1 < s_end) {
+          stage(next, 0, other, false);
+        }
+        multiply(stage_base, P::a_of(pass) + P::b_of(pass) > 0);
+        // the next tiles have landed (this wave's copies), and every wave is done with these
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        stage_base = other;
+      }
+      at = next;
+    }
+  } else {
+    // Three stages: the copies of the NEXT TWO tile products are in flight while one is
+    // multiplied.  Per product q: wait for this wave's copies of q (all but the youngest
+    // stage's -- counted, the copies are the loop's only vector-memory operations),
+    // rendezvous (every wave's copies of q have landed, and every wave is done reading the
+    // stage that q + 2 goes into: it held q - 1), issue q + 2, multiply q.
+    constexpr int kCopies = MapA::kPieces + MapB::kPieces;   // per wave and stage
+    const int products = (s_end - s_begin) * NP;
+    // (q = (s - s_begin) * NP + pass: product q + d belongs to step s + (pass + d) / NP)
+    StepAt at[3];
+    at[0] = at0;
+    at[1] = advanced(at[0]);
+    at[2] = advanced(at[1]);
+    if (products > 0) stage(at[0], 0, 0, true);
+    if (products > 1) stage(at[1 / NP], 1 % NP, G::kStage, NP > 1);
+    unsigned cur = 0, nxt = G::kStage, nxt2 = 2 * G::kStage;
+    int q = 0;
+    for (int s = s_begin; s < s_end; ++s) {
+#pragma unroll
+      for (int pass = 0; pass < NP; ++pass, ++q) {
+        if (q + 1 < products) {
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kCopies) : "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (q + 2 < products) stage(at[(pass + 2) / NP], (pass + 2) % NP, nxt2, false);
+        multiply(cur, P::a_of(pass) + P::b_of(pass) > 0);
+        const unsigned t = cur;
+        cur = nxt;
+        nxt = nxt2;
+        nxt2 = t;
+      }
+      at[0] = at[1];
+      at[1] = at[2];
+      at[2] = advanced(at[2]);
+    }
+    __syncthreads();   // (the epilogue below writes over the stages)
   }
 
   auto value = [&](int i, int j, int reg) {
@@ -284,28 +416,46 @@ __global__ __launch_bounds__(256, 2) void mfma_gemm_kernel(
 
   if constexpr (EPI != kSampled) {
     // ---- the accumulators' 32 x 32 blocks (column = lane & 31: 128- / 64-byte runs) ----
+    // (vmcnt retires in order: a load between the stores would make every store wait for
+    // the ones before it -- the bias values are all fetched BEFORE the first store, and
+    // the path without a bias holds no load at all)
     using TO = typename std::conditional<EPI == kDenseHalf, T, float>::type;
     TO* __restrict__ o = static_cast<TO*>(out.dense) + outer * out.outer_stride;
+    const int row_base = r0 + wr * 64 + 4 * (lane >> 5);
+    const int col_base = c0 + wc * 64 + (lane & 31);
+    auto store_all = [&](auto bias_of) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int row = r0 + wr * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-        if (row < m) {
-          const float bv = out.bias != nullptr ? out.bias[row] : 0.f;
+        for (int reg = 0; reg < 16; ++reg) {
+          const int row = row_base + i * 32 + (reg & 3) + 8 * (reg >> 2);
+          if (row < m) {
+            TO* __restrict__ orow = o + static_cast<int64_t>(row) * out.ld;
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int col = c0 + wc * 64 + j * 32 + (lane & 31);
-            float v = value(i, j, reg) + bv;
-            if (out.relu) v = fmaxf(v, 0.f);
-            if (col < n) o[static_cast<int64_t>(row) * out.ld + col] = static_cast<TO>(v);
+            for (int j = 0; j < 2; ++j) {
+              const int col = col_base + j * 32;
+              float v = value(i, j, reg) + bias_of(i, reg);
+              if (out.relu) v = fmaxf(v, 0.f);
+              if (col < n) orow[col] = static_cast<TO>(v);
+            }
           }
         }
-      }
+    };
+    if (out.bias == nullptr) {
+      store_all([](int, int) { return 0.f; });
+    } else {
+      float bv[2][16];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+          bv[i][reg] = out.bias[min(row_base + i * 32 + (reg & 3) + 8 * (reg >> 2), m - 1)];
+      store_all([&](int i, int reg) { return bv[i][reg]; });
+    }
   } else {
     // ---- the tile to LDS, then the mask rows' entries that fall into it ----
     float* tile_lds = reinterpret_cast<float*>(smem);
-    int* bounds = reinterpret_cast<int*>(smem + kTileBytes);   // [kTile + 1]
+    int* bounds = reinterpret_cast<int*>(smem + G::kTileFloats * 4);   // [TM + 1]
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -322,48 +472,69 @@ __global__ __launch_bounds__(256, 2) void mfma_gemm_kernel(
     // rows all have ascending columns, a row's entries inside this tile are one known run.
     bool by_table = out.plan != nullptr;
     if (by_table) {
-      const int ok = threadIdx.x < kTile ? out.plan[min(r0 + static_cast<int>(threadIdx.x), m - 1)] : 1;
+      const int ok = threadIdx.x < TM ? out.plan[min(r0 + static_cast<int>(threadIdx.x), m - 1)] : 1;
       by_table = __syncthreads_and(ok) != 0;
     } else {
       __syncthreads();
     }
     if (by_table) {
       const int* table = out.plan + plan_rows(m);
+      constexpr int kGroups = G::kThreads / 16;
       const int group = threadIdx.x >> 4, l16 = threadIdx.x & 15;
       int from[8], to[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {   // (all bounds requested before the first is used)
-        const int row = r0 + group + 16 * j;
+        const int row = r0 + group + kGroups * j;
         const int* run = table + static_cast<int64_t>(min(row, m - 1)) * (tiles_n + 1) + ct;
         from[j] = run[0];
         to[j] = row < m ? run[1] : run[0];
       }
+      // vmcnt retires in order, so a column load behind a store waits for that store: the
+      // first 32 entries of every row's run -- all of them at layer densities -- have their
+      // columns fetched BEFORE the first store; longer runs (dense masks) go on below
+      int cols[8][2];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int p = from[j] + l16 + 16 * e;
+          cols[j][e] = p < to[j] ? column_indices[p] : c0;
+        }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float* tile_row = tile_lds + (group + 16 * j) * kPitch - c0;
-        for (int p = from[j] + l16; p < to[j]; p += 16) o[p] = tile_row[column_indices[p]];
+        const float* tile_row = tile_lds + (group + kGroups * j) * kPitch - c0;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int p = from[j] + l16 + 16 * e;
+          if (p < to[j]) o[p] = tile_row[cols[j][e]];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float* tile_row = tile_lds + (group + kGroups * j) * kPitch - c0;
+        for (int p = from[j] + l16 + 32; p < to[j]; p += 16) o[p] = tile_row[column_indices[p]];
       }
       return;
     }
     // No plan, or a row whose columns do not ascend: the workgroup walks the CSR entries of
     // its 128 rows FLAT (they are contiguous in column_indices), sixteen bytes per lane,
     // and stores those whose column lies in the tile.
-    if (threadIdx.x <= kTile)
+    if (threadIdx.x <= TM)
       bounds[threadIdx.x] = out.row_offsets[min(r0 + static_cast<int>(threadIdx.x), m)];
     __syncthreads();
-    const int first = bounds[0], last = bounds[kTile];
+    const int first = bounds[0], last = bounds[TM];
     // a lane takes four consecutive entries per round; its row moves forward only
     int row = 0;
     const int start = (first & ~3) + 4 * static_cast<int>(threadIdx.x);
     {  // first row whose end lies behind `start` (binary search over the 128 bounds)
-      int lo = 0, hi = kTile;   // answer in [lo, hi]
+      int lo = 0, hi = TM;   // answer in [lo, hi]
       while (lo < hi) {
         const int mid = (lo + hi) >> 1;
         if (bounds[mid + 1] > start) hi = mid; else lo = mid + 1;
       }
       row = lo;
     }
-    for (int p = start; p < last; p += 4 * 256) {
+    for (int p = start; p < last; p += 4 * G::kThreads) {
       int cols[4];
       if (out.vector_columns && p + 3 < out.nonzeros) {
         const int4 v = *reinterpret_cast<const int4*>(column_indices + p);
@@ -375,7 +546,7 @@ __global__ __launch_bounds__(256, 2) void mfma_gemm_kernel(
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int q = p + e;
-        while (row < kTile && bounds[row + 1] <= q) ++row;
+        while (row < TM && bounds[row + 1] <= q) ++row;
         const unsigned c = static_cast<unsigned>(cols[e] - c0);
         if (q >= first && q < last && c < static_cast<unsigned>(kTile)) o[q] = tile_lds[row * kPitch + c];
       }
@@ -383,22 +554,39 @@ __global__ __launch_bounds__(256, 2) void mfma_gemm_kernel(
   }
 }
 
+// 256-row tiles (one workgroup of eight waves per CU, three stages: 87 flop per staged byte
+// instead of 64) are built and parity-tested, and NOT taken by default: measured at config 5
+// (tools/half_linear_bench.py, us, 128 / 256 rows): forward 40.4 / 41.7, weight gradient
+// 75.3 / 80.6, input gradient 72.4 / 79.4 (float32 values: 90.3 / 105.2) -- with the steps'
+// loop at 1.6 PFLOP/s either way, what is left of a launch at this size is its skeleton
+// (launch, first tiles, the output's stores), and one workgroup per CU hides less of it than
+// two.  SPUTNIK_HIP_MFMA_TILE=256 takes them wherever the output has 256 rows.
+inline bool wide_tile(int m, int n, int64_t independent_outputs) {
+  (void)n;
+  (void)independent_outputs;
+  return options().mfma_tile == 256 && m >= 256;
+}
+
 // Host side of a launch.  outers: independent outputs (dense) or workgroups that share a
 // tile of ONE summed output (sampled, outer_is_split).
-template <typename T, bool AKM, bool BKM, int PA, int PB, int ACCS, int EPI>
+template <typename T, int TM, bool AKM, bool BKM, int PA, int PB, int ACCS, int EPI>
 inline int launch_mfma_gemm(int m, int n, int k, int replicas, int outers, bool outer_is_split,
                             const GemmOperand& a, const GemmOperand& b, const GemmOut& out,
                             float low_scale, hipStream_t stream) {
-  const int tiles_m = ceil_div(m, kTile), tiles_n = ceil_div(n, kTile);
+  using G = TileGeometry<TM, EPI>;
+  const int tiles_m = ceil_div(m, TM), tiles_n = ceil_div(n, kTile);
   const int steps_per_replica = k / kStep;
   const int64_t total_steps = static_cast<int64_t>(replicas) * steps_per_replica;
   const int64_t blocks = static_cast<int64_t>(tiles_m) * tiles_n * outers;
   if (total_steps >= (int64_t{1} << 31) || blocks >= (int64_t{1} << 31) || outers < 1)
     return SPUTNIK_HIP_INVALID_ARGUMENT;
-  hipLaunchKernelGGL((mfma_gemm_kernel<T, AKM, BKM, PA, PB, ACCS, EPI>),
-                     dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, m, n, k, tiles_m,
-                     tiles_n, steps_per_replica, static_cast<int>(total_steps), outers,
-                     outer_is_split ? 1 : 0, a, b, out, low_scale);
+  GemmOut out_dbg = out;
+  out_dbg.debug = options().mfma_debug;
+  auto kernel = mfma_gemm_kernel<T, TM, AKM, BKM, PA, PB, ACCS, EPI>;
+  // (G::kSmem is static LDS: up to the CU's 160 KiB launches as it is)
+  hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(blocks)), dim3(G::kThreads), 0, stream, m, n, k,
+                     tiles_m, tiles_n, steps_per_replica, static_cast<int>(total_steps), outers,
+                     outer_is_split ? 1 : 0, a, b, out_dbg, low_scale);
   return launch_status();
 }
 
@@ -408,11 +596,16 @@ inline int launch_mfma_gemm(int m, int n, int k, int replicas, int outers, bool 
 template <bool AKM, bool BKM, int EPI>
 inline int launch_mfma_gemm_typed(int tile_type, int pa, int pb, int m, int n, int k, int replicas,
                                   int outers, bool outer_is_split, const GemmOperand& a,
-                                  const GemmOperand& b, const GemmOut& out, hipStream_t stream) {
+                                  const GemmOperand& b, const GemmOut& out, hipStream_t stream,
+                                  bool wide) {
   const float low = 1.f / kLowPlaneScale;
-#define SPUTNIK_HIP_GEMM(T, PA, PB, ACCS, LOW)                                                   \
-  return launch_mfma_gemm<T, AKM, BKM, PA, PB, ACCS, EPI>(m, n, k, replicas, outers,             \
-                                                          outer_is_split, a, b, out, LOW, stream)
+#define SPUTNIK_HIP_GEMM(T, PA, PB, ACCS, LOW)                                                    \
+  return wide ? launch_mfma_gemm<T, 256, AKM, BKM, PA, PB, ACCS, EPI>(m, n, k, replicas, outers,  \
+                                                                      outer_is_split, a, b, out,  \
+                                                                      LOW, stream)                \
+              : launch_mfma_gemm<T, 128, AKM, BKM, PA, PB, ACCS, EPI>(m, n, k, replicas, outers,  \
+                                                                      outer_is_split, a, b, out,  \
+                                                                      LOW, stream)
   if (tile_type == SPUTNIK_HIP_F16) {
     if (pa == 1 && pb == 1) SPUTNIK_HIP_GEMM(_Float16, 1, 1, 1, 1.f);
     if (pa == 2 && pb == 1) SPUTNIK_HIP_GEMM(_Float16, 2, 1, 2, low);

@@ -15,6 +15,8 @@ struct Options {
   int sddmm_debug = 0;    // SPUTNIK_HIP_SDDMM_DEBUG: timing experiments only (bits 8.. : the pair-flat kernel's)
   int sddmm_slab = 0;     // SPUTNIK_HIP_SDDMM_SLAB: 80 / 128 forces the slab rows of the summed product's 256-wide panels
   int sddmm_flat = 1;     // SPUTNIK_HIP_SDDMM_FLAT: 0 = planned products keep the rhs-stationary kernels
+  int mfma_tile = 0;      // SPUTNIK_HIP_MFMA_TILE: 128 / 256 forces the rows of the matrix-core kernels' tile (0 = by shape)
+  int mfma_debug = 0;     // SPUTNIK_HIP_MFMA_DEBUG: timing experiments only (wrong results)
   int softmax_rpg = 0;    // SPUTNIK_HIP_SOFTMAX_RPG: rows per group (0 = automatic)
   int softmax_nt = -1;    // SPUTNIK_HIP_SOFTMAX_NT (developer): nontemporal 0 none, 1 loads, 2 stores, 3 both; -1 default
   int softmax_depth = 1;  // SPUTNIK_HIP_SOFTMAX_DEPTH: rows in flight ahead (1..3)

@@ -136,10 +136,12 @@ bool sddmm_mfma_applicable(int m, int k, int n, int nonzeros, int replicas, cons
 }
 
 int sddmm_mfma_splits(int m, int k, int n, int replicas, int planes) {
-  const int64_t tiles = static_cast<int64_t>(ceil_div(m, kTile)) * ceil_div(n, kTile);
+  const bool wide = wide_tile(m, n, 0);
+  const int64_t tiles = static_cast<int64_t>(ceil_div(m, wide ? 256 : kTile)) * ceil_div(n, kTile);
   const int64_t steps = static_cast<int64_t>(replicas) * (k / kStep);
-  // two workgroups per CU (68 KiB of LDS each), at least eight tile products per workgroup
-  int64_t splits = ceil_div64(512, tiles);
+  // 128-row tiles: two workgroups per CU (68 KiB of LDS each); 256-row tiles: one; at
+  // least eight tile products per workgroup
+  int64_t splits = ceil_div64(wide ? 256 : 512, tiles);
   if (splits > steps * planes / 8) splits = steps * planes / 8;
   if (splits > steps) splits = steps;
   if (splits > 8) splits = 8;
@@ -176,7 +178,8 @@ int sddmm_mfma_launch(int m, int k, int n, int nonzeros, int replicas, const int
   out.vector_columns = aligned_to(column_indices, 16) ? 1 : 0;
   // lhs [m, k] and rhs [n, k] are both k-contiguous (src/sddmm_cuda.cu:48-53's layout)
   return launch_mfma_gemm_typed<false, false, kSampled>(in_type, pa, pb, m, n, k, replicas, splits,
-                                                        /*outer_is_split=*/true, a, b, out, stream);
+                                                        /*outer_is_split=*/true, a, b, out, stream,
+                                                        wide_tile(m, n, 0));
 }
 
 int sddmm_mfma_planes_of(int half_type) { return half_type == SPUTNIK_HIP_BF16 ? 3 : 2; }

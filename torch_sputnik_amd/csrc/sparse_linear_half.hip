@@ -114,7 +114,8 @@ int sputnik_hip_sparse_linear_half_forward(int out_features, int in_features, in
   o.bias = bias;
   o.relu = relu;
   return launch_mfma_gemm_typed<false, false, kDense>(tile_type, pw, 1, out_features, seq, in_features,
-                                                      batch, batch, false, a, b, o, stream);
+                                                      batch, batch, false, a, b, o, stream,
+                                                      wide_tile(out_features, seq, batch));
 }
 
 size_t sputnik_hip_sparse_linear_half_plan_bytes(int out_features, int in_features) {
@@ -164,7 +165,8 @@ int sputnik_hip_sparse_linear_half_weight_gradient(int out_features, int in_feat
   o.nonzeros = nonzeros;
   o.vector_columns = aligned_to(column_indices, 16) ? 1 : 0;
   const int st = launch_mfma_gemm_typed<false, true, kSampled>(tile_type, pg, 1, out_features, in_features,
-                                                               seq, batch, splits, true, a, b, o, stream);
+                                                               seq, batch, splits, true, a, b, o, stream,
+                                                               wide_tile(out_features, in_features, 0));
   if (st != 0 || splits == 1) return st;
   return sum_partial_vectors(nonzeros, splits, static_cast<const float*>(scratch), grad_values, stream);
 }
@@ -192,9 +194,11 @@ int sputnik_hip_sparse_linear_half_input_gradient(int out_features, int in_featu
   o.outer_stride = static_cast<int64_t>(seq) * in_features;
   if (grad_input_type == SPUTNIK_HIP_F32)
     return launch_mfma_gemm_typed<true, true, kDense>(tile_type, pg, pw, seq, in_features, out_features,
-                                                      batch, batch, false, a, b, o, stream);
+                                                      batch, batch, false, a, b, o, stream,
+                                                      wide_tile(seq, in_features, batch));
   return launch_mfma_gemm_typed<true, true, kDenseHalf>(tile_type, pg, pw, seq, in_features, out_features,
-                                                        batch, batch, false, a, b, o, stream);
+                                                        batch, batch, false, a, b, o, stream,
+                                                        wide_tile(seq, in_features, batch));
 }
 
 }  // extern "C"

@@ -175,7 +175,8 @@ int spmm_mfma_launch(int m, int k, int n, int nonzeros, int replicas, const int*
   // the densified weight is k-contiguous, the dense operand [k][n] k-major (the layout
   // src/left_replicated_spmm.cu:36 takes): its fragments are transposing reads
   return launch_mfma_gemm_typed<false, true, kDense>(tile_type, pa, pb, m, n, k, replicas, replicas,
-                                                     /*outer_is_split=*/false, a, bop, o, stream);
+                                                     /*outer_is_split=*/false, a, bop, o, stream,
+                                                     wide_tile(m, n, replicas));
 }
 
 }  // namespace sputnik_hip

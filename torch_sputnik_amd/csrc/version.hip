@@ -28,6 +28,8 @@ Options read_options() {
   o.sddmm_flat = num("SPUTNIK_HIP_SDDMM_FLAT", 1);
   o.sddmm_slab = num("SPUTNIK_HIP_SDDMM_SLAB", 0);
   o.sddmm_panel = num("SPUTNIK_HIP_SDDMM_PANEL", 0);
+  o.mfma_tile = num("SPUTNIK_HIP_MFMA_TILE", 0);
+  o.mfma_debug = num("SPUTNIK_HIP_MFMA_DEBUG", 0);
   o.softmax_rpg = num("SPUTNIK_HIP_SOFTMAX_RPG", 0);
   o.softmax_depth = num("SPUTNIK_HIP_SOFTMAX_DEPTH", 1);
   o.softmax_nt = num("SPUTNIK_HIP_SOFTMAX_NT", -1);
