@@ -117,6 +117,10 @@ SPUTNIK_HIP_API int sputnik_hip_spmm_batched(int m, int k, int n, int nonzeros, 
  * with that workspace (values, dense and out may change between calls; the
  * three index arrays, m, k and n may not).  No counterpart in the reference,
  * which re-derives everything per call (src/spmm_cuda.cu:48-57).
+ * A planned workspace is also the call's SCRATCH (a single product against a narrow dense
+ * operand keeps the partial tiles of its K split there): calls that share one workspace
+ * must be ordered on one stream; concurrent streams take a workspace each (the plan is
+ * topology only: `plan` may be run into any number of them).
  */
 /* (Round 4) A single product against a narrow dense operand (n < 512, k >= 2048, one
  * replica) deals its K chunks to several workgroups per tile; their partial tiles live in

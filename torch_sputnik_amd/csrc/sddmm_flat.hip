@@ -77,6 +77,10 @@ struct Geometry {
   static constexpr int kThreads = WAVES * kWave;
   static constexpr int kCap = STAGE - 8;                 // steps of a round
   static constexpr int kDescBytes = STAGE * kFStep * 8;
+  // written behind tile_start by the plan, checked by the kernel: a plan made under one
+  // geometry is never walked with the other's offsets (the geometry follows a
+  // developer knob that a test may reload between plan and product)
+  static constexpr int kTag = (BR << 16) | (SR << 4) | 0x5;
   static_assert(BR <= 256 && 2 * SR <= 256, "row fields of a descriptor are 8 bits");
   static_assert(kDescBytes % 1024 == 0, "descriptor stages are copied in 1 KiB pieces");
 };
@@ -105,7 +109,7 @@ FlatPlan make_plan(int m, int n, int nonzeros) {
   p.tiles = p.blocks * p.slabs;
   auto up = [](size_t v) { return (v + 1023) / 1024 * 1024; };
   p.start_off = 0;
-  p.seg_off = up(sizeof(int) * (static_cast<size_t>(p.tiles) + 1));
+  p.seg_off = up(sizeof(int) * (static_cast<size_t>(p.tiles) + 2));   // (+ the geometry tag)
   p.desc_off = up(p.seg_off + sizeof(int) * static_cast<size_t>(p.slots) * p.slabs);
   p.desc_capacity = static_cast<int64_t>(nonzeros) + static_cast<int64_t>(kFStep) * p.tiles +
                     G::kDescBytes / 8;
@@ -191,7 +195,8 @@ __global__ __launch_bounds__(G::kBlock) void sddmm_flat_tile_steps_kernel(
     tile_steps[tile] = (total + kFStep - 1) / kFStep;
   }
 }
-__global__ __launch_bounds__(1024) void sddmm_flat_scan_kernel(int tiles, int* __restrict__ tile_start) {
+__global__ __launch_bounds__(1024) void sddmm_flat_scan_kernel(int tiles, int* __restrict__ tile_start,
+                                                              int geometry_tag) {
   // in place: tile_start[t] holds the tile's steps on entry, the steps before it on exit;
   // tile_start[tiles] = all steps
   __shared__ int partial[1024];
@@ -214,7 +219,10 @@ __global__ __launch_bounds__(1024) void sddmm_flat_scan_kernel(int tiles, int* _
     tile_start[i] = run;
     run += steps;
   }
-  if (t == 1023) tile_start[tiles] = partial[1023];
+  if (t == 1023) {
+    tile_start[tiles] = partial[1023];
+    tile_start[tiles + 1] = geometry_tag;
+  }
 }
 
 // Plan, step 3: one workgroup per tile; row slot r's descriptors go behind those of the
@@ -329,6 +337,9 @@ __global__ __launch_bounds__(G::kThreads) void sddmm_flat_kernel(
   lhs += replica * lhs_stride;
   rhs += replica * rhs_stride;
   out += replica * out_stride;
+
+  // a plan of the other geometry (or no plan at all) is not walked: nothing is written
+  if (tile_start[static_cast<int64_t>(gridDim.x) * slabs + 1] != G::kTag) return;
 
   const unsigned ld_bytes = static_cast<unsigned>(ld) * static_cast<unsigned>(sizeof(T));
   const int piece_row = (lane * 16) / kRowBytes;               // row of a 1 KiB piece this lane copies
@@ -491,7 +502,8 @@ __global__ __launch_bounds__(G::kThreads) void sddmm_flat_kernel(
         if (d.x & kFSingle) {
           *dst = static_cast<TO>(res_a);
         } else if constexpr (std::is_same_v<TO, float>) {
-          *reinterpret_cast<v2f*>(dst) = v2f{res_a, res_b};   // 8 bytes, 4-byte aligned
+          typedef float v2f_a4 __attribute__((ext_vector_type(2), aligned(4)));
+          *reinterpret_cast<v2f_a4*>(dst) = v2f_a4{res_a, res_b};   // 8 bytes, 4-byte aligned: the type says so
         } else {
           dst[0] = static_cast<TO>(res_a);
           dst[1] = static_cast<TO>(res_b);
@@ -548,7 +560,7 @@ int plan_flat(int m, int n, int nonzeros, const int* row_indices, const int* row
                      p.slots, p.slabs, row_indices, row_offsets, column_indices, seg);
   hipLaunchKernelGGL(sddmm_flat_tile_steps_kernel<G>, dim3(p.tiles), dim3(G::kBlock), 0, stream, seg,
                      tile_start);
-  hipLaunchKernelGGL(sddmm_flat_scan_kernel, dim3(1), dim3(1024), 0, stream, p.tiles, tile_start);
+  hipLaunchKernelGGL(sddmm_flat_scan_kernel, dim3(1), dim3(1024), 0, stream, p.tiles, tile_start, G::kTag);
   hipLaunchKernelGGL(sddmm_flat_emit_kernel<G>, dim3(p.tiles), dim3(G::kBlock), 0, stream, m, n,
                      p.slots, p.slabs, row_indices, row_offsets, column_indices, seg, tile_start, desc);
   return launch_status();

@@ -150,8 +150,16 @@ __global__ __launch_bounds__(kRPW * 64) void spmm_flat_fill_kernel(
       rows[r] = e < m ? row_indices[e] : -1;
     }
 #pragma unroll
-    for (int r = 0; r < RPW; ++r)
-      bounds[r] = rows[r] >= 0 ? *reinterpret_cast<const int2*>(row_offsets + rows[r]) : make_int2(0, 0);
+    for (int r = 0; r < RPW; ++r) {
+      // (an 8-byte load of a 4-byte aligned pair: the type says so -- ADVICE r4)
+      typedef int int2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+      if (rows[r] >= 0) {
+        const int2_a4 pair = *reinterpret_cast<const int2_a4*>(row_offsets + rows[r]);
+        bounds[r] = make_int2(pair.x, pair.y);
+      } else {
+        bounds[r] = make_int2(0, 0);
+      }
+    }
 #pragma unroll
     for (int r = 0; r < RPW; ++r) len += bounds[r].y - bounds[r].x;
     before += (len + kWindow - 1) / kWindow;
