@@ -254,7 +254,7 @@ SPUTNIK_HIP_API int sputnik_hip_left_spmm_half_tiles(int m, int k, int n, int no
  *   input gradient   dx[b][s][i] = sum_o dy[b][o][s] W[o][i]           [batch, seq, in], float32 or tile type
  * x [batch, seq, in] in `tile_type` (SPUTNIK_HIP_F16 / BF16).  W is given as its IMAGE: the
  * CSR values (float32 or tile_type) scattered into a zeroed [planes][out][in] array of the
- * tile type -- sputnik_hip_sparse_linear_half_image, one memset + one launch per step, shared
+ * tile type -- sputnik_hip_sparse_linear_half_image, one launch per step, shared
  * by the forward pass and the input gradient.  dy [batch, out, seq] is given either in the
  * tile type (grad_type = tile_type) or as the PLANES of the float32 tensor
  * (sputnik_hip_half_planes, grad_type = SPUTNIK_HIP_F32): float32 operands are never rounded

@@ -580,6 +580,7 @@ def _operand(x, kind, tile, dev):
     (200, 192, 136, 0.8, 3),     # ragged: the last row tile and the last column tile are partial
     (130, 256, 72, 0.7, 2),      # the reference's test width (tests/test_spmm.py:13): one partial tile
     (384, 512, 264, 0.95, 2),    # very sparse
+    (136, 2176, 128, 0.9, 1),    # k beyond one 2048-column segment of the image's rows
 ])
 def test_left_spmm_half_tiles_vs_oracle(capi, dev, spmm_mfma, mfma_tile, tile, values_kind, dense_kind, m, k, n,
                                         sparsity, replicas):

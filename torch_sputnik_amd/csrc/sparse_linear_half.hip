@@ -10,7 +10,7 @@
 //
 // with x [batch, seq, in] as the module receives it, dy [batch, out, seq] as autograd hands
 // it over, and ONE densified image of the weight [out, in] (sputnik_hip_sparse_linear_half_image:
-// a memset and a scatter of the CSR values) shared by the forward pass and the input
+// one launch: every row assembled in LDS and written whole) shared by the forward pass and the input
 // gradient.  float32 values and the float32 dy are not rounded to the storage type: they
 // enter as half planes whose sum is the value (mfma_gemm.h; dy is split once per backward
 // pass, sputnik_hip_half_planes, and both gradients read the planes).

@@ -12,9 +12,9 @@
 // unit sixteen times faster than the packed-float32 vector pipe (config 5: 34.4 dense
 // GFLOP per pass against 6.9 sparse ones at 40-50 TFLOP/s).
 //
-// Two launches per call (plus a memset):
-//   1. densify: the CSR values scattered into a zeroed [m rounded up to 128, k] half image
-//      (one wave per row).  float32 values are NOT rounded to the storage type: they leave
+// Two launches per call:
+//   1. densify: the [m rounded up to 128, k] half image of the CSR matrix (one wave per row
+//      assembles the row in LDS and writes it whole: no memset, no 2-byte stores).  float32 values are NOT rounded to the storage type: they leave
 //      as half planes whose (scaled) sum is the value, as the float32 operand of the
 //      weight gradient does (sddmm_mfma.hip, split_planes_kernel) -- float16: two planes,
 //      the low one scaled by 2^11 and accumulated in a tile of its own; bfloat16: three.
@@ -41,30 +41,49 @@ namespace {
 
 using namespace mfma_tiles;
 
-// The CSR values scattered into the zeroed dense image(s) [PLANES][rows][k]: one wave per
-// row.  TV = float: split into planes as split_planes_kernel does (sddmm_mfma.hip); TV = T:
-// as they are (PLANES = 1).  A column outside [0, k) is skipped.
+// The weight's dense image(s) [PLANES][rows][k] of the tile type from its CSR form: one wave
+// per row assembles the row in LDS (zeros, then the row's entries scattered in) and writes
+// it out whole in 16-byte pieces -- every byte of the image is written exactly once, no
+// memset pass, no 2-byte stores to memory (k a multiple of 8; rows beyond m come out zero;
+// k beyond 2048 in segments of 2048 columns, each walking the row's entries again).
+// TV = float: split into planes as split_planes_kernel does (sddmm_mfma.hip); TV = T: as
+// they are (PLANES = 1).  A column outside [0, k) is skipped.
 template <typename T, typename TV, int PLANES>
-__global__ __launch_bounds__(256) void densify_kernel(int m, int k, const int* __restrict__ row_offsets,
+__global__ __launch_bounds__(256) void densify_kernel(int m, int rows, int k,
+                                                      const int* __restrict__ row_offsets,
                                                       const int* __restrict__ column_indices,
                                                       const TV* __restrict__ values, T* __restrict__ image,
                                                       int64_t plane_stride, float scale1) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= m) return;
+  constexpr int kSeg = 2048;
+  __shared__ __attribute__((aligned(16))) T segment[4][PLANES][kSeg];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= rows) return;
+  const int p0 = row < m ? row_offsets[row] : 0, p1 = row < m ? row_offsets[row + 1] : 0;
   T* dst = image + static_cast<int64_t>(row) * k;
-  const int p1 = row_offsets[row + 1];
-  for (int p = row_offsets[row] + lane; p < p1; p += 64) {
-    const unsigned col = static_cast<unsigned>(column_indices[p]);
-    if (col >= static_cast<unsigned>(k)) continue;
-    float rest = static_cast<float>(values[p]);
+  for (int c0 = 0; c0 < k; c0 += kSeg) {
+    const int width = min(kSeg, k - c0);
+    // (a wave's LDS operations execute in order: zeros, then the entries, then the reads)
+    for (int i = lane * 8; i < width; i += 512)
 #pragma unroll
-    for (int z = 0; z < PLANES; ++z) {
-      const float scaled = z == 1 ? rest * scale1 : rest;
-      const T h = PLANES == 1 && sizeof(TV) == 2 ? static_cast<T>(values[p]) : static_cast<T>(scaled);
-      dst[z * plane_stride + col] = h;
-      rest -= z == 1 ? static_cast<float>(h) / scale1 : static_cast<float>(h);
+      for (int z = 0; z < PLANES; ++z) *reinterpret_cast<uint4*>(&segment[wave][z][i]) = uint4{0, 0, 0, 0};
+    for (int p = p0 + lane; p < p1; p += 64) {
+      const unsigned col = static_cast<unsigned>(column_indices[p] - c0);
+      if (col >= static_cast<unsigned>(width)) continue;
+      float rest = static_cast<float>(values[p]);
+#pragma unroll
+      for (int z = 0; z < PLANES; ++z) {
+        const float scaled = z == 1 ? rest * scale1 : rest;
+        const T h = PLANES == 1 && sizeof(TV) == 2 ? static_cast<T>(values[p]) : static_cast<T>(scaled);
+        segment[wave][z][col] = h;
+        rest -= z == 1 ? static_cast<float>(h) / scale1 : static_cast<float>(h);
+      }
     }
+    for (int i = lane * 8; i < width; i += 512)
+#pragma unroll
+      for (int z = 0; z < PLANES; ++z)
+        *reinterpret_cast<uint4*>(dst + z * plane_stride + c0 + i) =
+            *reinterpret_cast<const uint4*>(&segment[wave][z][i]);
   }
 }
 
@@ -84,19 +103,16 @@ int passes_of(int pa, int pb) {
 
 }  // namespace
 
-// A zeroed image [planes][rows_padded][k] of the tile type with the CSR values scattered in
-// (memset + one launch).
+// The image [planes][rows_padded][k] of the tile type (one launch: every byte written once).
 int densify_into(int m, int k, const int* row_offsets, const int* column_indices, const void* values,
                  int values_type, int tile_type, void* image, int64_t rows_padded, hipStream_t stream) {
-  const int pa = planes_of(values_type, tile_type);
+  if (k % 8 != 0 || !aligned_to(image, 16)) return SPUTNIK_HIP_INVALID_ARGUMENT;
   const int64_t a_plane = rows_padded * k;
-  hipError_t e = hipMemsetAsync(image, 0, static_cast<size_t>(pa) * a_plane * 2, stream);
-  if (e != hipSuccess) return static_cast<int>(e);
-  const dim3 rows_grid(ceil_div(m, 4));
+  const dim3 rows_grid(static_cast<unsigned>(ceil_div64(rows_padded, 4)));
 #define SPUTNIK_HIP_DENSIFY(T, TV, PLANES, SCALE)                                                  \
-  hipLaunchKernelGGL((densify_kernel<T, TV, PLANES>), rows_grid, dim3(256), 0, stream, m, k,       \
-                     row_offsets, column_indices, static_cast<const TV*>(values),                  \
-                     static_cast<T*>(image), a_plane, SCALE)
+  hipLaunchKernelGGL((densify_kernel<T, TV, PLANES>), rows_grid, dim3(256), 0, stream, m,          \
+                     static_cast<int>(rows_padded), k, row_offsets, column_indices,                \
+                     static_cast<const TV*>(values), static_cast<T*>(image), a_plane, SCALE)
   if (tile_type == SPUTNIK_HIP_F16) {
     if (values_type == SPUTNIK_HIP_F32) SPUTNIK_HIP_DENSIFY(_Float16, float, 2, kLowPlaneScale);
     else SPUTNIK_HIP_DENSIFY(_Float16, _Float16, 1, 1.f);
