@@ -615,10 +615,43 @@ def other_ops(dev):
             cmat = torch.empty(mk, nn, device=dev)
             wsn = torch.empty(capi.spmm_workspace_bytes(mk, mk, nn, nnz) + 16, dtype=torch.uint8, device=dev)
             t = event_time_ms(lambda: capi.spmm_batched(mk, mk, nn, 1, ri, vals, 0, ro, ci, bmat, cmat, wsn), 20)
-            sweep_n.append({"n": nn, "ms": t, "gflops": 2.0 * nnz * nn / t / 1e6})
+            # (`planned_ms`: the topology pre-pass done once, as the modules' plan cache does
+            # for a static pattern -- the per-call form above re-derives it like the reference)
+            capi.spmm_plan(mk, mk, nn, ri, ro, ci, wsn)
+            tp = event_time_ms(lambda: capi.spmm_batched_planned(mk, mk, nn, 1, ri, vals, 0, ro, ci, bmat,
+                                                                 cmat, wsn), 20)
+            sweep_n.append({"n": nn, "ms": t, "gflops": 2.0 * nnz * nn / t / 1e6, "planned_ms": tp,
+                            "planned_gflops": 2.0 * nnz * nn / tp / 1e6})
         res["spmm_4096x4096_d010_by_n"] = sweep_n
     except Exception as e:  # noqa: BLE001 - extra metric, best effort
         res["spmm_4096x4096_d010_by_n"] = {"error": str(e)[:200]}
+    # Config 2's product on HALF-stored operands (this library's extension; the reference is
+    # float32 only): the matrix-core route of round 5 (csrc/spmm_mfma.hip) by density --
+    # one densified image of A per call + the dense tiles, so the time hardly depends on the
+    # density; `float32_values`: A's values float32 (two half planes), B float16
+    try:
+        from torch_sputnik_amd.synthetic import random_csr as _rc
+        half_sweep = []
+        for dd in (0.5, 0.25, 0.1, 0.05):
+            ri2, ro2, ci2, nnz2 = _rc(4096, 4096, dd, dev, seed=31)
+            v2 = uniform((nnz2,), dev, 32)
+            b2 = uniform((1, 4096, 4096), dev, 33).half()
+            c2 = torch.empty(1, 4096, 4096, device=dev)
+            row = {"density": dd, "nnz": nnz2}
+            for key, vv in (("half_values", v2.half()), ("float32_values", v2)):
+                need = capi.left_spmm_half_tiles_workspace_bytes(4096, 4096, 4096, nnz2, 1, vv, b2, torch.float16)
+                if need == 0:
+                    row[key] = None
+                    continue
+                wsh = torch.empty(need, dtype=torch.uint8, device=dev)
+                t = event_time_ms(lambda: capi.left_spmm_half_tiles(4096, 4096, 4096, 1, ro2, ci2, vv, b2,
+                                                                    torch.float16, c2, wsh), 10)
+                row[key] = {"ms": t, "gflops": 2.0 * nnz2 * 4096 / t / 1e6}
+            half_sweep.append(row)
+            del b2, c2
+        res["spmm_c2_f16_tiles_by_density"] = half_sweep
+    except Exception as e:  # noqa: BLE001 - extra metric, best effort
+        res["spmm_c2_f16_tiles_by_density"] = {"error": str(e)[:200]}
     m = n = 2048  # config 5: transpose of a 2048^2, density 0.2 weight
     ri, ro, ci, nnz = random_csr(m, n, 0.2, dev, seed=9)
     vals = uniform((nnz,), dev, 10)

@@ -42,6 +42,11 @@ def main():
             ws = torch.empty(capi.spmm_workspace_bytes(m, k, n, nnz) + 16, dtype=torch.uint8, device=dev)
             t = timeit(lambda: capi.spmm_batched(m, k, n, 1, ri, vals, 0, ro, ci, b, out, ws), iters=50, warmup=10)
             row[name + "_us"] = round(1000 * t, 1)
+            if name == "split":   # (the topology pre-pass done once: a static pattern)
+                capi.spmm_plan(m, k, n, ri, ro, ci, ws)
+                tp = timeit(lambda: capi.spmm_batched_planned(m, k, n, 1, ri, vals, 0, ro, ci, b, out, ws),
+                            iters=50, warmup=10)
+                row[name + "_planned_us"] = round(1000 * tp, 1)
             row[name + "_tflops"] = round(2.0 * nnz * n / t / 1e9, 2)
         print(json.dumps(row), flush=True)
     os.environ.pop("SPUTNIK_HIP_SPMM_DEBUG", None)
