@@ -187,6 +187,10 @@ def _many_mask_inputs(b, heads, s, hn, sparsities, seed):
     (4, 8, 512, 64, (0.2, 0.5)),      # tests/test_attention_many_masks.py:26-36 sparsities
     (2, 4, 256, 64, (0.9,)),          # equal counts: no padding anywhere
     (8, 8, 1024, 64, (0.9, 0.8, 0.95, 0.5)),   # attention size, mixed sparsity: every op ONE launch
+    # round 5: the SDDMM starts its masks largest first and deals a mask's heads over the XCDs
+    # (15 replicas: no multiple of 8 -- the plain XCD order; two masks of one size; an empty one)
+    (5, 3, 256, 64, (0.5, 0.9, 1.0, 0.7, 0.5)),
+    (16, 4, 256, 64, (0.95, 0.5, 0.9, 0.9)),
 ])
 @pytest.mark.parametrize("plan_per_mask", [False, True],
                          ids=["single_mask_workspace", "many_mask_workspace"])

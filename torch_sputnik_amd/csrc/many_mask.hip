@@ -80,7 +80,11 @@ extern "C" {
 size_t sputnik_hip_sddmm_many_mask_workspace_bytes(int masks, int m, int k, int n,
                                                    int largest_nonzeros) {
   if (masks <= 0 || m <= 0 || k <= 0 || n <= 0 || largest_nonzeros <= 0) return 0;
-  const size_t one = (sddmm_tiled_workspace_bytes(m, k, n, largest_nonzeros, false) + 255) / 256 * 256;
+  // (= sddmm.hip's sddmm_many_mask_plan_bytes: a region ends in the spare word that keeps the
+  // masks' start order)
+  const size_t tables = sddmm_tiled_workspace_bytes(m, k, n, largest_nonzeros, false);
+  if (tables == 0) return 0;
+  const size_t one = (tables + sizeof(int) + 255) / 256 * 256;
   return one * static_cast<size_t>(masks);
 }
 

@@ -33,8 +33,9 @@ int sddmm_tiled_launch(int m, int k, int n, int nonzeros, int replicas, const in
                        int64_t out_stride, const void* workspace, hipStream_t stream,
                        int mask_heads = 0, int64_t mask_plan_ints = 0, bool flat = false);
 // Bytes between the plans of consecutive masks in a "many mask" workspace.
+// (the last word of a region is spare: the masks' start order, mask_start_word)
 inline size_t sddmm_many_mask_plan_bytes(int m, int k, int n, int nonzeros) {
-  return (sddmm_tiled_workspace_bytes(m, k, n, nonzeros) + 255) / 256 * 256;
+  return (sddmm_tiled_workspace_bytes(m, k, n, nonzeros) + sizeof(int) + 255) / 256 * 256;
 }
 
 int sddmm_tiled_panels(int m, int k, int n, int nonzeros);

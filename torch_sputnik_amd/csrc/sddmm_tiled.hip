@@ -51,6 +51,9 @@ constexpr int kSWaves = 8;
 constexpr int kSGroups = kSWaves * 4;  // 16-lane row groups per workgroup
 constexpr int kSRows = 8;              // mask rows per group: a workgroup owns 256 rows
 constexpr int kWin = 2;                // 16-entry column windows fetched ahead per row
+// Bit of the kernels' `debug` word, set by the launcher (never by the knob): the launch holds
+// ALL replicas of a many-mask batch and its plan carries the masks' start order.
+constexpr int kMasksLargestFirst = 1 << 30;
 
 constexpr int default_slab_rows(int kv) { return (kv <= 2 ? 64 * 1024 : 128 * 1024) / (64 * kv * 4); }
 
@@ -107,10 +110,14 @@ void sddmm_stationary_kernel(
   const int g = lane >> 4, i = lane & 15;
   // (slab fastest, then row block, then replica / panel: the workgroups that share
   // an lhs row block or an rhs slab sit behind one XCD's L2, see xcd_local_index)
-  const unsigned long long work = xcd_local_index();
+  const unsigned long long work = mask_heads > 0 && panels == 1   // (many masks: their replicas dealt over the XCDs)
+                                      ? xcd_spread_replicas_index(gridDim.x * gridDim.y, gridDim.z)
+                                      : xcd_local_index();
   const int slab = static_cast<int>(work % gridDim.x);
   const int row_block = static_cast<int>((work / gridDim.x) % gridDim.y);
-  const int grid_z = static_cast<int>(work / (static_cast<unsigned long long>(gridDim.x) * gridDim.y));
+  int grid_z = static_cast<int>(work / (static_cast<unsigned long long>(gridDim.x) * gridDim.y));
+  if (debug & kMasksLargestFirst)   // (many masks, all of them in this launch)
+    grid_z = row_ok[mask_start_word(grid_z / mask_heads, mask_plan_ints)] * mask_heads + grid_z % mask_heads;
   // grid z = replica * panels + panel (panels == 1: the launch is one panel of
   // every replica; > 1: all panels at once, each into its own output, see
   // sddmm_tiled_launch_partials)
@@ -378,10 +385,14 @@ void sddmm_quad_kernel(
   const int g = lane >> 4, i = lane & 15;
   const int q = i >> 2, t = i & 3;       // quad of the group, lane of the quad
   const int e = 4 * t + q;               // this lane's entry of a 16-entry window
-  const unsigned long long work = xcd_local_index();
+  const unsigned long long work = mask_heads > 0 && panels == 1   // (many masks: their replicas dealt over the XCDs)
+                                      ? xcd_spread_replicas_index(gridDim.x * gridDim.y, gridDim.z)
+                                      : xcd_local_index();
   const int slab = static_cast<int>(work % gridDim.x);
   const int row_block = static_cast<int>((work / gridDim.x) % gridDim.y);
-  const int z = static_cast<int>(work / (static_cast<unsigned long long>(gridDim.x) * gridDim.y));
+  int z = static_cast<int>(work / (static_cast<unsigned long long>(gridDim.x) * gridDim.y));
+  if (debug & kMasksLargestFirst)   // (many masks, all of them in this launch)
+    z = row_ok[mask_start_word(z / mask_heads, mask_plan_ints)] * mask_heads + z % mask_heads;
   const int replica = panels > 1 ? z / panels : z;
   const int panel = z - replica * panels;
   lhs += replica * lhs_stride + panel * Q::kdim;
@@ -693,6 +704,11 @@ int launch(int m, int k, int n, int nonzeros, int replicas, int slots, const int
   int st = 0;
   const int row_blocks = slots / (kSGroups * kSRows);
   if (row_blocks > kMaxGridYZ) return SPUTNIK_HIP_INVALID_ARGUMENT;
+  // (more than one mask: their tables came from spmm_chunk_table_masks_kernel, which also
+  // ranks them; the knob's word keeps its low bits)
+  debug &= ~kMasksLargestFirst;
+  if (mask_heads > 0 && replicas > mask_heads && replicas <= kMaxGridYZ && !(debug & 64))
+    debug |= kMasksLargestFirst;
   for (int k0 = 0; k0 < k; k0 += S::kdim) {  // one launch per panel; later panels accumulate
     for (int r0 = 0; r0 < replicas; r0 += kMaxGridYZ) {
       const int rz = min(replicas - r0, kMaxGridYZ);

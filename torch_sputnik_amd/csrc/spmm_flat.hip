@@ -546,12 +546,25 @@ int flat_mode(int m, int k, int nonzeros) {
 // quarter padding (n need not be a multiple of 4: see the kernel's store phase), within the pre-pass's LDS (a row mask per
 // column) and its per-group prefix sum over the groups before.  (Whether it is
 // TAKEN is the dispatcher's matter: spmm_tiled.hip, use_flat.)
+// The fill kernel's tables for a long k need more than the default 64 KiB of dynamic LDS,
+// asked for once; a device that refuses serves the shapes whose tables fit the default.
+// (Part of the shape rule, so that a plan the dispatcher can ask for can always be made:
+// spmm_tiled_plan builds this plan ahead of calls that may or may not take it.)
+static bool fill_lds_available(int k) {
+  static const bool extended = [] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_flat_fill_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                               static_cast<int>(fill_lds_bytes(kMaxColumns / kBK, 0))) == hipSuccess;
+  }();
+  return extended || fill_lds_bytes(ceil_div(k, kBK), 0) <= 64 * 1024;
+}
+
 bool spmm_flat_applicable(int m, int k, int n, int nonzeros) {
   if (n < 4 || k < kBK || m < 64 || nonzeros < 16 * static_cast<int64_t>(m) ||
       nonzeros >= (1 << 29))
     return false;
   if (static_cast<int64_t>(ceil_div(n, kBN)) * kBN * 3 > static_cast<int64_t>(n) * 4) return false;
-  return k <= kMaxColumns && m <= 16384;
+  return k <= kMaxColumns && m <= 16384 && fill_lds_available(k);
 }
 
 const char* spmm_flat_kernel_name(int m, int k, int nonzeros) {
@@ -573,13 +586,8 @@ int spmm_flat_plan(int m, int k, int n, int nonzeros, const int* row_indices,
                    hipStream_t stream) {
   const FlatPlan p = make_flat_plan(m, k, n, nonzeros);
   char* base = static_cast<char*>(workspace);
-  static const bool lds_ok = [] {   // more than the default 64 KiB for large k
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_flat_fill_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                               static_cast<int>(fill_lds_bytes(kMaxColumns / kBK, 0))) == hipSuccess;
-  }();
+  if (!fill_lds_available(k)) return SPUTNIK_HIP_UNSUPPORTED;   // (spmm_flat_applicable said so)
   const int stage_windows = fill_stage_windows(p.nchunks, nonzeros, p.groups);
-  if (!lds_ok && fill_lds_bytes(p.nchunks, stage_windows) > 64 * 1024) return SPUTNIK_HIP_UNSUPPORTED;
   hipLaunchKernelGGL(spmm_flat_fill_kernel, dim3(p.groups), dim3(kRPW * 64),
                      fill_lds_bytes(p.nchunks, stage_windows), stream, m, k, p.slots, p.nchunks, row_indices,
                      row_offsets, column_indices, reinterpret_cast<int*>(base + p.row_ok_off),

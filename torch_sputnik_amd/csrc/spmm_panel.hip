@@ -90,8 +90,10 @@ __device__ __forceinline__ void dpp_group4_pair(float (&acc_a)[4], float (&acc_b
 struct Place {
   int mblock, ntile, replica;
 };
-__device__ __forceinline__ Place place_of_workgroup(int n_tiles) {
-  const unsigned long long v = xcd_local_index();
+__device__ __forceinline__ Place place_of_workgroup(int n_tiles, int mask_heads = 0) {
+  // (many masks: the replicas of a mask dealt over the XCDs, see xcd_spread_replicas_index)
+  const unsigned long long v =
+      mask_heads > 0 ? xcd_spread_replicas_index(gridDim.x, gridDim.y * gridDim.z) : xcd_local_index();
   const unsigned mblocks = gridDim.x / n_tiles;
   Place p;
   p.mblock = static_cast<int>(v % mblocks);
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(kPThreads) void spmm_panel64_kernel(
   const int lane = threadIdx.x % kWave;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int g = lane >> 4, i = lane & 15;
-  const Place place = place_of_workgroup(n_tiles);
+  const Place place = place_of_workgroup(n_tiles, mask_heads);
   const int ntile = place.ntile, mblock = place.mblock, replica = place.replica;
   values += replica * values_stride;
   dense += replica * dense_stride;

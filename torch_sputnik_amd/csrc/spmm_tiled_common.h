@@ -46,6 +46,26 @@ __device__ __forceinline__ unsigned long long xcd_local_index() {
   return total % 8 == 0 ? (launch % 8) * (total / 8) + launch / 8 : launch;
 }
 
+// "Many mask" launches (common.h, select_mask: replica r works under mask r / heads).  The
+// masks of a batch differ in size -- tests/test_attention_many_masks.py:26-36 of the
+// reference draws a sparsity per batch element -- and consecutive work indices, i.e. one
+// XCD, would be the replicas of ONE mask: the XCD that draws the densest mask then works on
+// alone (b = 8 x 8 heads with densities 0.1 / 0.2 / 0.05 / 0.5: the 0.5 XCDs carry 2.4
+// times the mean).  Here XCD x takes the replicas r with r % 8 == x, whole replicas as
+// before (their workgroups share operands: one L2), so the heads of every mask are dealt
+// over all eight.  `per_replica` = workgroups of one replica, `replicas` the launch's;
+// falls back to xcd_local_index when the replicas do not divide by 8.
+__device__ __forceinline__ unsigned long long xcd_spread_replicas_index(unsigned per_replica,
+                                                                        unsigned replicas) {
+  using u64 = unsigned long long;
+  const u64 v = xcd_local_index();
+  if (replicas % 8 != 0) return v;
+  const u64 per_xcd = static_cast<u64>(per_replica) * (replicas / 8);   // (the total divides by 8)
+  const u64 xcd = v / per_xcd, local = v - xcd * per_xcd;
+  const u64 nth = local / per_replica, inner = local - nth * per_replica;
+  return (nth * 8 + xcd) * per_replica + inner;
+}
+
 // 32-bit form for the dense-output kernels, whose workgroup count is bounded by
 // memory: every workgroup owns at least 64 x 64 output elements (16 KiB), so 2^31
 // workgroups would be 32 TiB of output.  (Keeps 64-bit division out of the
@@ -114,6 +134,13 @@ __global__ __launch_bounds__(256) void spmm_chunk_table_kernel(
                        row_ok);
 }
 
+// Where a many-mask plan keeps which mask starts nth (in ints from the workspace's start).
+// A launch works through its masks largest first: the workgroups of the densest mask take
+// several times the mean, and started last they run on alone while the chip empties.
+__host__ __device__ __forceinline__ int64_t mask_start_word(int nth, int64_t mask_plan_ints) {
+  return (static_cast<int64_t>(nth) + 1) * mask_plan_ints - 1;
+}
+
 // The same for the concatenated topologies of a "many mask" batch (common.h,
 // select_mask) in ONE launch: blockIdx.y = mask, every mask's table and order words
 // `mask_plan_ints` ints behind the previous mask's (round 4: one pre-pass launch per mask
@@ -126,6 +153,17 @@ __global__ __launch_bounds__(256) void spmm_chunk_table_masks_kernel(
   const int mask = blockIdx.y;
   int first = 0;   // entries of the masks before this one
   for (int j = 0; j < mask; ++j) first += row_offsets[static_cast<int64_t>(j) * (m + 1) + m];
+  // Start order of the masks, largest first (mask_start_word): this mask's rank among the
+  // entry counts goes to the LAST word of region `rank` (the regions end in a spare word).
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const int mine = row_offsets[static_cast<int64_t>(mask) * (m + 1) + m];
+    int rank = 0;
+    for (int j = 0; j < static_cast<int>(gridDim.y); ++j) {
+      const int other = row_offsets[static_cast<int64_t>(j) * (m + 1) + m];
+      rank += (other > mine || (other == mine && j < mask)) ? 1 : 0;
+    }
+    row_ok[mask_start_word(rank, mask_plan_ints)] = mask;
+  }
   chunk_table_body<BK>(m, k, slots, per, nchunks, row_indices + static_cast<int64_t>(mask) * m,
                        row_offsets + static_cast<int64_t>(mask) * (m + 1), column_indices + first,
                        table + mask * mask_plan_ints, row_ok + mask * mask_plan_ints);
