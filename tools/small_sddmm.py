@@ -1,22 +1,50 @@
-"""Small-problem latency of SDDMM: tiled (pre-pass + stationary kernel) vs row-wave kernel."""
-import sys, os, torch
+#!/usr/bin/env python3
+"""Where the LDS-tiled SDDMM (pre-pass + stationary kernel) overtakes the row-wave kernel
+(one launch): both forced through SPUTNIK_HIP_SDDMM_KERNEL, per-call form (the pre-pass
+inside the call), and what the automatic rule picks (csrc/sddmm.hip, takes_tiled).
+
+    python tools/small_sddmm.py
+"""
+import json
+import os
+import sys
+
+import torch
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from torch_sputnik_amd import capi
-from torch_sputnik_amd.synthetic import random_csr, uniform
-dev = torch.device("cuda:0")
-def timeit(fn, iters=100):
-    for _ in range(5): fn()
-    torch.cuda.synchronize()
-    ts=[]
-    for _ in range(iters):
-        s=torch.cuda.Event(enable_timing=True); e=torch.cuda.Event(enable_timing=True)
-        s.record(); fn(); e.record(); torch.cuda.synchronize(); ts.append(s.elapsed_time(e))
-    return sorted(ts)[len(ts)//2] * 1e3
-for (sz, k, R) in ((64, 64, 1), (256, 64, 1), (1024, 64, 1), (1024, 64, 8), (1024, 64, 64), (512, 512, 1), (2048, 512, 1), (2048, 512, 8), (1024, 128, 16)):
-    for d in (0.5, 0.1):
-        ri, ro, ci, nnz = random_csr(sz, sz, d, dev, seed=3)
-        lhs = uniform((R, sz, k), dev, 4); rhs = uniform((R, sz, k), dev, 5); o = torch.empty(R, nnz, device=dev)
-        ws = torch.empty(capi.sddmm_workspace_bytes(sz, k, sz, nnz) + 16, dtype=torch.uint8, device=dev)
-        t1 = timeit(lambda: capi.sddmm_batched(sz, k, sz, R, ri, ro, ci, lhs, rhs, o, ws))
-        t2 = timeit(lambda: capi.sddmm_batched(sz, k, sz, R, ri, ro, ci, lhs, rhs, o, None))
-        print(f"m=n={sz} k={k} R={R} d={d} W={nnz*k*R/1e6:.0f}M: tiled {t1:.1f} us, row wave {t2:.1f} us", flush=True)
+
+from torch_sputnik_amd import capi  # noqa: E402
+from torch_sputnik_amd.synthetic import random_csr, uniform  # noqa: E402
+from tools.flat_bench import timeit  # noqa: E402
+
+SHAPES = ((256, 64, 1), (1024, 64, 1), (1024, 64, 8), (1024, 64, 16), (1024, 64, 32), (1024, 64, 64),
+          (512, 64, 64), (2048, 64, 8), (2048, 64, 16), (1024, 128, 16), (1024, 128, 64), (512, 512, 1),
+          (2048, 512, 1), (2048, 512, 8), (1024, 256, 8))
+
+
+def main():
+    dev = torch.device("cuda:0")
+    for (sz, k, reps) in SHAPES:
+        for d in (0.5, 0.1, 0.05, 0.02):
+            ri, ro, ci, nnz = random_csr(sz, sz, d, dev, seed=3)
+            if nnz < 4 * sz:
+                continue
+            lhs = uniform((reps, sz, k), dev, 4)
+            rhs = uniform((reps, sz, k), dev, 5)
+            out = torch.empty(reps, nnz, device=dev)
+            ws = torch.empty(capi.sddmm_workspace_bytes(sz, k, sz, nnz) + 16, dtype=torch.uint8, device=dev)
+            row = {"m": sz, "k": k, "replicas": reps, "density": d, "nnz": nnz,
+                   "nnz_k2_r_log2": round(float(torch.log2(torch.tensor(float(nnz) * k * k * reps))), 2)}
+            for name in ("tiled", "wave", ""):
+                if name:
+                    os.environ["SPUTNIK_HIP_SDDMM_KERNEL"] = name
+                else:
+                    os.environ.pop("SPUTNIK_HIP_SDDMM_KERNEL", None)
+                capi.reload_options()
+                t = timeit(lambda: capi.sddmm_batched(sz, k, sz, reps, ri, ro, ci, lhs, rhs, out, ws), iters=40)
+                row[(name or "auto") + "_us"] = round(1000 * t, 1)
+            print(json.dumps(row), flush=True)
+
+
+if __name__ == "__main__":
+    main()

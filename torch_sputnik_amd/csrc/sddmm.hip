@@ -290,13 +290,43 @@ namespace {
 // (tools/small_sddmm.py): about 2.7e8 multiply-adds at k = 64, 1.3e8 at k =
 // 128, 3e7 at k = 512, i.e. nnz * k^2 * replicas ~ 2^34.
 // Test knob SPUTNIK_HIP_SDDMM_KERNEL (options.h: read once): "tiled" / "wave".
+// Round 5: the one-number rule (nnz * k^2 * replicas < 2^34: row-wave) was up to 1.9 x off
+// in a band of mid-sized batched calls -- 1024^2 at density 0.05 x 64 replicas, k = 64: 71 us
+// on the row-wave kernel where the tiled path takes 40; tools/small_sddmm.py, 60 shapes,
+// profiles/r5_sddmm_tiled_vs_wave.jsonl: mean regret 14 %, worst 86 %.  The float product now
+// compares two estimates fitted to that sweep (mean regret 1.5 %, worst 26 %), in us:
+//   row-wave: a wave per (row, replica), 0.85 ns each, plus the entries' dot products
+//     (8.2 / 28 / 55 / 90 us per million entries at panel width 64 / 128 / 256 / 512), at
+//     least the time ONE wave needs for an average row (0.72 ns per element), at least 13;
+//   tiled: 20 (13 with the plan made ahead), 10 us per million entries of pre-pass, the
+//     rounds of slab-staging workgroups (9 us per round of 512 at widths <= 128, 4 / 15 per
+//     round of 256 at 256 / 512), 1.8 us per million entries and 64 elements.
+bool float_call_is_small(int m, int k, int n, int nonzeros, int replicas, bool planned) {
+  const int width = sddmm_tiled_panel_width(k);
+  if (width == 0 || m <= 0) return true;
+  const double entries = static_cast<double>(nonzeros) * replicas, panels = k / width;
+  const double per_million = width <= 64 ? 8.2 : width <= 128 ? 28.0 : width <= 256 ? 55.0 : 90.0;
+  const double wave = std::max({13.0, 0.85e-3 * m * replicas + per_million * 1e-6 * entries * panels,
+                                0.72e-3 * nonzeros / m * k});
+  const int slab_rows = width <= 64 ? 256 : width <= 256 ? 128 : 64;
+  const double workgroups = static_cast<double>(replicas) * ceil_div(m, 256) * ceil_div(n, slab_rows);
+  const double rounds = workgroups / (width <= 128 ? 512 : 256) * panels;
+  const double per_round = width <= 128 ? 9.0 : width <= 256 ? 4.0 : 15.0;
+  const double tiled = (planned ? 13.0 : 20.0 + 10e-6 * nonzeros) + per_round * rounds +
+                       1.8e-6 * entries * (k / 64.0);
+  return tiled >= 1.1 * wave;
+}
+
 bool takes_tiled(int m, int k, int n, int nonzeros, int replicas /* < 0: unknown */,
                  const float* lhs, int64_t lhs_stride, const float* rhs, int64_t rhs_stride,
-                 const void* workspace, size_t workspace_bytes, bool summed = false) {
+                 const void* workspace, size_t workspace_bytes, bool summed = false,
+                 bool planned = false) {
   const bool force_tiled = options().sddmm_kernel == 1;
   const bool force_wave = options().sddmm_kernel == 2;
+  // (the summed form keeps the one-number rule: its panels run side by side)
   const bool small = replicas >= 0 &&
-                     static_cast<double>(nonzeros) * k * k * replicas < 17179869184.0;  // 2^34
+                     (summed ? static_cast<double>(nonzeros) * k * k * replicas < 17179869184.0   // 2^34
+                             : float_call_is_small(m, k, n, nonzeros, replicas, planned));
   return !force_wave && (force_tiled || !small) && workspace != nullptr &&
          aligned_to(workspace, 16) &&
          sddmm_tiled_applicable(m, k, n, nonzeros, lhs, lhs_stride, rhs, rhs_stride) &&
@@ -325,7 +355,8 @@ int sddmm_exec(int m, int k, int n, int nonzeros, int replicas, const int* row_i
   const int masks = mask_heads > 0 ? replicas / mask_heads : 1;
   const size_t plan_bytes = sddmm_many_mask_plan_bytes(m, k, n, nonzeros);
   if (takes_tiled(m, k, n, nonzeros, replicas, lhs, lhs_stride, rhs, rhs_stride, workspace,
-                  mask_heads > 0 ? workspace_bytes / masks : workspace_bytes) &&
+                  mask_heads > 0 ? workspace_bytes / masks : workspace_bytes, /*summed=*/false,
+                  planned) &&
       (mask_heads == 0 || plan_bytes * masks <= workspace_bytes)) {
     if (!planned) {
       // (many mask: the tables of all topologies in ONE launch, round 4; the masks share
@@ -485,10 +516,13 @@ int sddmm_sum_exec(int m, int k, int n, int nonzeros, int replicas, const int* r
     tiled = false;
   const int panels = tiled ? sddmm_tiled_panels(m, k, n, nonzeros) : 1;
   const int64_t parts = static_cast<int64_t>(replicas) * panels;
-  if (parts == 1)   // (one panel: the summed form's plan is the plain one)
+  if (parts == 1)
+    // One replica and one panel: the plain product, which plans for itself -- a plan made
+    // for the summed form has that form's slabs and no pair-flat lists behind the tables,
+    // and the plain dispatch may choose differently from the `tiled` above.
     return sddmm_exec(m, k, n, nonzeros, 1, row_indices, row_offsets, column_indices, lhs,
-                      lhs_stride, rhs, rhs_stride, out, 0, workspace, workspace_bytes, planned,
-                      stream);
+                      lhs_stride, rhs, rhs_stride, out, 0, tiled ? workspace : nullptr,
+                      tiled ? workspace_bytes : 0, /*planned=*/false, stream);
   if (scratch == nullptr || !aligned_to(scratch, 16) ||
       scratch_bytes < sizeof(float) * static_cast<size_t>(parts) * nonzeros)
     return SPUTNIK_HIP_INVALID_ARGUMENT;
@@ -592,10 +626,11 @@ int sddmm_sum_exec_half(int m, int k, int n, int nonzeros, int replicas, const i
     tiled = false;
   const int panels = tiled ? sddmm_tiled_panels(m, k, n, nonzeros) : 1;
   const int64_t parts = static_cast<int64_t>(replicas) * panels;
-  if (parts == 1)
+  if (parts == 1)   // (the plain product, planning for itself: see sddmm_sum_exec)
     return sddmm_exec_half(m, k, n, nonzeros, 1, row_indices, row_offsets, column_indices, lhs,
-                           lhs_stride, rhs, rhs_stride, out, 0, in_type, SPUTNIK_HIP_F32, workspace,
-                           workspace_bytes, planned, stream);
+                           lhs_stride, rhs, rhs_stride, out, 0, in_type, SPUTNIK_HIP_F32,
+                           tiled ? workspace : nullptr, tiled ? workspace_bytes : 0,
+                           /*planned=*/false, stream);
   if (scratch == nullptr || !aligned_to(scratch, 16) ||
       scratch_bytes < sizeof(float) * static_cast<size_t>(parts) * nonzeros)
     return SPUTNIK_HIP_INVALID_ARGUMENT;
@@ -822,7 +857,9 @@ const char* sputnik_hip_sddmm_kernel_name(int m, int k, int n, int nonzeros, int
   if (m <= 0 || k <= 0 || n <= 0 || nonzeros <= 0 || replicas <= 0) return "none";
   const bool force_tiled = options().sddmm_kernel == 1;
   const bool force_wave = options().sddmm_kernel == 2;
-  const bool small = static_cast<double>(nonzeros) * k * k * replicas < 17179869184.0;  // 2^34
+  const bool small = elem_bytes == 4
+                         ? float_call_is_small(m, k, n, nonzeros, replicas, planned != 0)
+                         : static_cast<double>(nonzeros) * k * k * replicas < 17179869184.0;  // 2^34
   const bool shape = sddmm_tiled_workspace_bytes(m, k, n, nonzeros) != 0 &&
                      static_cast<int64_t>(n) * k * elem_bytes < (int64_t{1} << 32) &&
                      static_cast<int64_t>(m) * k * elem_bytes < (int64_t{1} << 32);
