@@ -566,7 +566,13 @@ inline Kernel choose_kernel(int m, int k, int n, int nonzeros, int replicas /* <
     // with its K chunks dealt to several workgroups per tile beats the row gather from
     // about 1.7e7 multiply-adds (tools/narrow_n_bench.py: 2048^2 x 72 at density 0.1, 3e7:
     // 24 against 40 us; 4096^2 x 72 40 against 75, x 200 59 against 88; 1024^2: a tie)
-    if (replicas == 1 && k >= 2048 && work >= (int64_t{1} << 24) && work < (int64_t{1} << 29) &&
+    // Round 5 (tools/spmm_dispatch_sweep.py, 180 shapes, profiles/r5_spmm_dispatch_sweep_*):
+    // what decides is the LENGTH OF THE ROWS, not k -- 1024^2 at density 0.3 x 64 columns: 27
+    // against 54 us for the row gather, which the k >= 2048 of round 4 kept; 4096^2 at density
+    // 0.02 (82 entries a row, 2.6 per row and chunk): 28 against 21, 2048^2 x 256: 29 against
+    // 16, which it took.  From 128 entries a row, any k of four chunks per split.
+    if (replicas == 1 && k >= 1024 && nonzeros >= 128 * static_cast<int64_t>(m) &&
+        work >= (int64_t{1} << 24) && work < (int64_t{1} << 29) &&
         spmm_tiled64_applicable(m, k, n, nonzeros) && spmm_tiled64_ksplits(m, k, n) >= 4 &&
         !use_flat(m, k, n, nonzeros))
       return Kernel::kNarrow;
@@ -586,15 +592,23 @@ inline Kernel choose_kernel(int m, int k, int n, int nonzeros, int replicas /* <
       return Kernel::kWide512;
   }
   const bool wide = tiled_applicable(m, k, n, nonzeros);
+  // (round 5, same sweep: the 64-column kernel visits every (row, 128-column chunk) -- with
+  // fewer than about 4.5 entries per visit the row gather is ahead whatever the batch:
+  // 4096^2 at density 0.02 x 64 columns x 8 replicas 42 against 85 us, x 64 replicas 274
+  // against 371; at density 0.1 it is 143 against 121 the other way)
   const bool narrow = spmm_tiled64_applicable(m, k, n, nonzeros);
-  if (!wide) return narrow ? Kernel::kNarrow : Kernel::kNone;
+  const Kernel narrow_or_gather =
+      forced == 0 && replicas >= 0 && static_cast<double>(nonzeros) < 0.035 * static_cast<double>(m) * k
+          ? Kernel::kNone
+          : Kernel::kNarrow;
+  if (!wide) return narrow ? narrow_or_gather : Kernel::kNone;
   if (!narrow || forced < 0) return Kernel::kWide;
   const int64_t small_tiles = static_cast<int64_t>(ceil_div(m, CfgSmall::kBM)) * ceil_div(n, CfgSmall::kBN);
   // cross-over measured between 256 (narrow 8-10 % ahead) and 512 (wide 20 % ahead) tiles
   constexpr int64_t kWideFrom = 384;
   if (small_tiles >= kWideFrom) return Kernel::kWide;  // whatever the replica count
   if (replicas < 0) return Kernel::kEither;
-  return small_tiles * replicas >= kWideFrom ? Kernel::kWide : Kernel::kNarrow;
+  return small_tiles * replicas >= kWideFrom ? Kernel::kWide : narrow_or_gather;
 }
 
 }  // namespace
