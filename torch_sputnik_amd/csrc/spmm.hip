@@ -330,7 +330,11 @@ bool takes_panel(int m, int k, int n, int nonzeros, int replicas, const float* d
     return false;
   const int choice = spmm_tiled_choice(m, k, n, nonzeros, replicas);
   const int64_t work = static_cast<int64_t>(nonzeros) * n * replicas;
-  return choice == 2 || choice == 3 || (choice == 0 && work >= (int64_t{1} << 24));
+  // (round 5, tools/spmm_dispatch_sweep.py: ONE resident panel against up to four column
+  // tiles also beats the 256-column kernel -- 512^2 x 256 x 64 replicas at density 0.3: 74
+  // against 87 us, at 0.1: 38 against 44; at 512 columns the wide kernels lead again)
+  return choice == 2 || choice == 3 || (choice == 0 && work >= (int64_t{1} << 24)) ||
+         (choice == 1 && k <= 512 && n <= 256);
 }
 
 int spmm_exec(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,

@@ -506,9 +506,19 @@ constexpr int64_t kTiles512From = 192;
 // workgroup per CU (its plan then does not depend on the replica count); the knob
 // "flat" takes it for any shape it can serve, "wide512" / "wide" keep the
 // visit-per-row kernels of this file.
+// (round 5, tools/spmm_dispatch_sweep.py: at density 0.02 the stream's windows run a third
+// full, and over SEVERAL rounds of the chip the 256-column visit-per-row kernel is 8-12 %
+// ahead -- 4096^2 x 1024 x 64 replicas 3.20 against 3.59 ms, 2048^2 x 512 x 64: 422 against
+// 469 us; in one or two rounds the flat kernel's larger tile still wins by a quarter --
+// 4096^2 x 512 x 8: 145 against 190 us; at 0.05 it leads everywhere: the line is drawn at
+// density 0.03 and 512 tiles)
+inline bool flat_pays(int m, int k, int nonzeros, int64_t tiles) {
+  return tiles < 512 || static_cast<double>(nonzeros) >= 0.03 * static_cast<double>(m) * k;
+}
 inline bool use_flat(int m, int k, int n, int nonzeros) {
   const int forced = forced_kernel();
-  return (forced == -3 || (forced == 0 && spmm_flat_tiles(m, n) >= kTiles512From)) &&
+  return (forced == -3 || (forced == 0 && spmm_flat_tiles(m, n) >= kTiles512From &&
+                           flat_pays(m, k, nonzeros, spmm_flat_tiles(m, n)))) &&
          spmm_flat_applicable(m, k, n, nonzeros);
 }
 // The flat-stream kernel also serves shapes that need SEVERAL replicas to fill the chip
@@ -522,7 +532,8 @@ inline bool flat_possible(int m, int k, int n, int nonzeros) {
 }
 inline bool flat_with_replicas(int m, int k, int n, int nonzeros, int replicas) {
   return replicas > 1 && flat_possible(m, k, n, nonzeros) &&
-         spmm_flat_tiles(m, n) * replicas >= kTiles512From;
+         spmm_flat_tiles(m, n) * replicas >= kTiles512From &&
+         flat_pays(m, k, nonzeros, spmm_flat_tiles(m, n) * replicas);
 }
 // A row has more than about two entries per 32-row chunk (below that the 64-row
 // chunks of the 256-column kernel win by 2 %: 4096^3 at density 0.05).
