@@ -478,7 +478,7 @@ def test_spmm_one_plan_serves_any_replica_count(capi, dev):
     256-column tiles, 12 the 512-column tiles' 64-row form, 24 the flat-stream kernel
     (round 4: taken when the tiles of ALL replicas fill the chip).  One planned
     workspace must serve all of them."""
-    m, k, n = 512, 128, 1024
+    m, k, n = 512, 512, 1024   # (round 5: the flat kernel wants k >= 512)
     _, vals, ri, ro, ci = make_csr(m, k, 0.8, seed=31)
     nnz = len(ci)
     names = {r: capi.spmm_kernel_name(m, k, n, nnz, r) for r in (2, 12, 24)}

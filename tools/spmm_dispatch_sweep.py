@@ -3,7 +3,7 @@
 (whole call, pre-pass included) -- the wide version of tests/test_zz_gpu_dispatch.py, to
 find the bands where the dispatcher's thresholds lose.  One JSON line per shape.
 
-    python tools/spmm_dispatch_sweep.py [--sizes 512,1024,2048,4096] [--ns 64,128,256,512,1024]
+    python tools/spmm_dispatch_sweep.py [--sizes 512,1024,2048,4096] [--ks 256,1024] [--ns 64,128,256,512,1024]
                                         [--replicas 1,8,64] [--densities 0.02,0.1,0.3]
 """
 import argparse
@@ -29,14 +29,14 @@ def ints(v):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sizes", type=ints, default=[512, 1024, 2048, 4096])
+    ap.add_argument("--ks", type=ints, default=[], help="inner dimensions (default: k = m)")
     ap.add_argument("--ns", type=ints, default=[64, 128, 256, 512, 1024])
     ap.add_argument("--replicas", type=ints, default=[1, 8, 64])
     ap.add_argument("--densities", type=lambda v: [float(x) for x in v.split(",")], default=[0.02, 0.1, 0.3])
     ap.add_argument("--max-elements", type=float, default=3e8, help="skip shapes with more output elements")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    for m in args.sizes:
-        k = m
+    for m, k in [(m, k) for m in args.sizes for k in (args.ks or [m])]:
         for d in args.densities:
             ri, ro, ci, nnz = random_csr(m, k, d, dev, seed=11)
             for n in args.ns:

@@ -512,8 +512,11 @@ constexpr int64_t kTiles512From = 192;
 // 469 us; in one or two rounds the flat kernel's larger tile still wins by a quarter --
 // 4096^2 x 512 x 8: 145 against 190 us; at 0.05 it leads everywhere: the line is drawn at
 // density 0.03 and 512 tiles)
+// (and a short k: 8192 x 256 at density 0.2 against 2048 columns: 70 us against 54 for the
+// 512-column kernel -- eight chunks do not pay for the stream's prologue; from 512 on the two
+// are within 6 %)
 inline bool flat_pays(int m, int k, int nonzeros, int64_t tiles) {
-  return tiles < 512 || static_cast<double>(nonzeros) >= 0.03 * static_cast<double>(m) * k;
+  return k >= 512 && (tiles < 512 || static_cast<double>(nonzeros) >= 0.03 * static_cast<double>(m) * k);
 }
 inline bool use_flat(int m, int k, int n, int nonzeros) {
   const int forced = forced_kernel();
@@ -528,7 +531,7 @@ inline bool use_flat(int m, int k, int n, int nonzeros) {
 // and the call decides.  (From 8 tiles per replica: fewer would need more than 24 replicas.)
 inline bool flat_possible(int m, int k, int n, int nonzeros) {
   return forced_kernel() == 0 && !use_flat(m, k, n, nonzeros) && spmm_flat_tiles(m, n) >= 8 &&
-         spmm_flat_applicable(m, k, n, nonzeros);
+         k >= 512 && spmm_flat_applicable(m, k, n, nonzeros);
 }
 inline bool flat_with_replicas(int m, int k, int n, int nonzeros, int replicas) {
   return replicas > 1 && flat_possible(m, k, n, nonzeros) &&
@@ -582,13 +585,21 @@ inline Kernel choose_kernel(int m, int k, int n, int nonzeros, int replicas /* <
     // against 54 us for the row gather, which the k >= 2048 of round 4 kept; 4096^2 at density
     // 0.02 (82 entries a row, 2.6 per row and chunk): 28 against 21, 2048^2 x 256: 29 against
     // 16, which it took.  From 128 entries a row, any k of four chunks per split.
-    if (replicas == 1 && k >= 1024 && nonzeros >= 128 * static_cast<int64_t>(m) &&
-        work >= (int64_t{1} << 24) && work < (int64_t{1} << 29) &&
-        spmm_tiled64_applicable(m, k, n, nonzeros) && spmm_tiled64_ksplits(m, k, n) >= 4 &&
-        !use_flat(m, k, n, nonzeros))
+    // The row gather walks a row entry after entry, 0.19 us each -- 40 us for rows of 205
+    // entries whatever the size of the call (512 x 1024 x 64 at density 0.2; 512 x 4096 x 64
+    // at 0.05: both 39.9 us, the 64-column kernel 23 and 25) -- so calls with such rows leave
+    // it early, from 2^22 multiply-adds: one product for the K split, a batch where the
+    // 64-column kernel's (row, chunk) visits are well filled, density >= 0.1 (512 x 1024 x 64
+    // x 16 replicas at 0.2: 47 against 68 us; 512 x 4096 x 64 x 4: 153 against 218; at 0.05,
+    // 2048 x 4096 x 64 x 4: 89 against 64 the other way).
+    const bool long_rows = nonzeros >= 128 * static_cast<int64_t>(m);
+    const bool small = work < (int64_t{1} << 27) || (replicas < 8 && work < (int64_t{1} << 29));
+    if (small && long_rows && work >= (int64_t{1} << 22) &&
+        spmm_tiled64_applicable(m, k, n, nonzeros) && !use_flat(m, k, n, nonzeros) &&
+        (replicas > 1 ? static_cast<double>(nonzeros) >= 0.1 * static_cast<double>(m) * k
+                      : k >= 1024 && spmm_tiled64_ksplits(m, k, n) >= 4))
       return Kernel::kNarrow;
-    if (work < (int64_t{1} << 27) || (replicas < 8 && work < (int64_t{1} << 29)))
-      return Kernel::kNone;
+    if (small) return Kernel::kNone;
   }
   if (use_flat(m, k, n, nonzeros) || flat_with_replicas(m, k, n, nonzeros, replicas))
     return Kernel::kFlat;
