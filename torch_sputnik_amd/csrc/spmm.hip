@@ -116,24 +116,47 @@ __global__ __launch_bounds__(kBlock) void spmm_rowgather_kernel(
 #pragma unroll
   for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
 
+  // A row is a chain of dependent memory round trips -- its window of LPR (column, value)
+  // pairs, then the rows of B they name -- and with four gathers in flight and the window
+  // fetched on demand an entry took 0.19 us (round 5, tools/spmm_dispatch_sweep.py: 40 us
+  // for rows of 205 entries whatever the size of the call).  Now the NEXT window is in
+  // flight while this one is worked on, and its gathers go out eight at a time (an entry
+  // past the row's end gathers nothing and multiplies a zero by a zero).
+  constexpr int kBatch = LPR < 8 ? LPR : 8;
+  int j = 0;
+  float a = 0.f;
+  if (p + l < p_end) {
+    j = column_indices[p + l];
+    a = static_cast<float>(values[p + l]);
+  }
   for (; p < p_end; p += LPR) {
-    const int q = p + l;
-    int j = 0;
-    float a = 0.f;
-    if (q < p_end) {
-      j = column_indices[q];
-      a = static_cast<float>(values[q]);
+    const int q_next = p + LPR + l;
+    int j_next = 0;
+    float a_next = 0.f;
+    if (q_next < p_end) {
+      j_next = column_indices[q_next];
+      a_next = static_cast<float>(values[q_next]);
     }
     const int cnt = min(LPR, p_end - p);
-#pragma unroll 4
-    for (int t = 0; t < cnt; ++t) {
-      const int jj = group_broadcast<LPR>(j, t);
-      const float aa = group_broadcast<LPR>(a, t);
-      float b[VEC];
-      load_widened<VEC, TB>(b, b_col + static_cast<int64_t>(jj) * n);
+    for (int t0 = 0; t0 < cnt; t0 += kBatch) {
+      float b[kBatch][VEC], aa[kBatch];
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) acc[v] = fmaf(aa, b[v], acc[v]);
+      for (int u = 0; u < kBatch; ++u) {
+        const int jj = group_broadcast<LPR>(j, t0 + u);
+        aa[u] = group_broadcast<LPR>(a, t0 + u);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) b[u][v] = 0.f;
+        if (t0 + u < cnt) load_widened<VEC, TB>(b[u], b_col + static_cast<int64_t>(jj) * n);
+      }
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        const float au = t0 + u < cnt ? aa[u] : 0.f;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = fmaf(au, b[u][v], acc[v]);
+      }
     }
+    j = j_next;
+    a = a_next;
   }
 
   if (row_ok && col_ok) {
@@ -333,7 +356,12 @@ bool takes_panel(int m, int k, int n, int nonzeros, int replicas, const float* d
   // (round 5, tools/spmm_dispatch_sweep.py: ONE resident panel against up to four column
   // tiles also beats the 256-column kernel -- 512^2 x 256 x 64 replicas at density 0.3: 74
   // against 87 us, at 0.1: 38 against 44; at 512 columns the wide kernels lead again)
-  return choice == 2 || choice == 3 || (choice == 0 && work >= (int64_t{1} << 24)) ||
+  // (against the row gather the panel kernel needs workgroups: one per 256 rows and 64
+  // columns -- 512^2 x 256 at density 0.3 is 8 of them and 31 us against 16; with 128,
+  // 512^2 x 512 x 8 replicas at 0.1, it is 18 against 24)
+  const int64_t workgroups = static_cast<int64_t>((m + 255) / 256) * ((n + 63) / 64) * replicas;
+  return choice == 2 || choice == 3 ||
+         (choice == 0 && work >= (int64_t{1} << 24) && workgroups >= 96) ||
          (choice == 1 && k <= 512 && n <= 256);
 }
 

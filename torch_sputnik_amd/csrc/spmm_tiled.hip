@@ -577,27 +577,21 @@ inline Kernel choose_kernel(int m, int k, int n, int nonzeros, int replicas /* <
   if (replicas >= 0 && forced == 0) {
     const int64_t work = static_cast<int64_t>(nonzeros) * n * replicas;
     // (round 4) ONE product against a narrow operand over a long K: the 64-column kernel
-    // with its K chunks dealt to several workgroups per tile beats the row gather from
-    // about 1.7e7 multiply-adds (tools/narrow_n_bench.py: 2048^2 x 72 at density 0.1, 3e7:
-    // 24 against 40 us; 4096^2 x 72 40 against 75, x 200 59 against 88; 1024^2: a tie)
-    // Round 5 (tools/spmm_dispatch_sweep.py, 180 shapes, profiles/r5_spmm_dispatch_sweep_*):
-    // what decides is the LENGTH OF THE ROWS, not k -- 1024^2 at density 0.3 x 64 columns: 27
-    // against 54 us for the row gather, which the k >= 2048 of round 4 kept; 4096^2 at density
-    // 0.02 (82 entries a row, 2.6 per row and chunk): 28 against 21, 2048^2 x 256: 29 against
-    // 16, which it took.  From 128 entries a row, any k of four chunks per split.
-    // The row gather walks a row entry after entry, 0.19 us each -- 40 us for rows of 205
-    // entries whatever the size of the call (512 x 1024 x 64 at density 0.2; 512 x 4096 x 64
-    // at 0.05: both 39.9 us, the 64-column kernel 23 and 25) -- so calls with such rows leave
-    // it early, from 2^22 multiply-adds: one product for the K split, a batch where the
-    // 64-column kernel's (row, chunk) visits are well filled, density >= 0.1 (512 x 1024 x 64
-    // x 16 replicas at 0.2: 47 against 68 us; 512 x 4096 x 64 x 4: 153 against 218; at 0.05,
-    // 2048 x 4096 x 64 x 4: 89 against 64 the other way).
-    const bool long_rows = nonzeros >= 128 * static_cast<int64_t>(m);
-    const bool small = work < (int64_t{1} << 27) || (replicas < 8 && work < (int64_t{1} << 29));
-    if (small && long_rows && work >= (int64_t{1} << 22) &&
-        spmm_tiled64_applicable(m, k, n, nonzeros) && !use_flat(m, k, n, nonzeros) &&
-        (replicas > 1 ? static_cast<double>(nonzeros) >= 0.1 * static_cast<double>(m) * k
-                      : k >= 1024 && spmm_tiled64_ksplits(m, k, n) >= 4))
+    // with its K chunks dealt to several workgroups per tile (tools/narrow_n_bench.py:
+    // 4096^2 x 72 at density 0.1: 40 against 75 us for the row gather of that round).
+    // Round 5, after the row gather learnt to keep eight gathers and the next window in
+    // flight (spmm.hip: an entry of a row now takes 0.09 us instead of 0.19; 512 x 4096 x 64
+    // x 4 replicas at density 0.2: 218 -> 90 us), both sweeps again: it leads up to 2^28
+    // multiply-adds for any batch (2048^2 x 64 x 8 at density 0.1: 42 against 60 us for the
+    // 64-column kernel), and ONE product leaves it for the K split where the rows are long
+    // enough for their serial walk to show -- from about 288 entries (1024^2 at density 0.3 x
+    // 64: 30 against 26; 512 x 4096 at 0.2, 819 entries: 69 against 35; at 205 entries the
+    // two tie or the gather leads: 2048^2 x 256 at density 0.1: 22 against 33).
+    const bool long_rows = nonzeros >= 288 * static_cast<int64_t>(m);
+    const bool small = work < (int64_t{1} << 28) || (replicas < 8 && work < (int64_t{1} << 29));
+    if (small && replicas == 1 && long_rows && k >= 1024 && work >= (int64_t{1} << 22) &&
+        spmm_tiled64_applicable(m, k, n, nonzeros) && spmm_tiled64_ksplits(m, k, n) >= 4 &&
+        !use_flat(m, k, n, nonzeros))
       return Kernel::kNarrow;
     if (small) return Kernel::kNone;
   }
