@@ -132,30 +132,45 @@ __global__ __launch_bounds__(kBlock) void sddmm_rowwave_kernel(
       }
     }
 
+    // (round 5, as the SpMM row gather: a block of entries was a chain of round trips --
+    // its columns on demand, then the rhs rows two at a time; now the NEXT block's columns
+    // are in flight while this one is worked on and the rhs rows go out kBatch at a time;
+    // an entry past the row's end gathers nothing.  Same sums in the same order.)
+    constexpr int kBatch = (KSL * VEC <= 8) ? (LPN < 4 ? LPN : 4) : (LPN < 2 ? LPN : 2);
+    int j_mine = (g < nblocks && p0 + g * LPN + l < p1) ? column_indices[p0 + g * LPN + l] : 0;
     for (int b = g; b < nblocks; b += kGroups) {
       const int pb = p0 + b * LPN;
       const int q = pb + l;
-      const int j_mine = (q < p1) ? column_indices[q] : 0;
+      const int q_next = q + kGroups * LPN;
+      const int j_next = (q_next < p1) ? column_indices[q_next] : 0;
       const int cnt = min(LPN, p1 - pb);
       float result = 0.f;
-#pragma unroll 2
-      for (int t = 0; t < cnt; ++t) {
-        const int j = __shfl(j_mine, t, LPN);
-        const T* __restrict__ rhs_row = rhs + static_cast<int64_t>(j) * k;
-        float partial = 0.f;
+      for (int t0 = 0; t0 < cnt; t0 += kBatch) {
+        float bv[kBatch][KSL][VEC];
 #pragma unroll
-        for (int s = 0; s < KSL; ++s) {
-          const int c = kp + (s * LPN + l) * VEC;
-          if (c < k) {
-            float bv[VEC];
-            load_elems<VEC, T>(bv, rhs_row + c);
+        for (int u = 0; u < kBatch; ++u) {
+          const int j = __shfl(j_mine, t0 + u, LPN);
+          const T* __restrict__ rhs_row = rhs + static_cast<int64_t>(j) * k;
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) partial = fmaf(a[s][v], bv[v], partial);
+          for (int s = 0; s < KSL; ++s) {
+            const int c = kp + (s * LPN + l) * VEC;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) bv[u][s][v] = 0.f;
+            if (c < k && t0 + u < cnt) load_elems<VEC, T>(bv[u][s], rhs_row + c);
           }
         }
-        const float total = group_sum<LPN>(partial);
-        if (l == t) result = total;
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+          float partial = 0.f;
+#pragma unroll
+          for (int s = 0; s < KSL; ++s)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) partial = fmaf(a[s][v], bv[u][s][v], partial);
+          const float total = group_sum<LPN>(partial);
+          if (l == t0 + u) result = total;
+        }
       }
+      j_mine = j_next;
       if (q < p1) {
         if (kp == 0) {
           out[q] = static_cast<TO>(result);
@@ -314,7 +329,11 @@ bool float_call_is_small(int m, int k, int n, int nonzeros, int replicas, bool p
   const double per_round = width <= 128 ? 9.0 : width <= 256 ? 4.0 : 15.0;
   const double tiled = (planned ? 13.0 : 20.0 + 10e-6 * nonzeros) + per_round * rounds +
                        1.8e-6 * entries * (k / 64.0);
-  return tiled >= 1.1 * wave;
+  // (fitted with a 10 % lean towards the tiled path; the row-wave kernel has since learnt to
+  // keep the next block's columns and four rhs rows in flight -- 1.2-2 x faster on long rows --
+  // and on the sweep repeated with it, profiles/r5_sddmm_tiled_vs_wave_final.jsonl, the
+  // estimates as they stand decide best WITHOUT the lean: mean regret 0.9 %, worst 23 %)
+  return tiled >= wave;
 }
 
 bool takes_tiled(int m, int k, int n, int nonzeros, int replicas /* < 0: unknown */,
