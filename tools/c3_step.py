@@ -27,18 +27,43 @@ def main():
     attn.differentiable_softmax = not fused
     x = torch.randn(batch, s, emb, device=dev).requires_grad_(True)
     gout = torch.randn(batch, s, emb, device=dev)
+    def step():
+        x.grad = None
+        for lin in attn.linears:
+            lin.values.grad = None
+        attn(x, x, x, None).backward(gout)
+
     for it in range(iters + 3):
         if it == 3:
             torch.cuda.synchronize()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-        x.grad = None
-        for lin in attn.linears:
-            lin.values.grad = None
-        attn(x, x, x, None).backward(gout)
+        step()
     b.record()
     torch.cuda.synchronize()
     print(f"c3 forward + backward: {a.elapsed_time(b) / iters:.4f} ms per step", flush=True)
+    if os.environ.get("C3_STEP_HOST_PROFILE"):
+        # where the HOST spends its time per step (the eager step is ~27 launches in ~0.58 ms:
+        # a host that needs more than ~20 us per launch leaves the GPU waiting): the device
+        # queue is drained after every step so that only host work is on the clock
+        import cProfile
+        import pstats
+        import time
+        prof = cProfile.Profile()
+        t0 = time.perf_counter()
+        n = 50
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        print(f"host wall per step, unprofiled: {(time.perf_counter() - t0) / n * 1e3:.4f} ms", flush=True)
+        prof.enable()
+        for _ in range(n):
+            step()
+        prof.disable()
+        torch.cuda.synchronize()
+        st = pstats.Stats(prof)
+        st.sort_stats("cumulative").print_stats(45)
+        st.sort_stats("tottime").print_stats(30)
 
 
 if __name__ == "__main__":
