@@ -548,6 +548,54 @@ def test_spmm_narrow_k_split(capi, dev, monkeypatch, m, k, n, bias):
         capi.reload_options()
 
 
+@pytest.mark.parametrize("n,k", [(8, 40), (20, 100), (64, 64), (72, 300), (130, 512), (1000, 96)])
+def test_workspace_free_kernels_on_every_row_length(capi, dev, monkeypatch, n, k):
+    """Round 5: the SpMM row gather and the SDDMM row-wave kernel keep the next window of a
+    row in flight and send their gathers out in batches, entries past a row's end gathering
+    nothing.  Rows of EVERY length from 0 to past three windows (so every remainder of the
+    window and of the batch occurs, next to empty rows), any lane-group width (n: 8 ... 64
+    lanes; k: 4 ... 64 lanes and two k slices), NaN in the rows of B / rhs that no entry names
+    (a padded gather must not reach the sum).  Bit-identical to the oracle's order: one row,
+    ascending entries."""
+    rng = np.random.default_rng(n + k)
+    lengths = list(range(0, 3 * 64 + 6)) + [0, 0, 1]
+    lengths = [min(l, k - 1) for l in lengths]
+    m = len(lengths)
+    ro = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int32)
+    # (column 0 is never named: its row of B / rhs is poisoned below)
+    ci = np.concatenate([np.sort(rng.choice(np.arange(1, k), size=l, replace=False)) for l in lengths]
+                        ).astype(np.int32)
+    ri = np.argsort(-np.asarray(lengths), kind="stable").astype(np.int32)
+    vals = rng.uniform(-1, 1, size=len(ci)).astype(np.float32)
+    topo = (T(ri, dev), T(ro, dev), T(ci, dev))
+    monkeypatch.setenv("SPUTNIK_HIP_SPMM_KERNEL", "gather")
+    monkeypatch.setenv("SPUTNIK_HIP_SDDMM_KERNEL", "wave")
+    capi.reload_options()
+    try:
+        b = rng.uniform(-1, 1, size=(k, n)).astype(np.float32)
+        want = c_oracle.spmm(m, k, vals, ro, ci, b)
+        b[0, :] = np.nan
+        out = torch.full((m, n), float("nan"), device=dev)
+        capi.spmm_batched(m, k, n, 1, topo[0], T(vals, dev), 0, topo[1], topo[2], T(b, dev), out, None)
+        got = out.cpu().numpy()
+        assert not np.isnan(got).any()
+        assert rel_err(got, want) < TOL
+        # SDDMM: mask m x k (the same topology), operands of inner dimension n
+        lhs = rng.uniform(-1, 1, size=(1, m, n)).astype(np.float32)
+        rhs = rng.uniform(-1, 1, size=(1, k, n)).astype(np.float32)
+        want_s = c_oracle.sddmm(m, k, ro, ci, lhs, rhs)
+        rhs[0, 0, :] = np.nan
+        out_s = torch.full((1, len(ci)), float("nan"), device=dev)
+        capi.sddmm_batched(m, n, k, 1, topo[0], topo[1], topo[2], T(lhs, dev), T(rhs, dev), out_s, None)
+        got_s = out_s.cpu().numpy()
+        assert not np.isnan(got_s).any()
+        assert rel_err(got_s, want_s.astype(np.float32), ro) < TOL
+    finally:
+        monkeypatch.delenv("SPUTNIK_HIP_SPMM_KERNEL", raising=False)
+        monkeypatch.delenv("SPUTNIK_HIP_SDDMM_KERNEL", raising=False)
+        capi.reload_options()
+
+
 def test_spmm_kernel_name_reports_the_dispatch(capi):
     assert capi.spmm_kernel_name(4096, 4096, 4096, 1677724, 1).startswith("spmm_flat_kernel")
     # config 5 at its stated size: 64 tiles per replica, the flat kernel from 3 replicas on
