@@ -34,6 +34,9 @@ def main():
     ap.add_argument("--replicas", type=ints, default=[1, 8, 64])
     ap.add_argument("--densities", type=lambda v: [float(x) for x in v.split(",")], default=[0.02, 0.1, 0.3])
     ap.add_argument("--max-elements", type=float, default=3e8, help="skip shapes with more output elements")
+    ap.add_argument("--half", action="store_true",
+                    help="float16 values and dense operand through sputnik_hip_spmm_typed (its own "
+                         "dispatch: matrix-core tiles / panel / row gather / widening + float kernels)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     for m, k in [(m, k) for m in args.sizes for k in (args.ks or [m])]:
@@ -45,6 +48,8 @@ def main():
                         continue
                     values = uniform((reps, nnz) if reps > 1 else (nnz,), dev, 12)
                     dense = uniform((reps, k, n) if reps > 1 else (k, n), dev, 13)
+                    if args.half:
+                        values, dense = values.half(), dense.half()
                     out = torch.empty((reps, m, n) if reps > 1 else (m, n), device=dev)
                     row = {"m": m, "k": k, "n": n, "replicas": reps, "density": d, "nnz": nnz}
                     for kern in KERNELS:
@@ -53,10 +58,19 @@ def main():
                         else:
                             os.environ["SPUTNIK_HIP_SPMM_KERNEL"] = kern
                         capi.reload_options()
-                        ws = torch.empty(capi.spmm_workspace_bytes(m, k, n, nnz) + 16, dtype=torch.uint8,
-                                         device=dev)
-                        t = timeit(lambda: capi.spmm_batched(m, k, n, reps, ri, values, nnz if reps > 1 else 0,
-                                                             ro, ci, dense, out, ws), iters=15, warmup=4)
+                        if args.half:
+                            vs = nnz if reps > 1 else 0
+                            ws = torch.empty(capi.spmm_typed_workspace_bytes(m, k, n, nnz, reps, values, vs,
+                                                                             dense) + 256, dtype=torch.uint8,
+                                             device=dev)
+                            t = timeit(lambda: capi.spmm_typed(m, k, n, reps, ri, values, vs, ro, ci, dense, out,
+                                                               ws), iters=15, warmup=4)
+                        else:
+                            ws = torch.empty(capi.spmm_workspace_bytes(m, k, n, nnz) + 16, dtype=torch.uint8,
+                                             device=dev)
+                            t = timeit(lambda: capi.spmm_batched(m, k, n, reps, ri, values,
+                                                                 nnz if reps > 1 else 0, ro, ci, dense, out, ws),
+                                       iters=15, warmup=4)
                         row[kern] = round(1000 * t, 1)
                         if kern == "auto":
                             row["auto_kernel"] = capi.spmm_kernel_name(m, k, n, nnz, reps)[:40]

@@ -625,7 +625,13 @@ int sputnik_hip_spmm_typed(int m, int k, int n, int nonzeros, int replicas,
                                                     dense_stride, out, out_stride) &&
                         (forced == 3 || k <= 512 ||
                          (k <= 1024 && nonzeros <= 320 * static_cast<int64_t>(m))) &&
-                        static_cast<int64_t>(nonzeros) * n * replicas >= (int64_t{1} << 22);
+                        static_cast<int64_t>(nonzeros) * n * replicas >= (int64_t{1} << 22) &&
+                        // (round 5, tools/spmm_dispatch_sweep.py --half: as for float operands the
+                        // panel kernel needs workgroups against the row gather -- 1024^2 x 256,
+                        // one replica, 16 of them: 35 against 23 us at density 0.1, 82 against 57
+                        // at 0.3)
+                        (forced == 3 ||
+                         static_cast<int64_t>((m + 255) / 256) * ((n + 63) / 64) * replicas >= 96);
   if (panel_ok)
     return spmm_panel_launch_typed(m, k, n, nonzeros, replicas, row_indices, values, values_type,
                                    values_stride, row_offsets, column_indices, dense, dense_type,
