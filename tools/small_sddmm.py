@@ -3,7 +3,7 @@
 (one launch): both forced through SPUTNIK_HIP_SDDMM_KERNEL, per-call form (the pre-pass
 inside the call), and what the automatic rule picks (csrc/sddmm.hip, takes_tiled).
 
-    python tools/small_sddmm.py [--summed]      (--summed: the form summed over the replicas,
+    python tools/small_sddmm.py [--summed] [--half]      (--half: float16 operands; --summed: the form summed over the replicas,
                                                  the weight gradient of a layer: sddmm_sum_batched)
 """
 import json
@@ -31,6 +31,7 @@ SUMMED_SHAPES = ((256, 256, 8), (512, 64, 8), (512, 256, 8), (512, 256, 32), (51
 def main():
     dev = torch.device("cuda:0")
     summed = "--summed" in sys.argv
+    half = "--half" in sys.argv     # float16 operands, float32 output: sputnik_hip_sddmm_typed
     for (sz, k, reps) in (SUMMED_SHAPES if summed else SHAPES):
         for d in (0.5, 0.1, 0.05, 0.02):
             ri, ro, ci, nnz = random_csr(sz, sz, d, dev, seed=3)
@@ -38,6 +39,8 @@ def main():
                 continue
             lhs = uniform((reps, sz, k), dev, 4)
             rhs = uniform((reps, sz, k), dev, 5)
+            if half:
+                lhs, rhs = lhs.half(), rhs.half()
             out = torch.empty(nnz if summed else (reps, nnz), device=dev)
             ws = torch.empty((capi.sddmm_sum_workspace_bytes if summed else capi.sddmm_workspace_bytes)(
                 sz, k, sz, nnz) + 16, dtype=torch.uint8, device=dev)
@@ -54,6 +57,8 @@ def main():
                                       device=dev)
                     t = timeit(lambda: capi.sddmm_sum_batched(sz, k, sz, reps, ri, ro, ci, lhs, rhs, out, ws,
                                                               scr), iters=40)
+                elif half:
+                    t = timeit(lambda: capi.sddmm_typed(sz, k, sz, reps, ri, ro, ci, lhs, rhs, out, ws), iters=40)
                 else:
                     t = timeit(lambda: capi.sddmm_batched(sz, k, sz, reps, ri, ro, ci, lhs, rhs, out, ws),
                                iters=40)

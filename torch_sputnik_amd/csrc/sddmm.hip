@@ -438,7 +438,9 @@ int sddmm_exec_half(int m, int k, int n, int nonzeros, int replicas, const int* 
   const bool half_out = out_type != SPUTNIK_HIP_F32;
   const bool force_tiled = options().sddmm_kernel == 1;
   const bool force_wave = options().sddmm_kernel == 2;
-  const bool small = static_cast<double>(nonzeros) * k * k * replicas < 17179869184.0;  // 2^34
+  // (the float product's estimates: on the half sweep, tools/small_sddmm.py --half, the
+  // one-number rule left 17 % mean regret, worst 2.9 x; these leave 1.1 %)
+  const bool small = float_call_is_small(m, k, n, nonzeros, replicas, planned);
   const bool tiled = !force_wave && (force_tiled || !small) && workspace != nullptr &&
                      aligned_to(workspace, 16) &&
                      sddmm_tiled_applicable_half(m, k, n, nonzeros, lhs, lhs_stride, rhs, rhs_stride) &&
@@ -876,9 +878,7 @@ const char* sputnik_hip_sddmm_kernel_name(int m, int k, int n, int nonzeros, int
   if (m <= 0 || k <= 0 || n <= 0 || nonzeros <= 0 || replicas <= 0) return "none";
   const bool force_tiled = options().sddmm_kernel == 1;
   const bool force_wave = options().sddmm_kernel == 2;
-  const bool small = elem_bytes == 4
-                         ? float_call_is_small(m, k, n, nonzeros, replicas, planned != 0)
-                         : static_cast<double>(nonzeros) * k * k * replicas < 17179869184.0;  // 2^34
+  const bool small = float_call_is_small(m, k, n, nonzeros, replicas, planned != 0);
   const bool shape = sddmm_tiled_workspace_bytes(m, k, n, nonzeros) != 0 &&
                      static_cast<int64_t>(n) * k * elem_bytes < (int64_t{1} << 32) &&
                      static_cast<int64_t>(m) * k * elem_bytes < (int64_t{1} << 32);
