@@ -316,19 +316,28 @@ namespace {
 //   tiled: 20 (13 with the plan made ahead), 10 us per million entries of pre-pass, the
 //     rounds of slab-staging workgroups (9 us per round of 512 at widths <= 128, 4 / 15 per
 //     round of 256 at 256 / 512), 1.8 us per million entries and 64 elements.
-bool float_call_is_small(int m, int k, int n, int nonzeros, int replicas, bool planned) {
-  const int width = sddmm_tiled_panel_width(k);
-  if (width == 0 || m <= 0) return true;
+// `summed`: the form summed over the replicas, whose panels (its own width) run side by
+// side in ONE launch.  And a workgroup is no faster than its own entries allow, 17 ps per
+// entry and element of the panel -- a mask of few workgroups with many entries each (256^2
+// at density 0.5, k = 256, 8 replicas: 16 workgroups, 56 us against 28 on the row-wave
+// kernel) is not carried by the chip-wide rate.
+bool float_call_is_small(int m, int k, int n, int nonzeros, int replicas, bool planned,
+                         bool summed = false) {
+  const int width = summed ? (sddmm_tiled_panels(m, k, n, nonzeros) > 0
+                                  ? k / sddmm_tiled_panels(m, k, n, nonzeros) : 0)
+                           : sddmm_tiled_panel_width(k);
+  if (width == 0 || m <= 0 || (width != 64 && width != 128 && width != 256 && width != 512)) return true;
   const double entries = static_cast<double>(nonzeros) * replicas, panels = k / width;
   const double per_million = width <= 64 ? 8.2 : width <= 128 ? 28.0 : width <= 256 ? 55.0 : 90.0;
   const double wave = std::max({13.0, 0.85e-3 * m * replicas + per_million * 1e-6 * entries * panels,
                                 0.72e-3 * nonzeros / m * k});
   const int slab_rows = width <= 64 ? 256 : width <= 256 ? 128 : 64;
-  const double workgroups = static_cast<double>(replicas) * ceil_div(m, 256) * ceil_div(n, slab_rows);
-  const double rounds = workgroups / (width <= 128 ? 512 : 256) * panels;
+  const double per_replica = static_cast<double>(ceil_div(m, 256)) * ceil_div(n, slab_rows);
+  const double rounds = per_replica * replicas / (width <= 128 ? 512 : 256) * panels;
   const double per_round = width <= 128 ? 9.0 : width <= 256 ? 4.0 : 15.0;
-  const double tiled = (planned ? 13.0 : 20.0 + 10e-6 * nonzeros) + per_round * rounds +
-                       1.8e-6 * entries * (k / 64.0);
+  const double own_entries = 1.7e-5 * (nonzeros / per_replica) * width * (summed ? 1.0 : panels);
+  const double tiled = (planned ? 13.0 : 20.0 + 10e-6 * nonzeros) +
+                       std::max(per_round * rounds + 1.8e-6 * entries * (k / 64.0), own_entries);
   // (fitted with a 10 % lean towards the tiled path; the row-wave kernel has since learnt to
   // keep the next block's columns and four rhs rows in flight -- 1.2-2 x faster on long rows --
   // and on the sweep repeated with it, profiles/r5_sddmm_tiled_vs_wave_final.jsonl, the
@@ -342,10 +351,7 @@ bool takes_tiled(int m, int k, int n, int nonzeros, int replicas /* < 0: unknown
                  bool planned = false) {
   const bool force_tiled = options().sddmm_kernel == 1;
   const bool force_wave = options().sddmm_kernel == 2;
-  // (the summed form keeps the one-number rule: its panels run side by side)
-  const bool small = replicas >= 0 &&
-                     (summed ? static_cast<double>(nonzeros) * k * k * replicas < 17179869184.0   // 2^34
-                             : float_call_is_small(m, k, n, nonzeros, replicas, planned));
+  const bool small = replicas >= 0 && float_call_is_small(m, k, n, nonzeros, replicas, planned, summed);
   return !force_wave && (force_tiled || !small) && workspace != nullptr &&
          aligned_to(workspace, 16) &&
          sddmm_tiled_applicable(m, k, n, nonzeros, lhs, lhs_stride, rhs, rhs_stride) &&
@@ -637,7 +643,7 @@ int sddmm_sum_exec_half(int m, int k, int n, int nonzeros, int replicas, const i
                                planned, scratch, scratch_bytes, stream, 1, 0, 0);
   const bool force_tiled = options().sddmm_kernel == 1;
   const bool force_wave = options().sddmm_kernel == 2;
-  const bool small = static_cast<double>(nonzeros) * k * k * replicas < 17179869184.0;  // 2^34
+  const bool small = float_call_is_small(m, k, n, nonzeros, replicas, planned, /*summed=*/true);
   bool tiled = !force_wave && (force_tiled || !small) && workspace != nullptr &&
                aligned_to(workspace, 16) &&
                sddmm_tiled_applicable_half(m, k, n, nonzeros, lhs, lhs_stride, rhs, rhs_stride) &&
