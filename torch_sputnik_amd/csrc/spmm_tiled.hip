@@ -563,30 +563,24 @@ inline size_t wide_workspace_bytes(int m, int k, int n) {
 }
 
 inline Kernel choose_kernel(int m, int k, int n, int nonzeros, int replicas /* < 0: unknown */) {
-  // Small calls are launch-latency bound: the workspace-free row-gather kernel is
-  // one launch, the tiled kernels are a pre-pass plus a kernel with a staging
-  // pipeline to fill, and a lone product gives them few workgroups.  Measured
-  // (tools/n_sweep.py, tools/small_sweep.py), W = multiply-adds of the call:
-  // below 1.3e8 the row-gather kernel always wins (64^3 12 vs 17 us, 1024^3 at
-  // density 0.1 31 vs 42 us); with 8 or more replicas the tiled kernels win from
-  // there on (512^2 x 1024, 8 replicas: 39 vs 51 us; config 3: 62 vs 91 us); with
-  // fewer they need about 5e8 (4096^2 x 256, one replica, 4.3e8: 94 us row gather
-  // vs 132 us tiled; 2048^3 at density 0.1, 8.6e8: tiled).
+  // Small calls are launch-latency bound: the workspace-free row-gather kernel is one launch,
+  // the tiled kernels are a pre-pass plus a kernel with a staging pipeline to fill, and a lone
+  // product gives them few workgroups.  The thresholds below are those of round 5's sweeps
+  // (tools/spmm_dispatch_sweep.py: every kernel the knob can force against this choice on 342
+  // shapes, profiles/r5_spmm_dispatch_sweep*; W = multiply-adds of the call), taken with the
+  // row gather as it is since that round (spmm.hip: the next window and eight gathers of a
+  // row in flight); rounds 1-4 drew them at 2^27 / 2^29 for a slower one.
   const int forced = forced_kernel();
   if (forced == 2) return Kernel::kNone;
   if (replicas >= 0 && forced == 0) {
     const int64_t work = static_cast<int64_t>(nonzeros) * n * replicas;
-    // (round 4) ONE product against a narrow operand over a long K: the 64-column kernel
-    // with its K chunks dealt to several workgroups per tile (tools/narrow_n_bench.py:
-    // 4096^2 x 72 at density 0.1: 40 against 75 us for the row gather of that round).
-    // Round 5, after the row gather learnt to keep eight gathers and the next window in
-    // flight (spmm.hip: an entry of a row now takes 0.09 us instead of 0.19; 512 x 4096 x 64
-    // x 4 replicas at density 0.2: 218 -> 90 us), both sweeps again: it leads up to 2^28
-    // multiply-adds for any batch (2048^2 x 64 x 8 at density 0.1: 42 against 60 us for the
-    // 64-column kernel), and ONE product leaves it for the K split where the rows are long
-    // enough for their serial walk to show -- from about 288 entries (1024^2 at density 0.3 x
-    // 64: 30 against 26; 512 x 4096 at 0.2, 819 entries: 69 against 35; at 205 entries the
-    // two tie or the gather leads: 2048^2 x 256 at density 0.1: 22 against 33).
+    // The row gather leads up to W = 2^28 for any batch (2048^2 x 64 x 8 replicas at density
+    // 0.1: 42 against 60 us for the 64-column kernel) and to 2^29 for fewer than 8 replicas.
+    // ONE product over a long K leaves it for the 64-column kernel's K split (round 4: K chunks
+    // dealt to several workgroups per tile) where the rows are long enough for the gather's
+    // serial walk, 0.09 us an entry, to show: from about 288 entries (1024^2 at density 0.3 x
+    // 64 columns: 30 against 26 us; 512 x 4096 at 0.2, 819 entries: 69 against 35; at 205
+    // entries the two tie or the gather leads: 2048^2 x 256 at density 0.1: 22 against 33).
     const bool long_rows = nonzeros >= 288 * static_cast<int64_t>(m);
     const bool small = work < (int64_t{1} << 28) || (replicas < 8 && work < (int64_t{1} << 29));
     if (small && replicas == 1 && long_rows && k >= 1024 && work >= (int64_t{1} << 22) &&
