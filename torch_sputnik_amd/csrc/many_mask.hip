@@ -21,7 +21,7 @@ namespace sputnik_hip {
 int softmax_many_mask(bool backward, int m, int width, int largest_nonzeros, int replicas, int heads,
                       const float* a, int64_t a_stride, const float* b, int64_t b_stride,
                       const int* row_offsets, float* out, int64_t out_stride, float scale,
-                      hipStream_t stream);
+                      hipStream_t stream, int masks, const int* mask_nonzeros);
 size_t sddmm_tiled_workspace_bytes(int m, int k, int n, int nonzeros, bool summed);
 bool spmm_panel_applicable(int m, int k, int n, int nonzeros, const float* dense,
                            int64_t dense_stride, const float* out, int64_t out_stride);
@@ -159,7 +159,7 @@ int sputnik_hip_sparse_softmax_many_mask(int masks, int m, const int* nonzeros, 
   const int width = static_cast<int>(std::min<int64_t>(values_stride, out_stride));
   if (width < largest) return SPUTNIK_HIP_INVALID_ARGUMENT;
   return softmax_many_mask(false, m, width, largest, replicas, w.heads, values, values_stride,
-                           nullptr, 0, row_offsets, out, out_stride, scale, stream);
+                           nullptr, 0, row_offsets, out, out_stride, scale, stream, masks, nonzeros);
 }
 
 int sputnik_hip_sparse_softmax_backward_many_mask(int masks, int m, const int* nonzeros,
@@ -179,7 +179,7 @@ int sputnik_hip_sparse_softmax_backward_many_mask(int masks, int m, const int* n
   if (width < largest) return SPUTNIK_HIP_INVALID_ARGUMENT;
   return softmax_many_mask(true, m, width, largest, replicas, w.heads, softmax_out, out_stride,
                            grad_out, grad_out_stride, row_offsets, grad_values, grad_values_stride,
-                           scale, stream);
+                           scale, stream, masks, nonzeros);
 }
 
 int sputnik_hip_csr_transpose_many_mask(int masks, int m, int n, const int* nonzeros,

@@ -99,7 +99,12 @@ __global__ __launch_bounds__(kBlock) void sparse_softmax_rows_kernel(
     int m, int rows_per_group, int nonzeros, const T* __restrict__ a, int64_t a_stride,
     const T* __restrict__ b, int64_t b_stride, const int* __restrict__ row_offsets,
     T* __restrict__ out, int64_t out_stride, float scale, int same_phase, int mask_heads,
-    int first_replica) {
+    int first_replica, unsigned long long mask_members) {
+  // "many mask", one launch per CLASS of masks (softmax_many_mask below): bit i set = mask i
+  // runs at this launch's lane count; the workgroups of the others leave at once
+  if (mask_members != 0 &&
+      !((mask_members >> ((first_replica + static_cast<int>(blockIdx.y)) / mask_heads)) & 1ull))
+    return;
   constexpr int E = Piece<T>::kEntries;   // entries per 16-byte piece
   using W = typename Piece<T>::wide;
   constexpr int kWindow = LPR * E * V;
@@ -305,7 +310,7 @@ inline int phase_of(const T* p) {
 template <typename T, int LPR, int BASE, int V, bool BACKWARD>
 int launch_rows(int m, int nonzeros, int replicas, const T* a, int64_t a_stride, const T* b,
                 int64_t b_stride, const int* row_offsets, T* out, int64_t out_stride,
-                float scale, hipStream_t stream, int mask_heads) {
+                float scale, hipStream_t stream, int mask_heads, unsigned long long mask_members) {
   // Two rows per group once the grid fills the chip (256 CUs x 8 workgroups):
   // measured at config 3's mask with 64 and 512 replicas (tools/softmax_sweep.sh),
   // short workgroups whose dispatch staggers the read and the write phases beat
@@ -337,7 +342,8 @@ int launch_rows(int m, int nonzeros, int replicas, const T* a, int64_t a_stride,
 #define SPUTNIK_HIP_SOFTMAX_LAUNCH(DEPTH, NT)                                                     \
   hipLaunchKernelGGL((sparse_softmax_rows_kernel<T, LPR, BASE, V, BACKWARD, DEPTH, NT>), dim3(gx, ry), \
                      dim3(kBlock), 0, stream, m, rows_per_group, nonzeros, a_r, a_stride, b_r,   \
-                     b_stride, row_offsets, out_r, out_stride, scale, same_phase, mask_heads, r0)
+                     b_stride, row_offsets, out_r, out_stride, scale, same_phase, mask_heads, r0, \
+                     mask_members)
     // Nontemporal STORES in the forward pass when the output is larger than the
     // caches can hand to the next kernel anyway (measured, 1024^2 mask at density
     // 0.1: 512 replicas, 215 MB out, 88.4 -> 75.8 us; 64 replicas 12.5 -> 12.2 us
@@ -366,21 +372,31 @@ int launch_rows(int m, int nonzeros, int replicas, const T* a, int64_t a_stride,
 // slot costs an exp); up to V pieces are there for the few longer rows and are
 // paid for only in the steps that need them.  Rows beyond LPR * 4 * V take the
 // strided passes.
+// Entries the window of a row has to hold for a mask of `nonzeros` entries in m rows: the
+// mean row + ~2.2 standard deviations of a random pattern + the alignment slack.
+inline int64_t entries_a_row_needs(int m, int64_t nonzeros) {
+  const int64_t mean = nonzeros / m;
+  int64_t dev = 1;
+  while (dev * dev < 5 * mean) ++dev;   // ~ 2.2 * sqrt(mean)
+  return mean + dev + 3;
+}
+// The float kernels' classes by that need (the cases of dispatch_rows below).
+inline int float_class_of(int64_t need) {
+  return need <= 64 ? 0 : need <= 128 ? 1 : need <= 192 ? 2 : need <= 256 ? 3 : need <= 512 ? 4 : 5;
+}
+
 template <typename T, bool BACKWARD>
 int dispatch_rows(int m, int nonzeros, int replicas, const T* a, int64_t a_stride,
                   const T* b, int64_t b_stride, const int* row_offsets, T* out,
                   int64_t out_stride, float scale, hipStream_t stream, int mask_heads = 0,
-                  int typical_nonzeros = -1) {
+                  int typical_nonzeros = -1, unsigned long long mask_members = 0) {
   // (many masks: `nonzeros` is the width of a value row -- what may be read --, the
-  // window is sized for the largest mask)
-  const int64_t mean = (typical_nonzeros >= 0 ? typical_nonzeros : nonzeros) / m;
-  int64_t dev = 1;
-  while (dev * dev < 5 * mean) ++dev;   // ~ 2.2 * sqrt(mean)
-  const int64_t need = mean + dev + 3;
+  // window is sized for `typical_nonzeros`, the largest mask of the launch)
+  const int64_t need = entries_a_row_needs(m, typical_nonzeros >= 0 ? typical_nonzeros : nonzeros);
 #define SPUTNIK_HIP_SOFTMAX_CASE(LPR, BASE, V)                                                    \
   return launch_rows<T, LPR, BASE, V, BACKWARD>(m, nonzeros, replicas, a, a_stride, b, b_stride,  \
                                                 row_offsets, out, out_stride, scale, stream,      \
-                                                mask_heads)
+                                                mask_heads, mask_members)
   if constexpr (Piece<T>::kEntries == 8) {   // half types: 8 entries per piece and lane
     if (need <= 128) SPUTNIK_HIP_SOFTMAX_CASE(16, 1, 2);
     if (need <= 256) SPUTNIK_HIP_SOFTMAX_CASE(16, 2, 3);
@@ -431,17 +447,44 @@ int dispatch_typed(int dtype, int m, int nonzeros, int replicas, const void* a, 
 
 // One launch for all masks of a "many mask" batch (many_mask.hip): value rows
 // [replicas][width], replica r under the topology number r / heads.
+// Round 5: one launch per CLASS of masks instead of one launch at the lane count of the
+// largest.  The masks of a batch differ in size (tests/test_attention_many_masks.py:26-36 of
+// the reference draws a sparsity per batch element), and a row of 51 entries walked by the 64
+// lanes x 4 pieces that a row of 512 needs keeps one piece in sixteen busy: 8 masks of
+// density 0.05 - 0.5 x 8 heads, S = 1024, ran at 36 us where the same entries in equal masks
+// take 22.  Every launch covers all replicas; the workgroups of the masks outside its class
+// (a bit per mask in a kernel argument: up to 64 masks, more keep the one launch) leave at
+// once.  `mask_nonzeros`: the masks' entry counts, a HOST array.
 int softmax_many_mask(bool backward, int m, int width, int largest_nonzeros, int replicas, int heads,
                       const float* a, int64_t a_stride, const float* b, int64_t b_stride,
                       const int* row_offsets, float* out, int64_t out_stride, float scale,
-                      hipStream_t stream) {
+                      hipStream_t stream, int masks, const int* mask_nonzeros) {
   if (m == 0 || width == 0 || replicas == 0 || largest_nonzeros == 0) return 0;
-  return backward ? dispatch_rows<float, true>(m, width, replicas, a, a_stride, b, b_stride,
-                                               row_offsets, out, out_stride, scale, stream, heads,
-                                               largest_nonzeros)
-                  : dispatch_rows<float, false>(m, width, replicas, a, a_stride, nullptr, 0,
-                                                row_offsets, out, out_stride, scale, stream, heads,
-                                                largest_nonzeros);
+  const auto launch = [&](int typical, unsigned long long members) {
+    return backward ? dispatch_rows<float, true>(m, width, replicas, a, a_stride, b, b_stride,
+                                                 row_offsets, out, out_stride, scale, stream, heads,
+                                                 typical, members)
+                    : dispatch_rows<float, false>(m, width, replicas, a, a_stride, nullptr, 0,
+                                                  row_offsets, out, out_stride, scale, stream, heads,
+                                                  typical, members);
+  };
+  if (mask_nonzeros == nullptr || masks < 2 || masks > 64 || replicas > kMaxGridYZ)
+    return launch(largest_nonzeros, 0ull);
+  constexpr int kClasses = 6;
+  unsigned long long members[kClasses] = {};
+  int typical[kClasses] = {};
+  for (int i = 0; i < masks; ++i) {
+    if (mask_nonzeros[i] <= 0) continue;   // (no entries: nothing to normalise)
+    const int c = float_class_of(entries_a_row_needs(m, mask_nonzeros[i]));
+    members[c] |= 1ull << i;
+    typical[c] = std::max(typical[c], mask_nonzeros[i]);
+  }
+  for (int c = 0; c < kClasses; ++c) {
+    if (members[c] == 0) continue;
+    const int st = launch(typical[c], members[c]);
+    if (st != 0) return st;
+  }
+  return 0;
 }
 
 }  // namespace sputnik_hip
