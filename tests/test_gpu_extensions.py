@@ -191,6 +191,7 @@ def _many_mask_inputs(b, heads, s, hn, sparsities, seed):
     # (15 replicas: no multiple of 8 -- the plain XCD order; two masks of one size; an empty one)
     (5, 3, 256, 64, (0.5, 0.9, 1.0, 0.7, 0.5)),
     (16, 4, 256, 64, (0.95, 0.5, 0.9, 0.9)),
+    (70, 1, 64, 8, (0.5, 0.9, 0.2)),   # more masks than the softmax's class launches carry bits for
 ])
 @pytest.mark.parametrize("plan_per_mask", [False, True],
                          ids=["single_mask_workspace", "many_mask_workspace"])
