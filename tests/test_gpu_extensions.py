@@ -639,22 +639,33 @@ def test_spmm_transposed_out(ts, dev, spmm_kernel, m, k, n, replicas, block, lef
     assert rel_err(got.cpu().numpy(), np.ascontiguousarray(want).astype(np.float32)) < TOL
 
 
-def test_spmm_transposed_out_with_permuted_values(ts, dev):
-    """The input gradient of a projection, head split: transposed topology, values
-    gathered through the permutation, product stored in blocks."""
-    m, n, width, replicas, block = 512, 512, 1024, 2, 64
+@pytest.mark.parametrize("m,n,width,replicas,block,left", [
+    (512, 512, 1024, 2, 64, True),     # the input gradient of a projection, head split
+    (1024, 1024, 64, 4, 64, False),    # round 5: attention dV / dK, TWO panels with cut rows
+])
+def test_spmm_transposed_out_with_permuted_values(ts, dev, m, n, width, replicas, block, left):
+    """Transposed topology, values gathered through the permutation INSIDE the kernel,
+    product stored in blocks: bit-identical to the permutation as a pass of its own
+    followed by the product (round 5: also with two panels, whose rows the kernel cuts
+    at the panel boundary so that every value is gathered once)."""
     a, vals, ri, ro, ci = make_csr(m, n, 0.9, seed=3)
     rng = np.random.default_rng(4)
-    v = rng.uniform(-1, 1, len(ci)).astype(np.float32)
+    v = rng.uniform(-1, 1, len(ci) if left else (replicas, len(ci))).astype(np.float32)
     x = rng.uniform(-1, 1, (replicas, m, width)).astype(np.float32)
-    _, ro_t, ci_t, perm = ts.csr_transpose_with_permutation(m, n, T(v, dev), T(ro, dev), T(ci, dev))
+    _, ro_t, ci_t, perm = ts.csr_transpose_with_permutation(m, n, T(v if left else v[0], dev), T(ro, dev),
+                                                            T(ci, dev))
+    from torch_sputnik_amd import ops
     from torch_sputnik_amd.topology import diffsort
+    assert ops.spmm_permuted_fused(n, m, width, len(ci))
     ri_t = diffsort(ro_t)
     got = ts.spmm_transposed_out(n, m, T(v, dev), ri_t, ro_t, ci_t, T(x, dev), block,
-                                 permutation=perm, left=True)
-    plain = ts.spmm_permuted(n, m, T(v, dev), perm, ri_t, ro_t, ci_t, T(x, dev), left=True)
+                                 permutation=perm, left=left)
+    plain = ts.spmm_permuted(n, m, T(v, dev), perm, ri_t, ro_t, ci_t, T(x, dev), left=left)
     moved = plain.reshape(replicas * (n // block), block, width).transpose(1, 2)
     assert torch.equal(got, moved.contiguous())
+    two_step = ts.spmm_transposed_out(n, m, ts.permute_last(T(v, dev), perm), ri_t, ro_t, ci_t, T(x, dev),
+                                      block, left=left)
+    assert torch.equal(got, two_step)
 
 
 @pytest.mark.parametrize("m,k,n,replicas,count,block", [

@@ -5,7 +5,11 @@ the panel boundary (the masked walk that serves any column order, round 2-3's on
 Host timing; run ONE variant under rocprofv3 --kernel-trace --stats (tools/prof_variants.sh)
 for device-side times.
 
-    python tools/spmm_c3_bench.py [--variants 0,16] [--transposed]
+    python tools/spmm_c3_bench.py [--variants 0,16] [--permuted]
+
+--permuted: the TRANSPOSED product of the backward pass (dV = P^T dO, dK = dS^T Q) with the
+values permuted by a pass of their own (LDS-banded permutation, then the product) against the
+kernel gathering them through the cached permutation (round 5: two panels with cut rows).
 """
 import argparse
 import json
@@ -27,6 +31,7 @@ def main():
     ap.add_argument("--replicas", type=int, default=64)
     ap.add_argument("--seq", type=int, default=1024)
     ap.add_argument("--density", type=float, default=0.1)
+    ap.add_argument("--permuted", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     s, d, reps = args.seq, 64, args.replicas
@@ -42,6 +47,24 @@ def main():
         print(json.dumps(dict(kernel=capi.spmm_kernel_name(s, s, d, nnz, reps), debug=dbg, us=round(1000 * t, 2),
                               tflops=round(2.0 * nnz * d * reps / t / 1e9, 2))), flush=True)
     os.environ.pop("SPUTNIK_HIP_SPMM_DEBUG", None)
+    capi.reload_options()
+    if args.permuted:
+        from torch_sputnik_amd import ops
+        from torch_sputnik_amd.topology import diffsort
+        _, rot, cit, perm = ops.csr_transpose_with_permutation(s, s, p[0].contiguous(), ro, ci)
+        rit = diffsort(rot)
+        lists = ops.banded_lists(perm)
+
+        def separate():
+            return ops.spmm_transposed_out(s, s, ops.permute_last_banded(p, *lists), rit, rot, cit, v, d)
+
+        def fused():
+            return ops.spmm_transposed_out(s, s, p, rit, rot, cit, v, d, permutation=perm)
+
+        print(json.dumps(dict(permute_then_product_us=round(1000 * timeit(separate, iters=40), 1),
+                              gathered_in_the_kernel_us=round(1000 * timeit(fused, iters=40), 1),
+                              bit_identical=bool(torch.equal(separate(), fused())),
+                              fused_by_rule=bool(ops.spmm_permuted_fused(s, s, d, nnz)))), flush=True)
 
 
 if __name__ == "__main__":

@@ -445,7 +445,16 @@ const char* sputnik_hip_spmm_kernel_name(int m, int k, int n, int nonzeros, int 
 
 int sputnik_hip_spmm_permuted_supported(int m, int k, int n, int nonzeros) {
   // (operand alignment is checked by the call itself)
-  return m > 0 && nonzeros > 0 && k <= 512 &&
+  // One panel, or (round 5) two with short rows: since round 4 the two-panel kernel CUTS its
+  // rows at the panel boundary and walks every entry once, so a value is gathered once --
+  // config 3's transposed attention products (1024^2 at density 0.1 x 64 x 64 replicas): 51.8
+  // us against 60.2 for the banded permutation + the product, bit-identical
+  // (tools/spmm_c3_bench.py --permuted).  (Round 2 measured 162 against 41 + 50 on the masked
+  // walk, which gathered every value twice; rows whose columns do not ascend still take it.)
+  // (SPUTNIK_HIP_SPMM_DEBUG bit 0x20000: one panel only, the rule of rounds 2-4 -- A/B runs)
+  const bool panels_ok = k <= 512 || (k <= 1024 && nonzeros <= 320 * static_cast<int64_t>(m) &&
+                                      !(options().spmm_debug & 0x20000));
+  return m > 0 && nonzeros > 0 && panels_ok &&
          spmm_panel_applicable(m, k, n, nonzeros, nullptr, 0, nullptr, 0) ? 1 : 0;
 }
 
