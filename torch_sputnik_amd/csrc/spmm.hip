@@ -346,7 +346,12 @@ bool takes_panel(int m, int k, int n, int nonzeros, int replicas, const float* d
   // More than one panel (k > 512): every pass walks (part of) the rows' streams
   // again, which pays for two panels (1024^2 x 64 x 64 replicas: density 0.1 36 vs
   // 47 us, 0.3 84 vs 90 us; four panels, 2048^2: 83 vs 60 us).
-  if (k > 1024 || (k > 512 && nonzeros > 320 * static_cast<int64_t>(m))) return false;
+  // (round 5: with the rows cut at the panel boundary the long rows that round 2's masked walk
+  // lost on -- 320 entries and more -- are won back where the product is one or two column
+  // tiles wide: 1024^2 at density 0.5 x 64 columns x 64 replicas 119 against 142 us for the
+  // 64-column kernel, x 128 columns 228 against 251; at 256 columns and more the chunked
+  // kernels keep their 12-15 %)
+  if (k > 1024 || (k > 512 && nonzeros > 320 * static_cast<int64_t>(m) && n > 128)) return false;
   // (two panels on a grid that does not fill the chip: 2048 x 1024 x 1024, one
   // replica, 128 workgroups: 33.0 vs 30.9 us for the chunked kernel)
   if (k > 512 && static_cast<int64_t>((m + 255) / 256) * ((n + 63) / 64) * replicas < 192)

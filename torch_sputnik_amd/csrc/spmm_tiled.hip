@@ -607,10 +607,19 @@ inline Kernel choose_kernel(int m, int k, int n, int nonzeros, int replicas /* <
   // 4096^2 at density 0.02 x 64 columns x 8 replicas 42 against 85 us, x 64 replicas 274
   // against 371; at density 0.1 it is 143 against 121 the other way)
   const bool narrow = spmm_tiled64_applicable(m, k, n, nonzeros);
+  // (and it needs workgroups -- one per 128 rows and 64 columns: with 128 of them or fewer
+  // the row gather, which spreads rows over the whole chip, leads up to 2^30 multiply-adds:
+  // 1024^2 at density 0.5 x 64 columns x 8 replicas, 64 workgroups: 63 against 92 us; 512 x
+  // 4096 x 64 x 16 replicas at 0.2: 103 against 157; with 256 workgroups, 4096^2 x 64 x 8 at
+  // density 0.1, it is 147 against 115 the other way)
+  const bool sparse_visits = static_cast<double>(nonzeros) < 0.035 * static_cast<double>(m) * k;
+  const bool few_workgroups =
+      replicas >= 0 &&
+      static_cast<int64_t>(ceil_div(m, 128)) * ceil_div(n, 64) * replicas *
+              (replicas == 1 ? spmm_tiled64_ksplits(m, k, n) : 1) <= 128 &&   // (one product: its K split)
+      static_cast<int64_t>(nonzeros) * n * replicas < (int64_t{1} << 30);
   const Kernel narrow_or_gather =
-      forced == 0 && replicas >= 0 && static_cast<double>(nonzeros) < 0.035 * static_cast<double>(m) * k
-          ? Kernel::kNone
-          : Kernel::kNarrow;
+      forced == 0 && replicas >= 0 && (sparse_visits || few_workgroups) ? Kernel::kNone : Kernel::kNarrow;
   if (!wide) return narrow ? narrow_or_gather : Kernel::kNone;
   if (!narrow || forced < 0) return Kernel::kWide;
   const int64_t small_tiles = static_cast<int64_t>(ceil_div(m, CfgSmall::kBM)) * ceil_div(n, CfgSmall::kBN);
