@@ -457,8 +457,8 @@ int sputnik_hip_spmm_permuted_supported(int m, int k, int n, int nonzeros) {
   // (tools/spmm_c3_bench.py --permuted).  (Round 2 measured 162 against 41 + 50 on the masked
   // walk, which gathered every value twice; rows whose columns do not ascend still take it.)
   // (SPUTNIK_HIP_SPMM_DEBUG bit 0x20000: one panel only, the rule of rounds 2-4 -- A/B runs)
-  const bool panels_ok = k <= 512 || (k <= 1024 && nonzeros <= 320 * static_cast<int64_t>(m) &&
-                                      !(options().spmm_debug & 0x20000));
+  const bool panels_ok = k <= 512 || (k <= 1024 && (nonzeros <= 320 * static_cast<int64_t>(m) || n <= 128) &&
+                                      !(options().spmm_debug & 0x20000));   // (as takes_panel)
   return m > 0 && nonzeros > 0 && panels_ok &&
          spmm_panel_applicable(m, k, n, nonzeros, nullptr, 0, nullptr, 0) ? 1 : 0;
 }
@@ -638,7 +638,7 @@ int sputnik_hip_spmm_typed(int m, int k, int n, int nonzeros, int replicas,
                         spmm_panel_applicable_typed(m, k, n, nonzeros, dense, dense_type,
                                                     dense_stride, out, out_stride) &&
                         (forced == 3 || k <= 512 ||
-                         (k <= 1024 && nonzeros <= 320 * static_cast<int64_t>(m))) &&
+                         (k <= 1024 && (nonzeros <= 320 * static_cast<int64_t>(m) || n <= 128))) &&
                         static_cast<int64_t>(nonzeros) * n * replicas >= (int64_t{1} << 22) &&
                         // (round 5, tools/spmm_dispatch_sweep.py --half: as for float operands the
                         // panel kernel needs workgroups against the row gather -- 1024^2 x 256,
