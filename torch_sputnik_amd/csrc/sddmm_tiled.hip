@@ -51,6 +51,22 @@ constexpr int kSWaves = 8;
 constexpr int kSGroups = kSWaves * 4;  // 16-lane row groups per workgroup
 constexpr int kSRows = 8;              // mask rows per group: a workgroup owns 256 rows
 constexpr int kWin = 2;                // 16-entry column windows fetched ahead per row
+// Grid y of the stationary kernel: all row blocks while the launch stays within about three
+// rounds of the chip; beyond that a workgroup walks several row blocks against the slab it
+// staged once -- the prologue (bookkeeping hops + up to 128 KiB of slab before anything is
+// computed, 5 us during which its CU idles) is then paid once per workgroup instead of once
+// per row block.  Measured (tools/sddmm_rows_bench.py, all row blocks / walked, us; boxes
+// and repeats differ by +-5 %): 2048^2 at density 0.2, k = 512 x 8 replicas, plain 262 / 221,
+// summed (config 5's weight gradient) 248 / 226-243; 4096^2 x 256 x 4 plain 165 / 130; 1024^2
+// at 0.3, k = 1024 x 8 summed 177 / 151; the sparse end pays a little (2048^2 at 0.05 summed
+// 130 / 136).  SPUTNIK_HIP_SDDMM_DEBUG bits 20..: that many hundred workgroups instead.
+inline int launch_rows_y(int slabs, int row_blocks, int64_t z, int debug, int slab_bytes) {
+  // (two workgroups per CU with slabs of at most 80 KiB: three rounds of 512; else two of 256)
+  const int64_t target = (debug >> 20) > 0 ? int64_t{100} * (debug >> 20) : slab_bytes <= 80 * 1024 ? 1536 : 512;
+  const int64_t per_y = static_cast<int64_t>(slabs) * z;
+  if (per_y * row_blocks <= target) return row_blocks;
+  return static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(row_blocks, (target + per_y - 1) / per_y)));
+}
 // Bit of the kernels' `debug` word, set by the launcher (never by the knob): the launch holds
 // ALL replicas of a many-mask batch and its plan carries the masks' start order.
 constexpr int kMasksLargestFirst = 1 << 30;
@@ -114,7 +130,9 @@ void sddmm_stationary_kernel(
                                       ? xcd_spread_replicas_index(gridDim.x * gridDim.y, gridDim.z)
                                       : xcd_local_index();
   const int slab = static_cast<int>(work % gridDim.x);
-  const int row_block = static_cast<int>((work / gridDim.x) % gridDim.y);
+  // (round 5: grid y may be SMALLER than the number of row blocks -- a workgroup then walks
+  // the row blocks y, y + gridDim.y, ... against the slab it staged once, see launch_rows_y)
+  const int first_row_block = static_cast<int>((work / gridDim.x) % gridDim.y);
   int grid_z = static_cast<int>(work / (static_cast<unsigned long long>(gridDim.x) * gridDim.y));
   if (debug & kMasksLargestFirst)   // (many masks, all of them in this launch)
     grid_z = row_ok[mask_start_word(grid_z / mask_heads, mask_plan_ints)] * mask_heads + grid_z % mask_heads;
@@ -158,10 +176,16 @@ void sddmm_stationary_kernel(
   // flight; a row's column windows and lhs fragment are fetched kRing-1 rows
   // ahead.  Everything is statically indexed (the row loop is fully
   // unrolled), so no register is ever copied while its load is outstanding.
-  const int slot_begin = row_block * (kSGroups * kSRows);
   const int gid = wave * 4 + g;
   const int* __restrict__ tab0 = table + static_cast<int64_t>(slab) * slots;
   const int* __restrict__ tab1 = tab0 + slots;
+  const char* __restrict__ lane_base = reinterpret_cast<const char*>(&tile[0] + i * 4);
+  const int row_blocks = slots / (kSGroups * kSRows);
+  for (int row_block = first_row_block; row_block < row_blocks; row_block += gridDim.y) {
+  // (the NEXT block's bookkeeping requested while this one is worked on was tried: 16 more
+  // registers, which the 80-row slab's two workgroups per CU do not have -- 223 -> 248 us at
+  // config 5's weight gradient)
+  const int slot_begin = row_block * (kSGroups * kSRows);
 
   constexpr int kRowsHere = S::kGroupRows;
   int row[kRowsHere], ps[kRowsHere], cnt[kRowsHere];
@@ -195,9 +219,8 @@ void sddmm_stationary_kernel(
 #pragma unroll
   for (int r = 0; r < kRing - 1; ++r) fetch(r, r);
   wait_vm<0>();
-  __syncthreads();
+  if (row_block == first_row_block) __syncthreads();   // (the slab is there: once per workgroup)
 
-  const char* __restrict__ lane_base = reinterpret_cast<const char*>(&tile[0] + i * 4);
   static_for<kRowsHere>([&](auto R) {
     constexpr int r = decltype(R)::value;
     if constexpr (r + kRing - 1 < kRowsHere) fetch(r + kRing - 1, (r + kRing - 1) % kRing);
@@ -316,6 +339,7 @@ void sddmm_stationary_kernel(
     for (int w0 = 16 * kWin; w0 < longest; w0 += 16)
       window(column_indices[min(cur_ps + w0 + i, last)], w0);
   });
+  }   // (row blocks of this workgroup)
 }
 
 // ----------------------------------------------------------------------------
@@ -731,7 +755,8 @@ int launch(int m, int k, int n, int nonzeros, int replicas, int slots, const int
         }
       }
 #define SPUTNIK_HIP_STAT(ACC)                                                                     \
-  hipLaunchKernelGGL((sddmm_stationary_kernel<KV, ACC>), dim3(slabs, row_blocks, rz),             \
+  hipLaunchKernelGGL((sddmm_stationary_kernel<KV, ACC>),                                          \
+                     dim3(slabs, launch_rows_y(slabs, row_blocks, rz, debug, S::kBytes), rz),                \
                      dim3(S::kThreads), 0, stream, m, n, nonzeros, slots, row_indices,            \
                      row_offsets, column_indices, table, row_ok, lhs + r0 * lhs_stride + k0,      \
                      lhs_stride, rhs + r0 * rhs_stride + k0, rhs_stride, k,                       \
@@ -826,7 +851,9 @@ int launch_partials(int m, int k, int n, int nonzeros, int replicas, int slots,
   const int panels = k / S::kdim;
   if (row_blocks > kMaxGridYZ || static_cast<int64_t>(replicas) * panels > kMaxGridYZ)
     return SPUTNIK_HIP_INVALID_ARGUMENT;
-  hipLaunchKernelGGL((sddmm_stationary_kernel<KV, false, ROWS>), dim3(slabs, row_blocks, replicas * panels),
+  hipLaunchKernelGGL((sddmm_stationary_kernel<KV, false, ROWS>),
+                     dim3(slabs, launch_rows_y(slabs, row_blocks, static_cast<int64_t>(replicas) * panels, debug, S::kBytes),
+                          replicas * panels),
                      dim3(S::kThreads), 0, stream, m, n, nonzeros, slots, row_indices, row_offsets,
                      column_indices, table, row_ok, lhs, lhs_stride, rhs, rhs_stride, k,
                      partials, static_cast<int64_t>(nonzeros), panels, debug, 0, int64_t{0}, 0);
