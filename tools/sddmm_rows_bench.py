@@ -15,7 +15,9 @@ from tools.flat_bench import timeit
 dev = torch.device("cuda:0")
 for (m, k, reps, d, summed) in ((2048, 512, 8, 0.2, True), (2048, 512, 8, 0.05, True), (4096, 512, 4, 0.1, True),
                                 (1024, 1024, 8, 0.3, True), (512, 1024, 8, 0.1, True), (2048, 2048, 8, 0.2, True),
-                                (2048, 512, 8, 0.2, False), (4096, 256, 4, 0.1, False), (2048, 128, 16, 0.2, False)):
+                                (2048, 512, 8, 0.2, False), (4096, 256, 4, 0.1, False), (2048, 128, 16, 0.2, False),
+                                # the quad kernel (k = 64)
+                                (2048, 64, 64, 0.1, False), (4096, 64, 16, 0.05, False), (2048, 64, 32, 0.3, False)):
     ri, ro, ci, nnz = random_csr(m, m, d, dev, seed=3)
     lhs = uniform((reps, m, k), dev, 4); rhs = uniform((reps, m, k), dev, 5)
     row = dict(m=m, k=k, replicas=reps, density=d, summed=summed)

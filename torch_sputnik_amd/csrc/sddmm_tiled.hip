@@ -58,11 +58,13 @@ constexpr int kWin = 2;                // 16-entry column windows fetched ahead 
 // per row block.  Measured (tools/sddmm_rows_bench.py, all row blocks / walked, us; boxes
 // and repeats differ by +-5 %): 2048^2 at density 0.2, k = 512 x 8 replicas, plain 262 / 221,
 // summed (config 5's weight gradient) 248 / 226-243; 4096^2 x 256 x 4 plain 165 / 130; 1024^2
-// at 0.3, k = 1024 x 8 summed 177 / 151; the sparse end pays a little (2048^2 at 0.05 summed
-// 130 / 136).  SPUTNIK_HIP_SDDMM_DEBUG bits 20..: that many hundred workgroups instead.
+// at 0.3, k = 1024 x 8 summed 177 / 151; the quad kernel (k = 64) 2048^2 at 0.1 x 64 replicas
+// 165 / 145, 4096^2 at 0.05 x 16: 125 / 111; the sparse end pays a little (2048^2 at 0.05
+// summed 130 / 136).  SPUTNIK_HIP_SDDMM_DEBUG bits 20..: that many hundred workgroups instead.
 inline int launch_rows_y(int slabs, int row_blocks, int64_t z, int debug, int slab_bytes) {
-  // (two workgroups per CU with slabs of at most 80 KiB: three rounds of 512; else two of 256)
-  const int64_t target = (debug >> 20) > 0 ? int64_t{100} * (debug >> 20) : slab_bytes <= 80 * 1024 ? 1536 : 512;
+  // (512 workgroups; the 80-row slabs of the summed form, 80 KiB and two workgroups per CU,
+  // measured best with 1536, the 64 KiB slabs of the narrow panels with 512 like the 128 KiB ones)
+  const int64_t target = (debug >> 20) > 0 ? int64_t{100} * (debug >> 20) : slab_bytes == 80 * 1024 ? 1536 : 512;
   const int64_t per_y = static_cast<int64_t>(slabs) * z;
   if (per_y * row_blocks <= target) return row_blocks;
   return static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(row_blocks, (target + per_y - 1) / per_y)));
@@ -413,7 +415,8 @@ void sddmm_quad_kernel(
                                       ? xcd_spread_replicas_index(gridDim.x * gridDim.y, gridDim.z)
                                       : xcd_local_index();
   const int slab = static_cast<int>(work % gridDim.x);
-  const int row_block = static_cast<int>((work / gridDim.x) % gridDim.y);
+  // (grid y may be smaller than the number of row blocks: launch_rows_y)
+  const int first_row_block = static_cast<int>((work / gridDim.x) % gridDim.y);
   int z = static_cast<int>(work / (static_cast<unsigned long long>(gridDim.x) * gridDim.y));
   if (debug & kMasksLargestFirst)   // (many masks, all of them in this launch)
     z = row_ok[mask_start_word(z / mask_heads, mask_plan_ints)] * mask_heads + z % mask_heads;
@@ -450,11 +453,13 @@ void sddmm_quad_kernel(
     }
   }
 
-  const int slot_begin = row_block * (kSGroups * kSRows);
   const int gid = wave * 4 + g;
   const int* __restrict__ tab0 = table + static_cast<int64_t>(slab) * slots;
   const int* __restrict__ tab1 = tab0 + slots;
   constexpr int kRowsHere = kSRows;
+  const int row_blocks = slots / (kSGroups * kSRows);
+  for (int row_block = first_row_block; row_block < row_blocks; row_block += gridDim.y) {
+  const int slot_begin = row_block * (kSGroups * kSRows);
   int row[kRowsHere], ps[kRowsHere], cnt[kRowsHere];
 #pragma unroll
   for (int r = 0; r < kRowsHere; ++r) {
@@ -506,7 +511,7 @@ void sddmm_quad_kernel(
 #pragma unroll
   for (int r = 0; r < kRing - 1; ++r) fetch(r, r);
   wait_vm<0>();
-  __syncthreads();
+  if (row_block == first_row_block) __syncthreads();   // (the slab is there: once per workgroup)
 
   const unsigned tile_base =
       static_cast<unsigned>(reinterpret_cast<uintptr_t>(AS_LDS(reinterpret_cast<float*>(tile))));
@@ -634,6 +639,7 @@ void sddmm_quad_kernel(
       window(col, w0);
     }
   });
+  }   // (row blocks of this workgroup)
 }
 
 inline int slots_of(int m) { return ceil_div(m, kSGroups * kSRows) * (kSGroups * kSRows); }
@@ -741,7 +747,8 @@ int launch(int m, int k, int n, int nonzeros, int replicas, int slots, const int
         if (!(debug & 8)) {
 #define SPUTNIK_HIP_QUAD(ACC)                                                                     \
   hipLaunchKernelGGL((sddmm_quad_kernel<KV, S::kRows, float, float, ACC>),                        \
-                     dim3(slabs, row_blocks, rz), dim3(Quad<KV, S::kRows, float>::kThreads), 0,   \
+                     dim3(slabs, launch_rows_y(slabs, row_blocks, rz, debug, Quad<KV, S::kRows, float>::kBytes), rz), \
+                     dim3(Quad<KV, S::kRows, float>::kThreads), 0,                                \
                      stream, m, n, nonzeros, slots, row_indices, row_offsets, column_indices,     \
                      table, row_ok, lhs + r0 * lhs_stride + k0, lhs_stride,                       \
                      rhs + r0 * rhs_stride + k0, rhs_stride, k, out + r0 * out_stride,            \
@@ -785,7 +792,9 @@ int launch_half(int m, int k, int n, int nonzeros, int replicas, int slots, cons
   if (row_blocks > kMaxGridYZ) return SPUTNIK_HIP_INVALID_ARGUMENT;
   if (panels_z > 1) {   // every (replica, panel) pair at once, each into its own vector
     if (static_cast<int64_t>(replicas) * panels_z > kMaxGridYZ) return SPUTNIK_HIP_INVALID_ARGUMENT;
-    hipLaunchKernelGGL((sddmm_quad_kernel<KV, ROWS, T, TO, false>), dim3(slabs, row_blocks, replicas * panels_z),
+    hipLaunchKernelGGL((sddmm_quad_kernel<KV, ROWS, T, TO, false>),
+                       dim3(slabs, launch_rows_y(slabs, row_blocks, static_cast<int64_t>(replicas) * panels_z, debug, Q::kBytes),
+                            replicas * panels_z),
                        dim3(Q::kThreads), 0, stream, m, n, nonzeros, slots, row_indices, row_offsets,
                        column_indices, table, row_ok, lhs, lhs_stride, rhs, rhs_stride, k, out,
                        out_stride, panels_z, debug, 0, int64_t{0}, 0);
@@ -795,7 +804,8 @@ int launch_half(int m, int k, int n, int nonzeros, int replicas, int slots, cons
     for (int r0 = 0; r0 < replicas; r0 += kMaxGridYZ) {
       const int rz = min(replicas - r0, kMaxGridYZ);
 #define SPUTNIK_HIP_QUADH(ACC)                                                                    \
-  hipLaunchKernelGGL((sddmm_quad_kernel<KV, ROWS, T, TO, ACC>), dim3(slabs, row_blocks, rz),      \
+  hipLaunchKernelGGL((sddmm_quad_kernel<KV, ROWS, T, TO, ACC>),                                   \
+                     dim3(slabs, launch_rows_y(slabs, row_blocks, rz, debug, Q::kBytes), rz),       \
                      dim3(Q::kThreads), 0, stream, m, n, nonzeros, slots, row_indices,            \
                      row_offsets, column_indices, table, row_ok, lhs + r0 * lhs_stride + k0,      \
                      lhs_stride, rhs + r0 * rhs_stride + k0, rhs_stride, k,                       \
