@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The rhs-stationary SDDMM kernel with a workgroup per (slab, row block) against workgroups that
 walk several row blocks of one staged slab (round 5, csrc/sddmm_tiled.hip launch_rows_y):
-SPUTNIK_HIP_SDDMM_DEBUG bits 20.. = the target workgroup count in hundreds (2047: every row
+SPUTNIK_HIP_SDDMM_DEBUG bits 20.. = the target workgroup count in hundreds (1023: every row
 block its own workgroup, the form of rounds 1-4).  Summed (weight gradient) and plain products.
 
     python tools/sddmm_rows_bench.py
@@ -21,7 +21,7 @@ for (m, k, reps, d, summed) in ((2048, 512, 8, 0.2, True), (2048, 512, 8, 0.05, 
     ri, ro, ci, nnz = random_csr(m, m, d, dev, seed=3)
     lhs = uniform((reps, m, k), dev, 4); rhs = uniform((reps, m, k), dev, 5)
     row = dict(m=m, k=k, replicas=reps, density=d, summed=summed)
-    for name, dbg in (("all_row_blocks", 2047 << 20), ("default_768", 0), ("t512", 5 << 20), ("t1536", 15 << 20)):
+    for name, dbg in (("all_row_blocks", 1023 << 20), ("default_768", 0), ("t512", 5 << 20), ("t1536", 15 << 20)):
         os.environ["SPUTNIK_HIP_SDDMM_DEBUG"] = str(dbg); capi.reload_options()
         if summed:
             out = torch.empty(nnz, device=dev)

@@ -51,6 +51,9 @@ constexpr int kSWaves = 8;
 constexpr int kSGroups = kSWaves * 4;  // 16-lane row groups per workgroup
 constexpr int kSRows = 8;              // mask rows per group: a workgroup owns 256 rows
 constexpr int kWin = 2;                // 16-entry column windows fetched ahead per row
+// Bit of the kernels' `debug` word, set by the launcher (never by the knob): the launch holds
+// ALL replicas of a many-mask batch and its plan carries the masks' start order.
+constexpr int kMasksLargestFirst = 1 << 30;
 // Grid y of the stationary kernel: all row blocks while the launch stays within about three
 // rounds of the chip; beyond that a workgroup walks several row blocks against the slab it
 // staged once -- the prologue (bookkeeping hops + up to 128 KiB of slab before anything is
@@ -62,16 +65,19 @@ constexpr int kWin = 2;                // 16-entry column windows fetched ahead 
 // 165 / 145, 4096^2 at 0.05 x 16: 125 / 111; the sparse end pays a little (2048^2 at 0.05
 // summed 130 / 136).  SPUTNIK_HIP_SDDMM_DEBUG bits 20..: that many hundred workgroups instead.
 inline int launch_rows_y(int slabs, int row_blocks, int64_t z, int debug, int slab_bytes) {
-  // (512 workgroups; the 80-row slabs of the summed form, 80 KiB and two workgroups per CU,
-  // measured best with 1536, the 64 KiB slabs of the narrow panels with 512 like the 128 KiB ones)
-  const int64_t target = (debug >> 20) > 0 ? int64_t{100} * (debug >> 20) : slab_bytes == 80 * 1024 ? 1536 : 512;
-  const int64_t per_y = static_cast<int64_t>(slabs) * z;
-  if (per_y * row_blocks <= target) return row_blocks;
+  // (a many-mask launch starts its masks largest first: its order is that of the grid)
+  if (debug & kMasksLargestFirst) return row_blocks;
+  const int64_t per_y = static_cast<int64_t>(slabs) * z, total = per_y * row_blocks;
+  const int knob = (debug >> 20) & 0x3ff;   // (bits 20-29 of the knob: hundreds of workgroups)
+  // From four rounds of the chip on (two workgroups per CU with slabs of at most 80 KiB): config
+  // 3's quad kernel, 1024 workgroups in two rounds, read 47.2 us as it is and 48.6 walked.
+  // Down to 512 workgroups; the 80-row slabs of the summed form measured best with 1536.
+  const int64_t per_round = 256 * (slab_bytes <= 80 * 1024 ? 2 : 1);
+  if (knob == 0 && total < 4 * per_round) return row_blocks;
+  const int64_t target = knob > 0 ? int64_t{100} * knob : slab_bytes == 80 * 1024 ? 1536 : 512;
+  if (total <= target) return row_blocks;
   return static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(row_blocks, (target + per_y - 1) / per_y)));
 }
-// Bit of the kernels' `debug` word, set by the launcher (never by the knob): the launch holds
-// ALL replicas of a many-mask batch and its plan carries the masks' start order.
-constexpr int kMasksLargestFirst = 1 << 30;
 
 constexpr int default_slab_rows(int kv) { return (kv <= 2 ? 64 * 1024 : 128 * 1024) / (64 * kv * 4); }
 
@@ -883,7 +889,7 @@ int sddmm_tiled_launch_partials(int m, int k, int n, int nonzeros, int replicas,
                                 const int* column_indices, const float* lhs, int64_t lhs_stride,
                                 const float* rhs, int64_t rhs_stride, float* partials,
                                 const void* workspace, hipStream_t stream) {
-  const int debug = options().sddmm_debug;
+  const int debug = options().sddmm_debug & ~kMasksLargestFirst;
   const int slots = slots_of(m);
   const int* row_ok = static_cast<const int*>(workspace);
   const int* table =
@@ -981,7 +987,7 @@ int sddmm_tiled_launch(int m, int k, int n, int nonzeros, int replicas, const in
                              rhs_stride, out, out_stride, SPUTNIK_HIP_F32, SPUTNIK_HIP_F32,
                              static_cast<const char*>(workspace) + flat_plan_offset(m, k, n, nonzeros),
                              stream);
-  const int debug = options().sddmm_debug;  // timing experiments only
+  const int debug = options().sddmm_debug & ~kMasksLargestFirst;  // timing experiments only
   const int slots = slots_of(m);
   const int* row_ok = static_cast<const int*>(workspace);
   const int* table =
@@ -1023,7 +1029,7 @@ int sddmm_tiled_launch_half(int m, int k, int n, int nonzeros, int replicas, con
                              rhs_stride, out, out_stride, in_type, out_type,
                              static_cast<const char*>(workspace) + flat_plan_offset(m, k, n, nonzeros),
                              stream);
-  const int debug = options().sddmm_debug;
+  const int debug = options().sddmm_debug & ~kMasksLargestFirst;
   const int slots = slots_of(m);
   const int* row_ok = static_cast<const int*>(workspace);
   const int* table =
@@ -1053,7 +1059,7 @@ int sddmm_tiled_launch_partials_half(int m, int k, int n, int nonzeros, int repl
                                      int64_t lhs_stride, const void* rhs, int64_t rhs_stride,
                                      int in_type, float* partials, const void* workspace,
                                      hipStream_t stream) {
-  const int debug = options().sddmm_debug;
+  const int debug = options().sddmm_debug & ~kMasksLargestFirst;
   const int slots = slots_of(m);
   const int* row_ok = static_cast<const int*>(workspace);
   const int* table =
