@@ -381,6 +381,32 @@ SPUTNIK_HIP_API int sputnik_hip_sddmm_sum_batched_planned(int m, int k, int n, i
                               void* scratch, size_t scratch_bytes,
                               sputnik_hip_stream_t stream);
 
+/* Up to four summed SDDMMs of ONE shape (m, k, n), replica count and operand strides in
+ * one call -- the weight gradients of a group of projections that share their input
+ * (modules/sparse_attention.py:108-110: dW_q, dW_k, dW_v = dY_q, dY_k, dY_v against the same
+ * x): each problem runs as sputnik_hip_sddmm_sum_batched_planned does, its own planned
+ * workspace and scratch, and ONE launch adds the partial vectors of all of them (a sum is
+ * four microseconds of launch and little else).  Results are those of the single calls,
+ * bit for bit. */
+typedef struct sputnik_hip_sddmm_sum_problem {
+  const int* row_indices;
+  const int* row_offsets;
+  const int* column_indices;
+  const float* lhs;        /* [replicas][m][k] */
+  const float* rhs;        /* [replicas][n][k] */
+  float* out;              /* [nonzeros] */
+  const void* workspace;   /* planned: sputnik_hip_sddmm_sum_plan */
+  size_t workspace_bytes;
+  void* scratch;           /* sputnik_hip_sddmm_sum_scratch_bytes */
+  size_t scratch_bytes;
+  int nonzeros;
+} sputnik_hip_sddmm_sum_problem;
+
+SPUTNIK_HIP_API int sputnik_hip_sddmm_sum_group_planned(int m, int k, int n, int replicas,
+                              int count, const sputnik_hip_sddmm_sum_problem* problems,
+                              int64_t lhs_stride, int64_t rhs_stride,
+                              sputnik_hip_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Sparse softmax: per CSR row, exp(x - max) / sum(exp(x - max)) over the
  * stored entries.  `n` is unused (the reference passes -1,

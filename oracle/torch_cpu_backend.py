@@ -236,6 +236,11 @@ def _sddmm_sum_planned(m, n, row_indices, row_offsets, column_indices, lhs, rhs,
     return _sddmm_sum(m, n, row_indices, row_offsets, column_indices, lhs, rhs)
 
 
+def _sddmm_sum_group_planned(m, n, row_indices, row_offsets, column_indices, lhs, rhs, plans):
+    return [_sddmm_sum(m, n, ri, ro, ci, left, rhs)
+            for ri, ro, ci, left in zip(row_indices, row_offsets, column_indices, lhs)]
+
+
 def _sparse_attention_planned(q, k, v, row_indices, row_offsets, column_indices, scale, plan):
     return _sparse_attention(q, k, v, row_indices, row_offsets, column_indices, scale)
 
@@ -276,6 +281,7 @@ def install():
     _lib.impl("left_spmm_group_sum", _left_spmm_group_sum, "CPU")
     _lib.impl("left_spmm_permuted", _left_spmm_permuted, "CPU")
     _lib.impl("sddmm_sum_planned", _sddmm_sum_planned, "CPU")
+    _lib.impl("sddmm_sum_group_planned", _sddmm_sum_group_planned, "CPU")
     _lib.impl("sparse_attention_planned", _sparse_attention_planned, "CPU")
     _lib.impl("spmm_many_mask", _spmm_many_mask, "CPU")
     _lib.impl("sddmm_many_mask", _sddmm_many_mask, "CPU")

@@ -639,6 +639,41 @@ def test_spmm_transposed_out(ts, dev, spmm_kernel, m, k, n, replicas, block, lef
     assert rel_err(got.cpu().numpy(), np.ascontiguousarray(want).astype(np.float32)) < TOL
 
 
+@pytest.mark.parametrize("m,n,k,replicas,count", [
+    (512, 512, 1024, 8, 3),    # config 3: the q, k, v weight gradients (4 panels x 8 replicas each)
+    (256, 320, 256, 3, 4),     # one panel per replica, ragged mask width, four products
+    (100, 60, 40, 5, 2),       # row-wave kernel ([R, nnz] partial vectors)
+    (512, 512, 256, 1, 2),     # one replica of one panel: nothing left to sum
+])
+def test_sddmm_sum_group_equals_the_single_calls(ts, dev, m, n, k, replicas, count):
+    """Round 5: the weight gradients of a group of projections in one call -- each product
+    as sddmm_sum_planned runs it, the partial vectors of all of them added by ONE launch.
+    Bit-identical to the single calls (same partial vectors, same order), masks of different
+    sizes (one with an entry count that is no multiple of 4, one EMPTY)."""
+    from torch_sputnik_amd import ops
+    rng = np.random.default_rng(m + k)
+    rhs = T(rng.uniform(-1, 1, (replicas, n, k)).astype(np.float32), dev)
+    topo, lhs, plans, want = [], [], [], []
+    for p in range(count):
+        sparsity = (0.9, 0.8, 1.0, 0.95)[p] if count == 4 else (0.9, 0.85, 0.8)[p]
+        _, _, ri, ro, ci = make_csr(m, n, sparsity, seed=p + n, round_to=1 if p == 1 else 4)
+        t = [T(x, dev) for x in (ri, ro, ci)]
+        left = T(rng.uniform(-1, 1, (replicas, m, k)).astype(np.float32), dev)
+        plan = ops.sddmm_sum_plan(m, n, k, *t)
+        topo.append(t)
+        lhs.append(left)
+        plans.append(plan)
+        want.append(ops.sddmm_sum_planned(m, n, *t, left, rhs, plan))
+    got = ops.sddmm_sum_group_planned(m, n, [t[0] for t in topo], [t[1] for t in topo],
+                                      [t[2] for t in topo], lhs, rhs, plans)
+    assert len(got) == count
+    for g, w in zip(got, want):
+        assert g.shape == w.shape and torch.equal(g, w)
+    with pytest.raises(RuntimeError):   # five products: more than one launch adds
+        ops.sddmm_sum_group_planned(m, n, [topo[0][0]] * 5, [topo[0][1]] * 5, [topo[0][2]] * 5,
+                                    [lhs[0]] * 5, rhs, [plans[0]] * 5)
+
+
 @pytest.mark.parametrize("m,n,width,replicas,block,left", [
     (512, 512, 1024, 2, 64, True),     # the input gradient of a projection, head split
     (1024, 1024, 64, 4, 64, False),    # round 5: attention dV / dK, TWO panels with cut rows

@@ -122,6 +122,7 @@ SIGNATURES = {
                                                                               _c_ptr, _c_size, _c_ptr]),
     "sputnik_hip_sparse_linear_half_input_gradient": (_c_int, [_c_int] * 4 + [_c_ptr, _c_int, _c_ptr, _c_int,
                                                                              _c_int, _c_ptr, _c_int, _c_ptr]),
+    "sputnik_hip_sddmm_sum_group_planned": (_c_int, [_c_int] * 5 + [_c_ptr, _c_i64, _c_i64, _c_ptr]),
     "sputnik_hip_sddmm_sum_mixed_scratch_bytes": (_c_size, [_c_int] * 7),
     "sputnik_hip_sddmm_sum_mixed": (_c_int, [_c_int] * 5 + [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int,
                                                            _c_i64, _c_ptr, _c_int, _c_i64, _c_ptr,
@@ -638,6 +639,38 @@ def spmm_group_batched(m, k, n, replicas, problems, block_rows=0, accumulate=Fal
     if st != -2:
         _check(st, "sputnik_hip_spmm_group_batched")
     return st
+
+
+class SddmmSumProblem(ctypes.Structure):
+    """sputnik_hip_sddmm_sum_problem (include/sputnik_hip.h)."""
+    _fields_ = [("row_indices", ctypes.c_void_p), ("row_offsets", ctypes.c_void_p),
+                ("column_indices", ctypes.c_void_p), ("lhs", ctypes.c_void_p),
+                ("rhs", ctypes.c_void_p), ("out", ctypes.c_void_p),
+                ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
+                ("scratch", ctypes.c_void_p), ("scratch_bytes", ctypes.c_size_t),
+                ("nonzeros", ctypes.c_int)]
+
+
+def sddmm_sum_group_planned(m, k, n, replicas, problems):
+    """`problems`: list of dicts with row_indices, row_offsets, column_indices, lhs, rhs, out,
+    workspace (planned: sddmm_sum_plan), scratch -- up to four summed SDDMMs of one shape,
+    their partial vectors added by one launch."""
+    array = (SddmmSumProblem * len(problems))()
+    for slot, p in zip(array, problems):
+        slot.row_indices = _ptr(p["row_indices"])
+        slot.row_offsets = _ptr(p["row_offsets"])
+        slot.column_indices = _ptr(p["column_indices"])
+        slot.lhs = _ptr(p["lhs"])
+        slot.rhs = _ptr(p["rhs"])
+        slot.out = _ptr(p["out"])
+        slot.workspace = _ptr(p["workspace"])
+        slot.workspace_bytes = _ws_bytes(p["workspace"])
+        slot.scratch = _ptr(p.get("scratch"))
+        slot.scratch_bytes = _ws_bytes(p.get("scratch"))
+        slot.nonzeros = p["column_indices"].numel()
+    _check(lib().sputnik_hip_sddmm_sum_group_planned(
+        m, k, n, replicas, len(problems), ctypes.cast(array, ctypes.c_void_p), m * k, n * k,
+        _stream(problems[0]["out"])), "sputnik_hip_sddmm_sum_group_planned")
 
 
 def sddmm_sum_workspace_bytes(m, k, n, nonzeros):

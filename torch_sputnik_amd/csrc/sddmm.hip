@@ -241,6 +241,31 @@ __global__ __launch_bounds__(kBlock) void sum_partials_kernel(int count /* of VE
   for (int e = 0; e < VEC; ++e) out[static_cast<int64_t>(i) * VEC + e] = acc[e];
 }
 
+// The same for up to four sums at once (grid y = the sum): the weight gradients of a group
+// of projections, whose four-microsecond sums are launch time and little else.
+constexpr int kMaxSumGroup = 4;
+struct SumGroup {
+  const float* partials[kMaxSumGroup];
+  float* out[kMaxSumGroup];
+  int length[kMaxSumGroup];   // floats per vector (= distance between the partial vectors)
+  int parts[kMaxSumGroup];
+};
+__global__ __launch_bounds__(kBlock) void sum_partials_group_kernel(SumGroup g) {
+  const int which = blockIdx.y;
+  // (selected with compares, not by indexing the argument: no copy of it in scratch memory)
+  const float* __restrict__ partials = which == 0 ? g.partials[0] : which == 1 ? g.partials[1]
+                                       : which == 2 ? g.partials[2] : g.partials[3];
+  float* __restrict__ out = which == 0 ? g.out[0] : which == 1 ? g.out[1] : which == 2 ? g.out[2] : g.out[3];
+  const int length = which == 0 ? g.length[0] : which == 1 ? g.length[1] : which == 2 ? g.length[2] : g.length[3];
+  const int parts = which == 0 ? g.parts[0] : which == 1 ? g.parts[1] : which == 2 ? g.parts[2] : g.parts[3];
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= length) return;
+  float acc = partials[i];
+#pragma unroll 4
+  for (int z = 1; z < parts; ++z) acc += partials[static_cast<int64_t>(z) * length + i];
+  out[i] = acc;
+}
+
 // out[i] = partials[0][i] + ... + partials[parts - 1][i]  (one launch, index order)
 int sum_partials_launch(int nonzeros, int parts, const float* partials, float* out, hipStream_t stream) {
   if (nonzeros % 4 == 0 && aligned_to(out, 16) && aligned_to(partials, 16)) {
@@ -523,11 +548,15 @@ int64_t sum_parts(int m, int k, int n, int nonzeros, int replicas) {
   return static_cast<int64_t>(replicas) * (tiled_shape ? sddmm_tiled_panels(m, k, n, nonzeros) : 1);
 }
 
+// `leave_parts` != nullptr: the call stops in front of its last launch and says how many
+// partial vectors of `nonzeros` floats it left in `scratch` (0: `out` is complete) -- for
+// sputnik_hip_sddmm_sum_group_planned, which adds the vectors of several calls in one launch.
 int sddmm_sum_exec(int m, int k, int n, int nonzeros, int replicas, const int* row_indices,
                    const int* row_offsets, const int* column_indices, const float* lhs,
                    int64_t lhs_stride, const float* rhs, int64_t rhs_stride, float* out,
                    void* workspace, size_t workspace_bytes, bool planned, void* scratch,
-                   size_t scratch_bytes, hipStream_t stream) {
+                   size_t scratch_bytes, hipStream_t stream, int* leave_parts = nullptr) {
+  if (leave_parts != nullptr) *leave_parts = 0;
   if (m < 0 || k < 0 || n < 0 || nonzeros < 0 || replicas < 0) return SPUTNIK_HIP_INVALID_ARGUMENT;
   if (m == 0 || nonzeros == 0) return 0;
   if (k == 0 || replicas == 0) {
@@ -571,6 +600,10 @@ int sddmm_sum_exec(int m, int k, int n, int nonzeros, int replicas, const int* r
   }
   if (st != 0) return st;
   const int nparts = static_cast<int>(parts);
+  if (leave_parts != nullptr) {
+    *leave_parts = nparts;
+    return 0;
+  }
   if (nonzeros % 4 == 0 && aligned_to(out, 16)) {
     hipLaunchKernelGGL(sum_partials_kernel<4>, dim3(ceil_div(nonzeros / 4, kBlock)), dim3(kBlock),
                        0, stream, nonzeros / 4, nparts, static_cast<int64_t>(nonzeros), partials,
@@ -749,6 +782,36 @@ int sputnik_hip_sddmm_sum_batched_planned(int m, int k, int n, int nonzeros, int
   return sddmm_sum_exec(m, k, n, nonzeros, replicas, row_indices, row_offsets, column_indices,
                         lhs, lhs_stride, rhs, rhs_stride, out, const_cast<void*>(workspace),
                         workspace_bytes, /*planned=*/true, scratch, scratch_bytes, stream);
+}
+
+int sputnik_hip_sddmm_sum_group_planned(int m, int k, int n, int replicas, int count,
+                                        const sputnik_hip_sddmm_sum_problem* problems,
+                                        int64_t lhs_stride, int64_t rhs_stride,
+                                        sputnik_hip_stream_t stream) {
+  if (count < 0 || count > kMaxSumGroup || (count > 0 && problems == nullptr))
+    return SPUTNIK_HIP_INVALID_ARGUMENT;
+  SumGroup g = {};
+  int sums = 0, longest = 0;
+  for (int p = 0; p < count; ++p) {
+    const sputnik_hip_sddmm_sum_problem& q = problems[p];
+    int parts = 0;
+    const int st = sddmm_sum_exec(m, k, n, q.nonzeros, replicas, q.row_indices, q.row_offsets,
+                                  q.column_indices, q.lhs, lhs_stride, q.rhs, rhs_stride, q.out,
+                                  const_cast<void*>(q.workspace), q.workspace_bytes, /*planned=*/true,
+                                  q.scratch, q.scratch_bytes, stream, &parts);
+    if (st != 0) return st;
+    if (parts == 0) continue;   // (`out` is complete: an empty mask, or one replica of one panel)
+    g.partials[sums] = static_cast<const float*>(q.scratch);
+    g.out[sums] = q.out;
+    g.length[sums] = q.nonzeros;
+    g.parts[sums] = parts;
+    longest = max(longest, q.nonzeros);
+    ++sums;
+  }
+  if (sums == 0) return 0;
+  hipLaunchKernelGGL(sum_partials_group_kernel, dim3(ceil_div(longest, kBlock), sums), dim3(kBlock), 0,
+                     stream, g);
+  return launch_status();
 }
 
 int sputnik_hip_sddmm_sum_typed(int m, int k, int n, int nonzeros, int replicas,

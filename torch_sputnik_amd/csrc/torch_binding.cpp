@@ -870,6 +870,63 @@ Tensor sddmm_plan(int64_t m64, int64_t n64, int64_t k64, const Tensor& row_indic
   return plan;
 }
 
+// Several summed products of one shape in one call: the weight gradients of a group of
+// projections (sputnik_hip.h: sddmm_sum_group_planned).  float32, 3-D contiguous operands,
+// one planned workspace per weight; rhs is shared.
+std::vector<Tensor> sddmm_sum_group_planned(int64_t m64, int64_t n64,
+                                            const std::vector<Tensor>& row_indices,
+                                            const std::vector<Tensor>& row_offsets,
+                                            const std::vector<Tensor>& column_indices,
+                                            const std::vector<Tensor>& lhs_in, const Tensor& rhs_in,
+                                            const std::vector<Tensor>& plans) {
+  const int m = to_int(m64, "m"), n = to_int(n64, "n");
+  const size_t count = lhs_in.size();
+  TORCH_CHECK(count >= 1 && count <= 4, "sddmm_sum_group: one to four products, got ", count);
+  TORCH_CHECK(row_indices.size() == count && row_offsets.size() == count &&
+                  column_indices.size() == count && plans.size() == count,
+              "sddmm_sum_group: one topology, lhs and plan per product");
+  const Tensor rhs = as_float(rhs_in, "rhs_matrix");
+  TORCH_CHECK(rhs.dim() == 3 && rhs.size(1) == n, "sddmm_sum_group: rhs_matrix should be [replicas, n = ",
+              n, ", k]");
+  const int replicas = to_int(rhs.size(0), "replicas"), k = to_int(rhs.size(2), "k");
+  const c10::DeviceGuard guard(rhs.device());
+  std::vector<Tensor> lhs(count), outs(count), scratch(count);
+  std::vector<Topology> topo;
+  std::vector<sputnik_hip_sddmm_sum_problem> problems(count);
+  for (size_t p = 0; p < count; ++p) {
+    lhs[p] = as_float(lhs_in[p], "lhs_matrix");
+    TORCH_CHECK(lhs[p].device() == rhs.device() && lhs[p].dim() == 3 && lhs[p].size(0) == replicas &&
+                    lhs[p].size(1) == m && lhs[p].size(2) == k,
+                "sddmm_sum_group: lhs_matrix ", p, " should be [", replicas, ", ", m, ", ", k, "] on ",
+                rhs.device());
+    topo.push_back(check_topology(m, row_indices[p], row_offsets[p], column_indices[p], lhs[p]));
+    const int nnz = topo[p].nonzeros;
+    outs[p] = at::empty({nnz}, rhs.options());
+    const size_t ws_bytes = sputnik_hip_sddmm_sum_workspace_bytes(m, k, n, nnz);
+    check_plan(plans[p], ws_bytes, rhs);
+    const size_t scratch_bytes = sputnik_hip_sddmm_sum_scratch_bytes(m, k, n, nnz, replicas);
+    if (scratch_bytes > 0)
+      scratch[p] = at::empty({static_cast<int64_t>(scratch_bytes)}, rhs.options().dtype(at::kByte));
+    sputnik_hip_sddmm_sum_problem& q = problems[p];
+    q.row_indices = topo[p].row_indices.data_ptr<int>();
+    q.row_offsets = topo[p].row_offsets.data_ptr<int>();
+    q.column_indices = topo[p].column_indices.data_ptr<int>();
+    q.lhs = lhs[p].data_ptr<float>();
+    q.rhs = rhs.data_ptr<float>();
+    q.out = outs[p].data_ptr<float>();
+    q.workspace = ws_bytes ? plans[p].data_ptr() : nullptr;
+    q.workspace_bytes = ws_bytes;
+    q.scratch = scratch_bytes ? scratch[p].data_ptr() : nullptr;
+    q.scratch_bytes = scratch_bytes;
+    q.nonzeros = nnz;
+  }
+  check_status(sputnik_hip_sddmm_sum_group_planned(m, k, n, replicas, static_cast<int>(count),
+                                                   problems.data(), static_cast<int64_t>(m) * k,
+                                                   static_cast<int64_t>(n) * k, current_stream(rhs)),
+               "sddmm_sum_group_planned");
+  return outs;
+}
+
 // the summed product has a plan of its own (sputnik_hip.h: sddmm_sum_plan)
 Tensor sddmm_sum_plan(int64_t m64, int64_t n64, int64_t k64, const Tensor& row_indices,
                       const Tensor& row_offsets, const Tensor& column_indices) {
@@ -1562,6 +1619,9 @@ TORCH_LIBRARY(torch_sputnik, m) {
       "sddmm_sum_planned(int m, int n, Tensor row_indices, Tensor row_offsets, "
       "Tensor column_indices, Tensor lhs_matrix, Tensor rhs_matrix, Tensor plan) -> Tensor");
   m.def(
+      "sddmm_sum_group_planned(int m, int n, Tensor[] row_indices, Tensor[] row_offsets, "
+      "Tensor[] column_indices, Tensor[] lhs_matrices, Tensor rhs_matrix, Tensor[] plans) -> Tensor[]");
+  m.def(
       "sparse_attention_plan(int m, int n, int d, Tensor row_indices, Tensor row_offsets, "
       "Tensor column_indices) -> Tensor");
   m.def(
@@ -1639,6 +1699,7 @@ TORCH_LIBRARY_IMPL(torch_sputnik, CUDA, m) {
   m.impl("sddmm_sum", &sddmm_sum);
   m.impl("sddmm_sum_plan", &sddmm_sum_plan);
   m.impl("sddmm_sum_planned", &sddmm_sum_planned);
+  m.impl("sddmm_sum_group_planned", &sddmm_sum_group_planned);
   m.impl("sparse_attention_plan", &sparse_attention_plan);
   m.impl("sparse_attention_planned", &sparse_attention_planned);
   m.impl("spmm_many_mask", &spmm_many_mask);

@@ -696,8 +696,20 @@ class GroupProjectionFunction(torch.autograd.Function):
             live.append(w)
             grad_ys.append(g)
         grad_values = [None] * len(values)
-        for w, g in zip(live, grad_ys):
-            if ctx.needs_input_grad[4 + 4 * w]:
+        wanted = [(w, g) for w, g in zip(live, grad_ys) if ctx.needs_input_grad[4 + 4 * w]]
+        grouped = (_plans is not None and 2 <= len(wanted) <= 4 and dense.dim() == 3 and dense.is_cuda
+                   and dense.dtype == torch.float32 and all(g.dtype == torch.float32 for _, g in wanted))
+        if grouped:   # one call: every weight's partial sums added by ONE launch
+            topo = [ctx.topologies[w] for w, _ in wanted]
+            plans = [_plans.sddmm(m, k, dense.size(-1), *t, summed=True) for t in topo]
+            grouped = all(p is not None for p in plans)
+        if grouped:
+            outs = ops.sddmm_sum_group_planned(m, k, [t[0] for t in topo], [t[1] for t in topo],
+                                               [t[2] for t in topo], [g for _, g in wanted], dense, plans)
+            for (w, _), out in zip(wanted, outs):
+                grad_values[w] = out
+        else:
+            for w, g in wanted:
                 ri, ro, ci = ctx.topologies[w]
                 grad_values[w] = _sddmm(m, k, ri, ro, ci, g, dense, sum_replicas=True)
         grad_dense = None

@@ -356,6 +356,17 @@ def sddmm_sum_planned(m, n, row_indices, row_offsets, column_indices, lhs_matrix
                                   lhs_matrix, rhs_matrix, plan)
 
 
+def sddmm_sum_group_planned(m, n, row_indices, row_offsets, column_indices, lhs_matrices, rhs_matrix,
+                            plans):
+    """Up to four summed SDDMMs of one shape against ONE rhs in one call (lists with an entry
+    per product; float32, [replicas, rows, k]): the weight gradients of a group of projections
+    (modules/sparse_attention.py:108-110), whose partial sums one launch adds.  Bit-identical
+    to sddmm_sum_planned product by product."""
+    return _ops.sddmm_sum_group_planned(int(m), int(n), list(row_indices), list(row_offsets),
+                                        list(column_indices), list(lhs_matrices), rhs_matrix,
+                                        list(plans))
+
+
 def sparse_attention_plan(m, n, d, row_indices, row_offsets, column_indices):
     """Pre-pass for the fused attention over an m x n mask with head dimension d."""
     return _ops.sparse_attention_plan(int(m), int(n), int(d), row_indices, row_offsets,
